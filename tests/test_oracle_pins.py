@@ -1,0 +1,345 @@
+"""Pins the CPU oracle against every known answer the reference's own tests hold.
+
+The reference has no golden vectors (its tests check closed forms, self-consistency identities and
+one unseeded sample mean), so these are the pins available:
+  1. test/SpecialDistributions/polyagamma.jl:27-28,30   closed-form PG means
+  2. test/SpecialDistributions/polyagamma.jl:36         |mean(10000 draws) - E| <= 1e-2, six (b,c)
+  3. test/SpecialDistributions/polyagamma.jl:3-19,34-35 density series == independent 4001-term series
+  4. src/SpecialDistributions/polyagamma.jl:231         hard-coded r(z=0)
+  5. test/utils.jl:6-13                                 second_moment, approx_expected_logistic
+  6. src/TestUtils.jl:80-88,107-148,162-171             shape/sign rules + the two full-conditional identities
+  7. test/likelihoods/laplace.jl:6-9                    Laplace KL closed form
+plus the Random123 known-answer vectors for Philox4x32-10.
+"""
+import numpy as np
+import pytest
+from scipy import special, stats
+
+PAIRS = ((1, 0), (1, 2.0), (3, 0), (3, 2.5), (3, 3.2), (1.2, 3.2))
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors: philox4x32 10
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert oracle.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert oracle.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_uniform_stream_open_interval_and_reproducible(oracle):
+    u = oracle.uniforms(7, 3, 1, 10001)
+    assert np.all(u > 0) and np.all(u < 1)
+    assert np.array_equal(u, oracle.uniforms(7, 3, 1, 10001))
+    assert not np.array_equal(u[:100], oracle.uniforms(7, 4, 1, 100))
+    assert abs(u.mean() - 0.5) < 0.01
+
+
+def test_pg_mean_closed_forms(oracle):
+    assert oracle.pg_mean(1, 0) == 1 / 4  # polyagamma.jl test :27
+    assert oracle.pg_mean(1, 2.0) == np.tanh(1.0) / 4  # :28
+    for b, c in PAIRS:
+        ref = b / 4 if c == 0 else b / (2 * c) * np.tanh(c / 2)
+        assert oracle.pg_mean(b, c) == ref
+
+
+def test_mass_texpon_hardcoded_constant(oracle):
+    # polyagamma.jl:231 hard-codes r at z = 0; mass_texpon(z -> 0) must reproduce it bit for bit
+    assert oracle.pg_mass_texpon(1e-300) == 0.5776972428360435
+    # independent evaluation through scipy's normal logcdf
+    for z in (0.5, 1.0, 2.5, 10.0, 40.0, 60.0):
+        K = np.pi ** 2 / 8 + z * z / 2
+        t = 0.64
+        b = (t * z - 1) / np.sqrt(t)
+        a = -(t * z + 1) / np.sqrt(t)
+        x0 = np.log(K) + K * t
+        q = 4 / np.pi * (np.exp(x0 - z + stats.norm.logcdf(b)) + np.exp(x0 + z + stats.norm.logcdf(a)))
+        assert oracle.pg_mass_texpon(z) == pytest.approx(1 / (1 + q), rel=1e-11)
+
+
+def test_normlogcdf_matches_scipy(oracle):
+    for z in np.concatenate([np.linspace(-60, 8, 137), [-35.0, -34.999, -1.0, -0.999]]):
+        assert oracle.normlogcdf(z) == pytest.approx(stats.norm.logcdf(z), rel=2e-12, abs=1e-300)
+
+
+def test_a_coefficients_continuous_at_truncation(oracle):
+    # the two branches of a(n,x) (polyagamma.jl:167-177) are two series for the same function and agree
+    # to O(1e-4) at the truncation point t = 0.64 (Devroye); the piecewise choice is what is tested here.
+    for n in range(4):
+        lo, hi = oracle.pg_a(n, 0.64), oracle.pg_a(n, 0.64 + 1e-12)
+        k = (n + 0.5) * np.pi
+        assert hi == pytest.approx(k * np.exp(-k * k * 0.64 / 2), rel=1e-12)
+        assert lo == pytest.approx(k * np.exp(-1.5 * (np.log(np.pi / 2) + np.log(0.64)) - 2 * (n + 0.5) ** 2 / 0.64),
+                                   rel=1e-12)
+    assert np.isnan(oracle.pg_a(0, 0.0)) and np.isnan(oracle.pg_a(1, -1.0))  # DomainError in the reference
+
+
+@pytest.mark.parametrize("b,c", PAIRS)
+def test_sampler_mean_within_reference_tolerance(oracle, b, c):
+    # test/SpecialDistributions/polyagamma.jl:36 -- mean(rand(p, 10000)) ~ mean(p) atol 1e-2
+    s = oracle.rand_pg(b, c, 10000, seed=20240807)
+    assert abs(s.mean() - oracle.pg_mean(b, c)) <= 1e-2
+    assert np.all(s > 0)
+
+
+def _ref_logpdf(b, c, x):
+    # test/SpecialDistributions/polyagamma.jl:3-23 independent 4001-term series
+    n = np.arange(0, 4002)
+    terms = special.gammaln(n + b) - special.gammaln(n + 1) - (2 * n + b) ** 2 / (8 * x) + np.log(2 * n + b)
+    pos = special.logsumexp(terms[0::2])
+    neg = special.logsumexp(terms[1::2])
+    logcosh = abs(c / 2) + np.log1p(np.exp(-abs(c))) - np.log(2)
+    ext = b * logcosh - c * c * x / 2 + (b - 1) * np.log(2) - special.gammaln(b) - (np.log(2 * np.pi) + 3 * np.log(x)) / 2
+    return ext + np.log(np.exp(pos) - np.exp(neg))
+
+
+@pytest.mark.parametrize("b,c", PAIRS)
+def test_logpdf_series_against_independent_series(oracle, b, c):
+    xs = 10.0 ** np.arange(-2.5, 0.5001, 0.1)  # :34
+    got = np.array([oracle.pg_logpdf(b, c, x) for x in xs])
+    ref = np.array([_ref_logpdf(b, c, x) for x in xs])
+    assert np.allclose(got, ref, rtol=1e-8, atol=0)  # Julia isapprox default rtol = sqrt(eps)
+    wide = np.array([oracle.pg_logpdf(b, c, x) for x in 10.0 ** np.arange(-7, 7.01, 0.1)])  # :32
+    assert not np.any(np.isnan(wide))
+
+
+@pytest.mark.parametrize("b,c", ((1, 0), (1, 2.0), (3, 2.5), (1, 9.0)))
+def test_sampler_distribution_ks_against_density_series(oracle, b, c):
+    # strengthens the reference's mean-only check: KS distance of 20000 draws against the CDF obtained by
+    # integrating the reference's own density series (polyagamma.jl:37-91)
+    s = np.sort(oracle.rand_pg(b, c, 20000, seed=99))
+    grid = np.concatenate([[1e-6], np.geomspace(1e-4, s.max() * 1.5 + 1, 6000)])
+    pdf = np.exp([oracle.pg_logpdf(b, c, x) for x in grid])
+    cdf = np.concatenate([[0], np.cumsum((pdf[1:] + pdf[:-1]) / 2 * np.diff(grid))])
+    assert cdf[-1] == pytest.approx(1.0, abs=2e-3)
+    emp = np.arange(1, s.size + 1) / s.size
+    d = np.max(np.abs(emp - np.interp(s, grid, cdf / cdf[-1])))
+    assert d < 1.63 / np.sqrt(s.size) + 2e-3  # 1% KS critical value + quadrature slack
+
+
+def test_third_party_samplers_distribution(oracle):
+    # Distributions.jl samplers are not under /root/reference ("upstream, unpinned"): check the laws.
+    for shape in (0.3, 1.0, 2.25, 7.5):
+        g = oracle.rand_gamma(shape, 1.7, 20000, seed=5)
+        assert stats.kstest(g, stats.gamma(shape, scale=1.7).cdf).pvalue > 1e-3
+    for mu in (0.05, 0.9, 5.5, 6.0, 40.0, 300.0):
+        k = oracle.rand_poisson(mu, 40000, seed=6)
+        assert abs(k.mean() - mu) < 5 * np.sqrt(mu / k.size)
+        assert abs(k.var() - mu) < 0.06 * mu + 0.01
+        hi = int(stats.poisson(mu).ppf(0.999)) + 1
+        obs = np.bincount(np.minimum(k, hi), minlength=hi + 1)
+        exp = stats.poisson(mu).pmf(np.arange(hi + 1)) * k.size
+        exp[-1] = k.size - exp[:-1].sum()
+        keep = exp > 5
+        chi = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+        assert chi < stats.chi2(keep.sum()).ppf(0.9999)
+    for mu, lam in ((0.5, 0.5), (2.0, 0.125), (0.1, 3.0)):
+        x = oracle.rand_invgaussian(mu, lam, 20000, seed=8)
+        assert stats.kstest(x, stats.invgauss(mu / lam, scale=lam).cdf).pvalue > 1e-3
+
+
+def test_utils(oracle):
+    rng = np.random.default_rng(42)
+    m, s = rng.normal(), rng.uniform()
+    c = m * m + s * s
+    # test/utils.jl:8
+    assert oracle.approx_expected_logistic(m, c) == pytest.approx(np.exp(m / 2) / np.cosh(c / 2) / 2, abs=1e-5)
+    # test/utils.jl:9-13: saturation for Float64 and Float32
+    for f32 in (False, True):
+        big = 1000.0
+        assert oracle.approx_expected_logistic(big, big + abs(rng.normal()), f32=f32) == pytest.approx(1.0)
+        assert oracle.approx_expected_logistic(-big, big + 1.0, f32=f32) == 0.0
+
+
+def _liks(O):
+    return {
+        "bernoulli": O.bernoulli(),
+        "negbin10": O.negbinomial(10),
+        "negbin5.5": O.negbinomial(5.5),
+        "studentt": O.studentt(3.0, 1.5),
+        "poisson": O.poisson(10.0),
+        "laplace": O.laplace(1.0),
+        "cat3": O.categorical(np.zeros(3)),
+        "cat3bij": O.categorical(np.zeros(3), bijective=True),
+        "hetero": O.heterogauss(5.0),
+    }
+
+
+def _gen_y(O, lik, f, rng):
+    n = f.size // lik.nlatent
+    if lik.kind == O.BERNOULLI:
+        return (rng.uniform(size=n) < 1 / (1 + np.exp(-f))).astype(np.uint8)
+    if lik.kind in (O.NEGBINOMIAL, O.POISSON):
+        return rng.poisson(3.0, size=n).astype(np.int32)
+    if lik.kind in (O.CATEGORICAL, O.CATEGORICAL_BIJ):
+        L = lik.nlatent
+        K = L + (1 if lik.kind == O.CATEGORICAL_BIJ else 0)
+        lab = rng.integers(0, K, size=n)
+        return (lab[:, None] == np.arange(L)[None, :]).astype(np.uint8)
+    return rng.normal(size=n)
+
+
+@pytest.mark.parametrize("name", ["bernoulli", "negbin10", "negbin5.5", "studentt", "poisson", "laplace", "cat3",
+                                  "cat3bij", "hetero"])
+def test_auglik_conformance(oracle, name):
+    """Restates src/TestUtils.jl:57-206 test_auglik(lik; n=10): arity, shapes, gamma >= 0,
+    potential_and_precision agreement (trivially the same call here), VI outputs finite."""
+    O = oracle
+    lik = _liks(O)[name]
+    rng = np.random.default_rng(1)
+    n, L = 10, lik.nlatent
+    f = rng.normal(size=(n, L))
+    y = _gen_y(O, lik, f.ravel() if L == 1 else f, rng)
+    draw = O.aux_sample(lik, y, f, seed=11)
+    assert draw["omega"].shape[0] == n
+    beta, gamma = O.potential_precision(lik, y, draw["omega"], draw.get("n"), fg=f if name == "hetero" else None)
+    assert beta.shape == gamma.shape == (L, n)  # TestUtils.jl:83 length == nlatent
+    assert np.all(gamma >= 0)  # :88
+    assert np.all(np.isfinite(beta))
+    qmu, qvar = rng.normal(size=(n, L)), np.ones((n, L))
+    q1, q2, q3 = O.aux_posterior(lik, y, qmu, qvar)
+    eb, eg = O.expected_potential_precision(lik, y, q1, q2, mu_g=qmu[:, -1] if name == "hetero" else None)
+    assert eb.shape == eg.shape == (L, n)  # :165
+    assert np.all(eg >= 0)  # :171
+    if name not in ("cat3", "hetero"):
+        assert np.isfinite(O.aux_kl(lik, y, q1, q2))  # :201-203
+    else:
+        assert np.isnan(O.aux_kl(lik, y, q1, q2))  # error() categorical.jl:165-170
+    if name != "hetero":
+        assert np.isfinite(O.expected_logtilt(lik, y, q1, q2, qmu, qvar))  # :202
+
+
+@pytest.mark.parametrize("name", ["bernoulli", "negbin10", "studentt"])
+def test_full_conditional_omega_identity(oracle, name):
+    """src/TestUtils.jl:107-116: log p(y,Omega|f) - log p(Omega|y,f) is the same for two independent
+    draws of Omega (atol 1e-5) -- pins the conditional's parameters against tilt + prior through the
+    density series."""
+    O = oracle
+    lik = _liks(O)[name]
+    rng = np.random.default_rng(3)
+    n = 10
+    f = rng.normal(size=n)
+    y = _gen_y(O, lik, f, rng)
+
+    def cond_logpdf(om):
+        if name == "bernoulli":
+            return sum(O.pg_logpdf(1, abs(fi), w) for fi, w in zip(f, om))
+        if name == "negbin10":
+            return sum(O.pg_logpdf(yi + 10, abs(fi), w) for yi, fi, w in zip(y, f, om))
+        a = (3.0 + 1) / 2
+        sc = 2 / (3.0 / 1.5 ** 2 + (y - f) ** 2)
+        return stats.gamma(a, scale=sc).logpdf(om).sum()
+
+    vals = []
+    for seed in (1, 2):
+        om = O.aux_sample(lik, y, f, seed=seed)["omega"]
+        vals.append(O.aug_loglik(lik, y, om, f) - cond_logpdf(om))
+    assert vals[0] == pytest.approx(vals[1], abs=1e-5)
+
+
+@pytest.mark.parametrize("name", ["bernoulli", "negbin10", "studentt", "poisson", "laplace"])
+def test_full_conditional_f_identity(oracle, name):
+    """src/TestUtils.jl:118-131: with K = AA', S = (K^-1 + Diag gamma)^-1, m = S beta:
+    logtilt(f) + log p(f) - log q(f) is the same for two draws f ~ q (atol 1e-5) -- pins beta, gamma
+    against logtilt."""
+    O = oracle
+    lik = _liks(O)[name]
+    rng = np.random.default_rng(4)
+    n = 10
+    f0 = rng.normal(size=n)
+    y = _gen_y(O, lik, f0, rng)
+    d = O.aux_sample(lik, y, f0, seed=21)
+    beta, gamma = O.potential_precision(lik, y, d["omega"], d.get("n"))
+    A = rng.uniform(size=(n, n))
+    K = A @ A.T
+    S = np.linalg.inv(np.linalg.inv(K) + np.diag(gamma[0]))
+    S = (S + S.T) / 2
+    m = S @ beta[0]
+    qF, pF = stats.multivariate_normal(m, S), stats.multivariate_normal(np.zeros(n), K, allow_singular=True)
+    vals = []
+    for _ in range(2):
+        f = qF.rvs(random_state=rng)
+        vals.append(O.logtilt(lik, y, d["omega"], f, d.get("n")) + pF.logpdf(f) - qF.logpdf(f))
+    assert vals[0] == pytest.approx(vals[1], abs=1e-5)
+
+
+def test_laplace_kl_closed_form(oracle):
+    # test/likelihoods/laplace.jl:6-9
+    rng = np.random.default_rng(0)
+    mu = rng.uniform(0.1, 1.0, size=5)
+    beta = 0.8
+    lam = 1 / (2 * beta) ** 2
+    lik = oracle.laplace(beta)
+    ref = np.sum(np.log(2 * lam) / 2 - np.log(2 * np.pi) / 2 - np.log(lam) / 2 + special.gammaln(0.5) + lam / mu)
+    assert oracle.aux_kl(lik, np.zeros(5), mu) == pytest.approx(ref, rel=1e-13)
+
+
+def test_expected_values_match_sampled_means(oracle):
+    """expected_auglik_precision == E_q[auglik_precision] (tvmean, ntdist.jl:63-65): Monte-Carlo check of
+    the categorical / poisson joint means (polyagammanegativemultinomial.jl:41-49, polyagammapoisson.jl:35-41)
+    using the conditional sampler with f fixed so that the conditional equals q."""
+    O = oracle
+    lik = O.poisson(4.0)
+    n = 60000
+    f = np.full(n, 0.7)
+    y = np.full(n, 2, dtype=np.int32)
+    d = O.aux_sample(lik, y, f, seed=3)
+    lam = 4.0 / (1 + np.exp(0.7))
+    assert d["n"].mean() == pytest.approx(lam, abs=4 * np.sqrt(lam / n))
+    assert d["omega"].mean() == pytest.approx(O.pg_mean(2 + lam, 0.7), abs=5e-3)
+    lik = O.categorical(np.zeros(3))
+    f = np.tile(np.array([0.3, -0.5, 1.0]), (n, 1))
+    y = np.tile(np.array([0, 1, 0], dtype=np.uint8), (n, 1))
+    d = O.aux_sample(lik, y, f, seed=4)
+    p = 1 / (1 + np.exp(-f[0])) / 3
+    nbar = p / (1 - p.sum())
+    assert np.allclose(d["n"].mean(axis=0), nbar, atol=0.02)
+    for k in range(3):
+        assert d["omega"][:, k].mean() == pytest.approx(O.pg_mean(y[0, k] + nbar[k], abs(f[0, k])), abs=6e-3)
+
+
+def test_cavi_pass_matches_dense_numpy(oracle):
+    """The sparse pass (a11+a9+a10+a12) against a direct float64 numpy evaluation of the same formulas."""
+    O = oracle
+    rng = np.random.default_rng(7)
+    N, M = 300, 16
+    Phi = rng.normal(size=(N, M)).astype(np.float32) / 4
+    W = rng.normal(size=(M, M))
+    W = (W + W.T) / 20
+    alpha = rng.normal(size=M)
+    kd = 1.0 + rng.uniform(size=N)
+    y = (rng.uniform(size=N) < 0.5).astype(np.uint8)
+    G, g, pts = O.cavi_pass(O.bernoulli(), Phi, kd, y, W, alpha, want_points=True)
+    P = Phi.astype(np.float64)
+    mu = P @ alpha
+    var = kd - np.einsum("ia,ab,ib->i", P, W, P)
+    c = np.sqrt(mu ** 2 + var)
+    gam = np.tanh(c / 2) / (2 * c)
+    bet = (y.astype(float) - 0.5)
+    assert np.allclose(pts["mu"][:, 0], mu, rtol=1e-12, atol=1e-14)
+    assert np.allclose(pts["var"][:, 0], var, rtol=1e-12, atol=1e-14)
+    assert np.allclose(pts["gamma"][0], gam, rtol=1e-12)
+    assert np.allclose(G[0], (P * gam[:, None]).T @ P, rtol=1e-12, atol=1e-14)
+    assert np.allclose(g[0], P.T @ bet, rtol=1e-12, atol=1e-14)
+    G2, g2 = O.accumulate(Phi, pts["beta"], pts["gamma"])
+    assert np.allclose(G2, G, rtol=1e-13) and np.allclose(g2, g, rtol=1e-13)
+
+
+def test_sparse_update_equals_dense_reference_update(oracle):
+    """The whitened sparse update used by the product equals the reference's dense CAVI update
+    (examples/bernoulli/script.jl:35-36) when Z = X (the only case the reference ever executes, F3)."""
+    O = oracle
+    rng = np.random.default_rng(9)
+    n = 25
+    x = np.linspace(-10, 10, n)
+    K = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 2.0) ** 2) + 1e-6 * np.eye(n)
+    lam = rng.uniform(0.05, 0.25, size=n)
+    h = rng.choice([-0.5, 0.5], size=n)
+    S_ref = np.linalg.inv(np.linalg.inv(K) + np.diag(lam))  # script.jl:35
+    m_ref = S_ref @ h  # :36 with zero prior mean
+    Lc = np.linalg.cholesky(K)
+    Phi = np.linalg.solve(Lc, K).T  # whitened features phi_i = L^-1 k_i   [N, M]
+    G = (Phi * lam[:, None]).T @ Phi
+    g = Phi.T @ h
+    Sv, mv = O.gaussian_update(G[None], g[None])
+    assert np.allclose(Lc @ Sv[0] @ Lc.T, S_ref, rtol=1e-6, atol=1e-9)
+    assert np.allclose(Lc @ mv[0], m_ref, rtol=1e-6, atol=1e-9)
