@@ -1,0 +1,78 @@
+// agpl_common.h -- context, error plumbing and small device helpers shared by the libagpl.so sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <utility>
+#include <vector>
+
+#include "../../include/agpl.h"
+
+struct rocblas_handle_s; // fwd (rocblas_handle is a pointer to an opaque struct)
+
+struct agpl_ctx {
+    int device = 0;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *rocblas = nullptr; // rocblas_handle, created lazily by agpl_update.hip
+    // scratch (lazily grown)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    void *ws2 = nullptr; // small persistent scratch (reductions, info flags)
+    size_t ws2_bytes = 0;
+    double *logtheta_dev = nullptr; // categorical link parameters mirrored on device
+    int logtheta_cap = 0;
+    double logtheta_host[128];      // last uploaded values (skip the copy when unchanged)
+    int logtheta_n = 0;
+    // optional kernel timing (agpl_timing_*): event pairs per kernel family
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    char err[512] = {0};
+};
+
+// RAII-less helpers: record a start event now, and the matching stop event after the launch
+int32_t agpl_timing_begin(agpl_ctx *ctx, int which);
+int32_t agpl_timing_end(agpl_ctx *ctx, int which);
+
+#define AGPL_FAIL(ctx, code, ...)                                   \
+    do {                                                            \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+        return (code);                                              \
+    } while (0)
+
+#define AGPL_HIP(ctx, call)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            AGPL_FAIL(ctx, AGPL_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define AGPL_LAUNCH_CHECK(ctx)                                                              \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess)                                                              \
+            AGPL_FAIL(ctx, AGPL_ERR_HIP, "kernel launch failed: %s (%s:%d)",                \
+                      hipGetErrorString(e__), __FILE__, __LINE__);                          \
+    } while (0)
+
+// grow-only scratch
+int32_t agpl_ws_reserve(agpl_ctx *ctx, size_t bytes);
+int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes);
+
+// device-side view of a likelihood descriptor (logtheta mirrored to device memory)
+struct agpl_lik_dev {
+    int32_t kind;
+    int32_t nlatent;
+    double p[4];
+    const double *logtheta; // device
+    double sum_theta;       // categorical.jl:16-20
+    double cat_const;       // categorical.jl:12-14 (bijective only)
+};
+int32_t agpl_lik_to_device(agpl_ctx *ctx, const agpl_lik_desc *lik, agpl_lik_dev *out);
+
+static inline int64_t agpl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

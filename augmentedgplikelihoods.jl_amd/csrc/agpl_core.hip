@@ -1,0 +1,184 @@
+// agpl_core.hip -- context lifetime, stream binding, scratch memory, likelihood descriptor upload.
+#include <math.h>
+
+#include "agpl_common.h"
+
+extern "C" void agpl_update_release(agpl_ctx *ctx); // agpl_update.hip (destroys the rocBLAS handle)
+
+extern "C" int32_t agpl_version(void) { return AGPL_VERSION; }
+
+extern "C" int32_t agpl_ctx_create(agpl_ctx **out, int32_t device_id, uint64_t seed) {
+    if (!out) return AGPL_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AGPL_ERR_HIP;
+    if (device_id < 0 || device_id >= ndev) return AGPL_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device_id) != hipSuccess) return AGPL_ERR_HIP;
+    agpl_ctx *ctx = new (std::nothrow) agpl_ctx();
+    if (!ctx) return AGPL_ERR_OUT_OF_MEMORY;
+    ctx->device = device_id;
+    ctx->seed = seed;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return AGPL_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
+    if (!ctx) return AGPL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    agpl_update_release(ctx);
+    for (int w = 0; w < 2; ++w)
+        for (auto &pr : ctx->ev[w]) ctx->ev_pool.push_back(pr);
+    for (auto &pr : ctx->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_ctx_set_stream(agpl_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    AGPL_HIP(ctx, hipSetDevice(ctx->device));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) AGPL_HIP(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream; // NULL = the device's default (null) stream
+    ctx->own_stream = false;
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    ctx->seed = seed;
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_ctx_synchronize(agpl_ctx *ctx) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AGPL_OK;
+}
+
+extern "C" const char *agpl_last_error(const agpl_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t agpl_ws_reserve(agpl_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return AGPL_OK;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) AGPL_HIP(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    if (hipMalloc(&ctx->ws, bytes) != hipSuccess)
+        AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the workspace failed", bytes);
+    ctx->ws_bytes = bytes;
+    return AGPL_OK;
+}
+
+int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws2_bytes) return AGPL_OK;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws2) AGPL_HIP(ctx, hipFree(ctx->ws2));
+    ctx->ws2 = nullptr;
+    ctx->ws2_bytes = 0;
+    if (hipMalloc(&ctx->ws2, bytes) != hipSuccess)
+        AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the small workspace failed", bytes);
+    ctx->ws2_bytes = bytes;
+    return AGPL_OK;
+}
+
+int32_t agpl_lik_to_device(agpl_ctx *ctx, const agpl_lik_desc *lik, agpl_lik_dev *out) {
+    if (!lik) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null likelihood descriptor");
+    if (lik->kind < AGPL_LIK_BERNOULLI_LOGISTIC || lik->kind > AGPL_LIK_HETEROGAUSS)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "unknown likelihood kind %d", lik->kind);
+    out->kind = lik->kind;
+    out->nlatent = lik->nlatent;
+    for (int i = 0; i < 4; ++i) out->p[i] = lik->p[i];
+    out->logtheta = nullptr;
+    out->sum_theta = 0.0;
+    out->cat_const = 0.0;
+    const bool cat = lik->kind == AGPL_LIK_CATEGORICAL || lik->kind == AGPL_LIK_CATEGORICAL_BIJ;
+    const int want_l = lik->kind == AGPL_LIK_HETEROGAUSS ? 2 : 1;
+    if (!cat && lik->nlatent != want_l)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "nlatent = %d, expected %d", lik->nlatent, want_l);
+    if (cat) {
+        if (lik->nlatent < 1 || lik->nlatent > 64 || !lik->logtheta)
+            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "categorical needs 1 <= nlatent <= 64 and logtheta");
+        const int K = lik->nlatent + (lik->kind == AGPL_LIK_CATEGORICAL_BIJ ? 1 : 0);
+        if (K > ctx->logtheta_cap) {
+            AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->logtheta_dev) AGPL_HIP(ctx, hipFree(ctx->logtheta_dev));
+            ctx->logtheta_dev = nullptr;
+            AGPL_HIP(ctx, hipMalloc((void **)&ctx->logtheta_dev, sizeof(double) * 128));
+            ctx->logtheta_cap = 128;
+        }
+        if (ctx->logtheta_n != K || memcmp(ctx->logtheta_host, lik->logtheta, sizeof(double) * K) != 0) {
+            // synchronous small copy: the descriptor's host memory need not outlive the call
+            AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AGPL_HIP(ctx, hipMemcpy(ctx->logtheta_dev, lik->logtheta, sizeof(double) * K, hipMemcpyHostToDevice));
+            memcpy(ctx->logtheta_host, lik->logtheta, sizeof(double) * K);
+            ctx->logtheta_n = K;
+        }
+        out->logtheta = ctx->logtheta_dev;
+        double s = 0.0;
+        for (int k = 0; k < lik->nlatent; ++k) s += exp(lik->logtheta[k]); // categorical.jl:16-20
+        if (lik->kind == AGPL_LIK_CATEGORICAL_BIJ) {
+            out->cat_const = exp(lik->logtheta[lik->nlatent]) * 0.5; // categorical.jl:12-14
+            s += out->cat_const;
+        }
+        out->sum_theta = s;
+    }
+    if (lik->kind == AGPL_LIK_NEGBINOMIAL && !(lik->p[0] > 0.0))
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "NegBinomial failures r must be > 0");
+    if (lik->kind == AGPL_LIK_STUDENTT && !(lik->p[0] > 0.0 && lik->p[1] > 0.0))
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "StudentT needs nu > 0 and sigma > 0");
+    return AGPL_OK;
+}
+
+// ---- optional kernel timing -------------------------------------------------------------------------
+int32_t agpl_timing_begin(agpl_ctx *ctx, int which) {
+    if (!ctx->timing) return AGPL_OK;
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (!ctx->ev_pool.empty()) {
+        pr = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+    } else {
+        AGPL_HIP(ctx, hipEventCreate(&pr.first));
+        AGPL_HIP(ctx, hipEventCreate(&pr.second));
+    }
+    AGPL_HIP(ctx, hipEventRecord(pr.first, ctx->stream));
+    ctx->ev[which].push_back(pr);
+    return AGPL_OK;
+}
+int32_t agpl_timing_end(agpl_ctx *ctx, int which) {
+    if (!ctx->timing) return AGPL_OK;
+    AGPL_HIP(ctx, hipEventRecord(ctx->ev[which].back().second, ctx->stream));
+    return AGPL_OK;
+}
+extern "C" int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    ctx->timing = on != 0;
+    return AGPL_OK;
+}
+extern "C" int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host) {
+    if (!ctx || which < 0 || which > 1 || !total_ms_host || !launches_host) return AGPL_ERR_INVALID_ARGUMENT;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (auto &pr : ctx->ev[which]) {
+        float ms = 0.f;
+        AGPL_HIP(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        ctx->ev_pool.push_back(pr);
+    }
+    *total_ms_host = tot;
+    *launches_host = (int64_t)ctx->ev[which].size();
+    ctx->ev[which].clear();
+    return AGPL_OK;
+}

@@ -1,0 +1,775 @@
+// agpl_ops.hip -- the per-datapoint half of a sweep: aux_sample!, aux_posterior!,
+// (expected_)auglik_{potential,precision}, and the ELBO N-reductions.  HBM-bound streaming kernels
+// (the PG sampler is transcendental-heavy: see DESIGN.md for its measured fraction of the HBM roof).
+#include <math.h>
+
+#include "agpl_common.h"
+#include "agpl_random.h"
+
+using namespace agpl;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n) {
+    int64_t b = agpl_cdiv(n, kBlock);
+    if (b > 256 * 16) b = 256 * 16; // 256 CUs x 16 resident blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aux_sample!  src/generic.jl:5-12 ; one lane per point, per-lane Philox stream (seed, i, sweep)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                            const double *__restrict__ f,
+                                                            double *__restrict__ omega,
+                                                            int64_t *__restrict__ nout, uint64_t seed,
+                                                            uint32_t sweep, uint32_t *__restrict__ nuni_out,
+                                                            uint32_t *__restrict__ nterms_out,
+                                                            int *__restrict__ bad) {
+    const int L = lik.nlatent;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Philox g;
+        g.init(seed, (uint64_t)i, sweep);
+        uint32_t nt = 0;
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
+            omega[i] = rand_pg(g, 1.0, fabs(f[i]), nt);
+            break;
+        case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
+            const int32_t *y = (const int32_t *)yv;
+            omega[i] = rand_pg(g, (double)y[i] + lik.p[0], fabs(f[i]), nt);
+        } break;
+        case AGPL_LIK_STUDENTT: { // studentt.jl:46-48
+            const double *y = (const double *)yv;
+            double nu = lik.p[0], sg = lik.p[1];
+            double d = y[i] - f[i];
+            double scale = 2.0 / (nu / (sg * sg) + d * d);
+            omega[i] = scale * rand_gamma(g, (nu + 1.0) / 2.0);
+        } break;
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:72-78, polyagammanegativemultinomial.jl:27-31,
+                                         // negativemultinomial.jl:35-45
+            const uint8_t *y = (const uint8_t *)yv;
+            double sp = 0.0;
+            for (int k = 0; k < L; ++k)
+                sp += exp(lik.logtheta[k]) * logistic(f[i * L + k]) / lik.sum_theta;
+            double p0 = 1.0 - sp;
+            if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
+                atomicOr(bad, 1);
+                break;
+            }
+            double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
+            for (int k = 0; k < L; ++k) {
+                double pk = exp(lik.logtheta[k]) * logistic(f[i * L + k]) / lik.sum_theta;
+                double lam = pk * theta / (1.0 - p0);
+                nout[i * L + k] = rand_poisson(g, lam);
+            }
+            for (int k = 0; k < L; ++k)
+                omega[i * L + k] = rand_pg(g, (double)(nout[i * L + k] + (int64_t)y[i * L + k]),
+                                           fabs(f[i * L + k]), nt);
+        } break;
+        case AGPL_LIK_POISSON: { // poisson.jl:26-28, polyagammapoisson.jl:23-27
+            const int32_t *y = (const int32_t *)yv;
+            double lam = lik.p[0] * logistic(-f[i]);
+            int64_t nn = rand_poisson(g, lam);
+            nout[i] = nn;
+            omega[i] = rand_pg(g, (double)(nn + y[i]), fabs(f[i]), nt);
+        } break;
+        case AGPL_LIK_LAPLACE: { // laplace.jl:40-42
+            const double *y = (const double *)yv;
+            double beta = lik.p[0];
+            double lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
+            omega[i] = rand_invgaussian(g, 1.0 / (2.0 * beta * fabs(y[i] - f[i])), 2.0 * lam);
+        } break;
+        case AGPL_LIK_HETEROGAUSS: { // heteroscedasticgaussian.jl:28-32
+            const double *y = (const double *)yv;
+            double ff = f[2 * i], gg = f[2 * i + 1];
+            double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
+            int64_t nn = rand_poisson(g, lam);
+            nout[i] = nn;
+            omega[i] = rand_pg(g, 0.5 + (double)nn, fabs(gg), nt);
+        } break;
+        default:
+            break;
+        }
+        if (nuni_out) nuni_out[i] = g.nuni;
+        if (nterms_out) nterms_out[i] = nt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void rand_pg_kernel(double b, double c, int64_t n, uint64_t seed,
+                                                         uint32_t sweep, double *__restrict__ out,
+                                                         uint32_t *__restrict__ nuni_out,
+                                                         uint32_t *__restrict__ nterms_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Philox g;
+        g.init(seed, (uint64_t)i, sweep);
+        uint32_t nt = 0;
+        out[i] = rand_pg(g, b, c, nt);
+        if (nuni_out) nuni_out[i] = g.nuni;
+        if (nterms_out) nterms_out[i] = nt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aux_posterior!  (bernoulli.jl:17-25, negativebinomial.jl:24-33, studentt.jl:50-58,
+// categorical.jl:80-110, poisson.jl:30-39, laplace.jl:44-52, heteroscedasticgaussian.jl:34-46)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T second_moment(T mu, T var) { return mu * mu + var; } // utils.jl:1-3
+template <typename T>
+__device__ __forceinline__ T second_moment_y(T mu, T var, T y) { return (mu - y) * (mu - y) + var; } // :5-7
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void aux_posterior_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                               const T *__restrict__ mu,
+                                                               const T *__restrict__ var, T *__restrict__ out1,
+                                                               T *__restrict__ out2, T *__restrict__ out3) {
+    const int L = lik.nlatent;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC:
+        case AGPL_LIK_NEGBINOMIAL:
+            out1[i] = sqrt(second_moment(mu[i], var[i]));
+            break;
+        case AGPL_LIK_STUDENTT: {
+            const T *y = (const T *)yv;
+            T nu = (T)lik.p[0], sg = (T)lik.p[1];
+            out1[i] = (nu / (sg * sg) + second_moment_y(mu[i], var[i], y[i])) / T(2);
+        } break;
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: {
+            T den = lik.kind == AGPL_LIK_CATEGORICAL ? (T)L : (T)(lik.cat_const + (double)L);
+            for (int k = 0; k < L; ++k) {
+                T c = sqrt(second_moment(mu[i * L + k], var[i * L + k]));
+                out1[i * L + k] = c;
+                out2[i * L + k] = approx_expected_logistic(-mu[i * L + k], c) / den;
+            }
+        } break;
+        case AGPL_LIK_POISSON: {
+            T c = sqrt(second_moment(mu[i], var[i]));
+            out1[i] = c;
+            out2[i] = (T)lik.p[0] * approx_expected_logistic(-mu[i], c);
+        } break;
+        case AGPL_LIK_LAPLACE: {
+            const T *y = (const T *)yv;
+            out1[i] = T(1) / (T(2) * (T)lik.p[0] * sqrt(second_moment_y(mu[i], var[i], y[i])));
+        } break;
+        case AGPL_LIK_HETEROGAUSS: {
+            const T *y = (const T *)yv;
+            T psi = second_moment_y(mu[2 * i], var[2 * i], y[i]) / T(2);
+            T c = sqrt(second_moment(mu[2 * i + 1], var[2 * i + 1]));
+            out3[i] = psi;
+            out1[i] = c;
+            out2[i] = (T)lik.p[0] * approx_expected_logistic(-mu[2 * i + 1], c) * psi;
+        } break;
+        default:
+            break;
+        }
+    }
+}
+
+// expected_auglik_potential / expected_auglik_precision for one point (shared with the fused pass)
+// q1, q2 indexed [i*L + k]; outputs [k*n + i].
+template <typename T>
+__device__ __forceinline__ void expected_pp_point(const agpl_lik_dev &lik, int64_t n, int64_t i, const void *yv,
+                                                  const T *q1, const T *q2, const T *mu_g, T *beta, T *gamma) {
+    const int L = lik.nlatent;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:27-29,41-45
+        const uint8_t *y = (const uint8_t *)yv;
+        beta[i] = y[i] ? T(0.5) : T(-0.5);
+        gamma[i] = pg_mean(T(1), q1[i]);
+    } break;
+    case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:35-37,47-49
+        const int32_t *y = (const int32_t *)yv;
+        beta[i] = ((T)y[i] - (T)lik.p[0]) / T(2);
+        gamma[i] = pg_mean((T)y[i] + (T)lik.p[0], q1[i]);
+    } break;
+    case AGPL_LIK_STUDENTT: { // studentt.jl:41-43,68-74
+        const T *y = (const T *)yv;
+        T w = (((T)lik.p[0] + T(1)) / T(2)) * (T(1) / q1[i]);
+        gamma[i] = w;
+        beta[i] = w * y[i];
+    } break;
+    case AGPL_LIK_CATEGORICAL:
+    case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:121-136, polyagammanegativemultinomial.jl:41-49
+        const uint8_t *y = (const uint8_t *)yv;
+        T sp = T(0);
+        for (int k = 0; k < L; ++k) sp += q2[i * L + k];
+        T p0 = T(1) - sp;
+        for (int k = 0; k < L; ++k) {
+            T nbar = T(1) / p0 * q2[i * L + k];
+            T yk = (T)y[i * L + k];
+            beta[(int64_t)k * n + i] = (yk - nbar) / T(2);
+            gamma[(int64_t)k * n + i] = pg_mean(yk + nbar, q1[i * L + k]);
+        }
+    } break;
+    case AGPL_LIK_POISSON: { // poisson.jl:49-60, polyagammapoisson.jl:35-41
+        const int32_t *y = (const int32_t *)yv;
+        T nbar = q2[i];
+        beta[i] = ((T)y[i] - nbar) / T(2);
+        gamma[i] = pg_mean((T)y[i] + nbar, q1[i]);
+    } break;
+    case AGPL_LIK_LAPLACE: { // laplace.jl:62-68
+        const T *y = (const T *)yv;
+        gamma[i] = T(2) * q1[i];
+        beta[i] = T(2) * q1[i] * y[i];
+    } break;
+    case AGPL_LIK_HETEROGAUSS: { // heteroscedasticgaussian.jl:94-104
+        const T *y = (const T *)yv;
+        T lsg = (T)lik.p[0] * (T(1) - approx_expected_logistic(-mu_g[i], q1[i]));
+        T nbar = q2[i];
+        beta[i] = y[i] * lsg / T(2);
+        gamma[i] = lsg;
+        beta[n + i] = (T(0.5) - nbar) / T(2);
+        gamma[n + i] = pg_mean(T(0.5) + nbar, q1[i]);
+    } break;
+    default:
+        break;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void expected_pp_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                             const T *__restrict__ q1, const T *__restrict__ q2,
+                                                             const T *__restrict__ mu_g, T *__restrict__ beta,
+                                                             T *__restrict__ gamma) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        expected_pp_point<T>(lik, n, i, yv, q1, q2, mu_g, beta, gamma);
+}
+
+// auglik_potential / auglik_precision (sampled twins)
+__global__ __launch_bounds__(kBlock) void potential_precision_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                                     const double *__restrict__ omega,
+                                                                     const int64_t *__restrict__ nn,
+                                                                     const double *__restrict__ fg,
+                                                                     double *__restrict__ beta,
+                                                                     double *__restrict__ gamma) {
+    const int L = lik.nlatent;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: {
+            const uint8_t *y = (const uint8_t *)yv;
+            beta[i] = y[i] ? 0.5 : -0.5;
+            gamma[i] = omega[i];
+        } break;
+        case AGPL_LIK_NEGBINOMIAL: {
+            const int32_t *y = (const int32_t *)yv;
+            beta[i] = ((double)y[i] - lik.p[0]) / 2.0;
+            gamma[i] = omega[i];
+        } break;
+        case AGPL_LIK_STUDENTT: {
+            const double *y = (const double *)yv;
+            beta[i] = y[i] * omega[i];
+            gamma[i] = omega[i];
+        } break;
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: {
+            const uint8_t *y = (const uint8_t *)yv;
+            for (int k = 0; k < L; ++k) {
+                beta[(int64_t)k * n + i] = ((double)y[i * L + k] - (double)nn[i * L + k]) / 2.0;
+                gamma[(int64_t)k * n + i] = omega[i * L + k];
+            }
+        } break;
+        case AGPL_LIK_POISSON: {
+            const int32_t *y = (const int32_t *)yv;
+            beta[i] = ((double)y[i] - (double)nn[i]) / 2.0;
+            gamma[i] = omega[i];
+        } break;
+        case AGPL_LIK_LAPLACE: {
+            const double *y = (const double *)yv;
+            beta[i] = 2.0 * omega[i] * y[i];
+            gamma[i] = 2.0 * omega[i];
+        } break;
+        case AGPL_LIK_HETEROGAUSS: {
+            const double *y = (const double *)yv;
+            double il = lik.p[0] * logistic(fg[2 * i + 1]);
+            beta[i] = y[i] * il;
+            gamma[i] = il;
+            beta[n + i] = (0.5 - (double)nn[i]) / 2.0;
+            gamma[n + i] = omega[i];
+        } break;
+        default:
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ELBO N-reductions.  Per-point terms (float64), block tree-reduce, fixed-order final sum:
+// bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double logcosh_(double x) { // LogExpFunctions.logcosh
+    double ax = fabs(x);
+    return ax + log1p(exp(-2.0 * ax)) - kLogTwo;
+}
+__device__ __forceinline__ double pg_logtilt(double omega, double b, double c) { // polyagamma.jl:108-110
+    return b * logcosh_(c / 2.0) - c * c * omega / 2.0;
+}
+__device__ __forceinline__ double pg_kl(double b, double c) { // polyagamma.jl:99-106
+    return pg_logtilt(pg_mean(b, c), b, c);
+}
+__device__ __forceinline__ double negbin_logconst(double y, double r) { // negativebinomial.jl:51-52
+    return lgamma(y + r) - lgamma(y + 1.0) - lgamma(r);
+}
+__device__ __forceinline__ double digamma_(double x) {
+    double r = 0.0;
+    while (x < 6.0) {
+        r -= 1.0 / x;
+        x += 1.0;
+    }
+    double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x -
+           f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f / 132.0))));
+}
+
+enum { RED_LOGTILT = 0, RED_EXPECTED_LOGTILT = 1, RED_KL = 2 };
+
+struct RedArgs {
+    const void *y;
+    const double *a1; // omega | q1
+    const double *a2; // (unused) | q2
+    const int64_t *nn;
+    const double *f;   // f | mu
+    const double *var; // var
+};
+
+__device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
+    const int L = lik.nlatent;
+    const double nanv = __builtin_nan("");
+    if (mode == RED_LOGTILT) {
+        const double *omega = A.a1, *f = A.f;
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:47-49
+            double s = ((const uint8_t *)A.y)[i] ? 1.0 : -1.0;
+            return -kLogTwo + (s * f[i] - f[i] * f[i] * omega[i]) / 2.0;
+        }
+        case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:54-57
+            double r = lik.p[0], yy = (double)((const int32_t *)A.y)[i];
+            return negbin_logconst(yy, r) - (yy + r) * kLogTwo + (f[i] * (yy - r) - f[i] * f[i] * omega[i]) / 2.0;
+        }
+        case AGPL_LIK_STUDENTT: { // studentt.jl:76-78
+            double d = ((const double *)A.y)[i] - f[i];
+            return -0.5 * kLog2Pi + 0.5 * log(omega[i]) - 0.5 * d * d * omega[i];
+        }
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:138-145
+            const uint8_t *y = (const uint8_t *)A.y;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < L; ++k) {
+                double yk = (double)y[i * L + k], nk = (double)A.nn[i * L + k], fk = f[i * L + k];
+                s1 += yk + nk;
+                s2 += (yk - nk) * fk - fk * fk * omega[i * L + k];
+            }
+            return -s1 * kLogTwo + s2 / 2.0;
+        }
+        case AGPL_LIK_POISSON: { // poisson.jl:62-65
+            double yy = (double)((const int32_t *)A.y)[i], nk = (double)A.nn[i];
+            return yy * log(lik.p[0]) - (yy + nk) * kLogTwo - lgamma(yy + 1.0) +
+                   ((yy - nk) * f[i] - f[i] * f[i] * omega[i]) / 2.0;
+        }
+        case AGPL_LIK_LAPLACE: { // laplace.jl:78-81
+            double d = ((const double *)A.y)[i] - f[i];
+            return lgamma(0.5) - 0.5 * log(kPi) - log(2.0 * lik.p[0]) - d * d * omega[i];
+        }
+        default:
+            return nanv;
+        }
+    }
+    if (mode == RED_EXPECTED_LOGTILT) {
+        const double *q1 = A.a1, *q2 = A.a2, *mu = A.f, *var = A.var;
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:59-65
+            double s = ((const uint8_t *)A.y)[i] ? 1.0 : -1.0;
+            double th = pg_mean(1.0, q1[i]);
+            return -kLogTwo + (s * mu[i] - (mu[i] * mu[i] + var[i]) * th) / 2.0;
+        }
+        case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:59-65
+            double r = lik.p[0], yy = (double)((const int32_t *)A.y)[i];
+            double th = pg_mean(yy + r, q1[i]);
+            return negbin_logconst(yy, r) - (yy + r) * kLogTwo +
+                   (mu[i] * (yy - r) - (mu[i] * mu[i] + var[i]) * th) / 2.0;
+        }
+        case AGPL_LIK_STUDENTT: { // studentt.jl:80-83
+            double th = ((lik.p[0] + 1.0) / 2.0) / q1[i];
+            double d = mu[i] - ((const double *)A.y)[i];
+            return -0.5 * kLog2Pi + 0.5 * log(th) - 0.5 * d * d * th - var[i] * th / 2.0;
+        }
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:172-180
+            const uint8_t *y = (const uint8_t *)A.y;
+            double sp = 0.0;
+            for (int k = 0; k < L; ++k) sp += q2[i * L + k];
+            double p0 = 1.0 - sp, s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < L; ++k) {
+                double yk = (double)y[i * L + k], nbar = q2[i * L + k] / p0;
+                double w = pg_mean(yk + nbar, q1[i * L + k]);
+                double m = mu[i * L + k], v = var[i * L + k];
+                s1 += yk + nbar;
+                s2 += ((yk - nbar) * m - (m * m + v) * w) / 2.0;
+            }
+            return -s1 * kLogTwo + s2;
+        }
+        case AGPL_LIK_POISSON: { // poisson.jl:76-85
+            double yy = (double)((const int32_t *)A.y)[i], nbar = q2[i];
+            double w = pg_mean(yy + nbar, q1[i]);
+            return -(yy + nbar) * kLogTwo + ((yy - nbar) * mu[i] - (mu[i] * mu[i] + var[i]) * w) / 2.0 +
+                   yy * log(lik.p[0]) - lgamma(yy + 1.0);
+        }
+        case AGPL_LIK_LAPLACE: { // laplace.jl:83-88
+            double yy = ((const double *)A.y)[i];
+            return lgamma(0.5) - 0.5 * log(kPi) - log(2.0 * lik.p[0]) -
+                   ((mu[i] - yy) * (mu[i] - yy) + var[i]) * q1[i];
+        }
+        default:
+            return nanv;
+        }
+    }
+    // RED_KL: aux_kldivergence generic.jl:56-62
+    const double *q1 = A.a1, *q2 = A.a2;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC:
+        return pg_kl(1.0, q1[i]);
+    case AGPL_LIK_NEGBINOMIAL:
+        return pg_kl((double)((const int32_t *)A.y)[i] + lik.p[0], q1[i]);
+    case AGPL_LIK_STUDENTT: { // KL(Gamma(alpha, 1/beta_i) || Gamma(nu/2, 2 sigma^2/nu)) studentt.jl:85-91
+        double nu = lik.p[0], sg = lik.p[1];
+        double ap = (nu + 1.0) / 2.0, thp = 1.0 / q1[i];
+        double aq = nu / 2.0, thq = sg * sg / (nu / 2.0);
+        return (ap - aq) * digamma_(ap) - lgamma(ap) + lgamma(aq) + aq * (log(thq) - log(thp)) +
+               ap * (thp - thq) / thq;
+    }
+    case AGPL_LIK_POISSON: { // polyagammapoisson.jl:47-51
+        double lq = q2[i], lp = lik.p[0];
+        double klp = lq > 0 ? lq * (log(lq) - log(lp)) - lq + lp : lp;
+        return pg_kl((double)((const int32_t *)A.y)[i] + lq, q1[i]) + klp;
+    }
+    case AGPL_LIK_LAPLACE: { // laplace.jl:96-104
+        double lam = 1.0 / ((2.0 * lik.p[0]) * (2.0 * lik.p[0]));
+        return log(2.0 * lam) / 2.0 - log(2.0 * kPi) / 2.0 - log(lam) / 2.0 + lgamma(0.5) + lam / q1[i];
+    }
+    case AGPL_LIK_CATEGORICAL_BIJ: { // polyagammanegativemultinomial.jl:56-65, negativemultinomial.jl:72-82
+        const uint8_t *y = (const uint8_t *)A.y;
+        double sp = 0.0;
+        for (int k = 0; k < L; ++k) sp += q2[i * L + k];
+        double p0 = 1.0 - sp;
+        double pp = 1.0 / lik.sum_theta;
+        double p0p = 1.0 - L * pp;
+        double s = 0.0, acc = 0.0;
+        for (int k = 0; k < L; ++k) {
+            double nbar = q2[i * L + k] / p0;
+            acc += pg_kl((double)y[i * L + k] + nbar, q1[i * L + k]);
+            s += q2[i * L + k] * (log(q2[i * L + k]) - log(pp));
+        }
+        return acc + log(p0) - log(p0p) + s / p0;
+    }
+    default:
+        return nanv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_terms_kernel(int mode, agpl_lik_dev lik, int64_t n, RedArgs A,
+                                                              double *__restrict__ partial) {
+    __shared__ double sm[kBlock];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        acc += red_term(mode, lik, i, A);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ void reduce_final_kernel(int nparts, const double *__restrict__ partial, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < nparts; ++i) acc += partial[i];
+        *out = acc;
+    }
+}
+
+int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t n, const RedArgs &A,
+                      double *out_host) {
+    if (!ctx || !out_host) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    if (mode == RED_KL && lik->kind == AGPL_LIK_CATEGORICAL)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
+                  "the kl-divergence cannot be computed for the non-bijective LogisticSoftMaxLink "
+                  "(categorical.jl:165-170); use the bijective link");
+    if (lik->kind == AGPL_LIK_HETEROGAUSS)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "heteroscedastic ELBO terms are not split in the reference");
+    if (n <= 0) {
+        *out_host = 0.0;
+        return AGPL_OK;
+    }
+    int nb = grid_for(n);
+    if (nb > 1024) nb = 1024;
+    rc = agpl_ws2_reserve(ctx, sizeof(double) * (1024 + 8));
+    if (rc) return rc;
+    double *partial = (double *)ctx->ws2;
+    reduce_terms_kernel<<<nb, kBlock, 0, ctx->stream>>>(mode, ld, n, A, partial + 8);
+    AGPL_LAUNCH_CHECK(ctx);
+    reduce_final_kernel<<<1, 64, 0, ctx->stream>>>(nb, partial + 8, partial);
+    AGPL_LAUNCH_CHECK(ctx);
+    AGPL_HIP(ctx, hipMemcpyAsync(out_host, partial, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AGPL_OK;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                   const double *f, double *omega_out, int64_t *n_out, uint32_t sweep,
+                                   uint32_t *nuni_out, uint32_t *nterms_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    if (n < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "n < 0");
+    if (n == 0) return AGPL_OK;
+    if (!f || !omega_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null f / omega_out");
+    const bool needs_n = ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ ||
+                         ld.kind == AGPL_LIK_POISSON || ld.kind == AGPL_LIK_HETEROGAUSS;
+    if (needs_n && !n_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "this likelihood needs n_out");
+    if (ld.kind != AGPL_LIK_BERNOULLI_LOGISTIC && !y) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null y");
+    rc = agpl_ws2_reserve(ctx, sizeof(double) * (1024 + 8));
+    if (rc) return rc;
+    int *bad = (int *)ctx->ws2;
+    AGPL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    aux_sample_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, f, omega_out, n_out, ctx->seed, sweep,
+                                                               nuni_out, nterms_out, bad);
+    AGPL_LAUNCH_CHECK(ctx);
+    if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
+        int hbad = 0;
+        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hbad)
+            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
+                      "NegativeMultinomial: all p should be positive and their sum strictly smaller than 1 "
+                      "(negativemultinomial.jl:17-22)");
+    }
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_rand_polyagamma(agpl_ctx *ctx, double b, double c, int64_t n, uint32_t sweep,
+                                        double *out, uint32_t *nuni_out, uint32_t *nterms_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (n < 0 || !(b >= 0.0)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need n >= 0 and b >= 0");
+    if (n == 0) return AGPL_OK;
+    if (!out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null out");
+    rand_pg_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(b, c, n, ctx->seed, sweep, out, nuni_out, nterms_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_potential_precision(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                            const double *omega, const int64_t *n_aux, const double *fg,
+                                            double *beta_out, double *gamma_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    if (n < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "n < 0");
+    if (n == 0) return AGPL_OK;
+    if (!y || !omega || !beta_out || !gamma_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const bool needs_n = ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ ||
+                         ld.kind == AGPL_LIK_POISSON || ld.kind == AGPL_LIK_HETEROGAUSS;
+    if (needs_n && !n_aux) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "this likelihood needs n_aux");
+    if (ld.kind == AGPL_LIK_HETEROGAUSS && !fg) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "heterogauss needs fg");
+    potential_precision_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, omega, n_aux, fg, beta_out,
+                                                                        gamma_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_aux_posterior(agpl_ctx *ctx, const agpl_lik_desc *lik, int32_t dtype, int64_t n,
+                                      const void *y, const void *mu, const void *var, void *out1, void *out2,
+                                      void *out3) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    if (n < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "n < 0");
+    if (n == 0) return AGPL_OK;
+    if (!mu || !var || !out1) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null mu / var / out1");
+    const bool needs2 = ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ ||
+                        ld.kind == AGPL_LIK_POISSON || ld.kind == AGPL_LIK_HETEROGAUSS;
+    if (needs2 && !out2) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "this likelihood needs out2");
+    if (ld.kind == AGPL_LIK_HETEROGAUSS && !out3) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "heterogauss needs out3");
+    const bool needs_y = ld.kind == AGPL_LIK_STUDENTT || ld.kind == AGPL_LIK_LAPLACE || ld.kind == AGPL_LIK_HETEROGAUSS;
+    if (needs_y && !y) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null y");
+    if (dtype == AGPL_F64)
+        aux_posterior_kernel<double><<<grid_for(n), kBlock, 0, ctx->stream>>>(
+            ld, n, y, (const double *)mu, (const double *)var, (double *)out1, (double *)out2, (double *)out3);
+    else if (dtype == AGPL_F32)
+        aux_posterior_kernel<float><<<grid_for(n), kBlock, 0, ctx->stream>>>(
+            ld, n, y, (const float *)mu, (const float *)var, (float *)out1, (float *)out2, (float *)out3);
+    else
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "dtype must be AGPL_F32 or AGPL_F64");
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_expected_potential_precision(agpl_ctx *ctx, const agpl_lik_desc *lik, int32_t dtype,
+                                                     int64_t n, const void *y, const void *q1, const void *q2,
+                                                     const void *mu_g, void *beta_out, void *gamma_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    if (n < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "n < 0");
+    if (n == 0) return AGPL_OK;
+    if (!y || !q1 || !beta_out || !gamma_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const bool needs2 = ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ ||
+                        ld.kind == AGPL_LIK_POISSON || ld.kind == AGPL_LIK_HETEROGAUSS;
+    if (needs2 && !q2) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "this likelihood needs q2");
+    if (ld.kind == AGPL_LIK_HETEROGAUSS && !mu_g) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "heterogauss needs mu_g");
+    if (dtype == AGPL_F64)
+        expected_pp_kernel<double><<<grid_for(n), kBlock, 0, ctx->stream>>>(
+            ld, n, y, (const double *)q1, (const double *)q2, (const double *)mu_g, (double *)beta_out,
+            (double *)gamma_out);
+    else if (dtype == AGPL_F32)
+        expected_pp_kernel<float><<<grid_for(n), kBlock, 0, ctx->stream>>>(
+            ld, n, y, (const float *)q1, (const float *)q2, (const float *)mu_g, (float *)beta_out,
+            (float *)gamma_out);
+    else
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "dtype must be AGPL_F32 or AGPL_F64");
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                const double *omega, const int64_t *n_aux, const double *f, double *out_host) {
+    RedArgs A{y, omega, nullptr, n_aux, f, nullptr};
+    return run_reduction(ctx, RED_LOGTILT, lik, n, A, out_host);
+}
+extern "C" int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                         const double *q1, const double *q2, const double *mu, const double *var,
+                                         double *out_host) {
+    RedArgs A{y, q1, q2, nullptr, mu, var};
+    return run_reduction(ctx, RED_EXPECTED_LOGTILT, lik, n, A, out_host);
+}
+extern "C" int32_t agpl_aux_kldivergence(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                         const double *q1, const double *q2, double *out_host) {
+    RedArgs A{y, q1, q2, nullptr, nullptr, nullptr};
+    return run_reduction(ctx, RED_KL, lik, n, A, out_host);
+}
+
+// fused elementwise step of agpl_cavi_pass (agpl_sweep.hip): aux_posterior! + expected potential/precision
+// from marginals stored latent-major [L][N] float32; writes gamma, beta [L][N] (and optional c [L,N]).
+__global__ __launch_bounds__(kBlock) void agpl_fused_elementwise_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                                        const float *__restrict__ mu,
+                                                                        const float *__restrict__ var,
+                                                                        float *__restrict__ gamma,
+                                                                        float *__restrict__ beta,
+                                                                        float *__restrict__ c_out) {
+    const int L = lik.nlatent;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        switch (lik.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: {
+            const uint8_t *y = (const uint8_t *)yv;
+            float c = sqrtf(second_moment(mu[i], var[i]));
+            gamma[i] = pg_mean(1.0f, c);
+            beta[i] = y[i] ? 0.5f : -0.5f;
+            if (c_out) c_out[i] = c;
+        } break;
+        case AGPL_LIK_NEGBINOMIAL: {
+            const int32_t *y = (const int32_t *)yv;
+            float c = sqrtf(second_moment(mu[i], var[i]));
+            float r = (float)lik.p[0];
+            gamma[i] = pg_mean((float)y[i] + r, c);
+            beta[i] = ((float)y[i] - r) / 2.0f;
+            if (c_out) c_out[i] = c;
+        } break;
+        case AGPL_LIK_STUDENTT: {
+            const float *y = (const float *)yv;
+            float nu = (float)lik.p[0], sg = (float)lik.p[1];
+            float bi = (nu / (sg * sg) + second_moment_y(mu[i], var[i], y[i])) / 2.0f;
+            float w = ((nu + 1.0f) / 2.0f) * (1.0f / bi);
+            gamma[i] = w;
+            beta[i] = w * y[i];
+            if (c_out) c_out[i] = bi;
+        } break;
+        case AGPL_LIK_POISSON: {
+            const int32_t *y = (const int32_t *)yv;
+            float c = sqrtf(second_moment(mu[i], var[i]));
+            float nbar = (float)lik.p[0] * approx_expected_logistic(-mu[i], c);
+            gamma[i] = pg_mean((float)y[i] + nbar, c);
+            beta[i] = ((float)y[i] - nbar) / 2.0f;
+            if (c_out) c_out[i] = c;
+        } break;
+        case AGPL_LIK_LAPLACE: {
+            const float *y = (const float *)yv;
+            float m = 1.0f / (2.0f * (float)lik.p[0] * sqrtf(second_moment_y(mu[i], var[i], y[i])));
+            gamma[i] = 2.0f * m;
+            beta[i] = 2.0f * m * y[i];
+            if (c_out) c_out[i] = m;
+        } break;
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ: {
+            const uint8_t *y = (const uint8_t *)yv;
+            float den = lik.kind == AGPL_LIK_CATEGORICAL ? (float)L : (float)(lik.cat_const + (double)L);
+            float sp = 0.0f;
+            for (int k = 0; k < L; ++k) {
+                float m = mu[(int64_t)k * n + i];
+                float c = sqrtf(second_moment(m, var[(int64_t)k * n + i]));
+                sp += approx_expected_logistic(-m, c) / den;
+            }
+            float p0 = 1.0f - sp;
+            for (int k = 0; k < L; ++k) {
+                float m = mu[(int64_t)k * n + i];
+                float c = sqrtf(second_moment(m, var[(int64_t)k * n + i]));
+                float p = approx_expected_logistic(-m, c) / den;
+                float nbar = 1.0f / p0 * p;
+                float yk = (float)y[i * L + k];
+                beta[(int64_t)k * n + i] = (yk - nbar) / 2.0f;
+                gamma[(int64_t)k * n + i] = pg_mean(yk + nbar, c);
+                if (c_out) c_out[i * L + k] = c;
+            }
+        } break;
+        case AGPL_LIK_HETEROGAUSS: {
+            const float *y = (const float *)yv;
+            float psi = second_moment_y(mu[i], var[i], y[i]) / 2.0f;
+            float mg = mu[n + i];
+            float c = sqrtf(second_moment(mg, var[n + i]));
+            float ael = approx_expected_logistic(-mg, c);
+            float lam = (float)lik.p[0];
+            float nbar = lam * ael * psi;
+            float lsg = lam * (1.0f - ael);
+            beta[i] = y[i] * lsg / 2.0f;
+            gamma[i] = lsg;
+            beta[n + i] = (0.5f - nbar) / 2.0f;
+            gamma[n + i] = pg_mean(0.5f + nbar, c);
+            if (c_out) c_out[i] = c;
+        } break;
+        default:
+            break;
+        }
+    }
+}
+
+int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
+                                      const float *mu, const float *var, float *gamma, float *beta, float *c_out) {
+    agpl_fused_elementwise_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, mu, var, gamma, beta, c_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}

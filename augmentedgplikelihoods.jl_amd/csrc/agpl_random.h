@@ -1,0 +1,295 @@
+// agpl_random.h -- per-lane counter RNG and the scalar samplers of the Gibbs half, device side.
+//
+// One Philox4x32-10 stream per (context seed, point index, sweep): a lane owns its stream, so a sweep
+// is reproducible for any launch geometry and resumable from (seed, sweep) alone.  Uniform -> double
+// conversion, randexp and randn are fixed transforms of the stream (53-bit open-interval uniform,
+// inversion, cosine Box-Muller) so that a float64 host evaluation of the same formulas consumes the
+// stream identically.
+//
+// Sampler algorithms (reference file:line, paths relative to the reference repo):
+//   sample_pg1 / a / mass_texpon / rand_truncated_inverse_gaussian / draw_sum / rand_gamma_sum
+//       src/SpecialDistributions/polyagamma.jl:121-257
+//   Gamma  (Distributions.jl 0.25, un-vendored): Marsaglia-Tsang, shape<1 boosted by exp(-E/shape)
+//   Poisson(Distributions.jl 0.25, un-vendored): exponential-arrival count for mu<6; PTRS for mu>=6
+//   InverseGaussian (Distributions.jl 0.25, un-vendored): Michael-Schucany-Haas
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace agpl {
+
+constexpr double kPgT = 0.64;                        // polyagamma.jl:3
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi2_8 = kPi * kPi / 8.0;           // polyagamma.jl:4
+constexpr double kLogTwo = 0.69314718055994530942;
+constexpr double kLog2Pi = 1.83787706640934548356;
+constexpr double kSqrtHalf = 0.70710678118654752440;
+
+struct Philox {
+    uint32_t k0, k1;
+    uint32_t c0, c1, c2, c3;
+    uint32_t b0, b1, b2, b3;
+    int pos;
+    uint32_t nuni;
+
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t stream, uint32_t sweep) {
+        k0 = (uint32_t)seed;
+        k1 = (uint32_t)(seed >> 32);
+        c0 = 0;
+        c1 = sweep;
+        c2 = (uint32_t)stream;
+        c3 = (uint32_t)(stream >> 32);
+        pos = 4;
+        nuni = 0;
+    }
+    __device__ __forceinline__ void refill() {
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, q0 = k0, q1 = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
+            uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+            uint32_t n0 = hi1 ^ x1 ^ q0;
+            uint32_t n2 = hi0 ^ x3 ^ q1;
+            x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
+            q0 += 0x9E3779B9u;
+            q1 += 0xBB67AE85u;
+        }
+        b0 = x0; b1 = x1; b2 = x2; b3 = x3;
+        c0 += 1u;
+        pos = 0;
+    }
+    // uniform in the open interval (0,1), 53 random bits
+    __device__ __forceinline__ double u01() {
+        if (pos >= 4) refill();
+        uint32_t w0, w1;
+        if (pos == 0) { w0 = b0; w1 = b1; } else { w0 = b2; w1 = b3; }
+        pos += 2;
+        nuni += 1u;
+        uint64_t k = ((uint64_t)(w0 >> 5) << 26) | (uint64_t)(w1 >> 6);
+        return ((double)k + 0.5) * 0x1.0p-53;
+    }
+    __device__ __forceinline__ double exp1() { return -log(u01()); }
+    __device__ __forceinline__ double normal() {
+        double u1 = u01();
+        double u2 = u01();
+        return sqrt(-2.0 * log(u1)) * cos(2.0 * kPi * u2);
+    }
+};
+
+// StatsFuns.normlogcdf as called at polyagamma.jl:186-187
+__device__ __forceinline__ double normlogcdf(double z) {
+    if (z < -1.0) {
+        if (z > -35.0) return log(0.5 * erfc(-z * kSqrtHalf));
+        double iz2 = 1.0 / (z * z);
+        double ser = 1.0 - iz2 * (1.0 - 3.0 * iz2 * (1.0 - 5.0 * iz2 * (1.0 - 7.0 * iz2)));
+        return -0.5 * z * z - log(-z) - 0.5 * kLog2Pi + log(ser);
+    }
+    return log1p(-0.5 * erfc(z * kSqrtHalf));
+}
+
+// mean(::PolyaGamma) polyagamma.jl:25-31
+template <typename T>
+__device__ __forceinline__ T pg_mean(T b, T c) {
+    if (c == T(0)) return b / T(4);
+    return b / (T(2) * c) * tanh(c / T(2));
+}
+
+// a(n,x) polyagamma.jl:167-177
+__device__ __forceinline__ double pg_a(int n, double x) {
+    double k = (n + 0.5) * kPi;
+    if (x > kPgT) return k * exp(-k * k * x / 2.0);
+    if (x > 0.0) {
+        double expnt = -3.0 / 2.0 * (log(kPi / 2.0) + log(x)) - 2.0 * (n + 0.5) * (n + 0.5) / x;
+        return k * exp(expnt);
+    }
+    return __builtin_nan(""); // DomainError in the reference; unreachable from the sampler
+}
+
+// mass_texpon(z,K) polyagamma.jl:179-192
+__device__ __forceinline__ double pg_mass_texpon(double z, double K) {
+    const double t = kPgT;
+    double b = sqrt(1.0 / t) * (t * z - 1.0);
+    double a = -sqrt(1.0 / t) * (t * z + 1.0);
+    double x0 = log(K) + K * t;
+    double xb = x0 - z + normlogcdf(b);
+    double xa = x0 + z + normlogcdf(a);
+    double qdivp = (4.0 / kPi) * (exp(xb) + exp(xa));
+    return 1.0 / (1.0 + qdivp);
+}
+
+// rand_truncated_inverse_gaussian(rng,z) polyagamma.jl:195-221
+__device__ inline double rand_tig(Philox &g, double z) {
+    double mu = 1.0 / z;
+    double x = 1.0 + kPgT;
+    if (mu > kPgT) {
+        double alpha = 0.0;
+        while (alpha < g.u01()) {
+            double E = g.exp1();
+            double Ep = g.exp1();
+            while (E * E > (2.0 * Ep / kPgT)) {
+                E = g.exp1();
+                Ep = g.exp1();
+            }
+            double d = 1.0 + E * kPgT;
+            x = kPgT / (d * d);
+            alpha = exp(-z * z * x / 2.0);
+        }
+    } else {
+        while (x > kPgT) {
+            double nrm = g.normal();
+            double y = nrm * nrm;
+            double muy = mu * y;
+            x = mu + mu * muy / 2.0 - mu * sqrt(4.0 * muy + muy * muy) / 2.0;
+            if (mu / (mu + x) < g.u01()) x = mu * mu / x;
+        }
+    }
+    return x;
+}
+
+// Parameters of sample_pg1 that depend only on c (polyagamma.jl:226-236): hoisted so that the b draws of
+// draw_sum (polyagamma.jl:129-134) evaluate mass_texpon once.
+struct Pg1Params {
+    double z, K, r;
+    __device__ __forceinline__ void set(double c) {
+        z = fabs(c) / 2.0;
+        if (z == 0.0) {
+            r = 0.5776972428360435; // polyagamma.jl:231
+            K = kPi2_8;
+        } else {
+            K = kPi2_8 + z * z / 2.0;
+            r = pg_mass_texpon(z, K);
+        }
+    }
+};
+
+// sample_pg1(rng,c) polyagamma.jl:237-257.  The alternating-series accept loop runs with the wave's
+// exec mask shrinking as lanes accept (the compiler's divergent-loop lowering is the wave ballot: the
+// loop back-edge is s_cbranch on exec != 0).
+__device__ inline double sample_pg1(Philox &g, const Pg1Params &p, uint32_t &nterms) {
+    for (;;) {
+        double x;
+        if (p.r > g.u01())
+            x = kPgT + g.exp1() / p.K;
+        else
+            x = rand_tig(g, p.z);
+        double s = pg_a(0, x);
+        double y = g.u01() * s;
+        int n = 0;
+        bool accepted = false;
+        for (;;) {
+            n += 1;
+            if (n & 1) {
+                s -= pg_a(n, x);
+                if (y <= s) { accepted = true; break; }
+            } else {
+                s += pg_a(n, x);
+                if (y > s) break;
+            }
+        }
+        nterms += (uint32_t)n;
+        if (accepted) return x / 4.0;
+    }
+}
+
+// Marsaglia-Tsang
+__device__ inline double rand_gamma_mt(Philox &g, double shape) {
+    double d = shape - 1.0 / 3.0;
+    double c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x = g.normal();
+        double v = 1.0 + c * x;
+        while (v <= 0.0) {
+            x = g.normal();
+            v = 1.0 + c * x;
+        }
+        v = v * v * v;
+        double u = g.u01();
+        double x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2 || log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return d * v;
+    }
+}
+__device__ inline double rand_gamma(Philox &g, double shape) {
+    if (shape >= 1.0) return rand_gamma_mt(g, shape);
+    double x = rand_gamma_mt(g, shape + 1.0);
+    double e = g.exp1();
+    return x * exp(-e / shape);
+}
+
+// rand_gamma_sum polyagamma.jl:157-164
+__device__ inline double rand_gamma_sum(Philox &g, double c, double e) {
+    const double inv2pi2 = (1.0 / (2.0 * kPi)) * (1.0 / kPi);
+    double w = (c * (1.0 / (2.0 * kPi)));
+    w = w * w;
+    double acc = 0.0;
+    for (int k = 1; k <= 200; ++k) acc += rand_gamma(g, e) / ((k - 0.5) * (k - 0.5) + w);
+    return inv2pi2 * acc;
+}
+
+// rand(PolyaGamma(b,c)) polyagamma.jl:121-154
+__device__ inline double rand_pg(Philox &g, double b, double c, uint32_t &nterms) {
+    if (b == 0.0) return 0.0;
+    if (b < 1.0) return rand_gamma_sum(g, c, b);
+    long tb = (long)floor(b);
+    Pg1Params p;
+    p.set(c);
+    double acc = 0.0;
+    for (long i = 0; i < tb; ++i) acc += sample_pg1(g, p, nterms);
+    double res = b - (double)tb;
+    if (res == 0.0) return acc;
+    return acc + rand_gamma_sum(g, c, res);
+}
+
+__device__ inline int64_t rand_poisson(Philox &g, double mu) {
+    if (!(mu > 0.0)) return 0;
+    if (mu < 6.0) {
+        int64_t n = 0;
+        double c = g.exp1();
+        while (c < mu) {
+            n += 1;
+            c += g.exp1();
+        }
+        return n;
+    }
+    double slam = sqrt(mu), loglam = log(mu);
+    double b = 0.931 + 2.53 * slam;
+    double a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (;;) {
+        double U = g.u01() - 0.5;
+        double V = g.u01();
+        double us = 0.5 - fabs(U);
+        double kf = floor((2.0 * a / us + b) * U + mu + 0.43);
+        if (us >= 0.07 && V <= vr) return (int64_t)kf;
+        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+        if ((log(V) + log(invalpha) - log(a / (us * us) + b)) <= (-mu + kf * loglam - lgamma(kf + 1.0)))
+            return (int64_t)kf;
+    }
+}
+
+__device__ inline double rand_invgaussian(Philox &g, double mu, double lambda) {
+    double z = g.normal();
+    double v = z * z;
+    double w = mu * v;
+    double x1 = mu + mu / (2.0 * lambda) * (w - sqrt(w * (4.0 * lambda + w)));
+    double p1 = mu / (mu + x1);
+    double u = g.u01();
+    return u >= p1 ? mu * mu / x1 : x1;
+}
+
+template <typename T>
+__device__ __forceinline__ T logistic(T x) { return T(1) / (T(1) + exp(-x)); }
+
+// approx_expected_logistic src/utils.jl:11-14 with LogExpFunctions._logistic_bounds per element type
+__device__ __forceinline__ double approx_expected_logistic(double mu, double c) {
+    if (mu < -744.4400719213812) return 0.0;
+    if (mu > 36.7368005696771) return 1.0;
+    return exp(mu / 2.0) * (1.0 / cosh(c / 2.0)) / 2.0;
+}
+__device__ __forceinline__ float approx_expected_logistic(float mu, float c) {
+    if (mu < -103.27893f) return 0.0f;
+    if (mu > 16.635532f) return 1.0f;
+    return expf(mu / 2.0f) * (1.0f / coshf(c / 2.0f)) / 2.0f;
+}
+
+} // namespace agpl

@@ -1,0 +1,189 @@
+// agpl_update.hip -- the M x M Gaussian update of a sweep (a12, examples/bernoulli/script.jl:35-36 in the
+// sparse whitened form of docs/src/index.md:154-163) and the fused-pass orchestration.
+//
+//   S = (I + G)^-1   (float64 Cholesky + inverse: rocSOLVER potrf / potri, plain library calls)
+//   m = S (g + eta0)
+//   Wpack = packed(-S) float32 for agpl_marginals ; alpha = m float32
+//
+// M <= a few thousand: M^3 work is < 1 % of the N M^2 contractions and stays on the sweep's stream.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include "agpl_common.h"
+
+// agpl_ops.hip / agpl_mfma.hip internals
+int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
+                                      const float *mu, const float *var, float *gamma, float *beta, float *c_out);
+int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *beta,
+                             const float *gamma, double *G_out, double *g_out, void *slab_mem);
+size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
+
+namespace {
+
+#define AGPL_ROCBLAS(ctx, call)                                                                     \
+    do {                                                                                            \
+        rocblas_status s__ = (call);                                                                \
+        if (s__ != rocblas_status_success)                                                          \
+            AGPL_FAIL(ctx, AGPL_ERR_HIP, "%s failed: rocblas_status %d (%s:%d)", #call, (int)s__,   \
+                      __FILE__, __LINE__);                                                          \
+    } while (0)
+
+__global__ void add_identity_kernel(int M, const double *__restrict__ G, double *__restrict__ A) {
+    const int l = blockIdx.z, row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= M) return;
+    const int64_t idx = ((int64_t)l * M + row) * M + col;
+    A[idx] = G[idx] + (row == col ? 1.0 : 0.0);
+}
+
+// potri leaves one triangle valid.  With rocblas_fill_lower on our row-major storage (= upper in the
+// column-major view of rocSOLVER... the matrix is symmetric so either reading is the same matrix) the
+// valid entries are those with (column-major) row >= col, i.e. row-major A[c][r] for r >= c: element
+// (i, j) of the row-major array is valid when j >= i.
+__global__ void symmetrize_kernel(int M, double *__restrict__ A) {
+    const int l = blockIdx.z, row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= M || col >= row) return;
+    double *Al = A + (int64_t)l * M * M;
+    Al[(int64_t)row * M + col] = Al[(int64_t)col * M + row];
+}
+
+// m = S (g + eta0): one block per row, fixed-order tree reduce
+__global__ __launch_bounds__(256) void symv_kernel(int M, const double *__restrict__ S, const double *__restrict__ g,
+                                                   const double *__restrict__ eta0, double *__restrict__ m_out,
+                                                   float *__restrict__ alpha_out) {
+    __shared__ double sm[256];
+    const int l = blockIdx.y, row = blockIdx.x;
+    const double *Sr = S + ((int64_t)l * M + row) * M;
+    const double *gl = g + (int64_t)l * M;
+    const double *el = eta0 ? eta0 + (int64_t)l * M : nullptr;
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < M; c += 256) acc += Sr[c] * (gl[c] + (el ? el[c] : 0.0));
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (m_out) m_out[(int64_t)l * M + row] = sm[0];
+        if (alpha_out) alpha_out[(int64_t)l * M + row] = (float)sm[0];
+    }
+}
+
+// Wpack[b][a] = scale * (b > a ? 2 W[a][b] : (b == a ? W[a][a] : 0))
+__global__ void pack_w_kernel(int M, const double *__restrict__ W, double scale, float *__restrict__ Wp) {
+    const int l = blockIdx.z, b = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= M) return;
+    const double *Wl = W + (int64_t)l * M * M;
+    double v = 0.0;
+    if (b > a)
+        v = 2.0 * Wl[(int64_t)b * M + a]; // symmetric: W[a][b] == W[b][a]; row b is the coalesced read
+    else if (b == a)
+        v = Wl[(int64_t)b * M + a];
+    Wp[((int64_t)l * M + b) * M + a] = (float)(scale * v);
+}
+
+int32_t get_handle(agpl_ctx *ctx, rocblas_handle *h) {
+    if (!ctx->rocblas) {
+        rocblas_handle hh = nullptr;
+        AGPL_ROCBLAS(ctx, rocblas_create_handle(&hh));
+        ctx->rocblas = hh;
+    }
+    *h = (rocblas_handle)ctx->rocblas;
+    AGPL_ROCBLAS(ctx, rocblas_set_stream(*h, ctx->stream));
+    return AGPL_OK;
+}
+
+} // namespace
+
+extern "C" void agpl_update_release(agpl_ctx *ctx) {
+    if (ctx && ctx->rocblas) {
+        rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
+        ctx->rocblas = nullptr;
+    }
+}
+
+extern "C" int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale, float *Wpack_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || L <= 0 || !W || !Wpack_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
+    pack_w_kernel<<<grid, 128, 0, ctx->stream>>>(M, W, scale, Wpack_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                        const double *eta0, double *S_out, double *m_out, float *Wpack_out,
+                                        float *alpha_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || L <= 0 || !G || !g) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    rocblas_handle h;
+    int32_t rc = get_handle(ctx, &h);
+    if (rc) return rc;
+    const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
+    const size_t info_off = 16384; // ws2 head is used by the reductions
+    rc = agpl_ws2_reserve(ctx, info_off + sizeof(rocblas_int) * 2 * (size_t)L + 256 + (S_out ? 0 : mat_bytes));
+    if (rc) return rc;
+    rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + info_off);
+    double *A = S_out ? S_out : (double *)((char *)ctx->ws2 + info_off + 256 + sizeof(rocblas_int) * 2 * (size_t)L);
+    A = (double *)(((uintptr_t)A + 255) & ~(uintptr_t)255);
+
+    dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
+    add_identity_kernel<<<grid, 128, 0, ctx->stream>>>(M, G, A);
+    AGPL_LAUNCH_CHECK(ctx);
+    const rocblas_stride stride = (rocblas_stride)M * M;
+    AGPL_ROCBLAS(ctx, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, M, A, M, stride, info, L));
+    AGPL_ROCBLAS(ctx, rocsolver_dpotri_strided_batched(h, rocblas_fill_lower, M, A, M, stride, info + L, L));
+    symmetrize_kernel<<<grid, 128, 0, ctx->stream>>>(M, A);
+    AGPL_LAUNCH_CHECK(ctx);
+    if (m_out || alpha_out) {
+        dim3 g2((unsigned)M, (unsigned)L);
+        symv_kernel<<<g2, 256, 0, ctx->stream>>>(M, A, g, eta0, m_out, alpha_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    if (Wpack_out) {
+        pack_w_kernel<<<grid, 128, 0, ctx->stream>>>(M, A, -1.0, Wpack_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    // PosDefException check (one small D2H + sync per sweep)
+    rocblas_int hinfo[128];
+    const int ni = 2 * L > 128 ? 128 : 2 * L;
+    AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(rocblas_int) * ni, hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ni; ++i)
+        if (hinfo[i] != 0)
+            AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, %s info = %d)", i % L,
+                      i < L ? "potrf" : "potri", (int)hinfo[i]);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                  const float *kdiag, const float *mu0, const void *y, const float *Wpack,
+                                  const float *alpha, double *G_out, double *g_out, float *c_out, float *gamma_out,
+                                  float *beta_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    const int L = ld.nlatent;
+    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
+    if (M % 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 128 (zero-pad the features)", M);
+    if (!Phi || !kdiag || !y || !Wpack || !alpha || !G_out || !g_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
+    const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
+    rc = agpl_ws_reserve(ctx, slab + 4 * vec);
+    if (rc) return rc;
+    char *base = (char *)ctx->ws;
+    float *mu = (float *)(base + slab);
+    float *var = (float *)(base + slab + vec);
+    float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
+    float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
+    rc = agpl_marginals(ctx, N, M, L, Phi, kdiag, mu0, Wpack, alpha, mu, var);
+    if (rc) return rc;
+    rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
+    if (rc) return rc;
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+}

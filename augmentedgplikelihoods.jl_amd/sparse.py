@@ -1,0 +1,194 @@
+"""Sparse sweep drivers: the reference's user-level loops (``cavi!`` examples/bernoulli/script.jl:29-39,
+multi-latent examples/categorical/script.jl:64-77, ``gibbs_sample`` :76-87) restated in the sparse form the
+docs give only as a formula (docs/src/index.md:154-163), in the whitened feature basis
+
+    Phi = L^-1 K_ZX  (K_Z = L L'),   u = L v,   q(v) = N(m, S),
+    S = (I + G)^-1,  m = S g,        G = Phi Diag(gamma) Phi',  g = Phi beta,
+    q(f_i) = N(phi_i' m, d_i + phi_i' S phi_i),   d_i = k_ii - |phi_i|^2.
+
+All O(N) work is two MFMA passes over Phi per sweep (agpl_cavi_pass) plus an M x M update
+(agpl_gaussian_update).  N is sharded over ranks with one all-reduce of (G, g) per sweep.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .operators import Context, _prep, _prep_y, _ptr, _torch, default_context
+
+PAD = 128  # feature rows are padded to a multiple of the MFMA block
+
+
+def padded(M: int) -> int:
+    return (M + PAD - 1) // PAD * PAD
+
+
+def synth_xy(lik, seed: int, i0: int, n: int, ctx: Context | None = None, want_x: bool = True):
+    """Synthetic workload of SURVEY.md 8(d): x_i = -10 + 20 u_i, y_i ~ lik(f*(x_i)), pure function of
+    (seed, i0 + i).  Real-valued y comes back as float32 (the fused pass's element type)."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    L = lik._nlatent
+    x = torch.empty(n, dtype=torch.float64, device=ctx.device) if want_x else None
+    ydt = {"u8": torch.uint8, "i32": torch.int32, "real": torch.float32}[lik.ykind]
+    y = torch.empty((n,) if L == 1 else (n, L), dtype=ydt, device=ctx.device)
+    d = lik.desc()
+    ctx.call("agpl_synth_xy", C.byref(d), C.c_uint64(seed), C.c_int64(i0), C.c_int64(n), _ptr(x), _ptr(y))
+    return x, y
+
+
+def se_features(x, z, ell: float, ctx: Context | None = None, out=None):
+    """K_ZX for the squared-exponential kernel with lengthscale ``ell`` (examples/bernoulli/script.jl:15):
+    float32 [N, Mp] (= [Mp, N] column-major), rows M..Mp zero."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    x = _prep(x, torch.float64, "x")
+    z = _prep(z, torch.float64, "z")
+    N, M = x.numel(), z.numel()
+    Mp = padded(M)
+    if out is None:
+        out = torch.empty((N, Mp), dtype=torch.float32, device=x.device)
+    ctx.call("agpl_se_features", C.c_int64(N), C.c_int32(M), C.c_int32(Mp), _ptr(x), _ptr(z), C.c_double(ell),
+             _ptr(out))
+    return out
+
+
+def whitening_matrix(Kzz: np.ndarray, jitter: float = 0.0):
+    """Host float64 setup (M x M, once): L = chol(K_Z + jitter I) (``_chol_cov`` of
+    examples/bernoulli/script.jl:30 with the 1e-8 of :44) and L^-1."""
+    Kzz = np.asarray(Kzz, dtype=np.float64)
+    Lc = np.linalg.cholesky(Kzz + jitter * np.eye(Kzz.shape[0]))
+    import scipy.linalg as sla
+
+    Linv = sla.solve_triangular(Lc, np.eye(Kzz.shape[0]), lower=True)
+    return Lc, Linv
+
+
+def whiten_features(Kzx, Linv: np.ndarray, ctx: Context | None = None, out=None):
+    """Phi = L^-1 K_ZX on the matrix cores (agpl_transform_features).  Kzx: float32 [N, Mp]."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    Kzx = _prep(Kzx, torch.float32, "Kzx")
+    N, Mp = Kzx.shape
+    M = Linv.shape[0]
+    A = np.zeros((Mp, Mp), dtype=np.float32)
+    A[:M, :M] = Linv
+    At = torch.from_numpy(np.ascontiguousarray(A.T)).to(Kzx.device)  # column-major A
+    if out is None:
+        out = torch.empty_like(Kzx)
+    ctx.call("agpl_transform_features", C.c_int64(N), C.c_int32(Mp), _ptr(At), _ptr(Kzx), _ptr(out))
+    return out
+
+
+class SparseCAVI:
+    """CAVI sweeps over N local points and M features.
+
+    Phi: float32 [N, Mp] CUDA tensor (Mp % 128 == 0); kdiag: float32 [N] (d_i above); y as the likelihood
+    wants it (real-valued y: float32); mu0: optional prior mean at the data, float32 [L][N].
+    ``group``: a torch.distributed process group over which N is sharded (None = single GPU).
+    """
+
+    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False):
+        torch = _torch()
+        self.ctx = ctx or default_context()
+        self.lik = lik
+        self.Phi = _prep(Phi, torch.float32, "Phi")
+        self.N, self.M = self.Phi.shape
+        if self.M % PAD:
+            raise _ffi.ArgumentError(-1, f"feature count {self.M} must be a multiple of {PAD} (zero-pad)")
+        self.L = lik._nlatent
+        self.kdiag = _prep(kdiag, torch.float32, "kdiag")
+        self.y = _prep_y(lik, y, torch.float32)
+        self.mu0 = _prep(mu0, torch.float32, "mu0")
+        self.group = group
+        dev = self.Phi.device
+        L, M = self.L, self.M
+        f64, f32 = torch.float64, torch.float32
+        self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
+        self.g = torch.zeros((L, M), dtype=f64, device=dev)
+        self.S = torch.eye(M, dtype=f64, device=dev).repeat(L, 1, 1).contiguous()  # script.jl:42
+        self.m = torch.zeros((L, M), dtype=f64, device=dev)  # script.jl:41
+        self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
+        self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
+        self.ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), _ptr(self.S), C.c_double(-1.0), _ptr(self.Wpack))
+        self.gamma = self.beta = self.c = None
+        if keep_points:
+            self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
+            self.beta = torch.empty((L, self.N), dtype=f32, device=dev)
+            self.c = torch.empty((self.N,) if L == 1 else (self.N, L), dtype=f32, device=dev)
+        self.nsweeps = 0
+
+    def accumulate(self):
+        """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
+        d = self.lik.desc()
+        self.ctx.call("agpl_cavi_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
+                      _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.Wpack), _ptr(self.alpha),
+                      _ptr(self.G), _ptr(self.g), _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
+
+    def exchange(self):
+        """The one exchange step of a sweep: sum the M x M natural-parameter partials over ranks
+        (RCCL all-reduce over xGMI; float64 on the wire)."""
+        if self.group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.G, group=self.group)
+            dist.all_reduce(self.g, group=self.group)
+
+    def update(self):
+        """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form)."""
+        self.ctx.call("agpl_gaussian_update", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
+                      C.c_void_p(0), _ptr(self.S), _ptr(self.m), _ptr(self.Wpack), _ptr(self.alpha))
+
+    def sweep(self):
+        self.accumulate()
+        self.exchange()
+        self.update()
+        self.nsweeps += 1
+
+    def run(self, niter: int = 10):
+        for _ in range(niter):
+            self.sweep()
+        return self.m, self.S
+
+    def natural_parameters(self):
+        """(Lambda_v, eta_v) = (I + G, g): the whitened natural parameters of q(v)."""
+        torch = _torch()
+        eye = torch.eye(self.M, dtype=torch.float64, device=self.G.device)
+        return self.G + eye, self.g
+
+    def marginals(self):
+        """q(f_i) for the current (m, S): (mu, var) float32 [L][N]."""
+        torch = _torch()
+        mu = torch.empty((self.L, self.N), dtype=torch.float32, device=self.Phi.device)
+        var = torch.empty_like(mu)
+        self.ctx.call("agpl_marginals", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L), _ptr(self.Phi),
+                      _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.Wpack), _ptr(self.alpha), _ptr(mu), _ptr(var))
+        return mu, var
+
+
+def nystrom_residual(Phi, kxx, ctx: Context | None = None):
+    """d_i = k_ii - |phi_i|^2 through agpl_marginals with W = I, alpha = 0."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    Phi = _prep(Phi, torch.float32, "Phi")
+    N, M = Phi.shape
+    kxx = _prep(kxx, torch.float32, "kxx")
+    eye = torch.eye(M, dtype=torch.float64, device=Phi.device).unsqueeze(0).contiguous()
+    Wp = torch.empty((1, M, M), dtype=torch.float32, device=Phi.device)
+    ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(1), _ptr(eye), C.c_double(1.0), _ptr(Wp))
+    alpha = torch.zeros((1, M), dtype=torch.float32, device=Phi.device)
+    mu = torch.empty((1, N), dtype=torch.float32, device=Phi.device)
+    var = torch.empty_like(mu)
+    ctx.call("agpl_marginals", C.c_int64(N), C.c_int32(M), C.c_int32(1), _ptr(Phi), _ptr(kxx), C.c_void_p(0),
+             _ptr(Wp), _ptr(alpha), _ptr(mu), _ptr(var))
+    return var[0].contiguous()
+
+
+class SparseGibbs:
+    """Placeholder wired in a later step of this round (sparse Gibbs sweep: aux_sample! + agpl_accumulate +
+    agpl_gaussian_update + a draw of v)."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("SparseGibbs is not built yet")

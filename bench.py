@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- CAVI sweeps/s of the sparse augmented-likelihood sweep on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): BernoulliLikelihood(LogisticLink) SVGP, N = 1e7 observations,
+M = 512 inducing points, synthetic data (x ~ U(-10, 10), y ~ Bernoulli(logistic(f*(x))),
+squared-exponential kernel with lengthscale 1.5 * inducing spacing, whitened features).
+One "step" = one CAVI sweep = marginals (MFMA) -> aux_posterior! / expected_auglik_* (elementwise) ->
+G = Phi diag(gamma) Phi', g = Phi beta (MFMA, split over N) -> [all-reduce over ranks] -> M x M update.
+All inputs are resident in HBM before the timed region.
+
+N is a fixed total sharded over ranks (strong scaling), with one RCCL all-reduce of (G, g) per sweep.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000000] [--m 512] [--lik bernoulli]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20240807
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
+
+
+def make_lik(A, name):
+    if name == "bernoulli":
+        return A.BernoulliLikelihood()
+    if name == "negbin":
+        return A.NegativeBinomialLikelihood(15.0)  # examples/negativebinomial/script.jl:17
+    if name == "studentt":
+        return A.StudentTLikelihood(3.5, 2.0)  # examples/studentt/script.jl:17-19
+    if name == "categorical":
+        return A.CategoricalLikelihood(np.zeros(10))  # LogisticSoftMaxLink(zeros(10))
+    raise SystemExit(f"unknown --lik {name}")
+
+
+def make_olik(O, name):
+    return {"bernoulli": O.bernoulli, "negbin": lambda: O.negbinomial(15.0), "studentt": lambda: O.studentt(3.5, 2.0),
+            "categorical": lambda: O.categorical(np.zeros(10))}[name]()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=10_000_000, help="total observations (sharded over ranks)")
+    ap.add_argument("--m", type=int, default=512, help="inducing points")
+    ap.add_argument("--lik", default="bernoulli")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="points of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    import agpl_amd as A
+
+    ctx = A.Context(local_rank, seed=SEED)
+    lik = make_lik(A, args.lik)
+    N, M, L = args.n, args.m, A.nlatent(lik)
+    i0 = rank * N // world
+    i1 = (rank + 1) * N // world
+    n_loc = i1 - i0
+
+    # ---- setup (untimed): synthetic data, K_ZX, whitening, Nystrom residual -- all on device ----------------
+    t_setup = time.time()
+    x, y = A.synth_xy(lik, SEED, i0, n_loc, ctx=ctx)
+    z = np.linspace(-10.0, 10.0, M)
+    ell = 1.5 * (z[1] - z[0])
+    Kzz = np.exp(-0.5 * ((z[:, None] - z[None, :]) / ell) ** 2)
+    _, Linv = A.sparse.whitening_matrix(Kzz, 1e-8)
+    Kzx = A.se_features(x, torch.from_numpy(z).cuda(), ell, ctx=ctx)
+    Phi = A.whiten_features(Kzx, Linv, ctx=ctx)
+    del Kzx
+    kd = A.sparse.nystrom_residual(Phi, torch.ones(n_loc, device="cuda"), ctx=ctx)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t_setup = time.time() - t_setup
+    Mp = Phi.shape[1]
+
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cavi.sweep()
+    barrier()
+    from agpl_amd import _ffi
+    import ctypes as C
+
+    _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cavi.sweep()
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = []
+    for which in (0, 1):
+        ms, cnt = C.c_double(), C.c_int64()
+        _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
+        kt.append((ms.value, cnt.value))
+    _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = args.steps / dt
+
+    # ---- roofline of the dominant kernel (hipEvents inside libagpl.so around each launch) --------------------
+    # algorithmic flops per launch: marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)
+    flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
+    names = ("marginal_kernel<0>", "syrk_kernel")
+    per = []
+    for (ms, cnt), fl, nm in zip(kt, flops, names):
+        avg = ms / max(cnt, 1)
+        per.append({"kernel": nm, "avg_ms": round(avg, 4), "launches": cnt,
+                    "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None})
+    dom = 0 if kt[0][0] >= kt[1][0] else 1
+    achieved = per[dom]["algorithmic_tflops"]
+    roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
+                "traffic": None, "kernels": per,
+                "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
+
+    out = {
+        "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",
+        "value": round(value, 4), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.lik}-logistic SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, "
+                               f"N sharded over {world} GPU(s), 1 all-reduce of L*(M^2+M) f64 per sweep",
+                   "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}"},
+        "roofline": roofline, "setup_s": round(t_setup, 2),
+    }
+
+    # ---- parity leg: a slice of the same workload, GPU vs oracle, 3 sweeps -----------------------------------
+    if not args.no_parity:
+        from oracle import oracle as O
+
+        olik = make_olik(O, args.lik)
+        ns = min(20_000, n_loc)
+        Phi_s, kd_s, y_s = Phi[:ns].contiguous(), kd[:ns].contiguous(), y[:ns].contiguous()
+        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx)
+        Ph, kh, yh = Phi_s.cpu().numpy(), kd_s.cpu().numpy().astype(np.float64), y_s.cpu().numpy()
+        if lik.ykind == "real":
+            yh = yh.astype(np.float64)
+        S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+        for _ in range(3):
+            cs.sweep()
+            G, g = O.cavi_pass(olik, Ph, kh, yh, -S, m)
+            S, m = O.gaussian_update(G, g)
+        torch.cuda.synchronize()
+        dG = float(np.abs(cs.G.cpu().numpy() - G).max() / np.abs(G).max())
+        dg = float(np.abs(cs.g.cpu().numpy() - g).max() / np.abs(g).max())
+        out["parity"] = {"max_rel_dG": dG, "max_rel_dg": dg, "points": ns, "sweeps": 3, "tolerance": 1e-5,
+                         "pass": bool(dG < 1e-5 and dg < 1e-5)}
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------------
+    if world == 1 and not args.no_cpu:
+        from oracle import oracle as O
+
+        olik = make_olik(O, args.lik)
+        ns = min(args.cpu_sample, n_loc)
+        Ph, kh, yh = Phi[:ns].cpu().numpy(), kd[:ns].cpu().numpy().astype(np.float64), y[:ns].cpu().numpy()
+        if lik.ykind == "real":
+            yh = yh.astype(np.float64)
+        S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+        t0 = time.perf_counter()
+        G, g = O.cavi_pass(olik, Ph, kh, yh, -S, m)
+        S, m = O.gaussian_update(G, g)
+        t_cpu = time.perf_counter() - t0
+        cpu_value = 1.0 / (t_cpu * (n_loc / ns))
+        out["cpu_baseline"] = {
+            "value": cpu_value, "unit": "sweeps/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"1 sweep of the float64 oracle (OpenMP) on the first {ns} of the {N} points, "
+                      f"{t_cpu:.2f} s; value extrapolated linearly in N (labelled extrapolation)",
+            "gpu_over_cpu": round(value / cpu_value, 1)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * agpl.h -- C ABI of libagpl.so: the MI355X (gfx950) implementation of the inner inference loop of
+ * AugmentedGPLikelihoods.jl (per-datapoint augmented-variable draw / expectation + the
+ * diagonal-precision conditional Gaussian accumulation of one CAVI / Gibbs sweep).
+ *
+ * The reference has no FFI: its seam is Julia multiple dispatch on (lik, Omega | qOmega, y, f | qf)
+ * with SoA containers.  Each entry point below names the reference method it stands
+ * in for (paths relative to the reference repo root, v0.4.19); INTEGRATION.md shows the Julia
+ * `ccall` methods a maintainer adds to route device arrays here.
+ *
+ * Conventions
+ *   - every function returns an int32 status (AGPL_OK == 0, negative = error); the message of the
+ *     last error on a context is available from agpl_last_error().
+ *   - all array arguments are DEVICE pointers unless the name ends in _host; caller-owned; nothing is
+ *     retained past return (the reference mutates Omega / qOmega in place and returns them:
+ *     src/generic.jl:11, src/likelihoods/bernoulli.jl:23-24).
+ *   - work is enqueued on the context's stream and NOT synchronised, except for the functions that
+ *     return a host scalar (agpl_logtilt, agpl_expected_logtilt, agpl_aux_kldivergence).
+ *   - multi-latent layout follows the reference: per-point containers are [L, N] column-major
+ *     (L contiguous per point, src/likelihoods/categorical.jl:52-70); potentials / precisions are
+ *     returned "transposed" as L contiguous vectors of N (src/utils.jl:24).
+ *   - y: uint8 {0,1} for Bernoulli and one-hot categorical [L,N]; int32 counts for NegBinomial and
+ *     Poisson; real (dtype) for StudentT, Laplace, heteroscedastic Gaussian.
+ *   - one context per GPU; a context is not thread-safe (the reference is single-threaded).
+ */
+#ifndef AGPL_H
+#define AGPL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGPL_VERSION 100
+
+#if defined(__GNUC__)
+#define AGPL_API __attribute__((visibility("default")))
+#else
+#define AGPL_API
+#endif
+
+typedef struct agpl_ctx agpl_ctx;
+
+typedef enum {
+    AGPL_OK = 0,
+    AGPL_ERR_INVALID_ARGUMENT = -1, /* ArgumentError (e.g. negativemultinomial.jl:17-22), bad sizes    */
+    AGPL_ERR_DOMAIN = -2,           /* DomainError   (polyagamma.jl:175)                             */
+    AGPL_ERR_UNSUPPORTED = -3,      /* error(...)    (categorical.jl:165-170, polyagamma.jl:100-104) */
+    AGPL_ERR_HIP = -4,              /* a HIP / rocSOLVER / rocBLAS call failed                        */
+    AGPL_ERR_NOT_POSDEF = -5,       /* PosDefException of the M x M Cholesky                          */
+    AGPL_ERR_OUT_OF_MEMORY = -6
+} agpl_status;
+
+/* likelihood families = the files of the reference's src/likelihoods directory */
+typedef enum {
+    AGPL_LIK_BERNOULLI_LOGISTIC = 0, /* bernoulli.jl        BernoulliLikelihood(LogisticLink)              */
+    AGPL_LIK_NEGBINOMIAL = 1,        /* negativebinomial.jl NBParamFailure(r), p[0] = r                    */
+    AGPL_LIK_STUDENTT = 2,           /* studentt.jl         StudentTLikelihood(nu, sigma), p[0]=nu p[1]=sigma */
+    AGPL_LIK_CATEGORICAL = 3,        /* categorical.jl      LogisticSoftMaxLink(logtheta), nlatent = K      */
+    AGPL_LIK_CATEGORICAL_BIJ = 4,    /* categorical.jl      BijectiveSimplexLink(...), nlatent = K-1        */
+    AGPL_LIK_POISSON = 5,            /* poisson.jl          ScaledLogistic(lambda), p[0] = lambda           */
+    AGPL_LIK_LAPLACE = 6,            /* laplace.jl          LaplaceLikelihood(beta), p[0] = beta            */
+    AGPL_LIK_HETEROGAUSS = 7         /* heteroscedasticgaussian.jl InvScaledLogistic(lambda), nlatent = 2   */
+} agpl_lik_kind;
+
+/* constructor arguments of the likelihood (SURVEY.md 5 "config / flags"). */
+typedef struct {
+    int32_t kind;           /* agpl_lik_kind */
+    int32_t nlatent;        /* nlatent(lik): generic.jl:87, categorical.jl:46-47                       */
+    double p[4];            /* see agpl_lik_kind                                                       */
+    const double *logtheta; /* HOST pointer, categorical only: K entries (K = nlatent [+1 if bijective]) */
+} agpl_lik_desc;
+
+typedef enum { AGPL_F32 = 0, AGPL_F64 = 1 } agpl_dtype;
+
+/* ---- context: replaces GLOBAL_RNG / the rng argument (src/generic.jl:1-3,14-16,32-34) ---------- */
+AGPL_API int32_t agpl_ctx_create(agpl_ctx **out, int32_t device_id, uint64_t seed);
+AGPL_API int32_t agpl_ctx_destroy(agpl_ctx *ctx);
+/* enqueue on an existing hipStream_t (e.g. the caller's current stream) instead of the context's own
+ * non-blocking stream; NULL = the device's default (null) stream */
+AGPL_API int32_t agpl_ctx_set_stream(agpl_ctx *ctx, void *hip_stream);
+AGPL_API int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed);
+AGPL_API int32_t agpl_ctx_synchronize(agpl_ctx *ctx);
+AGPL_API const char *agpl_last_error(const agpl_ctx *ctx);
+AGPL_API int32_t agpl_version(void);
+
+/* ---- Gibbs half: aux_sample!(rng, Omega, lik, y, f)  src/generic.jl:5-12 ------------------------
+ * Omega_i <- one draw from aux_full_conditional(lik, y_i, f_i):
+ *   bernoulli.jl:13-15 PG(1,|f|); negativebinomial.jl:20-22 PG(y+r,|f|); studentt.jl:46-48 Gamma;
+ *   categorical.jl:72-78 PG o NegativeMultinomial; poisson.jl:26-28 PG o Poisson; laplace.jl:40-42
+ *   InverseGaussian; heteroscedasticgaussian.jl:28-32.
+ * The PG draw is polyagamma.jl:121-257 (Devroye alternating series, one lane per point, per-lane
+ * Philox4x32-10 stream keyed (ctx seed, point index, sweep)).  f, omega_out are float64.
+ * n_out: int64 counts ([L,N] categorical, [N] poisson / heterogauss) or NULL.
+ * nuni_out / nterms_out: optional uint32[N] bookkeeping (uniforms consumed, summed series index).   */
+AGPL_API int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                        const double *f, double *omega_out, int64_t *n_out, uint32_t sweep,
+                        uint32_t *nuni_out, uint32_t *nterms_out);
+
+/* rand(rng, PolyaGamma(b, c), n)  polyagamma.jl:121-126: n iid draws, stream index = draw index.   */
+AGPL_API int32_t agpl_rand_polyagamma(agpl_ctx *ctx, double b, double c, int64_t n, uint32_t sweep,
+                             double *out, uint32_t *nuni_out, uint32_t *nterms_out);
+
+/* auglik_potential / auglik_precision (+ _and_precision, src/generic.jl:64-66):
+ *   bernoulli.jl:27-33, negativebinomial.jl:35-41, studentt.jl:60-66, categorical.jl:112-119,
+ *   poisson.jl:41-47, laplace.jl:54-60, heteroscedasticgaussian.jl:48-66 (fg = [2,N] latents).     */
+AGPL_API int32_t agpl_potential_precision(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                 const double *omega, const int64_t *n_aux, const double *fg,
+                                 double *beta_out, double *gamma_out);
+
+/* ---- CAVI half --------------------------------------------------------------------------------
+ * aux_posterior!(qOmega, lik, y, qf): bernoulli.jl:17-25, negativebinomial.jl:24-33,
+ *   studentt.jl:50-58, categorical.jl:80-110, poisson.jl:30-39, laplace.jl:44-52,
+ *   heteroscedasticgaussian.jl:34-46.   qf = Normal marginals as SoA (mu, var), [L,N].
+ *   out1 = c (studentt: beta_i; laplace: mu_i), out2 = p [L,N] (categorical) / lambda (poisson,
+ *   heterogauss) or NULL, out3 = psi (heterogauss) or NULL.  dtype selects float / double arrays.   */
+AGPL_API int32_t agpl_aux_posterior(agpl_ctx *ctx, const agpl_lik_desc *lik, int32_t dtype, int64_t n,
+                           const void *y, const void *mu, const void *var, void *out1, void *out2,
+                           void *out3);
+
+/* expected_auglik_potential / expected_auglik_precision (+ _and_precision generic.jl:68-72):
+ *   bernoulli.jl:35-45, negativebinomial.jl:43-49, studentt.jl:68-74, categorical.jl:121-136,
+ *   poisson.jl:49-60, laplace.jl:62-68, heteroscedasticgaussian.jl:68-104 (mu_g = mean of q(g)).
+ *   q1,q2 = the aux_posterior outputs.                                                            */
+AGPL_API int32_t agpl_expected_potential_precision(agpl_ctx *ctx, const agpl_lik_desc *lik, int32_t dtype,
+                                          int64_t n, const void *y, const void *q1, const void *q2,
+                                          const void *mu_g, void *beta_out, void *gamma_out);
+
+/* ---- ELBO terms (N-reductions, float64, result to host) ----------------------------------------
+ * logtilt generic.jl:40-46 ; expected_logtilt api.jl:219-223 ; aux_kldivergence generic.jl:56-62.  */
+AGPL_API int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                     const double *omega, const int64_t *n_aux, const double *f, double *out_host);
+AGPL_API int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                              const double *q1, const double *q2, const double *mu,
+                              const double *var, double *out_host);
+AGPL_API int32_t agpl_aux_kldivergence(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                              const double *q1, const double *q2, double *out_host);
+
+/* ---- the sparse Gaussian half of a sweep -------------------------------------------------------
+ * Feature matrix Phi: float32, [M, N] column-major (M contiguous per point; ld = M), M % 128 == 0
+ * (zero-pad features).  In the reference's terms Phi = K_ZX (docs/src/index.md:154-163) or any basis
+ * of it; the host driver uses the whitened basis Phi = L^-1 K_ZX, K_Z = L L'.
+ *
+ * agpl_marginals: q(f_i) = N(mu_i, var_i), the `marginals(post_u(x))` call of
+ *   examples/bernoulli/script.jl:32-33 (un-vendored ApproximateGPs) in feature form:
+ *     mu[l,i]  = mu0[l,i] + phi_i' alpha_l          var[l,i] = kdiag[i] - phi_i' W_l phi_i
+ *   Wpack: [L, M, M] float32 in the packed form written by agpl_gaussian_update (lower-triangular
+ *   transpose with doubled off-diagonal: Wpack[b][a] = (b>a ? 2 W[a][b] : W[a][a]); upper part ignored).
+ *   alpha: [L, M] float32.  kdiag: [N] float32.  mu0: [L][N] float32 or NULL.  mu/var out: [L][N] float32.
+ *   f32-input MFMA (v_mfma_f32_32x32x2_f32), executes ~ (1 + 128/M) N M^2 flop per latent.          */
+AGPL_API int32_t agpl_marginals(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                       const float *kdiag, const float *mu0, const float *Wpack, const float *alpha,
+                       float *mu_out, float *var_out);
+
+/* agpl_accumulate: the only O(N) objects that cross a sweep:
+ *     G_l = Phi Diag(gamma_l) Phi'  (= kappa Diag(r) kappa' of docs/src/index.md:154-163)
+ *     g_l = Phi beta_l              (= kappa t)
+ *   gamma, beta: [L][N] float32.  G_out [L, M, M], g_out [L, M] float64 (full symmetric).
+ *   f32-input MFMA over 128 x 128 output tiles of the lower triangle, N split across workgroups,
+ *   two-level accumulation (f32 over <= 2048 points, then f64), fixed-order f64 slab reduction:
+ *   bitwise reproducible, no atomics.                                                             */
+AGPL_API int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                        const float *beta, const float *gamma, double *G_out, double *g_out);
+
+/* agpl_gaussian_update: S = (I + G)^-1, m = S (g + eta0)  -- the update of
+ *   examples/bernoulli/script.jl:35-36 (CAVI) / :82-83 (Gibbs) in the sparse whitened form of
+ *   docs/src/index.md:154-163.  float64 Cholesky (rocSOLVER potrf/potri) on device.
+ *   G [L,M,M], g [L,M], eta0 [L,M] or NULL.  Outputs (any may be NULL): S_out [L,M,M] f64,
+ *   m_out [L,M] f64, Wpack_out [L,M,M] f32 (packed -S, so that var = kdiag + phi' S phi through
+ *   agpl_marginals), alpha_out [L,M] f32 (= m).  Returns AGPL_ERR_NOT_POSDEF if I + G is not SPD.   */
+AGPL_API int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                             const double *eta0, double *S_out, double *m_out, float *Wpack_out,
+                             float *alpha_out);
+
+/* agpl_pack_w: Wpack (float32, packed as above) from a symmetric float64 W [L,M,M] scaled by `scale`. */
+AGPL_API int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
+                    float *Wpack_out);
+
+/* agpl_cavi_pass: one fused pass = agpl_marginals -> agpl_aux_posterior ->
+ *   agpl_expected_potential_precision -> agpl_accumulate (the loop body of
+ *   examples/bernoulli/script.jl:32-36 up to the M x M solve).  Single- and multi-latent.
+ *   Optional per-point outputs (float32): c_out [L,N] (out1 of aux_posterior), gamma_out, beta_out [L][N]. */
+AGPL_API int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                       const float *Phi, const float *kdiag, const float *mu0, const void *y,
+                       const float *Wpack, const float *alpha, double *G_out, double *g_out,
+                       float *c_out, float *gamma_out, float *beta_out);
+
+/* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
+ * pair is recorded on the context's stream around every launch of the marginal (which = 0) and the
+ * accumulation (which = 1) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel
+ * time [ms] and the number of launches since the last read, and resets the counters.                 */
+AGPL_API int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on);
+AGPL_API int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host);
+
+/* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
+AGPL_API int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L);
+
+/* ---- features and synthetic workloads (the step before the path) -----------
+ * agpl_se_features: K_ZX[a,i] = exp(-(x_i - z_a)^2 / (2 ell^2)) (with_lengthscale(SqExponentialKernel(),
+ *   ell), examples/bernoulli/script.jl:15), float32 [ld, N] column-major, rows >= M zero-filled.     */
+AGPL_API int32_t agpl_se_features(agpl_ctx *ctx, int64_t N, int32_t M, int32_t ld, const double *x,
+                         const double *z, double ell, float *out);
+/* agpl_transform_features: out[:, i] = A in[:, i]  with A [M, M] float32 row-major (e.g. A = L^-1 for
+ *   whitening).  in/out: [M, N] column-major float32; out may not alias in.                        */
+AGPL_API int32_t agpl_transform_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *A,
+                                const float *in, float *out);
+/* agpl_synth_xy: x_i = -10 + 20 u_i, y_i ~ lik(f*(x_i)), a pure function of (seed, i) through Philox
+ *   (bit-identical to oracle/agpl_oracle.c agplo_synth_*).  x_out float64 [n] or NULL.              */
+AGPL_API int32_t agpl_synth_xy(agpl_ctx *ctx, const agpl_lik_desc *lik, uint64_t seed, int64_t i0, int64_t n,
+                      double *x_out, void *y_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGPL_H */

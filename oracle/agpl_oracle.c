@@ -1126,6 +1126,24 @@ AGPLO_API void agplo_synth_y(const agplo_lik *lik, uint64_t seed, int64_t i0, in
             double ch = 2.0 * rand_gamma(&g, lik->p[0] / 2.0);
             ((double *)yv)[i] = fs + lik->p[1] * z / sqrt(ch / lik->p[0]);
         } break;
+        case LIK_CATEGORICAL:
+        case LIK_CATEGORICAL_BIJ: { /* class weights theta_k logistic(f*(x + 2k)); one-hot u8 [L,N] */
+            const int L = lik->nlatent;
+            double tot = lik->kind == LIK_CATEGORICAL_BIJ ? cat_get_const(lik) : 0.0;
+            for (int k = 0; k < L; ++k)
+                tot += exp(lik->logtheta[k]) * logistic_(agplo_synth_fstar(x + 2.0 * k));
+            double u = rng_u01(&g) * tot, cum = 0.0;
+            int cls = L;
+            for (int k = 0; k < L; ++k) {
+                cum += exp(lik->logtheta[k]) * logistic_(agplo_synth_fstar(x + 2.0 * k));
+                if (u < cum) {
+                    cls = k;
+                    break;
+                }
+            }
+            if (lik->kind == LIK_CATEGORICAL && cls == L) cls = L - 1;
+            for (int k = 0; k < L; ++k) ((uint8_t *)yv)[i * L + k] = (k == cls) ? 1 : 0;
+        } break;
         default:
             break;
         }

@@ -365,7 +365,8 @@ def synth_x(seed, i0, n):
 
 
 def synth_y(lik: Lik, seed, i0, n):
-    y = np.empty(n, dtype=lik.ydtype())
+    shape = (n, lik.nlatent) if lik.kind in (CATEGORICAL, CATEGORICAL_BIJ) else n
+    y = np.empty(shape, dtype=lik.ydtype())
     lc = lik.c()
     lib().agplo_synth_y(C.byref(lc), C.c_uint64(seed), C.c_int64(i0), C.c_int64(n), _p(y))
     return y
