@@ -71,6 +71,11 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        # torch bundles its own libamdhip64 / librocblas: load torch first so that libagpl.so's NEEDED
+        # entries resolve (by SONAME) to the runtime already in the process.  Two HIP runtimes in one
+        # process do not share a device context (hipGetDeviceCount fails in the second one).
+        import torch  # noqa: F401
+
         _lib = C.CDLL(LIB_PATH)
         _lib.agpl_last_error.restype = C.c_char_p
         _lib.agpl_last_error.argtypes = [C.c_void_p]

@@ -7,28 +7,29 @@
 //                           W' = upper-triangular with doubled off-diagonal, so only the block pairs
 //                           cb >= rb are visited: (nb+1)/(2 nb) of a full GEMM.
 //   syrk_kernel      (a12)  G = Phi Diag(gamma) Phi' on 128 x 128 output tiles of the lower triangle,
-//                           N split over workgroups (split-K), g = Phi beta on the diagonal tiles.
-//   reduce kernels          fixed-order float64 sum of the per-split slabs.
+//                           N split over workgroups in slices of 4096 points (one f32 accumulation run
+//                           each), g = Phi beta on the diagonal tiles.
+//   reduce kernels          fixed-order float64 sum of the per-slice f32 slabs.
 //
 // Both MFMA kernels: 256 threads = 4 waves, each wave a 64 x 64 sub-tile = 2 x 2 accumulators of
 // v_mfma_f32_32x32x2_f32 (64 accumulator VGPRs); operand tiles are staged global -> registers -> LDS
-// with one barrier per 32-deep k-slice and the next slice's global loads in flight during the MFMAs;
-// 2 workgroups per CU (<= 74 KB LDS each) so one workgroup's barrier hides behind the other's MFMAs.
+// with one barrier per 16-deep k-slice and the next slice's global loads in flight during the MFMAs;
+// <= 128 VGPRs and <= 40 KB LDS per workgroup: 4 workgroups = 16 waves per CU (4 per SIMD), so the LDS
+// latency and barrier waits of one wave hide behind the other waves' MFMAs (each MFMA holds the pipe 64 cycles).
 // LDS images: [k][row] with the row index contiguous (conflict-free ds_read_b32: lanes 0-31 read
 // consecutive rows at k, lanes 32-63 at k+1), except the Phi operand of marginal_kernel whose k index
-// is the contiguous one in memory: image [point][33] (odd pitch -> conflict-free).
+// is the contiguous one in memory: image [point][17] (odd pitch -> conflict-free).
 #include "agpl_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BS = 128; // block of feature rows
-constexpr int KT = 32;  // k-slice per stage
-constexpr int NT = 128; // points per marginal tile
+constexpr int BS = 128;      // block of feature rows
+constexpr int KT = 16;       // k-slice per stage
+constexpr int NT = 128;      // points per marginal tile
 constexpr int KPITCH = KT + 1;
-constexpr int HPITCH = BS + 4;
-constexpr int kFlushStages = 64; // f32 accumulation run: 64 stages x 32 points = 2048 points
+constexpr int kChunk = 4096; // points per accumulation workgroup = length of one f32 accumulation run
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -38,10 +39,10 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // marginal / transform kernel
 //   MODE 0: quadratic form + mean (outputs mu, var);  P = Wpack (block pairs cb >= rb only)
 //   MODE 1: transform out[:, i] = A in[:, i];         P = A' (all block pairs), writes float4 per lane
-// grid = (tiles of 128 points, L)
+// grid = (tiles of 128 points, L).  ~37-39 KB LDS, <= 128 VGPRs: 4 workgroups (16 waves) per CU.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, const float *__restrict__ Phi,
+__global__ __launch_bounds__(256, 4) void marginal_kernel(int64_t N, int M, const float *__restrict__ Phi,
                                                           const float *__restrict__ kdiag,
                                                           const float *__restrict__ mu0,
                                                           const float *__restrict__ Pall,
@@ -49,13 +50,11 @@ __global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, cons
                                                           float *__restrict__ mu_out, float *__restrict__ var_out,
                                                           float *__restrict__ t_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // region 0: staging (2 x (Pt 4096 + Kt 4224)) aliased with the Hadamard image (128 x 132)
-    float *stage0 = smem;
-    constexpr int kStageFloats = KT * BS + NT * KPITCH; // 8320
-    constexpr int kRegion0 = (NT * HPITCH > 2 * kStageFloats) ? NT * HPITCH : 2 * kStageFloats;
-    float *alpha_s = smem + kRegion0;          // M floats
-    float *qred = alpha_s + M;                 // 2 x 128
-    float *mred = qred + 2 * NT;               // 2 x 128
+    constexpr int kStageFloats = KT * BS + NT * KPITCH; // Pt [16][128] + Kt [128][17]
+    float *stage0 = smem;                                // [2][kStageFloats]
+    float *alpha_s = smem + 2 * kStageFloats;            // M floats
+    float *qred = alpha_s + M;                           // 2 x 128
+    float *mred = qred + 2 * NT;                         // 2 x 128
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,45 +71,52 @@ __global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, cons
         for (int a = tid; a < M; a += 256) alpha_s[a] = alpha[a];
     }
 
-    // per-thread staging coordinates
-    // Pt: q = tid + 256 j -> kk = q >> 5, a4 = q & 31
-    // Kt: q = tid + 256 j -> n = q >> 3, k4 = q & 7
-    int64_t krow[4];
+    // per-thread staging coordinates (2 float4 of each operand per stage), 32-bit offsets from uniform bases
+    //   Pt: q = tid + 256 j -> kk = q >> 5, a4 = q & 31     Kt: q -> n = q >> 2, k4 = q & 3
+    const float *tile = Phi + n0 * (int64_t)M;               // uniform
+    const int nlim = (int)((N - 1 - n0) < (NT - 1) ? (N - 1 - n0) : (NT - 1)); // last valid local point
+    int koff[2], poff[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int64_t n = n0 + ((tid + 256 * j) >> 3);
-        if (n > N - 1) n = N - 1;
-        krow[j] = n * (int64_t)M + ((tid & 7) << 2);
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;
+        int n = q >> 2;
+        n = n > nlim ? nlim : n;
+        koff[j] = n * M + ((q & 3) << 2);
+        poff[j] = (q >> 5) * M + ((q & 31) << 2);
+    }
+    // this lane's Hadamard / output columns
+    int hoff[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        int n = wc * 64 + jj * 32 + li;
+        n = n > nlim ? nlim : n;
+        hoff[jj] = n * M;
     }
 
     float qacc[2] = {0.f, 0.f};
     float macc = 0.f;
+    float4 pr0, pr1, kr0, kr1;
 
-    float4 pr[4], kr[4];
-    auto load_stage = [&](int rb, int cb, int ks) {
-        const int b0 = cb * BS + ks * KT;
-        const float *psrc = P + (int64_t)b0 * M + rb * BS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int q = tid + 256 * j;
-            pr[j] = *reinterpret_cast<const float4 *>(psrc + (int64_t)(q >> 5) * M + ((q & 31) << 2));
-            kr[j] = *reinterpret_cast<const float4 *>(Phi + krow[j] + b0);
-        }
-    };
-    auto store_stage = [&](int buf) {
-        float *Pt = stage0 + buf * kStageFloats;
-        float *Kt = Pt + KT * BS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int q = tid + 256 * j;
-            *reinterpret_cast<float4 *>(Pt + (q >> 5) * BS + ((q & 31) << 2)) = pr[j];
-            float *kd = Kt + (q >> 3) * KPITCH + ((q & 7) << 2);
-            kd[0] = kr[j].x;
-            kd[1] = kr[j].y;
-            kd[2] = kr[j].z;
-            kd[3] = kr[j].w;
-        }
-    };
+#define AGPL_MARG_LOAD(rb_, b0_)                                                        \
+    do {                                                                                \
+        const float *psrc_ = P + (int64_t)(b0_) * M + (rb_) * BS;                       \
+        const float *ksrc_ = tile + (b0_);                                              \
+        pr0 = *reinterpret_cast<const float4 *>(psrc_ + poff[0]);                       \
+        pr1 = *reinterpret_cast<const float4 *>(psrc_ + poff[1]);                       \
+        kr0 = *reinterpret_cast<const float4 *>(ksrc_ + koff[0]);                       \
+        kr1 = *reinterpret_cast<const float4 *>(ksrc_ + koff[1]);                       \
+    } while (0)
+#define AGPL_MARG_STORE(buf_)                                                           \
+    do {                                                                                \
+        float *Pt_ = stage0 + (buf_) * kStageFloats;                                    \
+        float *Kt_ = Pt_ + KT * BS;                                                     \
+        *reinterpret_cast<float4 *>(Pt_ + (tid >> 5) * BS + ((tid & 31) << 2)) = pr0;   \
+        *reinterpret_cast<float4 *>(Pt_ + ((tid >> 5) + 8) * BS + ((tid & 31) << 2)) = pr1; \
+        float *kd_ = Kt_ + (tid >> 2) * KPITCH + ((tid & 3) << 2);                      \
+        kd_[0] = kr0.x; kd_[1] = kr0.y; kd_[2] = kr0.z; kd_[3] = kr0.w;                 \
+        kd_ += 64 * KPITCH;                                                             \
+        kd_[0] = kr1.x; kd_[1] = kr1.y; kd_[2] = kr1.z; kd_[3] = kr1.w;                 \
+    } while (0)
 
     for (int rb = 0; rb < nb; ++rb) {
         f32x16 acc[2][2];
@@ -121,15 +127,14 @@ __global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
 
-        const int cb_first = (MODE == 0) ? rb : 0;
-        const int nstage = (nb - cb_first) * (BS / KT);
-        load_stage(rb, cb_first, 0);
-        __syncthreads(); // previous rb's Hadamard reads of region 0 are done
-        store_stage(0);
+        const int bfirst = (MODE == 0) ? rb * BS : 0;
+        const int nstage = (M - bfirst) / KT;
+        AGPL_MARG_LOAD(rb, bfirst);
+        AGPL_MARG_STORE(0);
         __syncthreads();
         for (int s = 0; s < nstage; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nstage) load_stage(rb, cb_first + ((s + 1) >> 2), (s + 1) & 3);
+            if (s + 1 < nstage) AGPL_MARG_LOAD(rb, bfirst + (s + 1) * KT);
             const float *Pt = stage0 + buf * kStageFloats;
             const float *Kt = Pt + KT * BS;
             const float *pa = Pt + lk * BS + wr * 64 + li;
@@ -144,73 +149,51 @@ __global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, cons
                 acc[1][1] = mfma(a1, b1, acc[1][1]);
             }
             if (MODE == 0 && rb == 0) { // mean: every feature row passes through exactly once when rb == 0
-                const int bbase = (s >> 2) * BS + (s & 3) * KT + (tid >> 7) * 16;
-                const float *kp = Kt + (tid & 127) * KPITCH + (tid >> 7) * 16;
+                const int bbase = s * KT + (tid >> 7) * 8;
+                const float *kp = Kt + (tid & 127) * KPITCH + (tid >> 7) * 8;
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) macc += alpha_s[bbase + kk] * kp[kk];
+                for (int kk = 0; kk < 8; ++kk) macc += alpha_s[bbase + kk] * kp[kk];
             }
-            if (s + 1 < nstage) store_stage(buf ^ 1);
+            if (s + 1 < nstage) AGPL_MARG_STORE(buf ^ 1);
             __syncthreads();
         }
 
-        if (MODE == 0) {
-            // Hadamard epilogue: q_n += sum_{a in rb} Phi[a, n] * T[a, n]
-            float *Ht = stage0;
+        // epilogue for this row block: the lane's accumulators hold T[a][n] for 4 consecutive a (r & 3) at
+        // a = rb*128 + wr*64 + ii*32 + 8*g4 + 4*lk and n = column li of sub-tile jj.
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                float4 h[4];
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int q = tid + 256 * (jb * 4 + j);
-                    int64_t n = n0 + (q >> 5);
-                    if (n > N - 1) n = N - 1;
-                    h[j] = *reinterpret_cast<const float4 *>(Phi + n * (int64_t)M + rb * BS + ((q & 31) << 2));
-                }
+            for (int jj = 0; jj < 2; ++jj) {
+                const int abase = rb * BS + wr * 64 + ii * 32 + 4 * lk;
+                if (MODE == 0) {
+                    // Hadamard with Phi straight from global/L2 (the tile was streamed moments ago):
+                    // q_n += sum_a Phi[a, n] * T[a, n]
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int q = tid + 256 * (jb * 4 + j);
-                    *reinterpret_cast<float4 *>(Ht + (q >> 5) * HPITCH + ((q & 31) << 2)) = h[j];
+                    for (int g2 = 0; g2 < 4; g2 += 2) { // two float4 in flight: keeps the kernel at 128 VGPRs
+                        const float4 h0 = *reinterpret_cast<const float4 *>(tile + hoff[jj] + abase + 8 * g2);
+                        const float4 h1 = *reinterpret_cast<const float4 *>(tile + hoff[jj] + abase + 8 * g2 + 8);
+                        qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
+                                    acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
+                        qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
+                                    acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
+                    }
+                } else {
+                    const int64_t n = n0 + wc * 64 + jj * 32 + li;
+                    if (n < N) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            *reinterpret_cast<float4 *>(t_out + n * (int64_t)M + abase + 8 * g4) =
+                                make_float4(acc[ii][jj][4 * g4 + 0], acc[ii][jj][4 * g4 + 1],
+                                            acc[ii][jj][4 * g4 + 2], acc[ii][jj][4 * g4 + 3]);
+                    }
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int a = wr * 64 + ii * 32 + 8 * g4 + 4 * lk;
-                        const int n = wc * 64 + jj * 32 + li;
-                        float4 h = *reinterpret_cast<const float4 *>(Ht + n * HPITCH + a);
-                        qacc[jj] += acc[ii][jj][4 * g4 + 0] * h.x + acc[ii][jj][4 * g4 + 1] * h.y +
-                                    acc[ii][jj][4 * g4 + 2] * h.z + acc[ii][jj][4 * g4 + 3] * h.w;
-                    }
-            // the __syncthreads() at the top of the next rb iteration protects region 0
-        } else {
-            // transform: out[n, rb*128 + a] = T[a][n]; one float4 (4 consecutive a) per lane
-            float *outl = t_out;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int a = wr * 64 + ii * 32 + 8 * g4 + 4 * lk;
-                        const int64_t n = n0 + wc * 64 + jj * 32 + li;
-                        if (n < N) {
-                            float4 v = make_float4(acc[ii][jj][4 * g4 + 0], acc[ii][jj][4 * g4 + 1],
-                                                   acc[ii][jj][4 * g4 + 2], acc[ii][jj][4 * g4 + 3]);
-                            *reinterpret_cast<float4 *>(outl + n * (int64_t)M + rb * BS + a) = v;
-                        }
-                    }
-        }
     }
 
     if (MODE == 0) {
         // combine: lane halves (rows 4*lk), the two wr waves, the two mean halves
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) qacc[jj] += __shfl_xor(qacc[jj], 32);
-        __syncthreads();
         if (lk == 0) {
             qred[wr * NT + wc * 64 + li] = qacc[0];
             qred[wr * NT + wc * 64 + 32 + li] = qacc[1];
@@ -230,108 +213,112 @@ __global__ __launch_bounds__(256, 2) void marginal_kernel(int64_t N, int M, cons
     }
 }
 
+#undef AGPL_MARG_LOAD
+#undef AGPL_MARG_STORE
+
 size_t marginal_lds_bytes(int M) {
     constexpr int kStageFloats = KT * BS + NT * KPITCH;
-    constexpr int kRegion0 = (NT * HPITCH > 2 * kStageFloats) ? NT * HPITCH : 2 * kStageFloats;
-    return sizeof(float) * (size_t)(kRegion0 + M + 4 * NT);
+    return sizeof(float) * (size_t)(2 * kStageFloats + M + 4 * NT);
 }
 
 // ------------------------------------------------------------------------------------------------
-// syrk kernel: grid = (pairs, splits, L)
+// syrk kernel: 1-D grid of npairs * nsplit8 * L workgroups, remapped so that the workgroups that share an
+// XCD (blockIdx % 8) walk whole point-slices: all tile pairs of a slice read the same Phi panels through
+// one L2.  One workgroup = one 128 x 128 tile pair x one slice of kChunk points, accumulated in f32
+// (chains of <= 4096 terms) and written as an f32 slab; the slabs are summed in float64 by the reduce kernels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void syrk_kernel(int64_t N, int M, const float *__restrict__ Phi,
+__global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npairs, int nsplit,
+                                                      const float *__restrict__ Phi,
                                                       const float *__restrict__ gamma_all,
                                                       const float *__restrict__ beta_all,
-                                                      double *__restrict__ slabG, double *__restrict__ slabg,
-                                                      int64_t chunk) {
+                                                      float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kPanel = KT * BS; // 4096 floats
-    float *panels = smem;           // [2 buf][2 panel][kPanel]
-    float *sgam = smem + 4 * kPanel; // [2][KT]
-    float *sbet = sgam + 2 * KT;     // [2][KT]
-    float *gred = sbet + 2 * KT;     // [128] doubles worth of floats x2 (used as double[128])
+    constexpr int kPanel = KT * BS;  // 2048 floats
+    float *panels = smem;            // [2 buf][2 panel][kPanel]
+    float *sgb = smem + 4 * kPanel;  // [2 buf][gamma KT | beta KT]
+    float *gred = sgb + 4 * KT;      // [128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
-    const int p = blockIdx.x, s = blockIdx.y, l = blockIdx.z;
-    const int nsplit = gridDim.y, npairs = gridDim.x;
+    // XCD-aware decode (speed only): id % 8 labels the XCD group; each group owns slices s = 8 t + xcd
+    const int nsplit8 = (nsplit + 7) / 8;
+    const int per_l = npairs * nsplit8 * 8;
+    const int l = blockIdx.x / per_l;
+    const int id = blockIdx.x - l * per_l;
+    const int xcd = id & 7, j = id >> 3;
+    const int s = (j / npairs) * 8 + xcd;
+    const int p = j % npairs;
+    if (s >= nsplit) return;
     const int nb = M / BS;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
     const int bj = p - bi * (bi + 1) / 2;
     const bool diag = (bi == bj);
 
-    const int64_t nbeg = (int64_t)s * chunk;
-    int64_t nend = nbeg + chunk;
+    const int64_t nbeg = (int64_t)s * kChunk;
+    int64_t nend = nbeg + kChunk;
     if (nend > N) nend = N;
-    const int nstage = nbeg < nend ? (int)((nend - nbeg + KT - 1) / KT) : 0;
+    const int nstage = (int)((nend - nbeg + KT - 1) / KT);
     const float *gam = gamma_all + (int64_t)l * N;
     const float *bet = beta_all + (int64_t)l * N;
 
     f32x16 acc[2][2];
-    double dacc[2][2][16];
     float gacc = 0.f;
-    double gdacc = 0.0;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[ii][jj][r] = 0.f;
-                dacc[ii][jj][r] = 0.0;
-            }
+            for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
 
-    float4 ar[4], br[4];
+    // branch-free staging: every load is unconditional (a diagonal pair loads its panel twice -- the second
+    // read is an L1 hit -- and out-of-range points are clamped, their gamma / beta zeroed), so the compiler
+    // keeps all of a stage's global loads in flight behind one counted wait.  Uniform base + 32-bit offsets.
+    float4 ar0, ar1, br0, br1;
     float gv = 0.f;
-    auto load_stage = [&](int st) {
-        const int64_t nbase = nbeg + (int64_t)st * KT;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int q = tid + 256 * j;
-            int64_t n = nbase + (q >> 5);
-            if (n > N - 1) n = N - 1;
-            const float *src = Phi + n * (int64_t)M + ((q & 31) << 2);
-            ar[j] = *reinterpret_cast<const float4 *>(src + bi * BS);
-            if (!diag) br[j] = *reinterpret_cast<const float4 *>(src + bj * BS);
-        }
-        if (tid < 2 * KT) {
-            int64_t n = nbase + (tid & (KT - 1));
-            gv = 0.f;
-            if (n < nend) gv = (tid < KT) ? gam[n] : bet[n];
-        }
-    };
-    auto store_stage = [&](int buf) {
-        float *A = panels + buf * 2 * kPanel;
-        float *B = A + kPanel;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int q = tid + 256 * j;
-            *reinterpret_cast<float4 *>(A + (q >> 5) * BS + ((q & 31) << 2)) = ar[j];
-            if (!diag) *reinterpret_cast<float4 *>(B + (q >> 5) * BS + ((q & 31) << 2)) = br[j];
-        }
-        if (tid < KT)
-            sgam[buf * KT + tid] = gv;
-        else if (tid < 2 * KT)
-            sbet[buf * KT + tid - KT] = gv;
-    };
+    const float *gbsrc = (tid & KT) ? bet : gam;
+    const int r0 = tid >> 5, c4 = (tid & 31) << 2; // staging row (point within the slice) and column
+#define AGPL_SYRK_LOAD(st_)                                                                  \
+    do {                                                                                     \
+        const int64_t nbase_ = nbeg + (int64_t)(st_) * KT;                                   \
+        const int lim_ = (int)((N - 1 - nbase_) < (KT - 1) ? (N - 1 - nbase_) : (KT - 1));   \
+        const float *base_ = Phi + nbase_ * (int64_t)M;                                      \
+        const int ra_ = (r0 > lim_ ? lim_ : r0) * M + c4;                                    \
+        const int rb_ = ((r0 + 8) > lim_ ? lim_ : (r0 + 8)) * M + c4;                        \
+        ar0 = *reinterpret_cast<const float4 *>(base_ + ra_ + bi * BS);                      \
+        ar1 = *reinterpret_cast<const float4 *>(base_ + rb_ + bi * BS);                      \
+        br0 = *reinterpret_cast<const float4 *>(base_ + ra_ + bj * BS);                      \
+        br1 = *reinterpret_cast<const float4 *>(base_ + rb_ + bj * BS);                      \
+        int64_t n_ = nbase_ + (tid & (KT - 1));                                              \
+        const float keep_ = n_ < nend ? 1.f : 0.f;                                           \
+        n_ = n_ > N - 1 ? N - 1 : n_;                                                        \
+        gv = gbsrc[n_] * keep_;                                                              \
+    } while (0)
+#define AGPL_SYRK_STORE(buf_)                                                                \
+    do {                                                                                     \
+        float *A_ = panels + (buf_) * 2 * kPanel;                                            \
+        float *B_ = A_ + kPanel;                                                             \
+        *reinterpret_cast<float4 *>(A_ + r0 * BS + c4) = ar0;                                \
+        *reinterpret_cast<float4 *>(A_ + (r0 + 8) * BS + c4) = ar1;                          \
+        *reinterpret_cast<float4 *>(B_ + r0 * BS + c4) = br0;                                \
+        *reinterpret_cast<float4 *>(B_ + (r0 + 8) * BS + c4) = br1;                          \
+        if (tid < 2 * KT) sgb[(buf_) * 2 * KT + tid] = gv; /* [gamma 0..15 | beta 0..15] */  \
+    } while (0)
 
-    if (nstage > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
+    AGPL_SYRK_LOAD(0);
+    AGPL_SYRK_STORE(0);
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nstage) load_stage(st + 1);
+        if (st + 1 < nstage) AGPL_SYRK_LOAD(st + 1);
         const float *A = panels + buf * 2 * kPanel;
-        const float *B = diag ? A : A + kPanel;
+        const float *B = A + kPanel;
         const float *pa = A + lk * BS + wr * 64 + li;
         const float *pb = B + lk * BS + wc * 64 + li;
-        const float *pg = sgam + buf * KT + lk;
+        const float *pg = sgb + buf * 2 * KT + lk;
 #pragma unroll
         for (int k0 = 0; k0 < KT; k0 += 2) {
             float ga = pg[k0];
@@ -342,37 +329,19 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(int64_t N, int M, const fl
             acc[1][0] = mfma(a1, b0, acc[1][0]);
             acc[1][1] = mfma(a1, b1, acc[1][1]);
         }
-        if (diag) { // g = Phi beta for the rows of this diagonal block
-            const float *ga = A + (tid >> 7) * 16 * BS + (tid & 127);
-            const float *gb = sbet + buf * KT + (tid >> 7) * 16;
+        if (diag) { // g = Phi beta for the rows of this diagonal block (wave-uniform branch)
+            const float *ga = A + (tid >> 7) * 8 * BS + (tid & 127);
+            const float *gb = sgb + buf * 2 * KT + KT + (tid >> 7) * 8;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) gacc += gb[kk] * ga[kk * BS];
+            for (int kk = 0; kk < 8; ++kk) gacc += gb[kk] * ga[kk * BS];
         }
-        if (((st + 1) % kFlushStages) == 0) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        dacc[ii][jj][r] += (double)acc[ii][jj][r];
-                        acc[ii][jj][r] = 0.f;
-                    }
-            gdacc += (double)gacc;
-            gacc = 0.f;
-        }
-        if (st + 1 < nstage) store_stage(buf ^ 1);
+        if (st + 1 < nstage) AGPL_SYRK_STORE(buf ^ 1);
         __syncthreads();
     }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dacc[ii][jj][r] += (double)acc[ii][jj][r];
-    gdacc += (double)gacc;
+#undef AGPL_SYRK_LOAD
+#undef AGPL_SYRK_STORE
 
-    double *slab = slabG + (((int64_t)l * npairs + p) * nsplit + s) * (int64_t)(BS * BS);
+    float *slab = slabG + (((int64_t)l * npairs + p) * nsplit + s) * (int64_t)(BS * BS);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -381,20 +350,81 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(int64_t N, int M, const fl
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const int col = wc * 64 + jj * 32 + li;
-                slab[row * BS + col] = dacc[ii][jj][r];
+                slab[row * BS + col] = acc[ii][jj][r];
             }
     if (diag) {
-        double *gd = reinterpret_cast<double *>(gred);
-        if (tid >= 128) gd[tid - 128] = gdacc;
+        if (tid >= 128) gred[tid - 128] = gacc;
         __syncthreads();
-        if (tid < 128) slabg[(((int64_t)l * nb + bi) * nsplit + s) * BS + tid] = gdacc + gd[tid];
+        if (tid < 128) slabg[(((int64_t)l * nb + bi) * nsplit + s) * BS + tid] = gacc + gred[tid];
     }
 }
 
-size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT) + sizeof(double) * 128; }
+size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT + 128); }
 
-// fixed-order reduction of the slabs into the full symmetric G and g
-__global__ void reduce_G_kernel(int M, int nsplit, const double *__restrict__ slabG, double *__restrict__ G) {
+// Fixed-order float64 reduction of the f32 slabs, two levels (HBM-bound streaming, 16 B per lane):
+//   level 1: one workgroup = 1 KB of one tile (256 consecutive elements) x one group of kRedGroup slices;
+//            wave w sums slices w, w+4, ... of the group (float4 loads, 8 in flight), waves combined in LDS
+//            in wave order -> partial[p][group][16384] (float64)
+//   level 2: G[row][col] = sum over groups (in order) of the lower-triangle partial, mirrored.
+constexpr int kRedGroup = 64;
+
+__global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup, const float *__restrict__ slab,
+                                                          double *__restrict__ partial) {
+    __shared__ double sm[3][64][4];
+    const int seg = blockIdx.x;  // 1 KB segment of the 128 x 128 tile (64 of them)
+    const int grp = blockIdx.y;
+    const int pl = blockIdx.z;   // l * npairs + p
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *base = slab + ((int64_t)pl * nsplit) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
+    const int s0 = grp * kRedGroup;
+    int s1 = s0 + kRedGroup;
+    if (s1 > nsplit) s1 = nsplit;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = s0 + wave;
+    for (; s + 28 < s1; s += 32) { // 8 independent 16-byte loads in flight
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 4 * u) * BS * BS);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 += (double)v[u].x;
+            a1 += (double)v[u].y;
+            a2 += (double)v[u].z;
+            a3 += (double)v[u].w;
+        }
+    }
+    for (; s < s1; s += 4) {
+        float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)s * BS * BS);
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
+        a3 += (double)v.w;
+    }
+    if (wave > 0) {
+        sm[wave - 1][lane][0] = a0;
+        sm[wave - 1][lane][1] = a1;
+        sm[wave - 1][lane][2] = a2;
+        sm[wave - 1][lane][3] = a3;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            a0 += sm[w][lane][0];
+            a1 += sm[w][lane][1];
+            a2 += sm[w][lane][2];
+            a3 += sm[w][lane][3];
+        }
+        double *dst = partial + ((int64_t)pl * ngroup + grp) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
+        dst[0] = a0;
+        dst[1] = a1;
+        dst[2] = a2;
+        dst[3] = a3;
+    }
+}
+
+__global__ __launch_bounds__(128) void reduce_G_kernel(int M, int ngroup, const double *__restrict__ partial,
+                                                       double *__restrict__ G) {
     const int nb = M / BS;
     const int npairs = nb * (nb + 1) / 2;
     const int l = blockIdx.z;
@@ -402,55 +432,59 @@ __global__ void reduce_G_kernel(int M, int nsplit, const double *__restrict__ sl
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= M) return;
     int r = row, c = col;
-    if (r < c) { // mirror: always read the lower-triangle element
+    if (r < c) { // mirror: always read the lower-triangle element (exact symmetry)
         int t = r;
         r = c;
         c = t;
     }
     const int rb = r / BS, cb = c / BS;
     const int p = rb * (rb + 1) / 2 + cb;
-    const double *slab = slabG + (((int64_t)l * npairs + p) * nsplit) * (int64_t)(BS * BS) + (r % BS) * BS + (c % BS);
+    const double *src = partial + (((int64_t)l * npairs + p) * ngroup) * (int64_t)(BS * BS) + (r % BS) * BS + (c % BS);
     double acc = 0.0;
-    for (int s = 0; s < nsplit; ++s) acc += slab[(int64_t)s * BS * BS];
+    for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS * BS];
     G[((int64_t)l * M + row) * M + col] = acc;
 }
 
-__global__ void reduce_g_kernel(int M, int nsplit, const double *__restrict__ slabg, double *__restrict__ g) {
+// g: level 1 = one workgroup of 128 threads per (row block, group of slices); level 2 sums the groups
+__global__ __launch_bounds__(128) void reduce_gslab_kernel(int nsplit, int ngroup, const float *__restrict__ slabg,
+                                                           double *__restrict__ partial) {
+    const int grp = blockIdx.x, bl = blockIdx.y; // bl = l * nb + bi
+    const float *base = slabg + ((int64_t)bl * nsplit) * BS + threadIdx.x;
+    const int s0 = grp * kRedGroup;
+    int s1 = s0 + kRedGroup;
+    if (s1 > nsplit) s1 = nsplit;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        a0 += (double)base[(int64_t)(s + 0) * BS];
+        a1 += (double)base[(int64_t)(s + 1) * BS];
+        a2 += (double)base[(int64_t)(s + 2) * BS];
+        a3 += (double)base[(int64_t)(s + 3) * BS];
+    }
+    for (; s < s1; ++s) a0 += (double)base[(int64_t)s * BS];
+    partial[((int64_t)bl * ngroup + grp) * BS + threadIdx.x] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void reduce_g_kernel(int M, int ngroup, const double *__restrict__ partial, double *__restrict__ g) {
     const int l = blockIdx.y;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= M) return;
     const int nb = M / BS;
-    const double *sl = slabg + (((int64_t)l * nb + a / BS) * nsplit) * BS + (a % BS);
+    const double *src = partial + (((int64_t)l * nb + a / BS) * ngroup) * BS + (a % BS);
     double acc = 0.0;
-    for (int s = 0; s < nsplit; ++s) acc += sl[(int64_t)s * BS];
+    for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS];
     g[(int64_t)l * M + a] = acc;
 }
 
-int syrk_nsplit(int64_t N, int M, int L, int64_t *chunk_out) {
-    const int nb = M / BS;
-    const int npairs = nb * (nb + 1) / 2;
-    // ~2 resident workgroups per CU x 256 CUs, a few waves of them for balance
-    int64_t target = (int64_t)(3 * 512) / ((int64_t)npairs * L);
-    if (target < 1) target = 1;
-    int64_t chunk = agpl_cdiv(agpl_cdiv(N, target), KT) * KT;
-    if (chunk < 4 * KT) chunk = 4 * KT;
-    int64_t ns = agpl_cdiv(N, chunk);
-    if (ns < 1) ns = 1;
-    *chunk_out = chunk;
-    return (int)ns;
-}
+inline int syrk_nsplit(int64_t N) { return (int)agpl_cdiv(N, kChunk); }
 
 } // namespace
 
+size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
+
 extern "C" int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L) {
     if (N <= 0 || M <= 0 || M % BS || L <= 0) return 0;
-    int64_t chunk;
-    const int ns = syrk_nsplit(N, M, L, &chunk);
-    const int nb = M / BS;
-    const int64_t npairs = (int64_t)nb * (nb + 1) / 2;
-    int64_t bytes = sizeof(double) * ((int64_t)L * npairs * ns * BS * BS + (int64_t)L * nb * ns * BS);
-    bytes += sizeof(float) * 4 * (int64_t)L * N; // mu, var, gamma, beta of the fused pass
-    return bytes + 1024;
+    return (int64_t)agpl_slab_bytes(N, M, L) + (int64_t)sizeof(float) * 4 * L * N + 2048;
 }
 
 extern "C" int32_t agpl_marginals(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
@@ -492,40 +526,61 @@ extern "C" int32_t agpl_transform_features(agpl_ctx *ctx, int64_t N, int32_t M, 
     return AGPL_OK;
 }
 
+// scratch layout of one accumulation: [f32 slabs G][f32 slabs g][f64 partials G][f64 partials g]
+struct SlabLayout {
+    int ns, ng, nb;
+    int64_t npairs;
+    size_t slabG, slabg, partG, partg; // byte offsets
+    size_t total;
+};
+static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
+    SlabLayout o;
+    o.ns = syrk_nsplit(N);
+    o.ng = (o.ns + kRedGroup - 1) / kRedGroup;
+    o.nb = M / BS;
+    o.npairs = (int64_t)o.nb * (o.nb + 1) / 2;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    o.slabG = 0;
+    o.slabg = al(o.slabG + sizeof(float) * (size_t)(L * o.npairs * o.ns * BS * BS));
+    o.partG = al(o.slabg + sizeof(float) * (size_t)((int64_t)L * o.nb * o.ns * BS));
+    o.partg = al(o.partG + sizeof(double) * (size_t)(L * o.npairs * o.ng * BS * BS));
+    o.total = al(o.partg + sizeof(double) * (size_t)((int64_t)L * o.nb * o.ng * BS));
+    return o;
+}
+
+size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) { return slab_layout(N, M, L).total; }
+
 // internal: accumulate with caller-provided slab storage (used by agpl_accumulate and agpl_cavi_pass)
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *beta,
                              const float *gamma, double *G_out, double *g_out, void *slab_mem) {
-    int64_t chunk;
-    const int ns = syrk_nsplit(N, M, L, &chunk);
-    const int nb = M / BS;
-    const int npairs = nb * (nb + 1) / 2;
-    double *slabG = (double *)slab_mem;
-    double *slabg = slabG + (int64_t)L * npairs * ns * BS * BS;
+    const SlabLayout lo = slab_layout(N, M, L);
+    const int ns = lo.ns, nb = lo.nb, npairs = (int)lo.npairs, ng = lo.ng;
+    float *slabG = (float *)((char *)slab_mem + lo.slabG);
+    float *slabg = (float *)((char *)slab_mem + lo.slabg);
+    double *partG = (double *)((char *)slab_mem + lo.partG);
+    double *partg = (double *)((char *)slab_mem + lo.partg);
     const size_t lds = syrk_lds_bytes();
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((unsigned)npairs, (unsigned)ns, (unsigned)L);
+    const int64_t nwg = (int64_t)L * npairs * ((ns + 7) / 8) * 8;
+    if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
-    syrk_kernel<<<grid, 256, lds, ctx->stream>>>(N, M, Phi, gamma, beta, slabG, slabg, chunk);
+    syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 1);
     if (rc) return rc;
+    dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs));
+    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, slabG, partG);
+    AGPL_LAUNCH_CHECK(ctx);
     dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ns, slabG, G_out);
+    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    dim3 r2((unsigned)ng, (unsigned)(L * nb));
+    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(ns, ng, slabg, partg);
     AGPL_LAUNCH_CHECK(ctx);
     dim3 rg2((unsigned)agpl_cdiv(M, 128), (unsigned)L);
-    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ns, slabg, g_out);
+    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ng, partg, g_out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
-}
-
-size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) {
-    int64_t chunk;
-    const int ns = syrk_nsplit(N, M, L, &chunk);
-    const int nb = M / BS;
-    const int64_t npairs = (int64_t)nb * (nb + 1) / 2;
-    return sizeof(double) * (size_t)((int64_t)L * npairs * ns * BS * BS + (int64_t)L * nb * ns * BS);
 }
 
 extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
