@@ -24,7 +24,9 @@ from .operators import (AuxPosterior, Context, TupleVector, aug_loglik_unsupport
                         aux_posterior_, aux_sample, aux_sample_, default_context, expected_auglik_potential,
                         expected_auglik_potential_and_precision, expected_auglik_precision, expected_logtilt,
                         init_aux_posterior, init_aux_variables, logtilt, rand_polyagamma)
-from .sparse import SparseCAVI, SparseGibbs, se_features, synth_xy, whiten_features
+from . import sparse
+from .sparse import (SparseCAVI, SparseGibbs, exchange_natural_parameters, se_features, shard_range, synth_xy,
+                     whiten_features)
 
 __all__ = [
     "AGPLError", "ArgumentError", "DomainError", "PosDefException", "build",
@@ -35,5 +37,6 @@ __all__ = [
     "auglik_potential", "auglik_precision", "auglik_potential_and_precision",
     "expected_auglik_potential", "expected_auglik_precision", "expected_auglik_potential_and_precision",
     "logtilt", "expected_logtilt", "aux_kldivergence", "rand_polyagamma",
-    "SparseCAVI", "SparseGibbs", "se_features", "whiten_features", "synth_xy",
+    "SparseCAVI", "SparseGibbs", "se_features", "whiten_features", "synth_xy", "shard_range",
+    "exchange_natural_parameters",
 ]

@@ -82,6 +82,25 @@ def whiten_features(Kzx, Linv: np.ndarray, ctx: Context | None = None, out=None)
     return out
 
 
+def shard_range(N: int, rank: int, world: int):
+    """Points [i0, i1) owned by ``rank`` when N observations are sharded over ``world`` ranks:
+    contiguous, sizes differ by at most one, a pure function of (N, rank, world)."""
+    return rank * N // world, (rank + 1) * N // world
+
+
+def exchange_natural_parameters(G, g, group=None):
+    """The one exchange step of a sweep: sum the per-rank partials of the M x M natural-parameter
+    accumulators over the ranks that shard N (torch.distributed all-reduce; backend "nccl" = RCCL over
+    xGMI on the GPU box, "gloo" in the CPU tests).  float64 on the wire; in place."""
+    if group is None:
+        return G, g
+    import torch.distributed as dist
+
+    dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return G, g
+
+
 class SparseCAVI:
     """CAVI sweeps over N local points and M features.
 
@@ -128,13 +147,8 @@ class SparseCAVI:
                       _ptr(self.G), _ptr(self.g), _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
 
     def exchange(self):
-        """The one exchange step of a sweep: sum the M x M natural-parameter partials over ranks
-        (RCCL all-reduce over xGMI; float64 on the wire)."""
-        if self.group is not None:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.G, group=self.group)
-            dist.all_reduce(self.g, group=self.group)
+        """Sum (G, g) over the ranks that shard N; every rank then performs the identical M x M update."""
+        exchange_natural_parameters(self.G, self.g, self.group)
 
     def update(self):
         """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form)."""

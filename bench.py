@@ -79,8 +79,7 @@ def main():
     ctx = A.Context(local_rank, seed=SEED)
     lik = make_lik(A, args.lik)
     N, M, L = args.n, args.m, A.nlatent(lik)
-    i0 = rank * N // world
-    i1 = (rank + 1) * N // world
+    i0, i1 = A.shard_range(N, rank, world)
     n_loc = i1 - i0
 
     # ---- setup (untimed): synthetic data, K_ZX, whitening, Nystrom residual -- all on device ----------------

@@ -1,0 +1,92 @@
+"""world_size-2 test of the N-sharded path on CPU (gloo): the product's shard_range() and
+exchange_natural_parameters() with the oracle standing in for the per-rank device pass.
+
+Checks: shards tile [0, N) exactly; the synthetic inputs of a shard are the slice of the
+global inputs (pure function of (seed, index)); sum over ranks of the per-shard (G, g) equals the
+single-process result to float64 round-off; every rank ends with identical natural parameters and hence the
+identical M x M update (no broadcast needed)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, N, M, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import agpl_amd as A
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = 20240807
+        olik = O.bernoulli()
+        i0, i1 = A.shard_range(N, rank, world)
+        x = O.synth_x(seed, i0, i1 - i0)
+        y = O.synth_y(olik, seed, i0, i1 - i0)
+        z = np.linspace(-10, 10, M)
+        ell = 1.5 * (z[1] - z[0])
+        Phi = O.se_kernel_f32(x, z, ell)
+        kd = np.ones(i1 - i0)
+        S, m = np.eye(M)[None] * 0.5, np.full((1, M), 0.1)
+        G, g = O.cavi_pass(olik, Phi, kd, y, -S, m)
+        Gt, gt = torch.from_numpy(G.copy()), torch.from_numpy(g.copy())
+        A.exchange_natural_parameters(Gt, gt, dist.group.WORLD)
+        Sn, mn = O.gaussian_update(Gt.numpy(), gt.numpy())
+        q.put((rank, i0, i1, x[:3].tolist(), Gt.numpy(), gt.numpy(), Sn, mn))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_tiles_exactly():
+    sys.path.insert(0, ROOT)
+    import agpl_amd as A
+
+    for N in (1, 7, 8, 1000, 10_000_000, 10_000_019):
+        for world in (1, 2, 3, 8):
+            rs = [A.shard_range(N, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == N
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_sweep_matches_single_process(oracle):
+    import torch.multiprocessing as mp
+
+    O = oracle
+    N, M, world = 6001, 32, 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference
+    seed = 20240807
+    olik = O.bernoulli()
+    x = O.synth_x(seed, 0, N)
+    y = O.synth_y(olik, seed, 0, N)
+    z = np.linspace(-10, 10, M)
+    Phi = O.se_kernel_f32(x, z, 1.5 * (z[1] - z[0]))
+    S, m = np.eye(M)[None] * 0.5, np.full((1, M), 0.1)
+    G, g = O.cavi_pass(olik, Phi, np.ones(N), y, -S, m)
+    assert res[0][1] == 0 and res[1][2] == N and res[0][2] == res[1][1]
+    assert res[1][3] == x[res[1][1]:res[1][1] + 3].tolist()  # shard inputs are slices of the global inputs
+    for r in res:
+        assert np.allclose(r[4], G, rtol=1e-12, atol=1e-12)
+        assert np.allclose(r[5], g, rtol=1e-12, atol=1e-12)
+    # identical on every rank, bit for bit -> identical update, no broadcast
+    assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
+    assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])

@@ -393,8 +393,11 @@ def test_cavi_natural_parameters_match_oracle(A, ctx, oracle, name, N, M):
     Lam, eta = cavi.natural_parameters()
     assert relmax(host(Lam), np.eye(Mp) + G) < NAT_TOL
     assert relmax(host(eta), g) < NAT_TOL
-    assert relmax(host(cavi.m), m) < 1e-4  # the solve amplifies by cond(I + G)
-    assert relmax(host(cavi.S), S) < 1e-4
+    # moments: the M x M solve amplifies the natural-parameter difference by cond(I + G) (why the bar is
+    # stated on natural parameters); bound = bar x condition number
+    kappa = max(np.linalg.cond(np.eye(Mp) + G[l]) for l in range(L))
+    assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
+    assert relmax(host(cavi.S), S) < max(1e-4, NAT_TOL * kappa)
     mu, var = cavi.marginals()
     assert (host(var) > 0).all()
 
