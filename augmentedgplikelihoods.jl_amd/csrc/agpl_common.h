@@ -29,7 +29,7 @@ struct agpl_ctx {
     int logtheta_n = 0;
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     char err[512] = {0};
 };

@@ -32,7 +32,7 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     agpl_update_release(ctx);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 4; ++w)
         for (auto &pr : ctx->ev[w]) ctx->ev_pool.push_back(pr);
     for (auto &pr : ctx->ev_pool) {
         (void)hipEventDestroy(pr.first);
@@ -168,7 +168,7 @@ extern "C" int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on) {
     return AGPL_OK;
 }
 extern "C" int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host) {
-    if (!ctx || which < 0 || which > 1 || !total_ms_host || !launches_host) return AGPL_ERR_INVALID_ARGUMENT;
+    if (!ctx || which < 0 || which > 3 || !total_ms_host || !launches_host) return AGPL_ERR_INVALID_ARGUMENT;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
     for (auto &pr : ctx->ev[which]) {

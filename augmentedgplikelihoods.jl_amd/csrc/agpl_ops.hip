@@ -21,7 +21,73 @@ inline int grid_for(int64_t n) {
 
 // ------------------------------------------------------------------------------------------------
 // aux_sample!  src/generic.jl:5-12 ; one lane per point, per-lane Philox stream (seed, i, sweep)
+// sample_point draws Omega_i from aux_full_conditional(lik, y_i, f_i); f / om / nn point at the point's own
+// latent values (global memory for agpl_aux_sample, LDS scratch for the Gibbs pass).
 // ------------------------------------------------------------------------------------------------
+__device__ inline void sample_point(const agpl_lik_dev &lik, Philox &g, int64_t i, const void *yv, const double *f,
+                                    double *om, int64_t *nn, uint32_t &nt, int *bad) {
+    const int L = lik.nlatent;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
+        om[0] = rand_pg(g, 1.0, fabs(f[0]), nt);
+        break;
+    case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
+        const int32_t *y = (const int32_t *)yv;
+        om[0] = rand_pg(g, (double)y[i] + lik.p[0], fabs(f[0]), nt);
+    } break;
+    case AGPL_LIK_STUDENTT: { // studentt.jl:46-48
+        const double *y = (const double *)yv;
+        double nu = lik.p[0], sg = lik.p[1];
+        double d = y[i] - f[0];
+        double scale = 2.0 / (nu / (sg * sg) + d * d);
+        om[0] = scale * rand_gamma(g, (nu + 1.0) / 2.0);
+    } break;
+    case AGPL_LIK_CATEGORICAL:
+    case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:72-78, polyagammanegativemultinomial.jl:27-31,
+                                     // negativemultinomial.jl:35-45
+        const uint8_t *y = (const uint8_t *)yv;
+        double sp = 0.0;
+        for (int k = 0; k < L; ++k) sp += exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+        double p0 = 1.0 - sp;
+        if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
+            atomicOr(bad, 1);
+            break;
+        }
+        double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
+        for (int k = 0; k < L; ++k) {
+            double pk = exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+            double lam = pk * theta / (1.0 - p0);
+            nn[k] = rand_poisson(g, lam);
+        }
+        for (int k = 0; k < L; ++k)
+            om[k] = rand_pg(g, (double)(nn[k] + (int64_t)y[i * L + k]), fabs(f[k]), nt);
+    } break;
+    case AGPL_LIK_POISSON: { // poisson.jl:26-28, polyagammapoisson.jl:23-27
+        const int32_t *y = (const int32_t *)yv;
+        double lam = lik.p[0] * logistic(-f[0]);
+        int64_t n1 = rand_poisson(g, lam);
+        nn[0] = n1;
+        om[0] = rand_pg(g, (double)(n1 + y[i]), fabs(f[0]), nt);
+    } break;
+    case AGPL_LIK_LAPLACE: { // laplace.jl:40-42
+        const double *y = (const double *)yv;
+        double beta = lik.p[0];
+        double lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
+        om[0] = rand_invgaussian(g, 1.0 / (2.0 * beta * fabs(y[i] - f[0])), 2.0 * lam);
+    } break;
+    case AGPL_LIK_HETEROGAUSS: { // heteroscedasticgaussian.jl:28-32
+        const double *y = (const double *)yv;
+        double ff = f[0], gg = f[1];
+        double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
+        int64_t n1 = rand_poisson(g, lam);
+        nn[0] = n1;
+        om[0] = rand_pg(g, 0.5 + (double)n1, fabs(gg), nt);
+    } break;
+    default:
+        break;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
                                                             const double *__restrict__ f,
                                                             double *__restrict__ omega,
@@ -29,73 +95,14 @@ __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, in
                                                             uint32_t sweep, uint32_t *__restrict__ nuni_out,
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
-    const int L = lik.nlatent;
+    const int Lf = lik.nlatent;
+    const int Lo = lik.kind == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         Philox g;
         g.init(seed, (uint64_t)i, sweep);
         uint32_t nt = 0;
-        switch (lik.kind) {
-        case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
-            omega[i] = rand_pg(g, 1.0, fabs(f[i]), nt);
-            break;
-        case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
-            const int32_t *y = (const int32_t *)yv;
-            omega[i] = rand_pg(g, (double)y[i] + lik.p[0], fabs(f[i]), nt);
-        } break;
-        case AGPL_LIK_STUDENTT: { // studentt.jl:46-48
-            const double *y = (const double *)yv;
-            double nu = lik.p[0], sg = lik.p[1];
-            double d = y[i] - f[i];
-            double scale = 2.0 / (nu / (sg * sg) + d * d);
-            omega[i] = scale * rand_gamma(g, (nu + 1.0) / 2.0);
-        } break;
-        case AGPL_LIK_CATEGORICAL:
-        case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:72-78, polyagammanegativemultinomial.jl:27-31,
-                                         // negativemultinomial.jl:35-45
-            const uint8_t *y = (const uint8_t *)yv;
-            double sp = 0.0;
-            for (int k = 0; k < L; ++k)
-                sp += exp(lik.logtheta[k]) * logistic(f[i * L + k]) / lik.sum_theta;
-            double p0 = 1.0 - sp;
-            if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
-                atomicOr(bad, 1);
-                break;
-            }
-            double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
-            for (int k = 0; k < L; ++k) {
-                double pk = exp(lik.logtheta[k]) * logistic(f[i * L + k]) / lik.sum_theta;
-                double lam = pk * theta / (1.0 - p0);
-                nout[i * L + k] = rand_poisson(g, lam);
-            }
-            for (int k = 0; k < L; ++k)
-                omega[i * L + k] = rand_pg(g, (double)(nout[i * L + k] + (int64_t)y[i * L + k]),
-                                           fabs(f[i * L + k]), nt);
-        } break;
-        case AGPL_LIK_POISSON: { // poisson.jl:26-28, polyagammapoisson.jl:23-27
-            const int32_t *y = (const int32_t *)yv;
-            double lam = lik.p[0] * logistic(-f[i]);
-            int64_t nn = rand_poisson(g, lam);
-            nout[i] = nn;
-            omega[i] = rand_pg(g, (double)(nn + y[i]), fabs(f[i]), nt);
-        } break;
-        case AGPL_LIK_LAPLACE: { // laplace.jl:40-42
-            const double *y = (const double *)yv;
-            double beta = lik.p[0];
-            double lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
-            omega[i] = rand_invgaussian(g, 1.0 / (2.0 * beta * fabs(y[i] - f[i])), 2.0 * lam);
-        } break;
-        case AGPL_LIK_HETEROGAUSS: { // heteroscedasticgaussian.jl:28-32
-            const double *y = (const double *)yv;
-            double ff = f[2 * i], gg = f[2 * i + 1];
-            double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
-            int64_t nn = rand_poisson(g, lam);
-            nout[i] = nn;
-            omega[i] = rand_pg(g, 0.5 + (double)nn, fabs(gg), nt);
-        } break;
-        default:
-            break;
-        }
+        sample_point(lik, g, i, yv, f + i * Lf, omega + i * Lo, nout ? nout + i * Lo : nullptr, nt, bad);
         if (nuni_out) nuni_out[i] = g.nuni;
         if (nterms_out) nterms_out[i] = nt;
     }
@@ -554,9 +561,13 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     if (rc) return rc;
     int *bad = (int *)ctx->ws2;
     AGPL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    rc = agpl_timing_begin(ctx, 3);
+    if (rc) return rc;
     aux_sample_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, f, omega_out, n_out, ctx->seed, sweep,
                                                                nuni_out, nterms_out, bad);
     AGPL_LAUNCH_CHECK(ctx);
+    rc = agpl_timing_end(ctx, 3);
+    if (rc) return rc;
     if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
         int hbad = 0;
         AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -770,6 +781,154 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_elementwise_kernel(agpl_lik
 int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out) {
     agpl_fused_elementwise_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, mu, var, gamma, beta, c_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gibbs pass, per-point half (sparse form of examples/bernoulli/script.jl:81-84):
+//   f_il = mu0_il + phi_i' v_l + sqrt(kdiag_i) eps_il      (the draw of f given v under the sparse model)
+//   Omega_i ~ aux_full_conditional(lik, y_i, f_i)           (aux_sample!, same per-point Philox stream)
+//   beta_i, gamma_i = auglik_potential / auglik_precision   (float32, [L][N], feed agpl_accumulate)
+// HBM-bound: one read of Phi (N*M*4 B).  One wave per 64-point chunk: the wave first forms the 64 x L
+// projections phi_i' v_l cooperatively (lane j owns features 4j.., 4j+256..: float4 loads, float64
+// products/sums in a fixed order, xor-butterfly 32..1), then every lane samples its own point.
+// The float64 summation order is part of the contract (the CPU check reproduces it bit for bit).
+// LDS: v [L][M] doubles + per-wave scratch (f, omega, n) [64][L].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
+    agpl_lik_dev lik, int64_t N, int M, const float *__restrict__ Phi, const float *__restrict__ kdiag,
+    const float *__restrict__ mu0, const void *yv, const double *__restrict__ v, uint64_t seed, uint32_t sweep,
+    float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out,
+    int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int Lf = lik.nlatent;
+    const int Lo = lik.kind == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
+    double *v_s = sh;                                   // [Lf][M]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *fS = sh + (size_t)Lf * M + (size_t)wave * 64 * (Lf + 2 * Lo); // [64][Lf]
+    double *omS = fS + 64 * Lf;                                            // [64][Lo]
+    int64_t *nnS = reinterpret_cast<int64_t *>(omS + 64 * Lo);             // [64][Lo]
+    for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
+    __syncthreads();
+
+    const int64_t nchunks = (N + 63) >> 6;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+        const int64_t base = chunk << 6;
+        const int np = (int)((N - base) < 64 ? (N - base) : 64);
+        for (int p = 0; p < np; ++p) {
+            const float *row = Phi + (base + p) * (int64_t)M;
+            for (int l = 0; l < Lf; ++l) {
+                const double *vl = v_s + (size_t)l * M;
+                double acc = 0.0;
+                for (int a = lane << 2; a < M; a += 256) {
+                    const float4 x = *reinterpret_cast<const float4 *>(row + a);
+                    acc += (double)x.x * vl[a];
+                    acc += (double)x.y * vl[a + 1];
+                    acc += (double)x.z * vl[a + 2];
+                    acc += (double)x.w * vl[a + 3];
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (lane == p) fS[p * Lf + l] = acc;
+            }
+        }
+        // every lane now owns one point
+        const int64_t i = base + lane;
+        if (lane < np) {
+            Philox g;
+            g.init(seed, (uint64_t)i, sweep);
+            const double kd = (double)kdiag[i];
+            const double sd = sqrt(kd > 0.0 ? kd : 0.0); // a float32 Nystrom residual can round below zero
+            for (int l = 0; l < Lf; ++l) {
+                double f = fS[lane * Lf + l] + sd * g.normal();
+                if (mu0) f += (double)mu0[(int64_t)l * N + i];
+                fS[lane * Lf + l] = f;
+                if (f_out) f_out[i * Lf + l] = f;
+            }
+            uint32_t nt = 0;
+            sample_point(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+            if (nuni_out) nuni_out[i] = g.nuni;
+            // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
+            switch (lik.kind) {
+            case AGPL_LIK_BERNOULLI_LOGISTIC:
+                beta[i] = ((const uint8_t *)yv)[i] ? 0.5f : -0.5f;
+                gamma[i] = (float)omS[lane];
+                break;
+            case AGPL_LIK_NEGBINOMIAL:
+                beta[i] = (float)(((double)((const int32_t *)yv)[i] - lik.p[0]) / 2.0);
+                gamma[i] = (float)omS[lane];
+                break;
+            case AGPL_LIK_STUDENTT:
+                beta[i] = (float)(((const double *)yv)[i] * omS[lane]);
+                gamma[i] = (float)omS[lane];
+                break;
+            case AGPL_LIK_CATEGORICAL:
+            case AGPL_LIK_CATEGORICAL_BIJ:
+                for (int k = 0; k < Lf; ++k) {
+                    beta[(int64_t)k * N + i] =
+                        (float)(((double)((const uint8_t *)yv)[i * Lf + k] - (double)nnS[lane * Lo + k]) / 2.0);
+                    gamma[(int64_t)k * N + i] = (float)omS[lane * Lo + k];
+                }
+                break;
+            case AGPL_LIK_POISSON:
+                beta[i] = (float)(((double)((const int32_t *)yv)[i] - (double)nnS[lane]) / 2.0);
+                gamma[i] = (float)omS[lane];
+                break;
+            case AGPL_LIK_LAPLACE:
+                beta[i] = (float)(2.0 * omS[lane] * ((const double *)yv)[i]);
+                gamma[i] = (float)(2.0 * omS[lane]);
+                break;
+            case AGPL_LIK_HETEROGAUSS: {
+                const double il = lik.p[0] * logistic(fS[lane * 2 + 1]);
+                beta[i] = (float)(((const double *)yv)[i] * il);
+                gamma[i] = (float)il;
+                beta[N + i] = (float)((0.5 - (double)nnS[lane]) / 2.0);
+                gamma[N + i] = (float)omS[lane];
+            } break;
+            default:
+                break;
+            }
+            if (omega_out)
+                for (int k = 0; k < Lo; ++k) omega_out[i * Lo + k] = omS[lane * Lo + k];
+            if (n_out)
+                for (int k = 0; k < Lo; ++k) n_out[i * Lo + k] = nnS[lane * Lo + k];
+        }
+    }
+}
+
+int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
+                                         const float *kdiag, const float *mu0, const void *y, const double *v,
+                                         uint32_t sweep, float *gamma, float *beta, double *f_out,
+                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad) {
+    const int Lf = ld.nlatent;
+    const int Lo = ld.kind == AGPL_LIK_HETEROGAUSS ? 1 : ld.nlatent;
+    const size_t lds = sizeof(double) * ((size_t)Lf * M + 4 * 64 * (size_t)(Lf + 2 * Lo));
+    if (lds > 160 * 1024)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "Gibbs pass: L * M = %d x %d does not fit the LDS working set", Lf, M);
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_sample_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t nb = agpl_cdiv(agpl_cdiv(N, 64), 4);
+    if (nb > 256 * 8) nb = 256 * 8;
+    int32_t rc = agpl_timing_begin(ctx, 2);
+    if (rc) return rc;
+    gibbs_project_sample_kernel<<<(unsigned)nb, 256, lds, ctx->stream>>>(ld, N, M, Phi, kdiag, mu0, y, v, ctx->seed,
+                                                                         sweep, gamma, beta, f_out, omega_out, n_out,
+                                                                         nuni_out, bad);
+    AGPL_LAUNCH_CHECK(ctx);
+    return agpl_timing_end(ctx, 2);
+}
+
+// z_a = standard normal from the stream (seed, a, sweep): the randn!(...) of the Gaussian conditional draw
+__global__ void randn_kernel(int64_t n, uint64_t seed, uint32_t sweep, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        Philox g;
+        g.init(seed, (uint64_t)i, sweep);
+        out[i] = g.normal();
+    }
+}
+int32_t agpl_launch_randn(agpl_ctx *ctx, int64_t n, uint32_t sweep, double *out) {
+    randn_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->seed, sweep, out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

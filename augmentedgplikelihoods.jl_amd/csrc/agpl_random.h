@@ -209,6 +209,7 @@ __device__ inline double rand_gamma_mt(Philox &g, double shape) {
     }
 }
 __device__ inline double rand_gamma(Philox &g, double shape) {
+    if (!(shape > 0.0)) return __builtin_nan(""); // NaN / invalid shape: no draw (the rejection loops would not end)
     if (shape >= 1.0) return rand_gamma_mt(g, shape);
     double x = rand_gamma_mt(g, shape + 1.0);
     double e = g.exp1();
@@ -227,6 +228,9 @@ __device__ inline double rand_gamma_sum(Philox &g, double c, double e) {
 
 // rand(PolyaGamma(b,c)) polyagamma.jl:121-154
 __device__ inline double rand_pg(Philox &g, double b, double c, uint32_t &nterms) {
+    // NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin or
+    // throw its DomainError from a(n, 0), polyagamma.jl:175)
+    if (!(b >= 0.0) || !(fabs(c) < __builtin_inf())) return __builtin_nan("");
     if (b == 0.0) return 0.0;
     if (b < 1.0) return rand_gamma_sum(g, c, b);
     long tb = (long)floor(b);

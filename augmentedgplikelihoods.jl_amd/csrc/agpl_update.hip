@@ -16,6 +16,11 @@ int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out);
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *beta,
                              const float *gamma, double *G_out, double *g_out, void *slab_mem);
+int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
+                                         const float *kdiag, const float *mu0, const void *y, const double *v,
+                                         uint32_t sweep, float *gamma, float *beta, double *f_out,
+                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad);
+int32_t agpl_launch_randn(agpl_ctx *ctx, int64_t n, uint32_t sweep, double *out);
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
 
 namespace {
@@ -186,4 +191,106 @@ extern "C" int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
     return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+}
+
+extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                   const float *kdiag, const float *mu0, const void *y, const double *v,
+                                   uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
+                                   int64_t *n_out, uint32_t *nuni_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    const int L = ld.nlatent;
+    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
+    if (M % 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 128 (zero-pad the features)", M);
+    if (!Phi || !kdiag || !v || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    if (ld.kind != AGPL_LIK_BERNOULLI_LOGISTIC && !y) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null y");
+    if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
+    const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
+    const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
+    rc = agpl_ws_reserve(ctx, slab + 2 * vec);
+    if (rc) return rc;
+    rc = agpl_ws2_reserve(ctx, sizeof(double) * (1024 + 8));
+    if (rc) return rc;
+    int *bad = (int *)ctx->ws2;
+    AGPL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    char *base = (char *)ctx->ws;
+    float *gam = (float *)(base + slab);
+    float *bet = (float *)(base + slab + vec);
+    rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
+                                          n_out, nuni_out, bad);
+    if (rc) return rc;
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    if (rc) return rc;
+    if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
+        int hbad = 0;
+        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hbad)
+            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
+                      "NegativeMultinomial: all p should be positive and their sum strictly smaller than 1 "
+                      "(negativemultinomial.jl:17-22)");
+    }
+    return AGPL_OK;
+}
+
+namespace {
+__global__ void add_vec_kernel(int n, const double *__restrict__ a, const double *__restrict__ b,
+                               double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.0);
+}
+} // namespace
+
+extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                     const double *eta0, uint32_t sweep, double *v_out, double *m_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
+    rocblas_handle h;
+    int32_t rc = get_handle(ctx, &h);
+    if (rc) return rc;
+    const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
+    const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
+    const size_t info_off = 16384;
+    rc = agpl_ws2_reserve(ctx, info_off + 512 + mat_bytes + 2 * vec_bytes + 256);
+    if (rc) return rc;
+    rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + info_off);
+    char *p = (char *)ctx->ws2 + info_off + 512;
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    double *A = (double *)p;
+    double *mvec = (double *)(p + mat_bytes);
+    double *z = (double *)(p + mat_bytes + vec_bytes);
+
+    dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
+    add_identity_kernel<<<grid, 128, 0, ctx->stream>>>(M, G, A);
+    AGPL_LAUNCH_CHECK(ctx);
+    const rocblas_stride stride = (rocblas_stride)M * M;
+    AGPL_ROCBLAS(ctx, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, M, A, M, stride, info, L));
+    add_vec_kernel<<<(unsigned)agpl_cdiv((int64_t)L * M, 256), 256, 0, ctx->stream>>>(L * M, g, eta0, mvec);
+    AGPL_LAUNCH_CHECK(ctx);
+    rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) {
+        double *Al = A + (size_t)l * M * M;
+        // m = (C C')^-1 (g + eta0)
+        AGPL_ROCBLAS(ctx, rocsolver_dpotrs(h, rocblas_fill_lower, M, 1, Al, M, mvec + (size_t)l * M, M));
+        // x = C^-T z  (in place)
+        AGPL_ROCBLAS(ctx, rocblas_dtrsv(h, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                        M, Al, M, z + (size_t)l * M, 1));
+    }
+    add_vec_kernel<<<(unsigned)agpl_cdiv((int64_t)L * M, 256), 256, 0, ctx->stream>>>(L * M, mvec, z, v_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    if (m_out)
+        AGPL_HIP(ctx, hipMemcpyAsync(m_out, mvec, sizeof(double) * (size_t)L * M, hipMemcpyDeviceToDevice, ctx->stream));
+    rocblas_int hinfo[64];
+    const int ni = L > 64 ? 64 : L;
+    AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(rocblas_int) * ni, hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ni; ++i)
+        if (hinfo[i] != 0)
+            AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, potrf info = %d)", i,
+                      (int)hinfo[i]);
+    return AGPL_OK;
 }

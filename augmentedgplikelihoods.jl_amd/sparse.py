@@ -201,8 +201,70 @@ def nystrom_residual(Phi, kxx, ctx: Context | None = None):
 
 
 class SparseGibbs:
-    """Placeholder wired in a later step of this round (sparse Gibbs sweep: aux_sample! + agpl_accumulate +
-    agpl_gaussian_update + a draw of v)."""
+    """Gibbs sweeps of the sparse model (``gibbs_sample`` of examples/bernoulli/script.jl:76-87 restated for M
+    inducing coordinates in the whitened basis):
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("SparseGibbs is not built yet")
+        f_i | v  ~ N(phi_i' v, d_i)            (agpl_gibbs_pass: projection + noise, per-point Philox stream)
+        Ω_i | f_i ~ aux_full_conditional       (aux_sample!, same stream)
+        v | Ω    ~ N(m, S), S = (I + G)^-1, m = S g,  G = Phi Diag(γ(Ω)) Phi', g = Phi β(Ω)   (agpl_gibbs_draw_v)
+
+    N is sharded over ``group`` exactly as in SparseCAVI: (G, g) are all-reduced, every rank draws the identical v
+    (same Philox key / counter).  Real-valued y must be float64 here (the Gibbs operators are Float64).
+    """
+
+    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False):
+        torch = _torch()
+        self.ctx = ctx or default_context()
+        self.lik = lik
+        self.Phi = _prep(Phi, torch.float32, "Phi")
+        self.N, self.M = self.Phi.shape
+        if self.M % PAD:
+            raise _ffi.ArgumentError(-1, f"feature count {self.M} must be a multiple of {PAD} (zero-pad)")
+        self.L = lik._nlatent
+        self.kdiag = _prep(kdiag, torch.float32, "kdiag")
+        self.y = _prep_y(lik, y, torch.float64)
+        self.mu0 = _prep(mu0, torch.float32, "mu0")
+        self.group = group
+        dev = self.Phi.device
+        L, M = self.L, self.M
+        f64 = torch.float64
+        self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
+        self.g = torch.zeros((L, M), dtype=f64, device=dev)
+        self.v = torch.empty((L, M), dtype=f64, device=dev)
+        self.m = torch.empty((L, M), dtype=f64, device=dev)
+        self.sweep_index = 0
+        self.f = self.omega = self.n = None
+        if keep_points:
+            Lo = 1 if lik.kind == 7 else L
+            self.f = torch.empty((self.N, L), dtype=f64, device=dev)
+            self.omega = torch.empty((self.N, Lo), dtype=f64, device=dev)
+            self.n = torch.zeros((self.N, Lo), dtype=torch.int64, device=dev)
+        self.draw()  # G = 0, g = 0: v ~ N(0, I), the prior draw (script.jl:89 `f = randn(N)`)
+
+    def draw(self):
+        self.ctx.call("agpl_gibbs_draw_v", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
+                      C.c_void_p(0), C.c_uint32(self.sweep_index), _ptr(self.v), _ptr(self.m))
+        self.sweep_index += 1
+
+    def accumulate(self):
+        d = self.lik.desc()
+        self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
+                      _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
+                      _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))
+
+    def exchange(self):
+        exchange_natural_parameters(self.G, self.g, self.group)
+
+    def sweep(self):
+        self.accumulate()
+        self.exchange()
+        self.draw()
+        return self.v
+
+    def run(self, nsamples: int = 200):
+        """Returns the [nsamples, L, M] chain of inducing draws."""
+        torch = _torch()
+        out = torch.empty((nsamples, self.L, self.M), dtype=torch.float64, device=self.Phi.device)
+        for t in range(nsamples):
+            out[t] = self.sweep()
+        return out

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="points of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-gibbs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -168,6 +169,48 @@ def main():
                    "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}"},
         "roofline": roofline, "setup_s": round(t_setup, 2),
     }
+
+    # ---- Gibbs half on the same resident workload (extra legs, not the headline value) ------------------------
+    if not args.no_gibbs:
+        def read_timing(which):
+            ms, cnt = C.c_double(), C.c_int64()
+            _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
+            return ms.value, cnt.value
+
+        yg = y.to(torch.float64) if lik.ykind == "real" else y
+        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None)
+        for _ in range(2):
+            gib.sweep()
+        torch.cuda.synchronize()
+        _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+        nsw = max(3, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(nsw):
+            gib.sweep()
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - t0) / nsw
+        pms, pcnt = read_timing(2)
+        read_timing(1)
+        # standalone aux_sample! (src/generic.jl:5-12) at the marginal means: the PG sampler kernel alone
+        f64 = cavi.marginals()[0].to(torch.float64).t().contiguous() if L > 1 else cavi.marginals()[0][0].to(torch.float64)
+        Om = A.aux_sample(lik, yg, f64, ctx=ctx, sweep=1)
+        for sw in range(3):
+            A.aux_sample_(Om, lik, yg, f64, ctx=ctx, sweep=2 + sw)
+        sms, scnt = read_timing(3)
+        _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+        bytes_pt = {"bernoulli": 16, "negbin": 20, "studentt": 24, "categorical": L * (8 + 1 + 8 + 8)}[args.lik]
+        samp_ms = sms / max(scnt, 1)
+        proj_ms = pms / max(pcnt, 1)
+        out["gibbs"] = {
+            "sweeps_per_s": round(1.0 / tg, 3), "ms_per_sweep": round(tg * 1e3, 3),
+            "point_pass": {"kernel": "gibbs_project_sample_kernel", "avg_ms": round(proj_ms, 3), "bound": "hbm",
+                           "algorithmic_bytes": n_loc * (Mp * 4 + 16),
+                           "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000},
+            "sampler": {"kernel": "aux_sample_kernel", "avg_ms": round(samp_ms, 4), "bound": "hbm (by contract)",
+                        "algorithmic_bytes_per_point": bytes_pt, "draws_per_s": round(n_loc / (samp_ms * 1e-3), 0),
+                        "achieved_GBps": round(n_loc * bytes_pt / (samp_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
+                        "frac": round(n_loc * bytes_pt / (samp_ms * 1e-3) / 8e12, 4)}}
+        del gib, Om, f64
 
     # ---- parity leg: a slice of the same workload, GPU vs oracle, 3 sweeps -----------------------------------
     if not args.no_parity:

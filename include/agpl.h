@@ -186,9 +186,28 @@ AGPL_API int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t
                        const float *Wpack, const float *alpha, double *G_out, double *g_out,
                        float *c_out, float *gamma_out, float *beta_out);
 
+/* ---- Gibbs half of the sparse sweep (examples/bernoulli/script.jl:76-87 in sparse form) ---------------
+ * agpl_gibbs_pass: for every point  f_il = mu0_il + phi_i' v_l + sqrt(kdiag_i) eps_il  (the draw of f given
+ *   the inducing draw v under the sparse model; eps from the point's Philox stream (seed, i, sweep)), then
+ *   aux_sample! (src/generic.jl:5-12) on the same stream, auglik_potential / auglik_precision of the draw, and
+ *   the accumulation G_l = Phi Diag(gamma_l) Phi', g_l = Phi beta_l (agpl_accumulate).  One read of Phi for
+ *   the projection + one for the accumulation.  v: [L, M] float64.  y real-valued: float64.
+ *   Optional outputs: f_out [L,N] col-major f64, omega_out f64, n_out i64, nuni_out u32[N].            */
+AGPL_API int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                 const float *Phi, const float *kdiag, const float *mu0, const void *y,
+                                 const double *v, uint32_t sweep, double *G_out, double *g_out,
+                                 double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
+
+/* agpl_gibbs_draw_v: v_l ~ N(m_l, S_l), S = (I + G)^-1, m = S (g + eta0): the `rand!(MvNormal(mu, Sigma), f)`
+ *   of examples/bernoulli/script.jl:82-84 for the M inducing coordinates.  Cholesky C C' = I + G (rocSOLVER
+ *   potrf), m by potrs, v = m + C^-T z with z_a = the normal of Philox stream (seed, l*M + a, sweep | 2^31).
+ *   v_out [L,M] f64; m_out [L,M] f64 or NULL.  sweep < 2^31.                                            */
+AGPL_API int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                   const double *eta0, uint32_t sweep, double *v_out, double *m_out);
+
 /* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
- * pair is recorded on the context's stream around every launch of the marginal (which = 0) and the
- * accumulation (which = 1) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel
+ * pair is recorded on the context's stream around every launch of the marginal (which = 0), the
+ * accumulation (which = 1), the Gibbs per-point (which = 2) and the aux_sample (which = 3) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel
  * time [ms] and the number of launches since the last read, and resets the counters.                 */
 AGPL_API int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on);
 AGPL_API int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host);

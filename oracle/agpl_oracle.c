@@ -275,6 +275,7 @@ static double rand_gamma_mt(agplo_rng *g, double shape) {
     }
 }
 static double rand_gamma(agplo_rng *g, double shape) {
+    if (!(shape > 0.0)) return NAN; /* NaN / invalid shape: no draw (the rejection loops would not end) */
     if (shape >= 1.0) return rand_gamma_mt(g, shape);
     double x = rand_gamma_mt(g, shape + 1.0);
     double e = rng_exp(g);
@@ -294,6 +295,9 @@ static double rand_gamma_sum(agplo_rng *g, double c, double e) {
 /* rand(PolyaGamma(b,c)) polyagamma.jl:121-154.  Integer-valued b follows draw_sum{<:Integer}
  * (:129-134); real b follows :137-154 (identical draws when the residual is zero). */
 static double rand_pg(agplo_rng *g, double b, double c, uint32_t *nterms) {
+    /* NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin
+     * or throw its DomainError from a(n, 0), polyagamma.jl:175) */
+    if (!(b >= 0.0) || !(fabs(c) < INFINITY)) return NAN;
     if (b == 0.0) return 0.0;
     if (b < 1.0) return rand_gamma_sum(g, c, b);
     long tb = (long)floor(b);
@@ -1159,6 +1163,122 @@ AGPLO_API void agplo_se_kernel_f32(int64_t n, int M, const double *x, const doub
             double d = (x[i] - z[a]) / ell;
             out[i * (int64_t)M + a] = (float)exp(-0.5 * d * d);
         }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Gibbs half of the sparse sweep (examples/bernoulli/script.jl:81-84 in sparse form):          */
+/*   f_il = mu0_il + phi_i' v_l + sqrt(kdiag_i) eps_il ; Omega_i ~ aux_full_conditional ;        */
+/*   beta, gamma = auglik_potential / auglik_precision (rounded to float32 as the device feeds    */
+/*   them to the accumulation).  The float64 summation order of phi_i' v_l is the device's:       */
+/*   64 partial sums (partial j takes features 4j.., 4j+256.., each float4 in order) combined by  */
+/*   an xor butterfly 32,16,...,1.                                                               */
+/* ------------------------------------------------------------------------------------------ */
+AGPLO_API void agplo_randn_many(uint64_t seed, uint64_t stream0, uint32_t sweep, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        agplo_rng g;
+        rng_init(&g, seed, stream0 + (uint64_t)i, sweep);
+        out[i] = rng_normal(&g);
+    }
+}
+
+static double project_device_order(const float *row, const double *vl, int M) {
+    double part[64], tmp[64];
+    for (int j = 0; j < 64; ++j) {
+        double acc = 0.0;
+        for (int a = j << 2; a < M; a += 256) {
+            acc += (double)row[a] * vl[a];
+            acc += (double)row[a + 1] * vl[a + 1];
+            acc += (double)row[a + 2] * vl[a + 2];
+            acc += (double)row[a + 3] * vl[a + 3];
+        }
+        part[j] = acc;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int j = 0; j < 64; ++j) tmp[j] = part[j] + part[j ^ off];
+        memcpy(part, tmp, sizeof(part));
+    }
+    return part[0];
+}
+
+AGPLO_API int agplo_gibbs_points(const agplo_lik *lik, int64_t N, int M, const float *Phi, const double *kdiag,
+                                 const double *mu0, const void *yv, const double *v, uint64_t seed,
+                                 uint32_t sweep, double *f_out, double *omega, int64_t *nout,
+                                 uint32_t *nuni_out, float *beta32, float *gamma32) {
+    const int Lf = lik->nlatent;
+    const int Lo = lik->kind == LIK_HETEROGAUSS ? 1 : lik->nlatent;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t i = 0; i < N; ++i) {
+        agplo_rng g;
+        rng_init(&g, seed, (uint64_t)i, sweep);
+        double sd = sqrt(kdiag[i] > 0.0 ? kdiag[i] : 0.0); /* a float32 Nystrom residual can round below zero */
+        double *fi = f_out + i * Lf;
+        for (int l = 0; l < Lf; ++l) {
+            double f = project_device_order(Phi + i * (int64_t)M, v + (int64_t)l * M, M) + sd * rng_normal(&g);
+            if (mu0) f += mu0[(int64_t)l * N + i];
+            fi[l] = f;
+        }
+        /* aux_sample! on the same stream: single-point call of the vector API would restart the stream, so the
+         * per-kind draw is restated through a 1-point slice with the rng carried over */
+        uint32_t nt = 0;
+        double *om = omega + i * Lo;
+        int64_t *nn = nout ? nout + i * Lo : NULL;
+        switch (lik->kind) {
+        case LIK_BERNOULLI_LOGISTIC:
+            om[0] = rand_pg(&g, 1.0, fabs(fi[0]), &nt);
+            break;
+        case LIK_NEGBINOMIAL:
+            om[0] = rand_pg(&g, (double)((const int32_t *)yv)[i] + lik->p[0], fabs(fi[0]), &nt);
+            break;
+        case LIK_STUDENTT: {
+            double nu = lik->p[0], sg = lik->p[1], d = ((const double *)yv)[i] - fi[0];
+            om[0] = (2.0 / (nu / (sg * sg) + d * d)) * rand_gamma(&g, (nu + 1.0) / 2.0);
+        } break;
+        case LIK_CATEGORICAL:
+        case LIK_CATEGORICAL_BIJ: {
+            const uint8_t *y = (const uint8_t *)yv;
+            double sumth = cat_sum_theta(lik), sp = 0.0;
+            for (int k = 0; k < Lf; ++k) sp += exp(lik->logtheta[k]) * logistic_(fi[k]) / sumth;
+            double p0 = 1.0 - sp;
+            if (!(sp < 1.0)) { bad |= 1; break; }
+            double theta = (1.0 / p0 - 1.0) * rand_gamma(&g, 1.0);
+            for (int k = 0; k < Lf; ++k)
+                nn[k] = rand_poisson(&g, exp(lik->logtheta[k]) * logistic_(fi[k]) / sumth * theta / (1.0 - p0));
+            for (int k = 0; k < Lf; ++k)
+                om[k] = rand_pg(&g, (double)(nn[k] + (int64_t)y[i * Lf + k]), fabs(fi[k]), &nt);
+        } break;
+        case LIK_POISSON: {
+            int64_t n1 = rand_poisson(&g, lik->p[0] * logistic_(-fi[0]));
+            nn[0] = n1;
+            om[0] = rand_pg(&g, (double)(n1 + ((const int32_t *)yv)[i]), fabs(fi[0]), &nt);
+        } break;
+        case LIK_LAPLACE: {
+            double beta = lik->p[0], lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
+            om[0] = rand_invgaussian(&g, 1.0 / (2.0 * beta * fabs(((const double *)yv)[i] - fi[0])), 2.0 * lam);
+        } break;
+        case LIK_HETEROGAUSS: {
+            double yy = ((const double *)yv)[i];
+            int64_t n1 = rand_poisson(&g, lik->p[0] * logistic_(-fi[1]) * (fi[0] - yy) * (fi[0] - yy) / 2.0);
+            nn[0] = n1;
+            om[0] = rand_pg(&g, 0.5 + (double)n1, fabs(fi[1]), &nt);
+        } break;
+        default:
+            bad |= 2;
+        }
+        if (nuni_out) nuni_out[i] = g.nuni;
+    }
+    if (bad) return -bad;
+    /* potentials / precisions of the draw, rounded to float32 */
+    double *b64 = (double *)malloc(sizeof(double) * 2 * (size_t)Lf * N);
+    if (!b64) return -4;
+    double *g64 = b64 + (size_t)Lf * N;
+    agplo_potential_precision(lik, N, yv, omega, nout, f_out, b64, g64);
+    for (int64_t k = 0; k < (int64_t)Lf * N; ++k) {
+        beta32[k] = (float)b64[k];
+        gamma32[k] = (float)g64[k];
+    }
+    free(b64);
+    return 0;
 }
 
 AGPLO_API int agplo_num_threads(void) {

@@ -357,6 +357,54 @@ def gaussian_update(G, g, eta0=None):
     return np.stack(S), np.stack(m)
 
 
+def randn(seed, stream0, sweep, n):
+    out = np.empty(n)
+    lib().agplo_randn_many(C.c_uint64(seed), C.c_uint64(stream0), C.c_uint32(sweep), C.c_int64(n), _p(out))
+    return out
+
+
+def gibbs_pass(lik: Lik, Phi, kdiag, y, v, seed, sweep, mu0=None):
+    """Per-point half of a sparse Gibbs sweep + accumulation.  Returns G, g and the per-point draws."""
+    Phi = np.ascontiguousarray(Phi, dtype=np.float32)
+    N, M = Phi.shape
+    Lf = lik.nlatent
+    Lo = 1 if lik.kind == HETEROGAUSS else Lf
+    v = _f64(v).reshape(Lf, M)
+    y = _ycast(lik, y)
+    f = np.empty((N, Lf))
+    omega = np.empty((N, Lo))
+    nn = np.zeros((N, Lo), dtype=np.int64)
+    nuni = np.zeros(N, dtype=np.uint32)
+    beta = np.empty((Lf, N), dtype=np.float32)
+    gamma = np.empty((Lf, N), dtype=np.float32)
+    lc = lik.c()
+    rc = lib().agplo_gibbs_points(C.byref(lc), C.c_int64(N), C.c_int(M), _p(Phi), _p(_f64(kdiag)), _p(_f64(mu0)),
+                                  _p(y), _p(v), C.c_uint64(seed), C.c_uint32(sweep), _p(f), _p(omega), _p(nn),
+                                  _p(nuni), _p(beta), _p(gamma))
+    if rc != 0:
+        raise ValueError(f"oracle gibbs_points failed rc={rc}")
+    G, g = accumulate(Phi, beta.astype(np.float64), gamma.astype(np.float64))
+    return G, g, dict(f=f, omega=omega, n=nn, nuni=nuni, beta=beta, gamma=gamma)
+
+
+def gibbs_draw_v(G, g, seed, sweep, eta0=None):
+    """v ~ N(m, S), S = (I + G)^-1, m = S (g + eta0); z from Philox streams (seed, l*M + a, sweep | 2^31).
+    numpy/LAPACK float64 (examples/bernoulli/script.jl:82-84 for the inducing coordinates)."""
+    import scipy.linalg as sla
+
+    G = np.asarray(G, dtype=np.float64)
+    L, M = G.shape[0], G.shape[1]
+    g = np.asarray(g, dtype=np.float64).reshape(L, M)
+    z = randn(seed, 0, (sweep | 0x80000000) & 0xFFFFFFFF, L * M).reshape(L, M)
+    v, m = np.empty((L, M)), np.empty((L, M))
+    for l in range(L):
+        Cf = np.linalg.cholesky(np.eye(M) + G[l])
+        rhs = g[l] + (0.0 if eta0 is None else np.asarray(eta0).reshape(L, M)[l])
+        m[l] = sla.cho_solve((Cf, True), rhs)
+        v[l] = m[l] + sla.solve_triangular(Cf.T, z[l], lower=False)
+    return v, m
+
+
 # ---------------------------------------------------------------- synthetic workload
 def synth_x(seed, i0, n):
     x = np.empty(n)

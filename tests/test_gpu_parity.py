@@ -167,6 +167,10 @@ def test_aux_sample_edge_cases(A, ctx, oracle):
     cat = A.CategoricalLikelihood(np.array([5.0, 5.0, -30.0]), bijective=False)
     with pytest.raises(A.ArgumentError):
         A.aux_sample(cat, dev(np.zeros((4, 3), np.uint8)), dev(np.full((4, 3), 40.0)), ctx=ctx)
+    # NaN / Inf latent values must not hang the accept loops: NaN in, NaN out
+    fn = dev(np.array([np.nan, 1.0, np.inf, -np.inf]))
+    got = host(A.aux_sample(lik, None, fn, ctx=ctx, sweep=2).ω)
+    assert np.isnan(got[0]) and np.isfinite(got[1]) and np.isnan(got[2]) and np.isnan(got[3])
     with pytest.raises(ValueError):  # the oracle refuses the same input
         oracle.aux_sample(oracle.categorical([5.0, 5.0, -30.0]), np.zeros((4, 3), np.uint8), np.full((4, 3), 40.0), seed=1)
 
@@ -444,3 +448,91 @@ def test_error_codes(A, ctx):
         d = A.PoissonLikelihood(3.0).desc()
         ctx.call("agpl_aux_sample", C.byref(d), C.c_int64(8), C.c_void_p(f.data_ptr()), C.c_void_p(f.data_ptr()),
                  C.c_void_p(f.data_ptr()), C.c_void_p(0), C.c_uint32(0), C.c_void_p(0), C.c_void_p(0))
+
+
+# ------------------------------------------------------------------------------------------ sparse Gibbs sweep
+@pytest.mark.parametrize("name", ["bernoulli", "negbin", "studentt", "poisson", "cat", "hetero"])
+def test_gibbs_pass_matches_oracle(A, ctx, oracle, name):
+    """Per-point half of a Gibbs sweep: projection in the contractual float64 order, noise, aux_sample! on the
+    same stream, sampled potentials, accumulation."""
+    import ctypes as C
+
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    rng = np.random.default_rng(17)
+    N, M = 3001, 256
+    L = olik.nlatent
+    Lo = 1 if name == "hetero" else L
+    Phi = _features(rng, N, M, 0.15)
+    kd = rng.uniform(0.0, 0.3, size=N).astype(np.float32)
+    v = rng.normal(size=(L, M))
+    y = gen_y(O, olik, N, rng)
+    dPhi, dkd, dv = dev(Phi), dev(kd), dev(v)
+    dy = dev(y)
+    G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    f = torch.empty((N, L), dtype=torch.float64, device="cuda")
+    om = torch.empty((N, Lo), dtype=torch.float64, device="cuda")
+    nn = torch.zeros((N, Lo), dtype=torch.int64, device="cuda")
+    nuni = torch.zeros(N, dtype=torch.int32, device="cuda")
+    d = lik.desc()
+    ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()),
+             C.c_void_p(dkd.data_ptr()), C.c_void_p(0), C.c_void_p(dy.data_ptr()), C.c_void_p(dv.data_ptr()),
+             C.c_uint32(9), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(f.data_ptr()),
+             C.c_void_p(om.data_ptr()), C.c_void_p(nn.data_ptr()), C.c_void_p(nuni.data_ptr()))
+    Gr, gr, pts = O.gibbs_pass(olik, Phi, kd.astype(np.float64), y, v, seed=SEED, sweep=9)
+    assert np.array_equal(host(nuni).astype(np.uint32), pts["nuni"])  # uniforms consumed: bit-exact
+    assert np.allclose(host(f), pts["f"], rtol=1e-13, atol=1e-15)  # same summation order; libm vs OCML in the noise
+    assert np.allclose(host(om), pts["omega"], rtol=1e-9, atol=0)
+    if name in ("poisson", "cat", "hetero"):
+        assert np.array_equal(host(nn), pts["n"])  # counts: bit-exact
+    assert relmax(host(G), Gr) < 5e-6
+    assert relmax(host(g), gr) < 5e-6
+
+
+def test_gibbs_draw_v_matches_oracle(A, ctx, oracle):
+    import ctypes as C
+
+    rng = np.random.default_rng(23)
+    L, M = 2, 256
+    B = rng.normal(size=(L, M, 2 * M)) * 0.3
+    G = B @ B.transpose(0, 2, 1)
+    g = rng.normal(size=(L, M))
+    dG, dg = dev(G), dev(g)
+    v = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    m = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    ctx.call("agpl_gibbs_draw_v", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()),
+             C.c_void_p(0), C.c_uint32(4), C.c_void_p(v.data_ptr()), C.c_void_p(m.data_ptr()))
+    vr, mr = oracle.gibbs_draw_v(G, g, seed=SEED, sweep=4)
+    assert relmax(host(m), mr) < 1e-9
+    assert relmax(host(v), vr) < 1e-9
+
+
+def test_sparse_gibbs_chain_matches_oracle_and_mixes(A, ctx, oracle):
+    """Three full sweeps of the device chain against the oracle chain (same seeds), then a longer device-only run
+    whose average of v must agree with the CAVI mean to Monte-Carlo accuracy (both target the same posterior
+    region for a PG-augmented Bernoulli model)."""
+    O = oracle
+    lik, olik = A.BernoulliLikelihood(), O.bernoulli()
+    N, M = 4000, 32
+    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
+    gctx = A.Context(0, seed=777)
+    gib = A.SparseGibbs(lik, Phi, kd, y, ctx=gctx, keep_points=True)
+    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
+    Mp = Phi_h.shape[1]
+    v, _ = O.gibbs_draw_v(np.zeros((1, Mp, Mp)), np.zeros((1, Mp)), seed=777, sweep=0)
+    assert np.allclose(host(gib.v), v, rtol=1e-12, atol=1e-14)
+    sweep = 1
+    for _ in range(3):
+        gib.sweep()
+        G, g, pts = O.gibbs_pass(olik, Phi_h, kd_h, y_h, v, seed=777, sweep=sweep)
+        v, _ = O.gibbs_draw_v(G, g, seed=777, sweep=sweep)  # the draw uses stream (sweep | 2^31)
+        sweep += 1
+        assert relmax(host(gib.G), G) < 1e-5
+        assert relmax(host(gib.v), v) < 1e-5 * np.linalg.cond(np.eye(Mp) + G[0])
+    chain = host(gib.run(200))[40:, 0, :M]
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    cavi.run(15)
+    m = host(cavi.m)[0, :M]
+    sd = chain.std(0) / np.sqrt(20)  # generous effective-sample-size allowance
+    assert np.all(np.abs(chain.mean(0) - m) < 6 * sd + 0.05)
