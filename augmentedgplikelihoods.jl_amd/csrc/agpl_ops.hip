@@ -24,10 +24,11 @@ inline int grid_for(int64_t n) {
 // sample_point draws Omega_i from aux_full_conditional(lik, y_i, f_i); f / om / nn point at the point's own
 // latent values (global memory for agpl_aux_sample, LDS scratch for the Gibbs pass).
 // ------------------------------------------------------------------------------------------------
+template <int KIND>
 __device__ inline void sample_point(const agpl_lik_dev &lik, Philox &g, int64_t i, const void *yv, const double *f,
                                     double *om, int64_t *nn, uint32_t &nt, int *bad) {
     const int L = lik.nlatent;
-    switch (lik.kind) {
+    switch (KIND) { // compile-time: each kernel instantiation carries one likelihood's sampler only
     case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
         om[0] = rand_pg(g, 1.0, fabs(f[0]), nt);
         break;
@@ -88,6 +89,7 @@ __device__ inline void sample_point(const agpl_lik_dev &lik, Philox &g, int64_t 
     }
 }
 
+template <int KIND>
 __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
                                                             const double *__restrict__ f,
                                                             double *__restrict__ omega,
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, in
         Philox g;
         g.init(seed, (uint64_t)i, sweep);
         uint32_t nt = 0;
-        sample_point(lik, g, i, yv, f + i * Lf, omega + i * Lo, nout ? nout + i * Lo : nullptr, nt, bad);
+        sample_point<KIND>(lik, g, i, yv, f + i * Lf, omega + i * Lo, nout ? nout + i * Lo : nullptr, nt, bad);
         if (nuni_out) nuni_out[i] = g.nuni;
         if (nterms_out) nterms_out[i] = nt;
     }
@@ -563,8 +565,24 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     AGPL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     rc = agpl_timing_begin(ctx, 3);
     if (rc) return rc;
-    aux_sample_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, f, omega_out, n_out, ctx->seed, sweep,
-                                                               nuni_out, nterms_out, bad);
+#define AGPL_LAUNCH_AUX(K)                                                                                     \
+    case K:                                                                                                    \
+        aux_sample_kernel<K><<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, f, omega_out, n_out, ctx->seed,   \
+                                                                      sweep, nuni_out, nterms_out, bad);       \
+        break;
+    switch (ld.kind) {
+        AGPL_LAUNCH_AUX(AGPL_LIK_BERNOULLI_LOGISTIC)
+        AGPL_LAUNCH_AUX(AGPL_LIK_NEGBINOMIAL)
+        AGPL_LAUNCH_AUX(AGPL_LIK_STUDENTT)
+        AGPL_LAUNCH_AUX(AGPL_LIK_CATEGORICAL)
+        AGPL_LAUNCH_AUX(AGPL_LIK_CATEGORICAL_BIJ)
+        AGPL_LAUNCH_AUX(AGPL_LIK_POISSON)
+        AGPL_LAUNCH_AUX(AGPL_LIK_LAPLACE)
+        AGPL_LAUNCH_AUX(AGPL_LIK_HETEROGAUSS)
+    default:
+        break;
+    }
+#undef AGPL_LAUNCH_AUX
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 3);
     if (rc) return rc;
@@ -791,11 +809,13 @@ int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int
 //   Omega_i ~ aux_full_conditional(lik, y_i, f_i)           (aux_sample!, same per-point Philox stream)
 //   beta_i, gamma_i = auglik_potential / auglik_precision   (float32, [L][N], feed agpl_accumulate)
 // HBM-bound: one read of Phi (N*M*4 B).  One wave per 64-point chunk: the wave first forms the 64 x L
-// projections phi_i' v_l cooperatively (lane j owns features 4j.., 4j+256..: float4 loads, float64
-// products/sums in a fixed order, xor-butterfly 32..1), then every lane samples its own point.
+// projections phi_i' v_l cooperatively (16 lanes per point, 4 points per round; lane q owns features 4q..,
+// 4q+64..: float4 loads, float64 products/sums in a fixed order, xor-butterfly 8..1), then every lane samples
+// its own point.  One kernel instantiation per likelihood keeps the sampler's register footprint down.
 // The float64 summation order is part of the contract (the CPU check reproduces it bit for bit).
 // LDS: v [L][M] doubles + per-wave scratch (f, omega, n) [64][L].
 // ------------------------------------------------------------------------------------------------
+template <int KIND>
 __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
     agpl_lik_dev lik, int64_t N, int M, const float *__restrict__ Phi, const float *__restrict__ kdiag,
     const float *__restrict__ mu0, const void *yv, const double *__restrict__ v, uint64_t seed, uint32_t sweep,
@@ -803,7 +823,7 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
     int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int Lf = lik.nlatent;
-    const int Lo = lik.kind == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
+    const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     double *v_s = sh;                                   // [Lf][M]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *fS = sh + (size_t)Lf * M + (size_t)wave * 64 * (Lf + 2 * Lo); // [64][Lf]
@@ -812,16 +832,23 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
     for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
     __syncthreads();
 
+    // projection geometry: 16 lanes per point, 4 points per wave-round.  Lane q = lane & 15 of a group owns
+    // features 4q.., 4q+64.., ...; the 16 partial sums are combined by an xor butterfly 8,4,2,1.
+    // (This float64 summation order is the contract the CPU check reproduces.)
+    const int q = lane & 15, grp = lane >> 4;
     const int64_t nchunks = (N + 63) >> 6;
     for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
         const int64_t base = chunk << 6;
         const int np = (int)((N - base) < 64 ? (N - base) : 64);
-        for (int p = 0; p < np; ++p) {
-            const float *row = Phi + (base + p) * (int64_t)M;
+        for (int r = 0; r < 16; ++r) {
+            int p = 4 * r + grp;
+            const int pc = p < np ? p : np - 1; // clamp: keeps every lane in the shuffles
+            const float *row = Phi + (base + pc) * (int64_t)M;
             for (int l = 0; l < Lf; ++l) {
                 const double *vl = v_s + (size_t)l * M;
                 double acc = 0.0;
-                for (int a = lane << 2; a < M; a += 256) {
+#pragma unroll 4
+                for (int a = q << 2; a < M; a += 64) {
                     const float4 x = *reinterpret_cast<const float4 *>(row + a);
                     acc += (double)x.x * vl[a];
                     acc += (double)x.y * vl[a + 1];
@@ -829,8 +856,8 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
                     acc += (double)x.w * vl[a + 3];
                 }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-                if (lane == p) fS[p * Lf + l] = acc;
+                for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (q == 0 && p < np) fS[p * Lf + l] = acc;
             }
         }
         // every lane now owns one point
@@ -847,10 +874,10 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
                 if (f_out) f_out[i * Lf + l] = f;
             }
             uint32_t nt = 0;
-            sample_point(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+            sample_point<KIND>(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
             if (nuni_out) nuni_out[i] = g.nuni;
             // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
-            switch (lik.kind) {
+            switch (KIND) {
             case AGPL_LIK_BERNOULLI_LOGISTIC:
                 beta[i] = ((const uint8_t *)yv)[i] ? 0.5f : -0.5f;
                 gamma[i] = (float)omS[lane];
@@ -906,15 +933,30 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
     const size_t lds = sizeof(double) * ((size_t)Lf * M + 4 * 64 * (size_t)(Lf + 2 * Lo));
     if (lds > 160 * 1024)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "Gibbs pass: L * M = %d x %d does not fit the LDS working set", Lf, M);
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_sample_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t nb = agpl_cdiv(agpl_cdiv(N, 64), 4);
     if (nb > 256 * 8) nb = 256 * 8;
     int32_t rc = agpl_timing_begin(ctx, 2);
     if (rc) return rc;
-    gibbs_project_sample_kernel<<<(unsigned)nb, 256, lds, ctx->stream>>>(ld, N, M, Phi, kdiag, mu0, y, v, ctx->seed,
-                                                                         sweep, gamma, beta, f_out, omega_out, n_out,
-                                                                         nuni_out, bad);
+#define AGPL_LAUNCH_GIBBS(K)                                                                                         \
+    case K:                                                                                                          \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_sample_kernel<K>),           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+        gibbs_project_sample_kernel<K><<<(unsigned)nb, 256, lds, ctx->stream>>>(                                     \
+            ld, N, M, Phi, kdiag, mu0, y, v, ctx->seed, sweep, gamma, beta, f_out, omega_out, n_out, nuni_out, bad); \
+        break;
+    switch (ld.kind) {
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_BERNOULLI_LOGISTIC)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_NEGBINOMIAL)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_STUDENTT)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_CATEGORICAL)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_CATEGORICAL_BIJ)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_POISSON)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_LAPLACE)
+        AGPL_LAUNCH_GIBBS(AGPL_LIK_HETEROGAUSS)
+    default:
+        break;
+    }
+#undef AGPL_LAUNCH_GIBBS
     AGPL_LAUNCH_CHECK(ctx);
     return agpl_timing_end(ctx, 2);
 }

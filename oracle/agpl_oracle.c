@@ -1170,8 +1170,8 @@ AGPLO_API void agplo_se_kernel_f32(int64_t n, int M, const double *x, const doub
 /*   f_il = mu0_il + phi_i' v_l + sqrt(kdiag_i) eps_il ; Omega_i ~ aux_full_conditional ;        */
 /*   beta, gamma = auglik_potential / auglik_precision (rounded to float32 as the device feeds    */
 /*   them to the accumulation).  The float64 summation order of phi_i' v_l is the device's:       */
-/*   64 partial sums (partial j takes features 4j.., 4j+256.., each float4 in order) combined by  */
-/*   an xor butterfly 32,16,...,1.                                                               */
+/*   16 partial sums (partial q takes features 4q.., 4q+64.., each float4 in order) combined by   */
+/*   an xor butterfly 8,4,2,1.                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 AGPLO_API void agplo_randn_many(uint64_t seed, uint64_t stream0, uint32_t sweep, int64_t n, double *out) {
     for (int64_t i = 0; i < n; ++i) {
@@ -1182,19 +1182,20 @@ AGPLO_API void agplo_randn_many(uint64_t seed, uint64_t stream0, uint32_t sweep,
 }
 
 static double project_device_order(const float *row, const double *vl, int M) {
-    double part[64], tmp[64];
-    for (int j = 0; j < 64; ++j) {
+    /* 16 partial sums: partial q takes features 4q.., 4q+64.., each float4 in order; xor butterfly 8,4,2,1 */
+    double part[16], tmp[16];
+    for (int q = 0; q < 16; ++q) {
         double acc = 0.0;
-        for (int a = j << 2; a < M; a += 256) {
+        for (int a = q << 2; a < M; a += 64) {
             acc += (double)row[a] * vl[a];
             acc += (double)row[a + 1] * vl[a + 1];
             acc += (double)row[a + 2] * vl[a + 2];
             acc += (double)row[a + 3] * vl[a + 3];
         }
-        part[j] = acc;
+        part[q] = acc;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        for (int j = 0; j < 64; ++j) tmp[j] = part[j] + part[j ^ off];
+    for (int off = 8; off > 0; off >>= 1) {
+        for (int q = 0; q < 16; ++q) tmp[q] = part[q] + part[q ^ off];
         memcpy(part, tmp, sizeof(part));
     }
     return part[0];
