@@ -25,7 +25,7 @@ from .operators import (AuxPosterior, Context, TupleVector, aug_loglik_unsupport
                         expected_auglik_potential_and_precision, expected_auglik_precision, expected_logtilt,
                         init_aux_posterior, init_aux_variables, logtilt, rand_polyagamma)
 from . import sparse
-from .sparse import (SparseCAVI, SparseGibbs, exchange_natural_parameters, se_features, shard_range, synth_xy,
+from .sparse import (DenseGibbs, SparseCAVI, SparseGibbs, exchange_natural_parameters, se_features, shard_range, synth_xy,
                      whiten_features)
 
 __all__ = [
@@ -37,6 +37,6 @@ __all__ = [
     "auglik_potential", "auglik_precision", "auglik_potential_and_precision",
     "expected_auglik_potential", "expected_auglik_precision", "expected_auglik_potential_and_precision",
     "logtilt", "expected_logtilt", "aux_kldivergence", "rand_polyagamma",
-    "SparseCAVI", "SparseGibbs", "se_features", "whiten_features", "synth_xy", "shard_range",
+    "SparseCAVI", "SparseGibbs", "DenseGibbs", "se_features", "whiten_features", "synth_xy", "shard_range",
     "exchange_natural_parameters",
 ]

@@ -30,7 +30,7 @@ __device__ inline void sample_point(const agpl_lik_dev &lik, Philox &g, int64_t 
     const int L = lik.nlatent;
     switch (KIND) { // compile-time: each kernel instantiation carries one likelihood's sampler only
     case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
-        om[0] = rand_pg(g, 1.0, fabs(f[0]), nt);
+        om[0] = rand_pg_int(g, 1, fabs(f[0]), nt);
         break;
     case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
         const int32_t *y = (const int32_t *)yv;

@@ -243,6 +243,17 @@ __device__ inline double rand_pg(Philox &g, double b, double c, uint32_t &nterms
     return acc + rand_gamma_sum(g, c, res);
 }
 
+// draw_sum(rng, PolyaGamma{<:Integer}) polyagamma.jl:129-134 for a compile-time-integer b (Bernoulli: b = 1):
+// identical draws to rand_pg(g, b, c, .) without carrying the non-integer Gamma-series code.
+__device__ inline double rand_pg_int(Philox &g, int b, double c, uint32_t &nterms) {
+    if (!(fabs(c) < __builtin_inf())) return __builtin_nan("");
+    Pg1Params p;
+    p.set(c);
+    double acc = 0.0;
+    for (int i = 0; i < b; ++i) acc += sample_pg1(g, p, nterms);
+    return acc;
+}
+
 __device__ inline int64_t rand_poisson(Philox &g, double mu) {
     if (!(mu > 0.0)) return 0;
     if (mu < 6.0) {

@@ -103,6 +103,13 @@ int32_t get_handle(agpl_ctx *ctx, rocblas_handle *h) {
 
 } // namespace
 
+int32_t agpl_get_rocblas(agpl_ctx *ctx, void **handle_out) {
+    rocblas_handle h;
+    int32_t rc = get_handle(ctx, &h);
+    *handle_out = h;
+    return rc;
+}
+
 extern "C" void agpl_update_release(agpl_ctx *ctx) {
     if (ctx && ctx->rocblas) {
         rocblas_destroy_handle((rocblas_handle)ctx->rocblas);

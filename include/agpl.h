@@ -205,6 +205,19 @@ AGPL_API int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_
 AGPL_API int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                    const double *eta0, uint32_t sweep, double *v_out, double *m_out);
 
+/* ---- the full-rank Gibbs step the reference executes (gibbs_sample, examples/bernoulli/script.jl:76-87) ---
+ * agpl_dense_cholesky: L_out = lower Cholesky factor of the symmetric N x N matrix A (float64, rocSOLVER potrf;
+ *   the `_chol_cov(fz)` of script.jl:77).  Stored in the triangle that LAPACK calls lower for a column-major
+ *   array (= the upper triangle of a row-major view); the other triangle keeps A.  PosDefException -> -5.
+ * agpl_dense_gibbs_step: Omega <- aux_sample!(lik, y, f) (:81); f ~ N(mu, Sigma) with
+ *   Sigma = (K^-1 + Diag(gamma))^-1, mu = Sigma (beta + K^-1 mu0) (:82-84), evaluated with one Cholesky of
+ *   B = I + D^1/2 K D^1/2 (written to B_work, N x N float64) and no inverse -- an exact draw (Matheron's rule).
+ *   Normals: Philox streams (seed, 0..2N-1, sweep | 2^31).  Single-latent likelihoods.  f_inout: f in, new f out. */
+AGPL_API int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A, double *L_out);
+AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, const double *K,
+                                       const double *Lk, const double *mu0, const void *y, double *f_inout,
+                                       double *B_work, uint32_t sweep, double *omega_out, int64_t *n_out);
+
 /* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
  * pair is recorded on the context's stream around every launch of the marginal (which = 0), the
  * accumulation (which = 1), the Gibbs per-point (which = 2) and the aux_sample (which = 3) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel

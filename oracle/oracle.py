@@ -405,6 +405,35 @@ def gibbs_draw_v(G, g, seed, sweep, eta0=None):
     return v, m
 
 
+def dense_gibbs_step(lik: Lik, K, Lk, y, f, seed, sweep, mu0=None):
+    """One full-rank Gibbs step (examples/bernoulli/script.jl:81-84) with the device's evaluation order:
+    B = I + D^1/2 K D^1/2, f = f0 + K D^1/2 B^-1 (beta / sqrt(gamma) - sqrt(gamma) f0 - z2), f0 = mu0 + L_K z1;
+    z from Philox streams (seed, 0..2N-1, sweep | 2^31).  numpy/LAPACK float64.  Returns (f_new, draw dict)."""
+    import scipy.linalg as sla
+
+    K = np.asarray(K, dtype=np.float64)
+    N = K.shape[0]
+    d = aux_sample(lik, y, f, seed=seed, sweep=sweep)
+    beta, gamma = potential_precision(lik, y, d["omega"], d.get("n"))
+    beta, gamma = beta[0], gamma[0]
+    z = randn(seed, 0, (sweep | 0x80000000) & 0xFFFFFFFF, 2 * N)
+    f0 = Lk @ z[:N] + (0.0 if mu0 is None else mu0)
+    sg = np.sqrt(gamma)
+    r = beta / sg - sg * f0 - z[N:]
+    B = np.eye(N) + sg[:, None] * K * sg[None, :]
+    s = sla.cho_solve(sla.cho_factor(B, lower=True), r)
+    return f0 + K @ (sg * s), d
+
+
+def dense_conditional(K, beta, gamma, mu0=None):
+    """The reference's literal formulas (examples/bernoulli/script.jl:82-83): Sigma = inv(inv(K) + Diag(gamma)),
+    mu = Sigma (beta + K \\ mu0)."""
+    K = np.asarray(K, dtype=np.float64)
+    Sigma = np.linalg.inv(np.linalg.inv(K) + np.diag(gamma))
+    rhs = beta + (0.0 if mu0 is None else np.linalg.solve(K, mu0))
+    return Sigma @ rhs, (Sigma + Sigma.T) / 2
+
+
 # ---------------------------------------------------------------- synthetic workload
 def synth_x(seed, i0, n):
     x = np.empty(n)

@@ -536,3 +536,29 @@ def test_sparse_gibbs_chain_matches_oracle_and_mixes(A, ctx, oracle):
     m = host(cavi.m)[0, :M]
     sd = chain.std(0) / np.sqrt(20)  # generous effective-sample-size allowance
     assert np.all(np.abs(chain.mean(0) - m) < 6 * sd + 0.05)
+
+
+# ------------------------------------------------------------------------------------------ full-rank Gibbs (C5)
+@pytest.mark.parametrize("name", ["studentt", "bernoulli", "negbin"])
+def test_dense_gibbs_step_matches_oracle(A, ctx, oracle, name):
+    """BASELINE config C5 at a size the oracle solves in seconds: StudentT (and the PG families) full-rank Gibbs,
+    3 steps of the device chain against the numpy chain on the same Philox streams."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    N = 700
+    rng = np.random.default_rng(31)
+    x = np.sort(rng.uniform(-10, 10, size=N))
+    K = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 2.0) ** 2) + 1e-6 * np.eye(N)  # script.jl:15, lf 1e-6 :18
+    y = gen_y(O, olik, N, rng)
+    dctx = A.Context(0, seed=4242)
+    dg = A.DenseGibbs(lik, dev(K), dev(y), ctx=dctx)
+    Lk = np.linalg.cholesky(K)
+    # the factor sits in the LAPACK-lower triangle of the column-major view = upper triangle of the torch tensor
+    assert np.allclose(np.triu(host(dg.Lk)).T, Lk, rtol=1e-6, atol=1e-9)  # cond(K) ~ 1e6 with the 1e-6 jitter
+    f = np.zeros(N)
+    for sweep in range(3):
+        dg.sweep()
+        f, d = O.dense_gibbs_step(olik, K, Lk, y, f, seed=4242, sweep=sweep)
+        assert np.allclose(host(dg.omega), d["omega"], rtol=1e-6)
+        # f passes through a solve with cond(B) ~ 1e3..1e5
+        assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max())

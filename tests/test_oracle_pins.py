@@ -343,3 +343,30 @@ def test_sparse_update_equals_dense_reference_update(oracle):
     Sv, mv = O.gaussian_update(G[None], g[None])
     assert np.allclose(Lc @ Sv[0] @ Lc.T, S_ref, rtol=1e-6, atol=1e-9)
     assert np.allclose(Lc @ mv[0], m_ref, rtol=1e-6, atol=1e-9)
+
+
+def test_dense_gibbs_step_is_an_exact_draw_from_the_reference_conditional(oracle):
+    """The inverse-free step used on the device (Matheron's rule through B = I + D^1/2 K D^1/2) samples
+    N(mu, Sigma) with the reference's mu, Sigma (examples/bernoulli/script.jl:82-84): for a fixed Omega the map
+    z -> f is affine, so its mean and covariance are checked exactly (no Monte-Carlo)."""
+    O = oracle
+    rng = np.random.default_rng(5)
+    n = 12
+    x = np.linspace(-3, 3, n)
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2) + 1e-6 * np.eye(n)
+    Lk = np.linalg.cholesky(K)
+    gamma = rng.uniform(0.1, 2.0, size=n)
+    beta = rng.normal(size=n)
+    mu0 = rng.normal(size=n) * 0.3
+    sg = np.sqrt(gamma)
+    B = np.eye(n) + sg[:, None] * K * sg[None, :]
+    Binv = np.linalg.inv(B)
+    # f = f0 + K D^1/2 B^-1 (beta/sg - sg f0 - z2),  f0 = mu0 + Lk z1  => affine in (z1, z2)
+    A0 = K @ (sg[:, None] * Binv)
+    J1 = (np.eye(n) - A0 * sg[None, :]) @ Lk
+    J2 = -A0
+    mean = (np.eye(n) - A0 * sg[None, :]) @ mu0 + A0 @ (beta / sg)
+    cov = J1 @ J1.T + J2 @ J2.T
+    mu_ref, Sigma_ref = O.dense_conditional(K, beta, gamma, mu0)
+    assert np.allclose(mean, mu_ref, rtol=1e-7, atol=1e-9)
+    assert np.allclose(cov, Sigma_ref, rtol=1e-6, atol=1e-9)
