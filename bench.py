@@ -154,9 +154,20 @@ def main():
                     "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None})
     dom = 0 if kt[0][0] >= kt[1][0] else 1
     achieved = per[dom]["algorithmic_tflops"]
+    # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
+    # the committed summary is attached when it was collected on exactly this configuration, else null.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as fh:
+            pm = json.load(fh)
+        if pm["config"] == {"lik": args.lik, "N": N, "M": M, "L": L} and world == 1:
+            traffic = pm["kernels"][names[dom]]["traffic_bytes"]
+    except Exception:
+        traffic = None
     roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
-                "traffic": None, "kernels": per,
+                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic_c2.json" if traffic else None,
+                "kernels": per,
                 "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
 
     out = {
