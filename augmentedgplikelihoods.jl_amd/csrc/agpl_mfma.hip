@@ -257,6 +257,10 @@ __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npai
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
     const int bj = p - bi * (bi + 1) / 2;
     const bool diag = (bi == bj);
+    // On a diagonal tile the upper 64 x 64 wave tile is the transpose of the lower one and is never read by the
+    // reduction (it mirrors from the lower triangle): that wave stages and synchronises but issues no MFMA, which
+    // frees its SIMD's matrix pipe for the other resident workgroups.
+    const bool active = !(diag && wr < wc);
 
     const int64_t nbeg = (int64_t)s * kChunk;
     int64_t nend = nbeg + kChunk;
@@ -319,15 +323,17 @@ __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npai
         const float *pa = A + lk * BS + wr * 64 + li;
         const float *pb = B + lk * BS + wc * 64 + li;
         const float *pg = sgb + buf * 2 * KT + lk;
+        if (active) { // wave-uniform: the (wr < wc) wave of a diagonal tile would only recompute the mirror image
 #pragma unroll
-        for (int k0 = 0; k0 < KT; k0 += 2) {
-            float ga = pg[k0];
-            float a0 = pa[k0 * BS] * ga, a1 = pa[k0 * BS + 32] * ga;
-            float b0 = pb[k0 * BS], b1 = pb[k0 * BS + 32];
-            acc[0][0] = mfma(a0, b0, acc[0][0]);
-            acc[0][1] = mfma(a0, b1, acc[0][1]);
-            acc[1][0] = mfma(a1, b0, acc[1][0]);
-            acc[1][1] = mfma(a1, b1, acc[1][1]);
+            for (int k0 = 0; k0 < KT; k0 += 2) {
+                float ga = pg[k0];
+                float a0 = pa[k0 * BS] * ga, a1 = pa[k0 * BS + 32] * ga;
+                float b0 = pb[k0 * BS], b1 = pb[k0 * BS + 32];
+                acc[0][0] = mfma(a0, b0, acc[0][0]);
+                acc[0][1] = mfma(a0, b1, acc[0][1]);
+                acc[1][0] = mfma(a1, b0, acc[1][0]);
+                acc[1][1] = mfma(a1, b1, acc[1][1]);
+            }
         }
         if (diag) { // g = Phi beta for the rows of this diagonal block (wave-uniform branch)
             const float *ga = A + (tid >> 7) * 8 * BS + (tid & 127);

@@ -132,13 +132,12 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-
-    if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.destroy_process_group()
-        return
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        # the single-GPU extra legs (Gibbs, parity slice, CPU baseline) are reported at N = 1 only
+        args.no_gibbs = args.no_cpu = args.no_parity = True
 
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
@@ -146,12 +145,18 @@ def main():
     # ---- roofline of the dominant kernel (hipEvents inside libagpl.so around each launch) --------------------
     # algorithmic flops per launch: marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)
     flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
+    # flops the kernels actually execute (padded M, 128-row blocks): the marginal pass visits block pairs cb >= rb
+    # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
+    nbk = Mp // 128
+    executed = ((1.0 + 1.0 / nbk) * L * n_loc * Mp * Mp, (nbk + 1.0) / nbk * L * n_loc * Mp * Mp)
     names = ("marginal_kernel<0>", "syrk_kernel")
     per = []
-    for (ms, cnt), fl, nm in zip(kt, flops, names):
+    for (ms, cnt), fl, ex, nm in zip(kt, flops, executed, names):
         avg = ms / max(cnt, 1)
         per.append({"kernel": nm, "avg_ms": round(avg, 4), "launches": cnt,
-                    "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None})
+                    "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
+                    "executed_tflops": round(ex / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
+                    "executed_frac_of_peak": round(ex / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg > 0 else None})
     dom = 0 if kt[0][0] >= kt[1][0] else 1
     achieved = per[dom]["algorithmic_tflops"]
     # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
