@@ -50,8 +50,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=10_000_000, help="total observations (sharded over ranks)")
-    ap.add_argument("--m", type=int, default=512, help="inducing points")
+    # (--points / --inducing: spellings that torch.distributed.run does not mistake for its own --n*/--m* options)
+    ap.add_argument("--n", "--points", dest="n", type=int, default=10_000_000,
+                    help="total observations (sharded over ranks)")
+    ap.add_argument("--m", "--inducing", dest="m", type=int, default=512, help="inducing points")
     ap.add_argument("--lik", default="bernoulli")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="points of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -66,13 +68,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # AGPL_BENCH_SINGLE_DEVICE=1 is a test hook for 1-GPU boxes: every rank uses cuda:0 and the exchange goes over
+    # gloo, so that the multi-rank code path (sharding, all-reduce, max-over-ranks timing, teardown) can be run
+    # where RCCL would refuse two ranks on one device.  Never set by the driver.
+    single_dev = os.environ.get("AGPL_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if single_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
 
     import agpl_amd as A
