@@ -1002,8 +1002,8 @@ AGPLO_API int agplo_cavi_pass(const agplo_lik *lik, int64_t N, int M, const floa
         double *phi = (double *)malloc(sizeof(double) * M);
         double *mu = (double *)malloc(sizeof(double) * L * 2);
         double *var = mu + L;
-        double *q1 = (double *)malloc(sizeof(double) * L * 4);
-        double *q2 = q1 + L, *bt = q1 + 2 * L, *gm = q1 + 3 * L;
+        double *q1 = (double *)malloc(sizeof(double) * L * 5);
+        double *q2 = q1 + L, *bt = q1 + 2 * L, *gm = q1 + 3 * L, *q3 = q1 + 4 * L;
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < N; ++i) {
             const float *pf = Phi + i * (int64_t)M;
@@ -1032,8 +1032,8 @@ AGPLO_API int agplo_cavi_pass(const agplo_lik *lik, int64_t N, int M, const floa
             case LIK_CATEGORICAL_BIJ: yi = (const uint8_t *)yv + i * L; break;
             default: yi = (const double *)yv + i; break;
             }
-            agplo_aux_posterior(lik, 1, yi, mu, var, q1, q2, NULL);
-            agplo_expected_potential_precision(lik, 1, yi, q1, q2, NULL, bt, gm);
+            agplo_aux_posterior(lik, 1, yi, mu, var, q1, q2, q3);
+            agplo_expected_potential_precision(lik, 1, yi, q1, q2, L > 1 ? mu + 1 : NULL, bt, gm);
             for (int l = 0; l < L; ++l) {
                 if (mu_out) mu_out[i * L + l] = mu[l];
                 if (var_out) var_out[i * L + l] = var[l];

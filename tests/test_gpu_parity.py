@@ -372,13 +372,23 @@ def _setup_svgp(A, ctx, O, lik, olik, N, M, ell_factor=1.5):
 
 
 @pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("studentt", 5_000, 64),
-                                      ("cat", 4_000, 64), ("catbij", 3_000, 64)])
+                                      ("cat", 4_000, 64), ("catbij", 3_000, 64), ("poisson", 4_000, 64),
+                                      ("laplace", 4_000, 64), ("hetero", 3_000, 64)])
 def test_cavi_natural_parameters_match_oracle(A, ctx, oracle, name, N, M):
     """BASELINE config C1 (Bernoulli, N = 10 000, M = 64, 10 CAVI sweeps) and its siblings: after 10 sweeps the
     posterior natural parameters agree with the float64 oracle to 1e-5 (relative to max|ref| per array)."""
     O = oracle
     lik, olik = lik_pairs(A, O)[name]
-    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
+    if name in ("poisson", "laplace", "hetero"):  # no synthetic generator for these: seeded numpy data
+        _, _, Phi, kd = _setup_svgp(A, ctx, O, A.BernoulliLikelihood(), O.bernoulli(), N, M)
+        rng = np.random.default_rng(41)
+        xs = host(A.synth_xy(A.BernoulliLikelihood(), SEED, 0, N, ctx=ctx)[0])
+        fs = 2 * np.sin(0.7 * xs) + np.cos(0.23 * xs)
+        yh = rng.poisson(10.0 / (1 + np.exp(-fs))).astype(np.int32) if name == "poisson" else (
+            fs + rng.laplace(scale=1.3, size=N) if name == "laplace" else fs + rng.normal(size=N) * 0.5)
+        y = dev(yh) if name == "poisson" else dev(yh, torch.float32)
+    else:
+        x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, keep_points=True)
     Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
     Mp, L = Phi_h.shape[1], olik.nlatent
@@ -393,7 +403,7 @@ def test_cavi_natural_parameters_match_oracle(A, ctx, oracle, name, N, M):
             assert relmax(host(cavi.g), g) < NAT_TOL
             # per-point float32 expectations (not a natural parameter): looser, informational bound
             assert relmax(host(cavi.gamma), pts["gamma"]) < 1e-4
-            assert np.allclose(host(cavi.beta), pts["beta"], rtol=1e-4, atol=1e-5)
+            assert relmax(host(cavi.beta), pts["beta"]) < 1e-4
     Lam, eta = cavi.natural_parameters()
     assert relmax(host(Lam), np.eye(Mp) + G) < NAT_TOL
     assert relmax(host(eta), g) < NAT_TOL
