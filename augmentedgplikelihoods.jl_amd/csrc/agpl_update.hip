@@ -126,9 +126,45 @@ extern "C" int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                        const double *eta0, double *S_out, double *m_out, float *Wpack_out,
-                                        float *alpha_out) {
+namespace {
+// logdet[l] = 2 sum_i log C_ii of the Cholesky factor (read between potrf and potri), fixed-order tree
+__global__ __launch_bounds__(256) void logdet_kernel(int M, const double *__restrict__ A, double *__restrict__ out) {
+    __shared__ double sm[256];
+    const int l = blockIdx.x;
+    const double *Al = A + (int64_t)l * M * M;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) acc += log(Al[(int64_t)i * M + i]);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[l] = 2.0 * sm[0];
+}
+// KL(N(m, S) || N(0, I)) = (tr S + m'm - M + logdet(I + G)) / 2 per latent
+__global__ __launch_bounds__(256) void gauss_kl_kernel(int M, const double *__restrict__ S, const double *__restrict__ m,
+                                                       const double *__restrict__ logdet, double *__restrict__ out) {
+    __shared__ double sm[256];
+    const int l = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        const double mi = m[(int64_t)l * M + i];
+        acc += S[((int64_t)l * M + i) * M + i] + mi * mi;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[l] = 0.5 * (sm[0] - (double)M + logdet[l]);
+}
+} // namespace
+
+static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                    const double *eta0, double *S_out, double *m_out, float *Wpack_out,
+                                    float *alpha_out, double *logdet_dev) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || !G || !g) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     rocblas_handle h;
@@ -147,6 +183,10 @@ extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, con
     AGPL_LAUNCH_CHECK(ctx);
     const rocblas_stride stride = (rocblas_stride)M * M;
     AGPL_ROCBLAS(ctx, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, M, A, M, stride, info, L));
+    if (logdet_dev) {
+        logdet_kernel<<<(unsigned)L, 256, 0, ctx->stream>>>(M, A, logdet_dev);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
     AGPL_ROCBLAS(ctx, rocsolver_dpotri_strided_batched(h, rocblas_fill_lower, M, A, M, stride, info + L, L));
     symmetrize_kernel<<<grid, 128, 0, ctx->stream>>>(M, A);
     AGPL_LAUNCH_CHECK(ctx);
@@ -168,6 +208,35 @@ extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, con
         if (hinfo[i] != 0)
             AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, %s info = %d)", i % L,
                       i < L ? "potrf" : "potri", (int)hinfo[i]);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                        const double *eta0, double *S_out, double *m_out, float *Wpack_out,
+                                        float *alpha_out) {
+    return gaussian_update_impl(ctx, M, L, G, g, eta0, S_out, m_out, Wpack_out, alpha_out, nullptr);
+}
+
+extern "C" int32_t agpl_gaussian_kl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                    const double *eta0, double *kl_out_host) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || L <= 0 || L > 64 || !G || !g || !kl_out_host) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    // scratch in the large workspace: S [L,M,M] | m [L,M] | logdet [L] | kl [L]
+    const size_t mat = sizeof(double) * (size_t)L * M * M, vec = sizeof(double) * (size_t)L * M;
+    int32_t rc = agpl_ws_reserve(ctx, mat + vec + 4096);
+    if (rc) return rc;
+    double *S = (double *)ctx->ws, *m = (double *)((char *)ctx->ws + mat);
+    double *ld = (double *)((char *)ctx->ws + mat + vec), *kl = ld + 64;
+    rc = gaussian_update_impl(ctx, M, L, G, g, eta0, S, m, nullptr, nullptr, ld);
+    if (rc) return rc;
+    gauss_kl_kernel<<<(unsigned)L, 256, 0, ctx->stream>>>(M, S, m, ld, kl);
+    AGPL_LAUNCH_CHECK(ctx);
+    double h[64];
+    AGPL_HIP(ctx, hipMemcpyAsync(h, kl, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int l = 0; l < L; ++l) tot += h[l];
+    *kl_out_host = tot;
     return AGPL_OK;
 }
 

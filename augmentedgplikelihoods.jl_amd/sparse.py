@@ -166,6 +166,28 @@ class SparseCAVI:
             self.sweep()
         return self.m, self.S
 
+    def elbo(self):
+        """aug_elbo of examples/bernoulli/script.jl:65-70 for the current q(v):
+        expected_logtilt(lik, qΩ, y, qf) - aux_kldivergence(lik, qΩ, y) - KL(q(v) || p(v)), with qf the current
+        marginals and qΩ = aux_posterior(lik, y, qf) (float64 operator kernels + agpl_gaussian_kl).  Local points
+        only: with N sharded, sum the first two terms over ranks and count the KL once."""
+        from . import operators as ops
+
+        torch = _torch()
+        mu, var = self.marginals()  # [L][N] float32
+        if self.L == 1:
+            qf = (mu[0].to(torch.float64), var[0].to(torch.float64))
+        else:
+            qf = (mu.t().contiguous().to(torch.float64), var.t().contiguous().to(torch.float64))
+        y = self.y.to(torch.float64) if self.lik.ykind == "real" else self.y
+        qΩ = ops.aux_posterior(self.lik, y, qf, ctx=self.ctx)
+        elt = ops.expected_logtilt(self.lik, qΩ, y, qf, ctx=self.ctx)
+        kl_aux = ops.aux_kldivergence(self.lik, qΩ, y, ctx=self.ctx)
+        kl = C.c_double()
+        self.ctx.call("agpl_gaussian_kl", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
+                      C.c_void_p(0), C.byref(kl))
+        return elt - kl_aux - kl.value
+
     def natural_parameters(self):
         """(Lambda_v, eta_v) = (I + G, g): the whitened natural parameters of q(v)."""
         torch = _torch()

@@ -173,6 +173,13 @@ AGPL_API int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const
                              const double *eta0, double *S_out, double *m_out, float *Wpack_out,
                              float *alpha_out);
 
+/* agpl_gaussian_kl: sum over latents of KL(q(v_l) || p(v_l)) = (tr S + m'm - M + logdet(I + G)) / 2 for the
+ *   q(v) that agpl_gaussian_update would produce from (G, g, eta0): the `kldivergence(u_post.approx.q,
+ *   u_post.approx.fz)` term of aug_elbo (examples/bernoulli/script.jl:65-70) in the whitened basis, where the
+ *   prior is N(0, I).  float64, synchronous, result to host.                                               */
+AGPL_API int32_t agpl_gaussian_kl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                  const double *eta0, double *kl_out_host);
+
 /* agpl_pack_w: Wpack (float32, packed as above) from a symmetric float64 W [L,M,M] scaled by `scale`. */
 AGPL_API int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
                     float *Wpack_out);

@@ -572,3 +572,28 @@ def test_dense_gibbs_step_matches_oracle(A, ctx, oracle, name):
         assert np.allclose(host(dg.omega), d["omega"], rtol=1e-6)
         # f passes through a solve with cond(B) ~ 1e3..1e5
         assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max())
+
+
+def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
+    """aug_elbo (examples/bernoulli/script.jl:65-70) on the device against the float64 oracle evaluation, and the
+    CAVI property the reference's commented-out test was after: the ELBO does not decrease across sweeps."""
+    O = oracle
+    lik, olik = A.BernoulliLikelihood(), O.bernoulli()
+    N, M = 6000, 64
+    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
+    Mp = Phi_h.shape[1]
+    vals = []
+    for it in range(6):
+        cavi.sweep()
+        vals.append(cavi.elbo())
+    assert all(b >= a - 1e-6 * abs(a) for a, b in zip(vals, vals[1:])), vals
+    # oracle ELBO for the device's current q(v)
+    S, m, G = host(cavi.S), host(cavi.m), host(cavi.G)
+    _, _, pts = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m, want_points=True)
+    mu, var = pts["mu"][:, 0], pts["var"][:, 0]
+    c, _, _ = O.aux_posterior(olik, y_h, mu, var)
+    kl_v = 0.5 * (np.trace(S[0]) + m[0] @ m[0] - Mp + np.linalg.slogdet(np.eye(Mp) + G[0])[1])
+    ref = O.expected_logtilt(olik, y_h, c, None, mu, var) - O.aux_kl(olik, y_h, c) - kl_v
+    assert vals[-1] == pytest.approx(ref, rel=2e-6)
