@@ -21,7 +21,8 @@ SYMBOLS = [
     "agpl_potential_precision", "agpl_aux_posterior", "agpl_expected_potential_precision", "agpl_logtilt",
     "agpl_expected_logtilt", "agpl_aux_kldivergence", "agpl_marginals", "agpl_accumulate",
     "agpl_gaussian_update", "agpl_pack_w", "agpl_cavi_pass", "agpl_workspace_bytes", "agpl_se_features",
-    "agpl_transform_features", "agpl_synth_xy", "agpl_timing_enable", "agpl_timing_read", "agpl_gibbs_pass", "agpl_gibbs_draw_v", "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_gaussian_kl",
+    "agpl_transform_features", "agpl_synth_xy", "agpl_timing_enable", "agpl_timing_read", "agpl_gibbs_pass", "agpl_gibbs_draw_v", "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_gaussian_kl", "agpl_split_features_bytes", "agpl_split_features", "agpl_pack_w_split",
+    "agpl_marginals_split", "agpl_cavi_pass_split",
 ]
 
 
@@ -80,6 +81,7 @@ def lib() -> C.CDLL:
         _lib.agpl_last_error.restype = C.c_char_p
         _lib.agpl_last_error.argtypes = [C.c_void_p]
         _lib.agpl_workspace_bytes.restype = C.c_int64
+        _lib.agpl_split_features_bytes.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # raises AttributeError if the library does not export the ABI
     return _lib

@@ -1,0 +1,283 @@
+// agpl_split.hip -- the marginal pass (a11) on the fast matrix cores: every float32 operand x is carried as two
+// float16 values, x ~= hi + lo with hi = f16(x), lo = f16(x - hi) (error <= max(2^-22 |x|, 3e-8), |x| < 6e4), and
+//   W' Phi  ~=  W'hi Phihi + W'hi Philo + W'lo Phihi          (the lo*lo term, <= 2^-22 relative, is dropped)
+// runs as three v_mfma_f32_32x32x16_f16 per 32x32x16 sub-product, accumulated in float32: 16x the rate of the
+// f32-input MFMA for 3x the instructions.  Both operands of this product have the reduction index (the feature b)
+// contiguous in memory, so each is stored ONCE in a blocked image that is both the global and the LDS layout:
+//
+//   block (row-block of 128, k-slice of 16)  =  [plane h = 2][row 128][8 halves]  = 4 KB contiguous
+//   (plane h holds k = 8h .. 8h+7 of the slice: the 16 bytes one MFMA lane needs; lanes 0-31 read plane 0, lanes
+//   32-63 plane 1, each a contiguous 512 B -> conflict-free ds_read_b128; a workgroup stages a block with one
+//   coalesced 16-byte load per thread.)
+//
+//   Phi: blocks [tile][M/16], written once by agpl_split_features;  W': blocks [l][rb][M/16], written each sweep by
+//   agpl_pack_w_split (upper-triangular, doubled off-diagonal, as the f32 Wpack).
+// The Hadamard epilogue and the output are float32 (the exact float32 Phi is read for it).
+#include "agpl_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BS = 128;
+constexpr int KS = 16;  // reduction slice per stage
+constexpr int NT = 128; // points per tile
+
+__device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// Phi [N][M] float32  ->  blocked hi / lo images (zero rows past N)
+__global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, const float *__restrict__ Phi,
+                                                             h8 *__restrict__ Ph, h8 *__restrict__ Pl) {
+    const int nks = M / KS;
+    const int64_t nblk = ((N + NT - 1) / NT) * nks;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t tile = blk / nks;
+        const int ks = (int)(blk - tile * nks);
+        const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
+        const int64_t n = tile * NT + row;
+        h8 hi, lo;
+        if (n < N) {
+            const float *src = Phi + n * (int64_t)M + ks * KS + plane * 8;
+            const float4 x0 = *reinterpret_cast<const float4 *>(src), x1 = *reinterpret_cast<const float4 *>(src + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 a, b;
+                split_f16(xs[j], a, b);
+                hi[j] = a;
+                lo[j] = b;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hi[j] = lo[j] = (_Float16)0.f;
+        }
+        Ph[blk * 256 + threadIdx.x] = hi;
+        Pl[blk * 256 + threadIdx.x] = lo;
+    }
+}
+
+// W [L][M][M] float64 symmetric -> blocked hi / lo images of scale * W' (W'[a][b] = 2 W[a][b] for b > a, W[a][a], 0 below)
+__global__ __launch_bounds__(256) void pack_w_split_kernel(int M, const double *__restrict__ W, double scale,
+                                                           h8 *__restrict__ Wh, h8 *__restrict__ Wl) {
+    const int nks = M / KS, nb = M / BS;
+    const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
+    const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
+    const int a = rb * BS + row;
+    const double *Wr = W + ((int64_t)l * M + a) * M;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b = ks * KS + plane * 8 + j;
+        double v = b > a ? 2.0 * Wr[b] : (b == a ? Wr[b] : 0.0);
+        _Float16 x, y;
+        split_f16((float)(scale * v), x, y);
+        hi[j] = x;
+        lo[j] = y;
+    }
+    const int64_t blk = ((int64_t)l * nb + rb) * nks + ks;
+    Wh[blk * 256 + threadIdx.x] = hi;
+    Wl[blk * 256 + threadIdx.x] = lo;
+}
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// grid = (tiles of 128 points, L); 256 threads = 4 waves, each a 64 x 64 sub-tile (2 x 2 accumulators)
+__global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M, const float *__restrict__ Phi,
+                                                                const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
+                                                                const float *__restrict__ kdiag,
+                                                                const float *__restrict__ mu0,
+                                                                const h8 *__restrict__ Wh, const h8 *__restrict__ Wl,
+                                                                const float *__restrict__ alpha_all,
+                                                                float *__restrict__ mu_out,
+                                                                float *__restrict__ var_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    h8 *stage = reinterpret_cast<h8 *>(smem_raw);                 // [2 buf][4 operand][256]
+    float *alpha_s = reinterpret_cast<float *>(smem_raw + 2 * 4 * 4096); // M floats
+    float *qred = alpha_s + M;                                     // 2 x 128
+    float *mred = qred + 2 * NT;                                   // 2 x 128
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int l = blockIdx.y;
+    const int nb = M / BS, nks = M / KS;
+    const int64_t tile = blockIdx.x;
+    const int64_t n0 = tile * NT;
+    const h8 *Wh_l = Wh + (int64_t)l * nb * nks * 256;
+    const h8 *Wl_l = Wl + (int64_t)l * nb * nks * 256;
+    const h8 *Ph_t = Ph + tile * nks * 256;
+    const h8 *Pl_t = Pl + tile * nks * 256;
+
+    const float *alpha = alpha_all + (int64_t)l * M;
+    for (int a = tid; a < M; a += 256) alpha_s[a] = alpha[a];
+
+    const int nlim = (int)((N - 1 - n0) < (NT - 1) ? (N - 1 - n0) : (NT - 1));
+    const float *tile32 = Phi + n0 * (int64_t)M;
+    float qacc[2] = {0.f, 0.f};
+    float macc = 0.f;
+    h8 r0, r1, r2, r3;
+
+#define AGPL_SPLIT_LOAD(rb_, ks_)                                     \
+    do {                                                              \
+        const int64_t wb_ = ((int64_t)(rb_) * nks + (ks_)) * 256 + tid; \
+        const int64_t pb_ = (int64_t)(ks_) * 256 + tid;               \
+        r0 = Wh_l[wb_];                                               \
+        r1 = Wl_l[wb_];                                               \
+        r2 = Ph_t[pb_];                                               \
+        r3 = Pl_t[pb_];                                               \
+    } while (0)
+#define AGPL_SPLIT_STORE(buf_)                                        \
+    do {                                                              \
+        h8 *st_ = stage + (buf_) * 4 * 256;                           \
+        st_[tid] = r0;                                                \
+        st_[256 + tid] = r1;                                          \
+        st_[512 + tid] = r2;                                          \
+        st_[768 + tid] = r3;                                          \
+    } while (0)
+
+    for (int rb = 0; rb < nb; ++rb) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
+
+        const int ks_first = rb * (BS / KS);
+        const int nstage = nks - ks_first;
+        AGPL_SPLIT_LOAD(rb, ks_first);
+        __syncthreads(); // previous row block's readers of slot 0 are done
+        AGPL_SPLIT_STORE(0);
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nstage) AGPL_SPLIT_LOAD(rb, ks_first + s + 1);
+            const h8 *st = stage + buf * 4 * 256;
+            // fragments: plane lk, row (sub-tile base + li)
+            const int fa = lk * 128 + wr * 64 + li;
+            const int fb = lk * 128 + wc * 64 + li;
+            const h8 ah0 = st[fa], ah1 = st[fa + 32], al0 = st[256 + fa], al1 = st[256 + fa + 32];
+            const h8 bh0 = st[512 + fb], bh1 = st[512 + fb + 32], bl0 = st[768 + fb], bl1 = st[768 + fb + 32];
+            acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
+            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+            acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
+            acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
+            acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
+            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+            acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
+            acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
+            acc[0][0] = mfma16(al0, bh0, acc[0][0]);
+            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+            acc[1][0] = mfma16(al1, bh0, acc[1][0]);
+            acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+            if (rb == 0) { // mean: thread (plane = tid >> 7, point = tid & 127) owns 8 features of the slice
+                const h8 ph = st[512 + tid], pl = st[768 + tid];
+                const float *as = alpha_s + s * KS + (tid >> 7) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) macc += as[j] * ((float)ph[j] + (float)pl[j]);
+            }
+            if (s + 1 < nstage) AGPL_SPLIT_STORE(buf ^ 1);
+            __syncthreads();
+        }
+
+        // Hadamard epilogue with the exact float32 Phi: q_n += sum_{a in rb} Phi[a, n] T[a, n]
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            int nl = wc * 64 + jj * 32 + li;
+            nl = nl > nlim ? nlim : nl;
+            const float *hsrc = tile32 + nl * M + rb * BS + wr * 64 + 4 * lk;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int g2 = 0; g2 < 4; g2 += 2) {
+                    const float4 h0 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2);
+                    const float4 h1 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2 + 8);
+                    qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
+                                acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
+                    qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
+                                acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
+                }
+        }
+    }
+#undef AGPL_SPLIT_LOAD
+#undef AGPL_SPLIT_STORE
+
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) qacc[jj] += __shfl_xor(qacc[jj], 32);
+    __syncthreads();
+    if (lk == 0) {
+        qred[wr * NT + wc * 64 + li] = qacc[0];
+        qred[wr * NT + wc * 64 + 32 + li] = qacc[1];
+    }
+    mred[(tid >> 7) * NT + (tid & 127)] = macc;
+    __syncthreads();
+    if (tid < NT) {
+        const int64_t n = n0 + tid;
+        if (n < N) {
+            float q = qred[tid] + qred[NT + tid];
+            float m = mred[tid] + mred[NT + tid];
+            if (mu0) m += mu0[(int64_t)l * N + n];
+            mu_out[(int64_t)l * N + n] = m;
+            var_out[(int64_t)l * N + n] = kdiag[n] - q;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
+    if (N <= 0 || M <= 0 || M % BS) return 0;
+    return (int64_t)sizeof(_Float16) * ((N + NT - 1) / NT) * NT * M; // per image (hi and lo each)
+}
+
+extern "C" int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *Phi_hi,
+                                       void *Phi_lo) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N <= 0 || M <= 0 || M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need N > 0 and M %% 128 == 0");
+    if (!Phi || !Phi_hi || !Phi_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
+    if (nblk > 65535 * 16) nblk = 65535 * 16;
+    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, (h8 *)Phi_hi, (h8 *)Phi_lo);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_pack_w_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
+                                     void *W_hi, void *W_lo) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || M % BS || L <= 0 || !W || !W_hi || !W_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
+    pack_w_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, W, scale, (h8 *)W_hi, (h8 *)W_lo);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                                        const void *Phi_hi, const void *Phi_lo, const float *kdiag,
+                                        const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
+                                        float *mu_out, float *var_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
+    if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
+    if (N == 0) return AGPL_OK;
+    if (!Phi || !Phi_hi || !Phi_lo || !kdiag || !W_hi || !W_lo || !alpha || !mu_out || !var_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t lds = 2 * 4 * 4096 + sizeof(float) * (size_t)(M + 4 * NT);
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)agpl_cdiv(N, NT), (unsigned)L);
+    int32_t rc = agpl_timing_begin(ctx, 0);
+    if (rc) return rc;
+    marginal_split_kernel<<<grid, 256, lds, ctx->stream>>>(N, M, Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag, mu0,
+                                                           (const h8 *)W_hi, (const h8 *)W_lo, alpha, mu_out, var_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return agpl_timing_end(ctx, 0);
+}

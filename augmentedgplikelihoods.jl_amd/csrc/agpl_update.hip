@@ -370,3 +370,38 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
                       (int)hinfo[i]);
     return AGPL_OK;
 }
+
+extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                                        const void *Phi_hi, const void *Phi_lo, const float *kdiag,
+                                        const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
+                                        float *mu_out, float *var_out);
+
+extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                        const float *Phi, const void *Phi_hi, const void *Phi_lo,
+                                        const float *kdiag, const float *mu0, const void *y, const void *W_hi,
+                                        const void *W_lo, const float *alpha, double *G_out, double *g_out,
+                                        float *c_out, float *gamma_out, float *beta_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    const int L = ld.nlatent;
+    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
+    if (M % 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 128 (zero-pad the features)", M);
+    if (!Phi || !Phi_hi || !Phi_lo || !kdiag || !y || !W_hi || !W_lo || !alpha || !G_out || !g_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
+    const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
+    rc = agpl_ws_reserve(ctx, slab + 4 * vec);
+    if (rc) return rc;
+    char *base = (char *)ctx->ws;
+    float *mu = (float *)(base + slab);
+    float *var = (float *)(base + slab + vec);
+    float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
+    float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
+    rc = agpl_marginals_split(ctx, N, M, L, Phi, Phi_hi, Phi_lo, kdiag, mu0, W_hi, W_lo, alpha, mu, var);
+    if (rc) return rc;
+    rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
+    if (rc) return rc;
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+}

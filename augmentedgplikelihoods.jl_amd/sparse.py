@@ -109,7 +109,10 @@ class SparseCAVI:
     ``group``: a torch.distributed process group over which N is sharded (None = single GPU).
     """
 
-    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False):
+    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
+                 marginal_precision: str = "f32"):
+        """``marginal_precision``: "f32" = float32-input MFMA marginal pass (default); "f16x2" = the split-float16
+        pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM)."""
         torch = _torch()
         self.ctx = ctx or default_context()
         self.lik = lik
@@ -122,9 +125,20 @@ class SparseCAVI:
         self.y = _prep_y(lik, y, torch.float32)
         self.mu0 = _prep(mu0, torch.float32, "mu0")
         self.group = group
+        if marginal_precision not in ("f32", "f16x2"):
+            raise _ffi.ArgumentError(-1, "marginal_precision must be 'f32' or 'f16x2'")
+        self.split = marginal_precision == "f16x2"
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
+        if self.split:
+            nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(self.N), C.c_int32(M)) // 2
+            self.Phi_hi = torch.empty(nh, dtype=torch.float16, device=dev)
+            self.Phi_lo = torch.empty(nh, dtype=torch.float16, device=dev)
+            self.ctx.call("agpl_split_features", C.c_int64(self.N), C.c_int32(M), _ptr(self.Phi), _ptr(self.Phi_hi),
+                          _ptr(self.Phi_lo))
+            self.W_hi = torch.empty(L * M * M, dtype=torch.float16, device=dev)
+            self.W_lo = torch.empty(L * M * M, dtype=torch.float16, device=dev)
         self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
         self.g = torch.zeros((L, M), dtype=f64, device=dev)
         self.S = torch.eye(M, dtype=f64, device=dev).repeat(L, 1, 1).contiguous()  # script.jl:42
@@ -132,6 +146,7 @@ class SparseCAVI:
         self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
         self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
         self.ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), _ptr(self.S), C.c_double(-1.0), _ptr(self.Wpack))
+        self._pack_split()
         self.gamma = self.beta = self.c = None
         if keep_points:
             self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
@@ -139,9 +154,20 @@ class SparseCAVI:
             self.c = torch.empty((self.N,) if L == 1 else (self.N, L), dtype=f32, device=dev)
         self.nsweeps = 0
 
+    def _pack_split(self):
+        if self.split:
+            self.ctx.call("agpl_pack_w_split", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.S), C.c_double(-1.0),
+                          _ptr(self.W_hi), _ptr(self.W_lo))
+
     def accumulate(self):
         """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
         d = self.lik.desc()
+        if self.split:
+            self.ctx.call("agpl_cavi_pass_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
+                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y),
+                          _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g), _ptr(self.c),
+                          _ptr(self.gamma), _ptr(self.beta))
+            return
         self.ctx.call("agpl_cavi_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.Wpack), _ptr(self.alpha),
                       _ptr(self.G), _ptr(self.g), _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
@@ -154,6 +180,7 @@ class SparseCAVI:
         """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form)."""
         self.ctx.call("agpl_gaussian_update", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
                       C.c_void_p(0), _ptr(self.S), _ptr(self.m), _ptr(self.Wpack), _ptr(self.alpha))
+        self._pack_split()
 
     def sweep(self):
         self.accumulate()

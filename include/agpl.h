@@ -232,6 +232,32 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
 AGPL_API int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on);
 AGPL_API int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host);
 
+/* ---- split-float16 marginal pass (agpl_split.hip): the same a11 computation on the fast matrix cores ----------
+ * Every float32 operand x is carried as hi = f16(x), lo = f16(x - hi); W' Phi ~= hi*hi + hi*lo + lo*hi runs as
+ * three v_mfma_f32_32x32x16_f16 per sub-product with float32 accumulation (representation error
+ * <= max(2^-22 |x|, 3e-8) per operand, |x| < 6e4).  Operands live in blocked images (4 KB blocks of
+ * [2 planes][128 rows][8 halves], one per (row block, 16-wide k-slice)) that are both the HBM and the LDS layout.
+ *   agpl_split_features_bytes: bytes of ONE image (hi or lo) for N points, M features.
+ *   agpl_split_features: Phi (float32 [M,N] col-major) -> Phi_hi, Phi_lo images (once per data set).
+ *   agpl_pack_w_split:   scale * W' (W symmetric float64 [L,M,M]) -> W_hi, W_lo images, L*M*M halves each
+ *                        (each sweep, after agpl_gaussian_update: W = S, scale = -1).
+ *   agpl_marginals_split / agpl_cavi_pass_split: drop-in twins of agpl_marginals / agpl_cavi_pass taking the
+ *                        images (the float32 Phi is still read by the Hadamard epilogue and the accumulation). */
+AGPL_API int64_t agpl_split_features_bytes(int64_t N, int32_t M);
+AGPL_API int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *Phi_hi,
+                                     void *Phi_lo);
+AGPL_API int32_t agpl_pack_w_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
+                                   void *W_hi, void *W_lo);
+AGPL_API int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                                      const void *Phi_hi, const void *Phi_lo, const float *kdiag,
+                                      const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
+                                      float *mu_out, float *var_out);
+AGPL_API int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                      const float *Phi, const void *Phi_hi, const void *Phi_lo,
+                                      const float *kdiag, const float *mu0, const void *y, const void *W_hi,
+                                      const void *W_lo, const float *alpha, double *G_out, double *g_out,
+                                      float *c_out, float *gamma_out, float *beta_out);
+
 /* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
 AGPL_API int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L);
 

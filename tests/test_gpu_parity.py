@@ -597,3 +597,71 @@ def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
     kl_v = 0.5 * (np.trace(S[0]) + m[0] @ m[0] - Mp + np.linalg.slogdet(np.eye(Mp) + G[0])[1])
     ref = O.expected_logtilt(olik, y_h, c, None, mu, var) - O.aux_kl(olik, y_h, c) - kl_v
     assert vals[-1] == pytest.approx(ref, rel=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ split-float16 marginals
+@pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (257, 384, 2), (129, 512, 1)])
+def test_split_f16_marginals_against_float64(A, ctx, N, M, L):
+    """agpl_marginals_split (3 float16 MFMA products per float32 product) against float64 numpy on the same
+    float32 inputs: the split representation keeps ~22 bits, so the bound is the float32 kernel's."""
+    import ctypes as C
+
+    rng = np.random.default_rng(N + 7 * M)
+    Phi = _features(rng, N, M)
+    Phi[::7] *= 1e-3  # small magnitudes exercise the float16 subnormal range of the lo parts
+    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
+    S = np.linalg.inv(np.eye(M) + B @ B.transpose(0, 2, 1) * 20.0)  # a posterior-like SPD matrix, entries <= 1
+    alpha = rng.normal(size=(L, M))
+    kd = rng.uniform(0.0, 0.5, size=N)
+    from agpl_amd import _ffi
+
+    nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(N), C.c_int32(M)) // 2
+    dPhi, dS, dal, dkd = dev(Phi), dev(S), dev(alpha, torch.float32), dev(kd, torch.float32)
+    Ph = torch.empty(nh, dtype=torch.float16, device="cuda")
+    Pl = torch.empty(nh, dtype=torch.float16, device="cuda")
+    Wh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+    Wl = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+    ctx.call("agpl_split_features", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()), C.c_void_p(Ph.data_ptr()),
+             C.c_void_p(Pl.data_ptr()))
+    ctx.call("agpl_pack_w_split", C.c_int32(M), C.c_int32(L), C.c_void_p(dS.data_ptr()), C.c_double(-1.0),
+             C.c_void_p(Wh.data_ptr()), C.c_void_p(Wl.data_ptr()))
+    mu = torch.empty((L, N), dtype=torch.float32, device="cuda")
+    var = torch.empty_like(mu)
+    ctx.call("agpl_marginals_split", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
+             C.c_void_p(Ph.data_ptr()), C.c_void_p(Pl.data_ptr()), C.c_void_p(dkd.data_ptr()), C.c_void_p(0),
+             C.c_void_p(Wh.data_ptr()), C.c_void_p(Wl.data_ptr()), C.c_void_p(dal.data_ptr()), C.c_void_p(mu.data_ptr()),
+             C.c_void_p(var.data_ptr()))
+    torch.cuda.synchronize()
+    # the split images reconstruct the float32 features to 2^-22 relative / 3e-8 absolute
+    rec = (Ph.float() + Pl.float()).cpu().numpy()
+    nks = M // 16
+    blk = rec[: (N // 128) * 128 * M].reshape(-1, nks, 2, 128, 8) if N >= 128 else None
+    if blk is not None:
+        full = blk.transpose(0, 3, 1, 2, 4).reshape(-1, M)  # [tile, row, ks, plane, 8] -> [n, b]
+        ref = Phi[: full.shape[0]]
+        assert np.abs(full - ref).max() <= np.maximum(2.0 ** -21 * np.abs(ref), 6e-8).max()
+    P = Phi.astype(np.float64)
+    af = host(dal).astype(np.float64)
+    for l in range(L):
+        ref_mu = P @ af[l]
+        ref_var = kd.astype(np.float32) + np.einsum("ia,ab,ib->i", P, S[l], P)
+        assert np.abs(host(mu)[l] - ref_mu).max() < 2e-6 * np.abs(P).sum(1).max() * np.abs(af[l]).max() + 1e-6
+        assert np.abs(host(var)[l] - ref_var).max() < 3e-6 * max(1.0, np.abs(ref_var).max())
+
+
+@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("cat", 4_000, 64)])
+def test_cavi_with_split_f16_marginals_matches_oracle(A, ctx, oracle, name, N, M):
+    """The same 10-sweep natural-parameter bar with the split-float16 marginal pass."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2")
+    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
+    Mp, L = Phi_h.shape[1], olik.nlatent
+    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+    for it in range(10):
+        cavi.sweep()
+        G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
+        S, m = O.gaussian_update(G, g)
+    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
+    assert relmax(host(cavi.g), g) < NAT_TOL

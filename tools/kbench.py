@@ -18,7 +18,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 Phi = torch.randn((N, M), device="cuda", generator=g) * 0.1
 kd = torch.ones(N, device="cuda")
 y = (torch.rand(N, device="cuda", generator=g) < 0.5).to(torch.uint8)
-cavi = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx)
+cavi = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision=os.environ.get("AGPL_PREC", "f32"))
 cavi.sweep()
 torch.cuda.synchronize()
 _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
@@ -28,4 +28,4 @@ torch.cuda.synchronize()
 for which, nm in ((0, "marginal"), (1, "syrk")):
     ms, cnt = C.c_double(), C.c_int64()
     _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt))
-    print(f"{nm:9s} N={N} M={M} avg {ms.value / cnt.value:8.3f} ms  variant={os.environ.get('AGPL_MARG_VARIANT', '0')}")
+    print(f"{nm:9s} N={N} M={M} avg {ms.value / cnt.value:8.3f} ms  prec={os.environ.get('AGPL_PREC', 'f32')}")
