@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--marginal", default="f16x2", choices=["f32", "f16x2"],
+                    help="marginal pass: f32-input MFMA, or split-float16 MFMA (3 f16 products per f32 product)")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +112,7 @@ def main():
     t_setup = time.time() - t_setup
     Mp = Phi.shape[1]
 
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group, marginal_precision=args.marginal)
 
     def barrier():
         if world > 1:
@@ -160,7 +162,7 @@ def main():
     # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
     nbk = Mp // 128
     executed = ((1.0 + 1.0 / nbk) * L * n_loc * Mp * Mp, (nbk + 1.0) / nbk * L * n_loc * Mp * Mp)
-    names = ("marginal_kernel<0>", "syrk_kernel")
+    names = ("marginal_split_kernel" if args.marginal == "f16x2" else "marginal_kernel<0>", "syrk_kernel")
     per = []
     for (ms, cnt), fl, ex, nm in zip(kt, flops, executed, names):
         avg = ms / max(cnt, 1)
@@ -177,7 +179,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as fh:
             pm = json.load(fh)
         if pm["config"] == {"lik": args.lik, "N": N, "M": M, "L": L} and world == 1:
-            traffic = pm["kernels"][names[dom]]["traffic_bytes"]
+            traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")
     except Exception:
         traffic = None
     roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -190,10 +192,11 @@ def main():
         "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",
         "value": round(value, 4), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.marginal == "f32" else "f32 (marginal pass: f16 hi/lo split operands, f32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{args.lik}-logistic SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, "
                                f"N sharded over {world} GPU(s), 1 all-reduce of L*(M^2+M) f64 per sweep",
-                   "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}"},
+                   "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}", "marginal_pass": args.marginal},
         "roofline": roofline, "setup_s": round(t_setup, 2),
     }
 
@@ -246,7 +249,7 @@ def main():
         olik = make_olik(O, args.lik)
         ns = min(20_000, n_loc)
         Phi_s, kd_s, y_s = Phi[:ns].contiguous(), kd[:ns].contiguous(), y[:ns].contiguous()
-        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx)
+        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx, marginal_precision=args.marginal)
         Ph, kh, yh = Phi_s.cpu().numpy(), kd_s.cpu().numpy().astype(np.float64), y_s.cpu().numpy()
         if lik.ykind == "real":
             yh = yh.astype(np.float64)
