@@ -28,6 +28,7 @@ struct agpl_ctx {
     double logtheta_host[128];      // last uploaded values (skip the copy when unchanged)
     int logtheta_n = 0;
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
+    int accumulate_split = 0; // 0: f32-input MFMA accumulation, 1: split-float16 (agpl_set_accumulate_precision)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -110,7 +110,7 @@ class SparseCAVI:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 marginal_precision: str = "f32"):
+                 marginal_precision: str = "f32", accumulate_precision: str = "f32"):
         """``marginal_precision``: "f32" = float32-input MFMA marginal pass (default); "f16x2" = the split-float16
         pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM)."""
         torch = _torch()
@@ -128,6 +128,9 @@ class SparseCAVI:
         if marginal_precision not in ("f32", "f16x2"):
             raise _ffi.ArgumentError(-1, "marginal_precision must be 'f32' or 'f16x2'")
         self.split = marginal_precision == "f16x2"
+        if accumulate_precision not in ("f32", "f16x2"):
+            raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
+        self.acc_split = 1 if accumulate_precision == "f16x2" else 0
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
@@ -162,6 +165,7 @@ class SparseCAVI:
     def accumulate(self):
         """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
         d = self.lik.desc()
+        self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
         if self.split:
             self.ctx.call("agpl_cavi_pass_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                           _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y),

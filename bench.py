@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 
 
 def make_lik(A, name):
@@ -59,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
+                    help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
     ap.add_argument("--marginal", default="f16x2", choices=["f32", "f16x2"],
                     help="marginal pass: f32-input MFMA, or split-float16 MFMA (3 f16 products per f32 product)")
     args = ap.parse_args()
@@ -112,7 +115,8 @@ def main():
     t_setup = time.time() - t_setup
     Mp = Phi.shape[1]
 
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group, marginal_precision=args.marginal)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group, marginal_precision=args.marginal,
+                        accumulate_precision=args.accumulate)
 
     def barrier():
         if world > 1:
@@ -162,14 +166,22 @@ def main():
     # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
     nbk = Mp // 128
     executed = ((1.0 + 1.0 / nbk) * L * n_loc * Mp * Mp, (nbk + 1.0) / nbk * L * n_loc * Mp * Mp)
-    names = ("marginal_split_kernel" if args.marginal == "f16x2" else "marginal_kernel<0>", "syrk_kernel")
+    names = ("marginal_split_kernel" if args.marginal == "f16x2" else "marginal_kernel<0>",
+             "syrk_split_kernel" if args.accumulate == "f16x2" else "syrk_kernel")
+    # split-float16 kernels issue 3 float16 MFMA products (hi hi + hi lo + lo hi) per float32-equivalent product
+    # and are priced against the dense float16 peak; the f32-input kernels against the f32 MFMA peak
+    mult = (3.0 if args.marginal == "f16x2" else 1.0, 3.0 if args.accumulate == "f16x2" else 1.0)
+    peaks = (PEAK_F16_MFMA_TFLOPS if args.marginal == "f16x2" else PEAK_F32_MFMA_TFLOPS,
+             PEAK_F16_MFMA_TFLOPS if args.accumulate == "f16x2" else PEAK_F32_MFMA_TFLOPS)
     per = []
-    for (ms, cnt), fl, ex, nm in zip(kt, flops, executed, names):
+    for (ms, cnt), fl, ex, nm, mu, pk in zip(kt, flops, executed, names, mult, peaks):
         avg = ms / max(cnt, 1)
         per.append({"kernel": nm, "avg_ms": round(avg, 4), "launches": cnt,
                     "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
-                    "executed_tflops": round(ex / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
-                    "executed_frac_of_peak": round(ex / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg > 0 else None})
+                    "mfma_dtype": "f16 (hi/lo split, x3 products)" if mu == 3.0 else "f32",
+                    "executed_mfma_tflops": round(mu * ex / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
+                    "peak_tflops": pk,
+                    "executed_frac_of_peak": round(mu * ex / (avg * 1e-3) / 1e12 / pk, 4) if avg > 0 else None})
     dom = 0 if kt[0][0] >= kt[1][0] else 1
     achieved = per[dom]["algorithmic_tflops"]
     # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
@@ -179,11 +191,14 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as fh:
             pm = json.load(fh)
         if pm["config"] == {"lik": args.lik, "N": N, "M": M, "L": L} and world == 1:
-            traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")
+            traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")  # null until a PMC pass of this kernel is committed
     except Exception:
         traffic = None
-    roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
+    # achieved = ALGORITHMIC (float32-equivalent) flops per launch / launch duration; peak = dense MFMA peak of the
+    # dtype the kernel issues.  For a split-float16 kernel the scheme's own ceiling in these terms is peak / 3.
+    roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": peaks[dom],
+                "unit": "TFLOP/s", "frac": round(achieved / peaks[dom], 4) if achieved else None,
+                "mfma_products_per_algorithmic_product": mult[dom],
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic_c2.json" if traffic else None,
                 "kernels": per,
                 "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
@@ -192,11 +207,13 @@ def main():
         "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",
         "value": round(value, 4), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if args.marginal == "f32" else "f32 (marginal pass: f16 hi/lo split operands, f32 accumulate)",
+        "dtype": "f32" if (args.marginal == "f32" and args.accumulate == "f32")
+                 else "f32 via f16 hi/lo split operands (3 f16 MFMA products per f32 product, f32 accumulate, "
+                      "f64 reductions and M x M update)",
         "data": "synthetic",
         "config": {"workload": f"{args.lik}-logistic SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, "
                                f"N sharded over {world} GPU(s), 1 all-reduce of L*(M^2+M) f64 per sweep",
-                   "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}", "marginal_pass": args.marginal},
+                   "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}", "marginal_pass": args.marginal, "accumulate_pass": args.accumulate},
         "roofline": roofline, "setup_s": round(t_setup, 2),
     }
 
@@ -249,7 +266,8 @@ def main():
         olik = make_olik(O, args.lik)
         ns = min(20_000, n_loc)
         Phi_s, kd_s, y_s = Phi[:ns].contiguous(), kd[:ns].contiguous(), y[:ns].contiguous()
-        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx, marginal_precision=args.marginal)
+        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx, marginal_precision=args.marginal,
+                           accumulate_precision=args.accumulate)
         Ph, kh, yh = Phi_s.cpu().numpy(), kd_s.cpu().numpy().astype(np.float64), y_s.cpu().numpy()
         if lik.ykind == "real":
             yh = yh.astype(np.float64)

@@ -258,6 +258,12 @@ AGPL_API int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, i
                                       const void *W_lo, const float *alpha, double *G_out, double *g_out,
                                       float *c_out, float *gamma_out, float *beta_out);
 
+/* agpl_set_accumulate_precision: which kernel agpl_accumulate / agpl_cavi_pass(_split) / agpl_gibbs_pass use for
+ *   G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default), 1 = split-float16 MFMA (psi = sqrt(gamma) phi is
+ *   split into hi/lo float16 while staging; 3 float16 products per float32 product; needs gamma >= 0 and
+ *   |sqrt(gamma) phi| < 6e4).  Same slabs, same fixed-order float64 reduction.                               */
+AGPL_API int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode);
+
 /* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
 AGPL_API int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L);
 

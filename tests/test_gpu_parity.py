@@ -665,3 +665,92 @@ def test_cavi_with_split_f16_marginals_matches_oracle(A, ctx, oracle, name, N, M
         S, m = O.gaussian_update(G, g)
     assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
     assert relmax(host(cavi.g), g) < NAT_TOL
+
+
+# --------------------------------------------------------------------------------------- split-float16 accumulation
+@pytest.fixture()
+def split_accumulate(ctx):
+    import ctypes as C
+
+    ctx.call("agpl_set_accumulate_precision", C.c_int32(1))
+    yield
+    ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+
+
+@pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (70001, 128, 2), (31, 128, 1), (5000, 384, 1),
+                                   (300000, 128, 1), (4097, 128, 1), (16, 128, 1), (100003, 512, 1)])
+def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M, L):
+    """agpl_accumulate with agpl_set_accumulate_precision(1): sqrt(gamma) phi split into hi/lo float16 while
+    staging, 3 float16 MFMA products per float32 product; the same bound, symmetry and reproducibility as f32."""
+    import ctypes as C
+
+    rng = np.random.default_rng(N + 3 * M)
+    Phi = _features(rng, N, M)
+    gamma = rng.uniform(0.0, 0.25, size=(L, N)).astype(np.float32)
+    beta = rng.choice([-0.5, 0.5], size=(L, N)).astype(np.float32)
+    G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
+    args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
+            C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
+            C.c_void_p(g.data_ptr()))
+    ctx.call("agpl_accumulate", *args)
+    G1 = host(G).copy()
+    Gr, gr = oracle.accumulate(Phi, beta, gamma)
+    assert relmax(G1, Gr) < 5e-6
+    assert relmax(host(g), gr) < 5e-6
+    assert np.array_equal(G1, G1.transpose(0, 2, 1))
+    ctx.call("agpl_accumulate", *args)
+    assert np.array_equal(host(G), G1)
+
+
+def test_split_accumulate_wide_dynamic_range(A, ctx, oracle, split_accumulate):
+    """gamma spanning 1e-6..1e2 and features spanning 1e-4..3: psi = 2^8 sqrt(gamma) phi stays inside the
+    float16 normal range for |sqrt(gamma) phi| in [2^-11, 2^8); smaller terms lose relative, not absolute, accuracy."""
+    import ctypes as C
+
+    N, M = 20000, 128
+    rng = np.random.default_rng(5)
+    Phi = (rng.normal(size=(N, M)) * 10.0 ** rng.uniform(-4, 0.5, size=(N, 1))).astype(np.float32)
+    gamma = (10.0 ** rng.uniform(-6, 2, size=(1, N))).astype(np.float32)
+    beta = rng.normal(size=(1, N)).astype(np.float32)
+    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
+    dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
+    ctx.call("agpl_accumulate", C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(dPhi.data_ptr()),
+             C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
+             C.c_void_p(g.data_ptr()))
+    Gr, gr = oracle.accumulate(Phi, beta, gamma)
+    assert relmax(host(G), Gr) < 5e-6
+    assert relmax(host(g), gr) < 5e-6
+
+
+def test_set_accumulate_precision_rejects_unknown_mode(A, ctx):
+    import ctypes as C
+
+    with pytest.raises(A.ArgumentError):
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(7))
+
+
+@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("cat", 4_000, 64),
+                                      ("studentt", 5_000, 128)])
+def test_cavi_with_split_f16_both_passes_matches_oracle(A, ctx, oracle, name, N, M):
+    """10-sweep natural-parameter bar with BOTH contractions on the float16 matrix cores (bench.py's default)."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2", accumulate_precision="f16x2")
+    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
+    Mp, L = Phi_h.shape[1], olik.nlatent
+    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+    try:
+        for it in range(10):
+            cavi.sweep()
+            G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
+            S, m = O.gaussian_update(G, g)
+    finally:
+        import ctypes as C
+
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
+    assert relmax(host(cavi.g), g) < NAT_TOL
