@@ -13,6 +13,8 @@
 //   Phi: blocks [tile][M/16], written once by agpl_split_features;  W': blocks [l][rb][M/16], written each sweep by
 //   agpl_pack_w_split (upper-triangular, doubled off-diagonal, as the f32 Wpack).
 // The Hadamard epilogue and the output are float32 (the exact float32 Phi is read for it).
+#include <cstdlib>
+
 #include "agpl_common.h"
 
 namespace {
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M
     const int nlim = (int)((N - 1 - n0) < (NT - 1) ? (N - 1 - n0) : (NT - 1));
     const float *tile32 = Phi + n0 * (int64_t)M;
     float qacc[2] = {0.f, 0.f};
-    float macc = 0.f;
+    float macc[2] = {0.f, 0.f};
     h8 r0, r1, r2, r3;
 
 #define AGPL_SPLIT_LOAD(rb_, ks_)                                     \
@@ -178,32 +180,32 @@ __global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M
             acc[0][1] = mfma16(al0, bh1, acc[0][1]);
             acc[1][0] = mfma16(al1, bh0, acc[1][0]);
             acc[1][1] = mfma16(al1, bh1, acc[1][1]);
-            if (rb == 0) { // mean: thread (plane = tid >> 7, point = tid & 127) owns 8 features of the slice
-                const h8 ph = st[512 + tid], pl = st[768 + tid];
-                const float *as = alpha_s + s * KS + (tid >> 7) * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) macc += as[j] * ((float)ph[j] + (float)pl[j]);
-            }
             if (s + 1 < nstage) AGPL_SPLIT_STORE(buf ^ 1);
             __syncthreads();
         }
 
-        // Hadamard epilogue with the exact float32 Phi: q_n += sum_{a in rb} Phi[a, n] T[a, n]
+        // Hadamard epilogue with the exact float32 Phi: q_n += sum_{a in rb} Phi[a, n] T[a, n], and the mean
+        // mu_n += sum_{a in rb} alpha_a Phi[a, n] from the same registers (lane rows a = .. + 8 g + 4 lk + 0..3)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             int nl = wc * 64 + jj * 32 + li;
             nl = nl > nlim ? nlim : nl;
             const float *hsrc = tile32 + nl * M + rb * BS + wr * 64 + 4 * lk;
+            const float *asrc = alpha_s + rb * BS + wr * 64 + 4 * lk;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int g2 = 0; g2 < 4; g2 += 2) {
                     const float4 h0 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2);
                     const float4 h1 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2 + 8);
+                    const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2 + 8);
                     qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
                                 acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
                     qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
                                 acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
+                    macc[jj] += a0.x * h0.x + a0.y * h0.y + a0.z * h0.z + a0.w * h0.w;
+                    macc[jj] += a1.x * h1.x + a1.y * h1.y + a1.z * h1.z + a1.w * h1.w;
                 }
         }
     }
@@ -211,13 +213,17 @@ __global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M
 #undef AGPL_SPLIT_STORE
 
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) qacc[jj] += __shfl_xor(qacc[jj], 32);
+    for (int jj = 0; jj < 2; ++jj) {
+        qacc[jj] += __shfl_xor(qacc[jj], 32);
+        macc[jj] += __shfl_xor(macc[jj], 32);
+    }
     __syncthreads();
     if (lk == 0) {
         qred[wr * NT + wc * 64 + li] = qacc[0];
         qred[wr * NT + wc * 64 + 32 + li] = qacc[1];
+        mred[wr * NT + wc * 64 + li] = macc[0];
+        mred[wr * NT + wc * 64 + 32 + li] = macc[1];
     }
-    mred[(tid >> 7) * NT + (tid & 127)] = macc;
     __syncthreads();
     if (tid < NT) {
         const int64_t n = n0 + tid;

@@ -11,6 +11,9 @@ import torch
 import agpl_amd as A
 from agpl_amd import _ffi
 
+if os.environ.get("AGPL_LIB_AB"):  # A/B a second build of libagpl.so in the same gpurun call
+    _ffi.LIB_PATH = os.environ["AGPL_LIB_AB"]
+
 N, M = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ctx = A.Context(0, seed=1)
