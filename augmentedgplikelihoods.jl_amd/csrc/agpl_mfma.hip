@@ -489,7 +489,7 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
             sv[0] = s2_.x; sv[1] = s2_.y; bv[0] = b2_.x; bv[1] = b2_.y;                            \
         } else {                                                                                   \
             const float4 s4_ = *reinterpret_cast<const float4 *>(ss_ + soff);                      \
-            sv[0] = s4_.x; sv[1] = s4_.y; sv[2] = s4_.z; sv[3] = s4_.w;                            \
+            sv[0] = s4_.x; sv[1] = s4_.y; sv[PQ - 2] = s4_.z; sv[PQ - 1] = s4_.w;                            \
         }                                                                                          \
     } while (0)
 #define AGPL_SS_STORE(buf_, gkeep_)                                                                \
@@ -517,19 +517,19 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
         } else {                                                                                   \
             uint2 h_, l_;                                                                          \
             AGPL_SPLIT2("v", x[0].x, sv[0], x[1].x, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[2].x, sv[2], x[3].x, sv[3], h_.y, l_.y);                            \
+            AGPL_SPLIT2("v", x[PQ - 2].x, sv[PQ - 2], x[PQ - 1].x, sv[PQ - 1], h_.y, l_.y);                            \
             *reinterpret_cast<uint2 *>(dst_ + 0 * 36 * 16) = h_;                                   \
             *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 0 * 36 * 16) = l_;                       \
             AGPL_SPLIT2("v", x[0].y, sv[0], x[1].y, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[2].y, sv[2], x[3].y, sv[3], h_.y, l_.y);                            \
+            AGPL_SPLIT2("v", x[PQ - 2].y, sv[PQ - 2], x[PQ - 1].y, sv[PQ - 1], h_.y, l_.y);                            \
             *reinterpret_cast<uint2 *>(dst_ + 1 * 36 * 16) = h_;                                   \
             *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 1 * 36 * 16) = l_;                       \
             AGPL_SPLIT2("v", x[0].z, sv[0], x[1].z, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[2].z, sv[2], x[3].z, sv[3], h_.y, l_.y);                            \
+            AGPL_SPLIT2("v", x[PQ - 2].z, sv[PQ - 2], x[PQ - 1].z, sv[PQ - 1], h_.y, l_.y);                            \
             *reinterpret_cast<uint2 *>(dst_ + 2 * 36 * 16) = h_;                                   \
             *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 2 * 36 * 16) = l_;                       \
             AGPL_SPLIT2("v", x[0].w, sv[0], x[1].w, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[2].w, sv[2], x[3].w, sv[3], h_.y, l_.y);                            \
+            AGPL_SPLIT2("v", x[PQ - 2].w, sv[PQ - 2], x[PQ - 1].w, sv[PQ - 1], h_.y, l_.y);                            \
             *reinterpret_cast<uint2 *>(dst_ + 3 * 36 * 16) = h_;                                   \
             *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 3 * 36 * 16) = l_;                       \
         }                                                                                          \

@@ -237,6 +237,246 @@ __global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// marginal_split256_kernel: the same product on 256 (rows of W') x 256 (points) tiles, ONE 1024-thread workgroup
+// (16 waves, each a 64 x 64 sub-tile) per CU.  Against four independent 128 x 128 workgroups per CU this halves
+// the operand bytes pulled from L2 per MFMA (the 128-tile kernel moves ~117 GB per launch at C2, ~9 TB/s: it sits
+// at the L2 -> CU rate, not at the matrix cores), and one barrier now covers the MFMAs of four waves per SIMD.
+// Operand blocks travel global -> LDS by the DMA path (global_load_lds_dwordx4; the 4 KB images are already the
+// LDS layout: no staging VGPRs, no ds_write) through a ring of R stage slots of 32 KB:
+//   slot = [A blk0 hi | A blk0 lo | A blk1 hi | A blk1 lo | B tile0 hi | B tile0 lo | B tile1 hi | B tile1 lo]
+//   per stage:  wait(stage t landed) ; barrier ; issue(stage t + R - 1 -> the slot read in iteration t - 1) ; MFMAs(t)
+// The flat stage list runs over 256-row blocks rb2 and k-slices ks = 16 rb2 .. M/16 - 1 (W' is upper triangular);
+// in the first 8 slices of a row block its lower 128 rows are still zero and their waves issue no MFMA.
+//
+// FACTOR = true is the one-pass form:  I + G = R R', U = R^-1 (lower triangular), T = U Phi,
+//   var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2,   mu_n = mu0_n + sum_a v_a T[a,n],  v = U (g + eta0)
+// (S = U'U, m = U'v): the epilogue needs T only, so the float32 features are not read at all -- the launch reads
+// the feature images once per 256-row block and nothing else from HBM.  A-operand images hold U (k-slices
+// 0 .. 16 (rb2 + 1) - 1 of row block rb2; the upper 128 rows are zero in the block's last 8 slices), `alpha` holds v
+// and `kdiag` holds the residual k_nn - |phi_n|^2.
+// ------------------------------------------------------------------------------------------------
+constexpr int NT2 = 256;
+
+template <int R, bool FACTOR>
+__global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
+    int64_t N, int M, int64_t ntiles128, const float *__restrict__ Phi, const h8 *__restrict__ Ph,
+    const h8 *__restrict__ Pl, const float *__restrict__ kdiag, const float *__restrict__ mu0,
+    const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ alpha_all,
+    float *__restrict__ mu_out, float *__restrict__ var_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int kSlot = 8 * 4096;
+    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // M floats
+    float *qred = alpha_s + M;                                         // 4 x 256
+    float *mred = qred + 4 * NT2;                                      // 4 x 256
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..15
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 31, lk = lane >> 5;
+    const int l = blockIdx.y;
+    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
+    const int64_t tile2 = blockIdx.x;
+    const int64_t n0 = tile2 * NT2;
+
+    // this wave's two DMA pieces per stage: image ia of the A half and of the B half, quarter qd
+    const int ia = wave >> 2, qd = wave & 3;
+    const int64_t t128 = 2 * tile2 + (ia >> 1) < ntiles128 ? 2 * tile2 + (ia >> 1) : ntiles128 - 1;
+    const h8 *a_src = ((ia & 1) ? Wl : Wh) + ((int64_t)l * nb + (ia >> 1)) * nks * 256 + qd * 64 + lane;
+    const h8 *b_src = ((ia & 1) ? Pl : Ph) + t128 * nks * 256 + qd * 64 + lane;
+    const int dma_off = ia * 4096 + qd * 1024;
+
+    const float *alpha = alpha_all + (int64_t)l * M;
+    for (int a = tid; a < M; a += 1024) alpha_s[a] = alpha[a];
+
+    const int nlim = (int)((N - 1 - n0) < (NT2 - 1) ? (N - 1 - n0) : (NT2 - 1));
+    const float *tile32 = FACTOR ? nullptr : Phi + n0 * (int64_t)M;
+    float qacc[2] = {0.f, 0.f};
+    float macc[2] = {0.f, 0.f};
+
+    const int T = nb2 * nks - 16 * nb2 * (nb2 - 1) / 2; // = 8 nb2 (nb2 + 1) in both forms
+    int irb = 0, iks = 0; // issue pointer
+    typedef __attribute__((address_space(3))) void lds_void;
+#define AGPL_DMA_ISSUE(t_)                                                                                  \
+    do {                                                                                                    \
+        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
+        __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks) * 256, (lds_void *)(slot_), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds(b_src + (int64_t)iks * 256, (lds_void *)(slot_ + 4 * 4096), 16, 0, 0); \
+        if (++iks == (FACTOR ? 16 * (irb + 1) : nks)) {                                                     \
+            ++irb;                                                                                          \
+            iks = FACTOR ? 0 : irb * 16;                                                                    \
+        }                                                                                                   \
+    } while (0)
+
+#pragma unroll
+    for (int t = 0; t < R - 1; ++t)
+        if (t < T) AGPL_DMA_ISSUE(t);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
+
+    // fragment indices (16-byte units within a slot)
+    const int fa = (wr >> 1) * 512 + lk * 128 + (wr & 1) * 64 + li;        // A blk (wr >> 1): hi at +0, lo at +256
+    const int fb = 1024 + (wc >> 1) * 512 + lk * 128 + (wc & 1) * 64 + li; // B tile (wc >> 1)
+
+    int rb = 0, ks = 0; // consume pointer
+    for (int t = 0; t < T; ++t) {
+        // stage t has landed once at most the stages issued after it are outstanding (2 DMAs each)
+        if (t + R - 2 < T) {
+            if (R == 2) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            else if (R == 3) __builtin_amdgcn_s_waitcnt(0x0F72); // vmcnt(2)
+            else __builtin_amdgcn_s_waitcnt(0x0F74);             // vmcnt(4)
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + R - 1 < T) AGPL_DMA_ISSUE(t + R - 1);
+        // rows 128..255 of the block are zero for the block's first 8 slices (strictly lower part of W');
+        // FACTOR: rows 0..127 are zero for its last 8 slices (strictly upper part of U)
+        if (FACTOR ? !(!(wr >> 1) && ks >= rb * 16 + 8) : !((wr >> 1) && ks < rb * 16 + 8)) {
+            const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
+            const h8 ah0 = st[fa], ah1 = st[fa + 32], bh0 = st[fb], bh1 = st[fb + 32];
+            acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
+            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+            acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
+            acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
+            const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
+            acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
+            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+            acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
+            acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
+            const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
+            acc[0][0] = mfma16(al0, bh0, acc[0][0]);
+            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+            acc[1][0] = mfma16(al1, bh0, acc[1][0]);
+            acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+        }
+        if (++ks == (FACTOR ? 16 * (rb + 1) : nks)) {
+            if (FACTOR) {
+                // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n] (lane rows a = .. + 8 g + 4 lk + 0..3)
+                const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * lk;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const float t0 = acc[ii][jj][4 * g + 0], t1 = acc[ii][jj][4 * g + 1];
+                            const float t2 = acc[ii][jj][4 * g + 2], t3 = acc[ii][jj][4 * g + 3];
+                            qacc[jj] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+                            macc[jj] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
+                        }
+                    }
+            } else {
+            // row block finished: Hadamard epilogue with the exact float32 Phi, and the mean from the same registers
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                int nl = wc * 64 + jj * 32 + li;
+                nl = nl > nlim ? nlim : nl;
+                const float *hsrc = tile32 + (int64_t)nl * M + rb * NT2 + wr * 64 + 4 * lk;
+                const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * lk;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
+                        const float4 h0 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2);
+                        const float4 h1 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2 + 8);
+                        const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2);
+                        const float4 a1 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2 + 8);
+                        qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
+                                    acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
+                        qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
+                                    acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
+                        macc[jj] += a0.x * h0.x + a0.y * h0.y + a0.z * h0.z + a0.w * h0.w;
+                        macc[jj] += a1.x * h1.x + a1.y * h1.y + a1.z * h1.z + a1.w * h1.w;
+                    }
+            }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
+            ++rb;
+            ks = FACTOR ? 0 : rb * 16;
+        }
+    }
+#undef AGPL_DMA_ISSUE
+
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        qacc[jj] += __shfl_xor(qacc[jj], 32);
+        macc[jj] += __shfl_xor(macc[jj], 32);
+    }
+    if (lk == 0) {
+        qred[wr * NT2 + wc * 64 + li] = qacc[0];
+        qred[wr * NT2 + wc * 64 + 32 + li] = qacc[1];
+        mred[wr * NT2 + wc * 64 + li] = macc[0];
+        mred[wr * NT2 + wc * 64 + 32 + li] = macc[1];
+    }
+    __syncthreads();
+    if (tid < NT2) {
+        const int64_t n = n0 + tid;
+        if (n < N) {
+            float q = (qred[tid] + qred[NT2 + tid]) + (qred[2 * NT2 + tid] + qred[3 * NT2 + tid]);
+            float m = (mred[tid] + mred[NT2 + tid]) + (mred[2 * NT2 + tid] + mred[3 * NT2 + tid]);
+            if (mu0) m += mu0[(int64_t)l * N + n];
+            mu_out[(int64_t)l * N + n] = m;
+            var_out[(int64_t)l * N + n] = FACTOR ? kdiag[n] + q : kdiag[n] - q;
+        }
+    }
+}
+
+// U = R^-1 as rocSOLVER leaves it: column-major lower triangle of A, i.e. U[a][b] = A[b * M + a] for b <= a
+// (the other triangle of A still holds I + G and is never read) -> blocked hi / lo images of U
+__global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
+                                                                h8 *__restrict__ Wh, h8 *__restrict__ Wl) {
+    const int nks = M / KS, nb = M / BS;
+    const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
+    const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
+    const int a = rb * BS + row;
+    const double *Al = A + (int64_t)l * M * M;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b = ks * KS + plane * 8 + j;
+        const double v = b <= a ? Al[(int64_t)b * M + a] : 0.0;
+        _Float16 x, y;
+        split_f16((float)v, x, y);
+        hi[j] = x;
+        lo[j] = y;
+    }
+    const int64_t blk = ((int64_t)l * nb + rb) * nks + ks;
+    Wh[blk * 256 + threadIdx.x] = hi;
+    Wl[blk * 256 + threadIdx.x] = lo;
+}
+
+// resid_n = k_nn - |phi_n|^2 (float64 accumulation, one wave per point)
+__global__ __launch_bounds__(256) void feature_residual_kernel(int64_t N, int M, const float *__restrict__ Phi,
+                                                               const float *__restrict__ kdiag,
+                                                               float *__restrict__ resid) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += (int64_t)gridDim.x * 4) {
+        const float *row = Phi + n * (int64_t)M;
+        double acc = 0.0;
+        for (int a = lane * 4; a < M; a += 256) {
+            const float4 x = *reinterpret_cast<const float4 *>(row + a);
+            acc += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) resid[n] = (float)((double)kdiag[n] - acc);
+    }
+}
+
 } // namespace
 
 extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
@@ -282,8 +522,68 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
     dim3 grid((unsigned)agpl_cdiv(N, NT), (unsigned)L);
     int32_t rc = agpl_timing_begin(ctx, 0);
     if (rc) return rc;
-    marginal_split_kernel<<<grid, 256, lds, ctx->stream>>>(N, M, Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag, mu0,
-                                                           (const h8 *)W_hi, (const h8 *)W_lo, alpha, mu_out, var_out);
+    static const int force128 = getenv("AGPL_MARGINAL_TILE") ? atoi(getenv("AGPL_MARGINAL_TILE")) == 128 : 0;
+    if (M % NT2 == 0 && !force128) {
+        constexpr int R = 4;
+        const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
+        marginal_split256_kernel<R, false><<<grid2, 1024, lds2, ctx->stream>>>(
+            N, M, agpl_cdiv(N, NT), Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag, mu0, (const h8 *)W_hi,
+            (const h8 *)W_lo, alpha, mu_out, var_out);
+    } else {
+        marginal_split_kernel<<<grid, 256, lds, ctx->stream>>>(N, M, Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag,
+                                                               mu0, (const h8 *)W_hi, (const h8 *)W_lo, alpha, mu_out,
+                                                               var_out);
+    }
+    AGPL_LAUNCH_CHECK(ctx);
+    return agpl_timing_end(ctx, 0);
+}
+
+extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
+    pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
+                                         float *resid_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N < 0 || M <= 0 || M % 4) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need N >= 0 and M %% 4 == 0");
+    if (N == 0) return AGPL_OK;
+    if (!Phi || !kdiag || !resid_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    int64_t nblk = agpl_cdiv(N, 4);
+    if (nblk > 262144) nblk = 262144;
+    feature_residual_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, kdiag, resid_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
+                                               const void *Phi_lo, const float *resid, const float *mu0,
+                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
+                                               float *var_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
+    if (M % NT2)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "the factor form runs on 256-row blocks: M = %d must be a multiple of 256", M);
+    if (N == 0) return AGPL_OK;
+    if (!Phi_hi || !Phi_lo || !resid || !U_hi || !U_lo || !v || !mu_out || !var_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    constexpr int R = 4;
+    const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
+    int32_t rc = agpl_timing_begin(ctx, 0);
+    if (rc) return rc;
+    marginal_split256_kernel<R, true><<<grid2, 1024, lds2, ctx->stream>>>(
+        N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
+        (const h8 *)U_lo, v, mu_out, var_out);
     AGPL_LAUNCH_CHECK(ctx);
     return agpl_timing_end(ctx, 0);
 }

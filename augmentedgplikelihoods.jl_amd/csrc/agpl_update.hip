@@ -211,6 +211,83 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     return AGPL_OK;
 }
 
+namespace {
+// v[a] = sum_{b <= a} U[a][b] (g + eta0)[b] with U[a][b] = A[b * M + a] (column-major lower triangle), one wave-row
+// of the fixed-order tree per output; also the float32 copy the marginal kernel stages
+__global__ __launch_bounds__(256) void factor_apply_kernel(int M, const double *__restrict__ A,
+                                                           const double *__restrict__ g,
+                                                           const double *__restrict__ eta0, double *__restrict__ v,
+                                                           float *__restrict__ v32) {
+    __shared__ double sm[256];
+    const int a = blockIdx.x, l = blockIdx.y;
+    const double *Al = A + (int64_t)l * M * M;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b <= a; b += 256) {
+        const double r = g[(int64_t)l * M + b] + (eta0 ? eta0[(int64_t)l * M + b] : 0.0);
+        acc += Al[(int64_t)b * M + a] * r;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (v) v[(int64_t)l * M + a] = sm[0];
+        if (v32) v32[(int64_t)l * M + a] = (float)sm[0];
+    }
+}
+} // namespace
+
+extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi,
+                                          void *U_lo);
+
+// I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
+// pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
+extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                        const double *eta0, double *A_work, double *v_out, float *v32_out,
+                                        void *U_hi, void *U_lo, double *logdet_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (M <= 0 || L <= 0 || L > 64 || !G || !g || !A_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    if ((U_hi == nullptr) != (U_lo == nullptr)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "U_hi and U_lo go together");
+    rocblas_handle h;
+    int32_t rc = get_handle(ctx, &h);
+    if (rc) return rc;
+    const size_t info_off = 16384;
+    rc = agpl_ws2_reserve(ctx, info_off + sizeof(rocblas_int) * 2 * (size_t)L + 256);
+    if (rc) return rc;
+    rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + info_off);
+    dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
+    add_identity_kernel<<<grid, 128, 0, ctx->stream>>>(M, G, A_work);
+    AGPL_LAUNCH_CHECK(ctx);
+    const rocblas_stride stride = (rocblas_stride)M * M;
+    AGPL_ROCBLAS(ctx, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, M, A_work, M, stride, info, L));
+    if (logdet_out) {
+        logdet_kernel<<<(unsigned)L, 256, 0, ctx->stream>>>(M, A_work, logdet_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    AGPL_ROCBLAS(ctx, rocsolver_dtrtri_strided_batched(h, rocblas_fill_lower, rocblas_diagonal_non_unit, M, A_work, M,
+                                                       stride, info + L, L));
+    if (v_out || v32_out) {
+        dim3 g2((unsigned)M, (unsigned)L);
+        factor_apply_kernel<<<g2, 256, 0, ctx->stream>>>(M, A_work, g, eta0, v_out, v32_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    if (U_hi) {
+        rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
+        if (rc) return rc;
+    }
+    rocblas_int hinfo[128];
+    const int ni = 2 * L;
+    AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(rocblas_int) * ni, hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ni; ++i)
+        if (hinfo[i] != 0)
+            AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, %s info = %d)", i % L,
+                      i < L ? "potrf" : "trtri", (int)hinfo[i]);
+    return AGPL_OK;
+}
+
 extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                         const double *eta0, double *S_out, double *m_out, float *Wpack_out,
                                         float *alpha_out) {
@@ -400,6 +477,40 @@ extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik,
     float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
     float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
     rc = agpl_marginals_split(ctx, N, M, L, Phi, Phi_hi, Phi_lo, kdiag, mu0, W_hi, W_lo, alpha, mu, var);
+    if (rc) return rc;
+    rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
+    if (rc) return rc;
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+}
+
+extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
+                                               const void *Phi_lo, const float *resid, const float *mu0,
+                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
+                                               float *var_out);
+
+extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                               const float *Phi, const void *Phi_hi, const void *Phi_lo,
+                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
+                                               const void *U_lo, const float *v, double *G_out, double *g_out,
+                                               float *c_out, float *gamma_out, float *beta_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    agpl_lik_dev ld;
+    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
+    if (rc) return rc;
+    const int L = ld.nlatent;
+    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
+    if (!Phi || !Phi_hi || !Phi_lo || !resid || !y || !U_hi || !U_lo || !v || !G_out || !g_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
+    const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
+    rc = agpl_ws_reserve(ctx, slab + 4 * vec);
+    if (rc) return rc;
+    char *base = (char *)ctx->ws;
+    float *mu = (float *)(base + slab);
+    float *var = (float *)(base + slab + vec);
+    float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
+    float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
+    rc = agpl_marginals_factor_split(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu, var);
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;

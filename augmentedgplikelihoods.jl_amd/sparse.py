@@ -112,7 +112,10 @@ class SparseCAVI:
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
                  marginal_precision: str = "f32", accumulate_precision: str = "f32"):
         """``marginal_precision``: "f32" = float32-input MFMA marginal pass (default); "f16x2" = the split-float16
-        pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM)."""
+        pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM);
+        "f16x2-factor" = the one-pass factor form of the same (agpl_marginals_factor_split: the update keeps
+        U = chol(I + G)^-1 and v = U g instead of S and m; M % 256 == 0).
+        ``accumulate_precision``: "f32" or "f16x2" for G = Phi diag(gamma) Phi'."""
         torch = _torch()
         self.ctx = ctx or default_context()
         self.lik = lik
@@ -125,9 +128,12 @@ class SparseCAVI:
         self.y = _prep_y(lik, y, torch.float32)
         self.mu0 = _prep(mu0, torch.float32, "mu0")
         self.group = group
-        if marginal_precision not in ("f32", "f16x2"):
-            raise _ffi.ArgumentError(-1, "marginal_precision must be 'f32' or 'f16x2'")
-        self.split = marginal_precision == "f16x2"
+        if marginal_precision not in ("f32", "f16x2", "f16x2-factor"):
+            raise _ffi.ArgumentError(-1, "marginal_precision must be 'f32', 'f16x2' or 'f16x2-factor'")
+        self.factor = marginal_precision == "f16x2-factor"
+        if self.factor and self.M % 256:
+            raise _ffi.ArgumentError(-1, f"the factor form needs a feature count that is a multiple of 256 (got {self.M})")
+        self.split = marginal_precision in ("f16x2", "f16x2-factor")
         if accumulate_precision not in ("f32", "f16x2"):
             raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
         self.acc_split = 1 if accumulate_precision == "f16x2" else 0
@@ -144,12 +150,20 @@ class SparseCAVI:
             self.W_lo = torch.empty(L * M * M, dtype=torch.float16, device=dev)
         self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
         self.g = torch.zeros((L, M), dtype=f64, device=dev)
-        self.S = torch.eye(M, dtype=f64, device=dev).repeat(L, 1, 1).contiguous()  # script.jl:42
-        self.m = torch.zeros((L, M), dtype=f64, device=dev)  # script.jl:41
-        self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
         self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
-        self.ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), _ptr(self.S), C.c_double(-1.0), _ptr(self.Wpack))
-        self._pack_split()
+        if self.factor:
+            # q(v) is carried as (U, v): S = U'U = I, m = U'v = 0 at the start (script.jl:41-42)
+            self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
+            self.A_work = torch.empty((L, M, M), dtype=f64, device=dev)
+            self.v = torch.zeros((L, M), dtype=f64, device=dev)
+            self._S = self._m = self.Wpack = None
+            self.update()
+        else:
+            self._S = torch.eye(M, dtype=f64, device=dev).repeat(L, 1, 1).contiguous()  # script.jl:42
+            self._m = torch.zeros((L, M), dtype=f64, device=dev)  # script.jl:41
+            self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
+            self.ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), _ptr(self._S), C.c_double(-1.0), _ptr(self.Wpack))
+            self._pack_split()
         self.gamma = self.beta = self.c = None
         if keep_points:
             self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
@@ -159,13 +173,34 @@ class SparseCAVI:
 
     def _pack_split(self):
         if self.split:
-            self.ctx.call("agpl_pack_w_split", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.S), C.c_double(-1.0),
+            self.ctx.call("agpl_pack_w_split", C.c_int32(self.M), C.c_int32(self.L), _ptr(self._S), C.c_double(-1.0),
                           _ptr(self.W_hi), _ptr(self.W_lo))
+
+    @property
+    def S(self):
+        """Covariance of q(v).  In the factor form it is materialised on demand: S = U'U, U' = triu of A_work viewed
+        row-major (rocSOLVER leaves U in the column-major lower triangle)."""
+        if not self.factor:
+            return self._S
+        Ut = _torch().triu(self.A_work)
+        return Ut @ Ut.transpose(1, 2)
+
+    @property
+    def m(self):
+        if not self.factor:
+            return self._m
+        return (_torch().triu(self.A_work) @ self.v.unsqueeze(-1)).squeeze(-1)
 
     def accumulate(self):
         """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
         d = self.lik.desc()
         self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
+        if self.factor:
+            self.ctx.call("agpl_cavi_pass_factor_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
+                          _ptr(self.Phi), _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0),
+                          _ptr(self.y), _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g),
+                          _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
+            return
         if self.split:
             self.ctx.call("agpl_cavi_pass_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                           _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y),
@@ -181,9 +216,15 @@ class SparseCAVI:
         exchange_natural_parameters(self.G, self.g, self.group)
 
     def update(self):
-        """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form)."""
+        """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the factor form
+        keeps U = chol(I + G)^-1 and v = U g (S = U'U, m = U'v) and packs the images of U."""
+        if self.factor:
+            self.ctx.call("agpl_gaussian_factor", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
+                          C.c_void_p(0), _ptr(self.A_work), _ptr(self.v), _ptr(self.alpha), _ptr(self.W_hi),
+                          _ptr(self.W_lo), C.c_void_p(0))
+            return
         self.ctx.call("agpl_gaussian_update", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
-                      C.c_void_p(0), _ptr(self.S), _ptr(self.m), _ptr(self.Wpack), _ptr(self.alpha))
+                      C.c_void_p(0), _ptr(self._S), _ptr(self._m), _ptr(self.Wpack), _ptr(self.alpha))
         self._pack_split()
 
     def sweep(self):
@@ -230,6 +271,11 @@ class SparseCAVI:
         torch = _torch()
         mu = torch.empty((self.L, self.N), dtype=torch.float32, device=self.Phi.device)
         var = torch.empty_like(mu)
+        if self.factor:
+            self.ctx.call("agpl_marginals_factor_split", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L),
+                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0), _ptr(self.W_hi),
+                          _ptr(self.W_lo), _ptr(self.alpha), _ptr(mu), _ptr(var))
+            return mu, var
         self.ctx.call("agpl_marginals", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.Wpack), _ptr(self.alpha), _ptr(mu), _ptr(var))
         return mu, var

@@ -62,8 +62,9 @@ def main():
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
-    ap.add_argument("--marginal", default="f16x2", choices=["f32", "f16x2"],
-                    help="marginal pass: f32-input MFMA, or split-float16 MFMA (3 f16 products per f32 product)")
+    ap.add_argument("--marginal", default="auto", choices=["auto", "f32", "f16x2", "f16x2-factor"],
+                    help="marginal pass: f32-input MFMA, split-float16 MFMA (3 f16 products per f32 product), or its "
+                         "one-pass factor form (needs padded M %% 256 == 0; auto picks it when it applies)")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +116,8 @@ def main():
     t_setup = time.time() - t_setup
     Mp = Phi.shape[1]
 
+    if args.marginal == "auto":
+        args.marginal = "f16x2-factor" if Mp % 256 == 0 else "f16x2"
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group, marginal_precision=args.marginal,
                         accumulate_precision=args.accumulate)
 
@@ -166,12 +169,13 @@ def main():
     # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
     nbk = Mp // 128
     executed = ((1.0 + 1.0 / nbk) * L * n_loc * Mp * Mp, (nbk + 1.0) / nbk * L * n_loc * Mp * Mp)
-    names = ("marginal_split_kernel" if args.marginal == "f16x2" else "marginal_kernel<0>",
+    msplit = args.marginal in ("f16x2", "f16x2-factor")
+    names = (("marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
              "syrk_split_kernel" if args.accumulate == "f16x2" else "syrk_kernel")
     # split-float16 kernels issue 3 float16 MFMA products (hi hi + hi lo + lo hi) per float32-equivalent product
     # and are priced against the dense float16 peak; the f32-input kernels against the f32 MFMA peak
-    mult = (3.0 if args.marginal == "f16x2" else 1.0, 3.0 if args.accumulate == "f16x2" else 1.0)
-    peaks = (PEAK_F16_MFMA_TFLOPS if args.marginal == "f16x2" else PEAK_F32_MFMA_TFLOPS,
+    mult = (3.0 if msplit else 1.0, 3.0 if args.accumulate == "f16x2" else 1.0)
+    peaks = (PEAK_F16_MFMA_TFLOPS if msplit else PEAK_F32_MFMA_TFLOPS,
              PEAK_F16_MFMA_TFLOPS if args.accumulate == "f16x2" else PEAK_F32_MFMA_TFLOPS)
     per = []
     for (ms, cnt), fl, ex, nm, mu, pk in zip(kt, flops, executed, names, mult, peaks):

@@ -258,6 +258,36 @@ AGPL_API int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, i
                                       const void *W_lo, const float *alpha, double *G_out, double *g_out,
                                       float *c_out, float *gamma_out, float *beta_out);
 
+/* ---- factor (one-pass) form of the split-float16 marginal pass -------------------------------------------------
+ * I + G = R R' (Cholesky), U = R^-1 (lower triangular), T = U Phi:
+ *     var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2        mu_n = mu0_n + sum_a v_a T[a,n],   v = U (g + eta0)
+ * which is the same q(f_n) as agpl_marginals (S = U'U, m = U'v; reference: the marginals of q(u) = N(m, S) pushed
+ * through K_XZ K_ZZ^-1, examples/<lik>/script.jl `u_posterior` + the SVGP predictive of ApproximateGPs) but needs T only:
+ * the launch reads the feature images once per 256-row block and never the float32 features.  M % 256 == 0.
+ *
+ * agpl_feature_residual : resid_n = k_nn - |phi_n|^2 (static; float64 accumulation).
+ * agpl_gaussian_factor  : A_work [L,M,M] f64 scratch/out (on return its column-major lower triangle holds U);
+ *                         v_out [L,M] f64 / v32_out [L,M] f32 / (U_hi, U_lo) images / logdet_out [L] f64 (device,
+ *                         log det(I + G)) are optional.  AGPL_ERR_NOT_POSDEF as agpl_gaussian_update.
+ * agpl_pack_factor_split: images of U from A_work (what agpl_gaussian_factor does when U_hi / U_lo are given).
+ * agpl_marginals_factor_split / agpl_cavi_pass_factor_split: the factor-form twins of agpl_marginals_split /
+ *                         agpl_cavi_pass_split (`resid` in place of kdiag, U images and v in place of W-pack and alpha).   */
+AGPL_API int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
+                                       float *resid_out);
+AGPL_API int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                      const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
+                                      void *U_lo, double *logdet_out);
+AGPL_API int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo);
+AGPL_API int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
+                                             const void *Phi_lo, const float *resid, const float *mu0,
+                                             const void *U_hi, const void *U_lo, const float *v, float *mu_out,
+                                             float *var_out);
+AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                             const float *Phi, const void *Phi_hi, const void *Phi_lo,
+                                             const float *resid, const float *mu0, const void *y, const void *U_hi,
+                                             const void *U_lo, const float *v, double *G_out, double *g_out,
+                                             float *c_out, float *gamma_out, float *beta_out);
+
 /* agpl_set_accumulate_precision: which kernel agpl_accumulate / agpl_cavi_pass(_split) / agpl_gibbs_pass use for
  *   G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default), 1 = split-float16 MFMA (psi = sqrt(gamma) phi is
  *   split into hi/lo float16 while staging; 3 float16 products per float32 product; needs gamma >= 0 and

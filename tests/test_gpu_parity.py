@@ -353,7 +353,7 @@ def test_gaussian_update_against_lapack(A, ctx, oracle):
                  C.c_void_p(m.data_ptr()), C.c_void_p(0), C.c_void_p(0))
 
 
-def _setup_svgp(A, ctx, O, lik, olik, N, M, ell_factor=1.5):
+def _setup_svgp(A, ctx, O, lik, olik, N, M, ell_factor=1.5, pad=128):
     x, y = A.synth_xy(lik, SEED, 0, N, ctx=ctx)
     z = np.linspace(-10, 10, M)
     ell = ell_factor * (z[1] - z[0])
@@ -368,6 +368,8 @@ def _setup_svgp(A, ctx, O, lik, olik, N, M, ell_factor=1.5):
     ref_Phi = ref_K.astype(np.float64) @ Linv.T
     assert np.abs(host(Phi)[:, :M] - ref_Phi).max() < 5e-5  # f32 GEMM with |L^-1| up to ~1e2
     kd = A.sparse.nystrom_residual(Phi, torch.ones(N, device="cuda"), ctx=ctx)
+    if Phi.shape[1] % pad:  # zero feature columns change nothing (M is padded, never truncated)
+        Phi = torch.nn.functional.pad(Phi, (0, pad - Phi.shape[1] % pad)).contiguous()
     return x, y, Phi, kd
 
 
@@ -754,3 +756,96 @@ def test_cavi_with_split_f16_both_passes_matches_oracle(A, ctx, oracle, name, N,
         ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
     assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
     assert relmax(host(cavi.g), g) < NAT_TOL
+
+
+# ------------------------------------------------------------------------------- factor (one-pass) marginal form
+@pytest.mark.parametrize("N,M,L", [(1000, 256, 1), (4099, 512, 1), (257, 256, 2), (70001, 256, 1)])
+def test_factor_marginals_against_float64(A, ctx, N, M, L):
+    """agpl_gaussian_factor + agpl_marginals_factor_split against float64 numpy: with I + G = R R', U = R^-1,
+    var = (k - |phi|^2) + |U phi|^2 and mu = mu0 + (U g)'(U phi) must equal k - phi'(I - S)phi and mu0 + m'phi."""
+    import ctypes as C
+
+    from agpl_amd import _ffi
+
+    rng = np.random.default_rng(N + M)
+    Phi = _features(rng, N, M)
+    kd = (np.sum(Phi.astype(np.float64) ** 2, axis=1) + rng.uniform(0.01, 0.5, size=N)).astype(np.float32)
+    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
+    G = np.einsum("lik,ljk->lij", B, B) * 3.0
+    g = rng.normal(size=(L, M))
+    mu0 = rng.normal(size=(L, N)).astype(np.float32)
+    dPhi, dkd, dG, dg, dmu0 = dev(Phi), dev(kd), dev(G), dev(g), dev(mu0)
+    nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(N), C.c_int32(M)) // 2
+    Ph = torch.empty(nh, dtype=torch.float16, device="cuda")
+    Pl = torch.empty(nh, dtype=torch.float16, device="cuda")
+    ctx.call("agpl_split_features", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()), C.c_void_p(Ph.data_ptr()),
+             C.c_void_p(Pl.data_ptr()))
+    resid = torch.empty(N, dtype=torch.float32, device="cuda")
+    ctx.call("agpl_feature_residual", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()),
+             C.c_void_p(dkd.data_ptr()), C.c_void_p(resid.data_ptr()))
+    ref_resid = kd.astype(np.float64) - np.sum(Phi.astype(np.float64) ** 2, axis=1)
+    assert np.abs(host(resid) - ref_resid).max() < 2e-7 * max(1.0, np.abs(kd).max())
+    Aw = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    v = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    v32 = torch.empty((L, M), dtype=torch.float32, device="cuda")
+    Uh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+    Ul = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+    ld = torch.empty(L, dtype=torch.float64, device="cuda")
+    ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()),
+             C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(v32.data_ptr()),
+             C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(ld.data_ptr()))
+    mu = torch.empty((L, N), dtype=torch.float32, device="cuda")
+    var = torch.empty((L, N), dtype=torch.float32, device="cuda")
+    ctx.call("agpl_marginals_factor_split", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(Ph.data_ptr()),
+             C.c_void_p(Pl.data_ptr()), C.c_void_p(resid.data_ptr()), C.c_void_p(dmu0.data_ptr()),
+             C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(v32.data_ptr()), C.c_void_p(mu.data_ptr()),
+             C.c_void_p(var.data_ptr()))
+    P = Phi.astype(np.float64)
+    for l in range(L):
+        S = np.linalg.inv(np.eye(M) + G[l])
+        m = S @ g[l]
+        # the factor itself: U'U = S, U'v = m, logdet
+        Ut = np.triu(host(Aw)[l])
+        assert relmax(Ut @ Ut.T, S) < 1e-10
+        assert relmax(Ut @ host(v)[l], m) < 1e-10
+        assert host(ld)[l] == pytest.approx(np.linalg.slogdet(np.eye(M) + G[l])[1], rel=1e-12)
+        ref_mu = mu0[l].astype(np.float64) + P @ m
+        ref_var = kd.astype(np.float64) - np.einsum("ia,ab,ib->i", P, np.eye(M) - S, P)
+        assert np.abs(host(mu)[l] - ref_mu).max() < 2e-6 * np.abs(P).sum(1).max() * np.abs(m).max() + 1e-6
+        assert np.abs(host(var)[l] - ref_var).max() < 3e-6 * max(1.0, np.abs(ref_var).max())
+
+
+def test_factor_form_rejects_unpadded_feature_count(A, ctx):
+    x = torch.zeros((64, 128), dtype=torch.float32, device="cuda")
+    with pytest.raises(A.ArgumentError):
+        A.SparseCAVI(A.BernoulliLikelihood(), x, torch.ones(64, device="cuda"),
+                     torch.zeros(64, dtype=torch.uint8, device="cuda"), ctx=ctx, marginal_precision="f16x2-factor")
+
+
+@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 200), ("negbin", 6_000, 256), ("cat", 4_000, 250),
+                                      ("studentt", 5_000, 256)])
+def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
+    """10-sweep natural-parameter bar with the one-pass factor marginals and the split-float16 accumulation
+    (bench.py's default path); S and m are materialised from (U, v) and compared too."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M, pad=256)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2-factor", accumulate_precision="f16x2")
+    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
+    Mp, L = Phi_h.shape[1], olik.nlatent
+    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+    try:
+        for it in range(10):
+            cavi.sweep()
+            G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
+            S, m = O.gaussian_update(G, g)
+    finally:
+        import ctypes as C
+
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
+    assert relmax(host(cavi.g), g) < NAT_TOL
+    # moments from (U, v): the M x M solve amplifies the natural-parameter difference by cond(I + G)
+    kappa = max(np.linalg.cond(np.eye(Mp) + G[l]) for l in range(L))
+    assert relmax(host(cavi.S), S) < max(1e-4, NAT_TOL * kappa)
+    assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
