@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
                                                             const float *__restrict__ Phi,
                                                             const float *__restrict__ sg_all,
                                                             const float *__restrict__ bp_all,
-                                                            float *__restrict__ slabG, float *__restrict__ slabg, int dbg) {
+                                                            float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nsplit8 = (nsplit + 7) / 8;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     if (nend > N) nend = N;
     const int nstage = (int)((nend - nbeg + 15) / 16);
     const int plast = (int)(nend - 1 - nbeg);
-    const float *sbase = Phi + (dbg ? (int64_t)0 : nbeg) * (int64_t)M;
+    const float *sbase = Phi + nbeg * (int64_t)M;
     const float *sgs = sg_all + (int64_t)l * Npad + nbeg;
     const float *bps = bp_all + (int64_t)l * Npad + nbeg;
 
@@ -622,9 +622,9 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     float gacc[4] = {0.f, 0.f, 0.f, 0.f};
 
     if (diag)
-        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, dbg ? 255 : plast, sgs, bps, acc, gacc);
+        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc);
     else
-        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, dbg ? 255 : plast, sgs, bps, acc, gacc);
+        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -867,7 +867,7 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         float *bp = sg + (int64_t)L * Npad;
         split_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, sg, bp);
         syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
-            N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->accumulate_split == 2);
+            N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg);
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
@@ -901,7 +901,7 @@ extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t 
 
 extern "C" int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (mode < 0 || mode > 2) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA) or 1 (split float16 MFMA)");
+    if (mode != 0 && mode != 1) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA) or 1 (split float16 MFMA)");
     ctx->accumulate_split = mode;
     return AGPL_OK;
 }

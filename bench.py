@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
+PMC_PROFILE = "r01_pmc_traffic_c2_v6.json"  # HBM bytes per launch of the split-float16 kernels (separate --pmc passes)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 
 
@@ -192,7 +193,7 @@ def main():
     # the committed summary is attached when it was collected on exactly this configuration, else null.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as fh:
             pm = json.load(fh)
         if pm["config"] == {"lik": args.lik, "N": N, "M": M, "L": L} and world == 1:
             traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")  # null until a PMC pass of this kernel is committed
@@ -203,7 +204,7 @@ def main():
     roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": peaks[dom],
                 "unit": "TFLOP/s", "frac": round(achieved / peaks[dom], 4) if achieved else None,
                 "mfma_products_per_algorithmic_product": mult[dom],
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic_c2.json" if traffic else None,
+                "traffic": traffic, "traffic_source": "profiles/" + PMC_PROFILE if traffic else None,
                 "kernels": per,
                 "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
 
