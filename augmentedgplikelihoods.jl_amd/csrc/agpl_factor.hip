@@ -1,0 +1,275 @@
+// agpl_factor.hip -- the M x M half of a sweep in ONE launch (M <= 512):
+//
+//     I + G = R R'   (Cholesky, float64)        U = R^-1        v = U (g + eta0)        logdet(I + G)
+//
+// which is what the factor form of the marginal pass consumes (agpl_marginals_factor_split: S = U'U and m = U'v are
+// never formed).  The rocSOLVER route (potrf + trtri) costs ~300 dependent launches of 5-140 us = 3.4 ms at M = 512
+// and at M = 1024 alike: latency, not flops (2 x M^3/3 = 90 MFLOP).  Here one 1024-thread workgroup per latent runs a
+// right-looking blocked Cholesky (block 32) and carries the identity along as right-hand sides, so the inverse factor
+// falls out of the same sweep over k:
+//
+//   for block k:   D  = T[k,k] -> R_kk = chol(D), W = R_kk^-1   (32 x 32 thread grid, one barrier per column)
+//                  P  = T[k+1:, k] W'            (the panel of R below the block: M' x 32, kept in LDS only)
+//                  X_k = W RHS[k, :]             (rows k of U: final; 32 x 32 (k+1), kept in LDS as X_k')
+//                  T[k+1:, k+1:]  -= P P'        (trailing update, lower triangle)
+//                  RHS[k+1:, :]   -= P X_k       (the identity's forward elimination)
+//
+// P has M - 32 (k+1) rows and X_k' has 32 (k+1): together always M rows of 32 doubles -- one LDS region of M x 33 doubles.
+// The panel / X_k products and both updates are the same routine C[u][w] (-)= sum_m Uop[u][m] Vop[w][m] on 32 x 32 wave
+// tiles of v_mfma_f64_16x16x4_f64 with both operands in LDS (pitch 33); the lanes of a result run along the
+// contiguous index of the output (T row-major, U column-major).
+// R itself is never stored: no later step needs an old panel.
+//
+// Output convention = rocSOLVER's (so agpl_pack_factor_split and the S / m accessors are shared with the library
+// route): U[a][b] (b <= a) at A[b * M + a]; the other triangle of A is left untouched.
+#include "agpl_common.h"
+
+namespace {
+
+constexpr int FB = 32;      // block size
+constexpr int FP = FB + 1;  // LDS pitch (doubles)
+
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// 32 x 32 macro tile on the float64 matrix cores:  acc[ti][tj] += Uop[16 ti + i][:] . Vop[16 tj + j][:]  over the 32
+// columns of both LDS operands (row pitch FP).  v_mfma_f64_16x16x4_f64 (layout probed on gfx950, tools/scratch):
+// lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
+// D[4 r + (l >> 4)][l & 15].
+__device__ __forceinline__ void macro_mac(const double *__restrict__ Uop, const double *__restrict__ Vop, int lane,
+                                          d4 (&acc)[2][2]) {
+    const int off = (lane & 15) * FP + (lane >> 4);
+    const double *u = Uop + off, *v = Vop + off;
+#pragma unroll
+    for (int kk = 0; kk < FB / 4; ++kk) {
+        const double a0 = u[4 * kk], a1 = u[16 * FP + 4 * kk];
+        const double b0 = v[4 * kk], b1 = v[16 * FP + 4 * kk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// 32 x 16 tile (two MFMA tiles sharing the B operand): the update tiles also hold the prefetched old values, and
+// 2 x (16 + 16) result / old VGPRs is what fits beside them under the 128-VGPR cap of a 1024-thread workgroup
+__device__ __forceinline__ void mac_2x1(const double *__restrict__ Uop, const double *__restrict__ Vop, int lane,
+                                        d4 (&acc)[2]) {
+    const int off = (lane & 15) * FP + (lane >> 4);
+    const double *u = Uop + off, *v = Vop + off;
+#pragma unroll
+    for (int kk = 0; kk < FB / 4; ++kk) {
+        const double a0 = u[4 * kk], a1 = u[16 * FP + 4 * kk], b0 = v[4 * kk];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__restrict__ Gall,
+                                                         const double *__restrict__ gall,
+                                                         const double *__restrict__ eta0all, double *__restrict__ Tall,
+                                                         double *__restrict__ Aall, double *__restrict__ vall,
+                                                         float *__restrict__ v32all, double *__restrict__ logdet,
+                                                         int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *PX = sm;                 // [M][FP]: rows 0..Mp-1 = P, rows Mp..M-1 = X_k' (one row per column c of U)
+    double *Ds = PX + (size_t)M * FP; // [32][FP] diagonal block being eliminated, then the identity's elimination
+    double *Rs = Ds + FB * FP;       // [32][FP] the identity block being eliminated alongside
+    double *Wf = Rs + FB * FP;       // [32][FP] W = R_kk^-1
+    __shared__ int bad;
+    __shared__ double ldsum;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = blockIdx.x;
+    const double *G = Gall + (size_t)l * M * M;
+    double *T = Tall + (size_t)l * M * M;
+    double *A = Aall + (size_t)l * M * M;
+    const int nb = M / FB;
+
+    if (tid == 0) {
+        bad = 0;
+        ldsum = 0.0;
+    }
+    // T (lower triangle) = I + G
+    for (int idx = tid; idx < M * M; idx += 1024) {
+        const int i = idx / M, j = idx - i * M;
+        if (j <= i) T[idx] = G[idx] + (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+
+    for (int k = 0; k < nb; ++k) {
+        const int kb = k * FB;
+        const int Mp = M - kb - FB; // trailing rows
+        const int ncx = kb + FB;    // columns of U that rows kb.. can touch
+        // ---- stage the diagonal block and the raw panel
+        {
+            const int r = tid >> 5, c = tid & 31;
+            Ds[r * FP + c] = c <= r ? T[(size_t)(kb + r) * M + kb + c] : 0.0;
+        }
+        for (int idx = tid; idx < Mp * FB; idx += 1024) {
+            const int ip = idx >> 5, m = idx & 31;
+            PX[(size_t)ip * FP + m] = T[(size_t)(kb + FB + ip) * M + kb + m];
+        }
+        // rows kb..kb+31 of the eliminated identity, one LDS row per column c (block (k,k) is still the identity)
+        for (int idx = tid; idx < ncx * FB; idx += 1024) {
+            const int c = idx >> 5, q = idx & 31;
+            PX[(size_t)(Mp + c) * FP + q] = c < kb ? A[(size_t)c * M + kb + q] : (c - kb == q ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
+        //      column c: column c of the working block D and row c of the eliminated identity Y are final since step
+        //      c - 1, and step c only writes columns > c of D and rows > c of Y.
+        //         R[r][c] = D[r][c] / sqrt(D[c][c]);   D[r][cc] -= R[r][c] R[cc][c]   (cc > c)
+        //         W[c][:] = Y[c][:] / R[c][c];         Y[r][:]  -= R[r][c] W[c][:]    (r > c)
+        {
+            const int r = tid >> 5, cc = tid & 31;
+            double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
+            Y[r * FP + cc] = r == cc ? 1.0 : 0.0;
+            for (int c = 0; c < FB; ++c) {
+                __syncthreads();
+                const double piv = Ds[c * FP + c];
+                // 1 / R[c][c]: v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle sqrt + divide
+                // sequences: this is the serial spine of the whole factorisation (32 dependent steps per block)
+                double rs = __builtin_amdgcn_rsq(piv);
+                rs = rs * (1.5 - 0.5 * piv * rs * rs);
+                rs = rs * (1.5 - 0.5 * piv * rs * rs);
+                const double lrc = Ds[r * FP + c] * rs; // R[r][c]   (r >= c)
+                if (cc > c && r >= cc) Ds[r * FP + cc] -= lrc * (Ds[cc * FP + c] * rs);
+                const double wc = Y[c * FP + cc] * rs;  // W[c][cc]
+                if (r == c) Wf[c * FP + cc] = wc;
+                if (r > c) Y[r * FP + cc] -= lrc * wc;
+                if (tid == 0) {
+                    ldsum += log(piv); // = 2 log R_cc
+                    if (!(piv > 0.0)) bad = kb + c + 1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every row of PX times W':  P[i'][c] = sum_m Araw[i'][m] W[c][m]  (panel of R below the block) and
+        //      X_k'[c][m] = sum_q RHS[kb+q][c] W[m][q]  (rows kb..kb+31 of U, final).  Wave w owns rows 32 w..32 w + 31
+        //      and nobody else touches them: in place without a barrier between its reads and its writes.
+        if (wave * 32 < M) {
+            d4 acc[2][2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+            double *rows = PX + (size_t)wave * 32 * FP;
+            macro_mac(rows, Wf, lane, acc);
+            const bool xrows = wave * 32 >= Mp; // Mp % 32 == 0: a wave's rows are all P rows or all X rows
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + 4 * r + (lane >> 4), m = 16 * tj + (lane & 15);
+                        const double val = acc[ti][tj][r];
+                        rows[i * FP + m] = val;
+                        if (xrows) {
+                            const int c = wave * 32 + i - Mp;
+                            if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // (the other triangle of A is not ours)
+                        }
+                    }
+        }
+        __syncthreads();
+        if (Mp > 0) {
+            // ---- 32 x 16 wave tiles: (a) T[i][j] -= P_i . P_j over the lower block triangle (16 wb <= 32 ub + 31);
+            //                          (b) RHS[i][c] -= X_k'[c] . P_i for every 32-column block cb (U is column-major:
+            //                              the lanes of a result run along i).
+            // The old values are loaded first (uniform tile origin + one 32-bit lane offset): their latency hides
+            // behind the 16 MFMAs.
+            const int nbp = Mp / 32, ncb = ncx / 32;
+            const int ntile_a = nbp * (nbp + 1), ntile_b = ncb * 2 * nbp;
+            const unsigned lo_ = (unsigned)(lane >> 4) * (unsigned)M + (unsigned)(lane & 15);
+            int ub = 0;
+            for (int w = wave; w < ntile_a + ntile_b; w += 16) {
+                d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
+                if (w < ntile_a) {
+                    while ((ub + 1) * (ub + 2) <= w) ++ub;
+                    const int wb = w - ub * (ub + 1); // 16-column block, 0 .. 2 ub + 1
+                    double *tp = T + (size_t)(kb + FB + 32 * ub) * M + kb + FB + 16 * wb;
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) old[ti][r] = tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                    mac_2x1(PX + (size_t)ub * 32 * FP, PX + (size_t)wb * 16 * FP, lane, acc);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ip = 32 * ub + 16 * ti + 4 * r + (lane >> 4), jp = 16 * wb + (lane & 15);
+                            // (elements above the diagonal of a diagonal tile were read too: inside T, unused)
+                            if (jp <= ip) tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                        }
+                } else {
+                    const int wbi = w - ntile_a;
+                    const int cb = wbi / (2 * nbp), ib = wbi - cb * 2 * nbp; // 32 columns c x 16 rows i
+                    double *ap = A + (size_t)(32 * cb) * M + kb + FB + 16 * ib;
+                    const bool fresh = 32 * cb >= kb; // column block k: nothing eliminated into it yet
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                    mac_2x1(PX + (size_t)(Mp + 32 * cb) * FP, PX + (size_t)ib * 16 * FP, lane, acc);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- v = U (g + eta0):  v[a] = sum_{b <= a} A[b * M + a] r[b].  Wave w takes b = w, w + 16, ...; lanes run along
+    //      a (coalesced); the 16 partial sums of an a are combined in wave order (fixed order: reproducible)
+    {
+        double *rs = PX;     // [M]
+        double *part = PX + M; // [16][M]
+        const double *g = gall + (size_t)l * M;
+        for (int b = tid; b < M; b += 1024) rs[b] = g[b] + (eta0all ? eta0all[(size_t)l * M + b] : 0.0);
+        __syncthreads();
+        for (int a = lane; a < M; a += 64) {
+            double acc = 0.0;
+#pragma unroll 4
+            for (int b = wave; b <= a; b += 16) acc += A[(size_t)b * M + a] * rs[b];
+            part[wave * M + a] = acc;
+        }
+        __syncthreads();
+        for (int a = tid; a < M; a += 1024) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) acc += part[w * M + a];
+            if (vall) vall[(size_t)l * M + a] = acc;
+            if (v32all) v32all[(size_t)l * M + a] = (float)acc;
+        }
+    }
+    if (tid == 0) {
+        if (logdet) logdet[l] = ldsum;
+        info[l] = bad;
+    }
+}
+
+} // namespace
+
+// internal: fused factorisation (M % 32 == 0, M <= 512); T_work / A_work [L][M][M] float64, info [L] int (device)
+int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
+                          double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
+                          int *info_dev) {
+    const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    factor_kernel<<<(unsigned)L, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
+                                                           info_dev);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}

@@ -9,6 +9,9 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "agpl_common.h"
 
 // agpl_ops.hip / agpl_mfma.hip internals
@@ -241,6 +244,9 @@ __global__ __launch_bounds__(256) void factor_apply_kernel(int M, const double *
 
 extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi,
                                           void *U_lo);
+int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
+                          double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
+                          int *info_dev);
 
 // I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
 // pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
@@ -250,6 +256,29 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || L > 64 || !G || !g || !A_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if ((U_hi == nullptr) != (U_lo == nullptr)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "U_hi and U_lo go together");
+    static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
+    if (M <= 512 && M % 32 == 0 && !use_lib) {
+        // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
+        const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
+        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes);
+        if (rc) return rc;
+        int *info = (int *)((char *)ctx->ws2 + info_off);
+        double *T = (double *)((char *)ctx->ws2 + info_off + 1024);
+        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info);
+        if (rc) return rc;
+        if (U_hi) {
+            rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
+            if (rc) return rc;
+        }
+        int hinfo[64];
+        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < L; ++i)
+            if (hinfo[i] != 0)
+                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot block at row %d)",
+                          i, (int)hinfo[i] - 1);
+        return AGPL_OK;
+    }
     rocblas_handle h;
     int32_t rc = get_handle(ctx, &h);
     if (rc) return rc;
