@@ -849,3 +849,41 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
     kappa = max(np.linalg.cond(np.eye(Mp) + G[l]) for l in range(L))
     assert relmax(host(cavi.S), S) < max(1e-4, NAT_TOL * kappa)
     assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
+
+
+@pytest.mark.parametrize("M,L", [(128, 1), (512, 2), (1024, 1)])
+def test_gaussian_factor_with_prior_term_and_both_routes(A, ctx, M, L):
+    """agpl_gaussian_factor with eta0: v = U (g + eta0); the fused kernel (M <= 512) and the rocSOLVER route (M = 1024)
+    satisfy the same identities: U'U = (I+G)^-1, U'v = (I+G)^-1 (g + eta0), log det."""
+    import ctypes as C
+
+    rng = np.random.default_rng(M + L)
+    B = rng.normal(size=(L, M, M + 7)) / np.sqrt(M)
+    G = np.einsum("lik,ljk->lij", B, B) * 5.0
+    g, eta0 = rng.normal(size=(L, M)), rng.normal(size=(L, M))
+    dG, dg, de = dev(G), dev(g), dev(eta0)
+    Aw = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    v = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    ld = torch.empty(L, dtype=torch.float64, device="cuda")
+    ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()),
+             C.c_void_p(de.data_ptr()), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(0),
+             C.c_void_p(0), C.c_void_p(0), C.c_void_p(ld.data_ptr()))
+    for l in range(L):
+        S = np.linalg.inv(np.eye(M) + G[l])
+        Ut = np.triu(host(Aw)[l])
+        assert relmax(Ut @ Ut.T, S) < 1e-10
+        assert relmax(Ut @ host(v)[l], S @ (g[l] + eta0[l])) < 1e-10
+        assert host(ld)[l] == pytest.approx(np.linalg.slogdet(np.eye(M) + G[l])[1], rel=1e-12)
+
+
+def test_gaussian_factor_reports_indefinite_matrix(A, ctx):
+    import ctypes as C
+
+    M = 256
+    G = -2.0 * np.eye(M)[None]  # I + G = -I
+    dG, dg = dev(G), dev(np.zeros((1, M)))
+    Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    with pytest.raises(A.PosDefException):
+        ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()),
+                 C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
+                 C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
