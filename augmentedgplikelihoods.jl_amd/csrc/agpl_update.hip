@@ -423,6 +423,32 @@ __global__ void add_vec_kernel(int n, const double *__restrict__ a, const double
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + (b ? b[i] : 0.0);
 }
+// m[b] = sum_{a >= b} U[a][b] vf[a],  v[b] = sum_{a >= b} U[a][b] (vf[a] + z[a])   with U[a][b] = A[b * M + a]:
+// one wave per b reads its row of A contiguously; fixed-order butterfly
+__global__ __launch_bounds__(256) void factor_draw_kernel(int M, const double *__restrict__ A,
+                                                          const double *__restrict__ vf, const double *__restrict__ z,
+                                                          double *__restrict__ v_out, double *__restrict__ m_out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), l = blockIdx.y;
+    if (b >= M) return;
+    const double *row = A + ((size_t)l * M + b) * M;
+    const double *vl = vf + (size_t)l * M, *zl = z + (size_t)l * M;
+    double am = 0.0, av = 0.0;
+    for (int a = b + lane; a < M; a += 64) {
+        const double u = row[a], f = vl[a];
+        am += u * f;
+        av += u * (f + zl[a]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        am += __shfl_xor(am, o);
+        av += __shfl_xor(av, o);
+    }
+    if (lane == 0) {
+        v_out[(size_t)l * M + b] = av;
+        if (m_out) m_out[(size_t)l * M + b] = am;
+    }
+}
 } // namespace
 
 extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
@@ -430,6 +456,34 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
+    static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
+    if (M <= 512 && M % 32 == 0 && L <= 64 && !use_lib) {
+        // I + G = C C', U = C^-1:  m = U'(U r),  v = m + C^-T z = U'(U r + z)   (one fused factor launch + one matvec)
+        const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
+        const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
+        const size_t info_off = 16384;
+        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512);
+        if (rc) return rc;
+        int *info = (int *)((char *)ctx->ws2 + info_off);
+        char *p = (char *)ctx->ws2 + info_off + 1024;
+        double *T = (double *)p, *A = (double *)(p + mat_bytes);
+        double *vf = (double *)(p + 2 * mat_bytes), *z = (double *)(p + 2 * mat_bytes + vec_bytes);
+        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A, vf, nullptr, nullptr, info);
+        if (rc) return rc;
+        rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
+        if (rc) return rc;
+        dim3 gd((unsigned)agpl_cdiv(M, 4), (unsigned)L);
+        factor_draw_kernel<<<gd, 256, 0, ctx->stream>>>(M, A, vf, z, v_out, m_out);
+        AGPL_LAUNCH_CHECK(ctx);
+        int hinfo[64];
+        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < L; ++i)
+            if (hinfo[i] != 0)
+                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot at row %d)", i,
+                          (int)hinfo[i] - 1);
+        return AGPL_OK;
+    }
     rocblas_handle h;
     int32_t rc = get_handle(ctx, &h);
     if (rc) return rc;

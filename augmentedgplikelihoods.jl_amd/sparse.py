@@ -311,9 +311,13 @@ class SparseGibbs:
     (same Philox key / counter).  Real-valued y must be float64 here (the Gibbs operators are Float64).
     """
 
-    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False):
+    def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
+                 accumulate_precision: str = "f32"):
         torch = _torch()
         self.ctx = ctx or default_context()
+        if accumulate_precision not in ("f32", "f16x2"):
+            raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
+        self.acc_split = 1 if accumulate_precision == "f16x2" else 0
         self.lik = lik
         self.Phi = _prep(Phi, torch.float32, "Phi")
         self.N, self.M = self.Phi.shape
@@ -347,6 +351,7 @@ class SparseGibbs:
 
     def accumulate(self):
         d = self.lik.desc()
+        self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
         self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
                       _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))

@@ -230,7 +230,7 @@ def main():
             return ms.value, cnt.value
 
         yg = y.to(torch.float64) if lik.ykind == "real" else y
-        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None)
+        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None, accumulate_precision=args.accumulate)
         for _ in range(2):
             gib.sweep()
         torch.cuda.synchronize()
