@@ -137,10 +137,23 @@ def main():
 
     _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
     t0 = time.perf_counter()
+    trace = os.environ.get("AGPL_BENCH_TRACE")  # debug: per-step wall times ("1" adds a sync per step)
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         cavi.sweep()
+        if trace == "1":
+            torch.cuda.synchronize()
+        if trace == "3":
+            step_times.append(time.perf_counter() - ts)
+        elif trace:
+            print(f"[trace] step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
+    t_loop = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if trace:
+        print(f"[trace] loop {1e3 * t_loop:.2f} ms, loop + final barrier {1e3 * dt:.2f} ms "
+              f"steps {[round(1e3 * t, 2) for t in step_times]}", file=sys.stderr)
     kt = []
     for which in (0, 1):
         ms, cnt = C.c_double(), C.c_int64()
