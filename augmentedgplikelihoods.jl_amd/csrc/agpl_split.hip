@@ -258,14 +258,14 @@ __global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M
 // ------------------------------------------------------------------------------------------------
 constexpr int NT2 = 256;
 
-template <int R, bool FACTOR>
+template <int R, bool FACTOR, int KU>
 __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
     int64_t N, int M, int64_t ntiles128, const float *__restrict__ Phi, const h8 *__restrict__ Ph,
     const h8 *__restrict__ Pl, const float *__restrict__ kdiag, const float *__restrict__ mu0,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ alpha_all,
     float *__restrict__ mu_out, float *__restrict__ var_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int kSlot = 8 * 4096;
+    constexpr int kSlot = KU * 8 * 4096; // KU 16-deep k-slices per stage (= per barrier)
     float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // M floats
     float *qred = alpha_s + M;                                         // 4 x 256
     float *mred = qred + 4 * NT2;                                      // 4 x 256
@@ -295,15 +295,20 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
     float qacc[2] = {0.f, 0.f};
     float macc[2] = {0.f, 0.f};
 
-    const int T = nb2 * nks - 16 * nb2 * (nb2 - 1) / 2; // = 8 nb2 (nb2 + 1) in both forms
+    const int T = (nb2 * nks - 16 * nb2 * (nb2 - 1) / 2) / KU; // slices: 8 nb2 (nb2 + 1) in both forms; 16 % KU == 0
     int irb = 0, iks = 0; // issue pointer
     typedef __attribute__((address_space(3))) void lds_void;
 #define AGPL_DMA_ISSUE(t_)                                                                                  \
     do {                                                                                                    \
         unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
-        __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks) * 256, (lds_void *)(slot_), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds(b_src + (int64_t)iks * 256, (lds_void *)(slot_ + 4 * 4096), 16, 0, 0); \
-        if (++iks == (FACTOR ? 16 * (irb + 1) : nks)) {                                                     \
+        _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                                 \
+            __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks + u_) * 256,          \
+                                             (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);                \
+            __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256,                             \
+                                             (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0);     \
+        }                                                                                                   \
+        iks += KU;                                                                                          \
+        if (iks == (FACTOR ? 16 * (irb + 1) : nks)) {                                                       \
             ++irb;                                                                                          \
             iks = FACTOR ? 0 : irb * 16;                                                                    \
         }                                                                                                   \
@@ -327,11 +332,11 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 
     int rb = 0, ks = 0; // consume pointer
     for (int t = 0; t < T; ++t) {
-        // stage t has landed once at most the stages issued after it are outstanding (2 DMAs each)
+        // stage t has landed once at most the stages issued after it are outstanding (2 KU DMAs each)
         if (t + R - 2 < T) {
-            if (R == 2) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-            else if (R == 3) __builtin_amdgcn_s_waitcnt(0x0F72); // vmcnt(2)
-            else __builtin_amdgcn_s_waitcnt(0x0F74);             // vmcnt(4)
+            constexpr int kOut = 2 * KU * (R - 2);
+            static_assert(kOut < 16, "vmcnt immediate");
+            __builtin_amdgcn_s_waitcnt(0x0F70 | kOut); // vmcnt(kOut)
         } else {
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
@@ -340,24 +345,28 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
         // rows 128..255 of the block are zero for the block's first 8 slices (strictly lower part of W');
         // FACTOR: rows 0..127 are zero for its last 8 slices (strictly upper part of U)
         if (FACTOR ? !(!(wr >> 1) && ks >= rb * 16 + 8) : !((wr >> 1) && ks < rb * 16 + 8)) {
-            const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
-            const h8 ah0 = st[fa], ah1 = st[fa + 32], bh0 = st[fb], bh1 = st[fb + 32];
-            acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
-            const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
-            acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
-            const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
-            acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(al1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot + u * 8 * 4096);
+                const h8 ah0 = st[fa], ah1 = st[fa + 32], bh0 = st[fb], bh1 = st[fb + 32];
+                acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
+                acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+                acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
+                acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
+                const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
+                acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
+                acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+                acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
+                acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
+                const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
+                acc[0][0] = mfma16(al0, bh0, acc[0][0]);
+                acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+                acc[1][0] = mfma16(al1, bh0, acc[1][0]);
+                acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+            }
         }
-        if (++ks == (FACTOR ? 16 * (rb + 1) : nks)) {
+        ks += KU;
+        if (ks == (FACTOR ? 16 * (rb + 1) : nks)) {
             if (FACTOR) {
                 // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n] (lane rows a = .. + 8 g + 4 lk + 0..3)
                 const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * lk;
@@ -526,10 +535,10 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
     if (M % NT2 == 0 && !force128) {
         constexpr int R = 4;
         const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, false>),
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, false, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
-        marginal_split256_kernel<R, false><<<grid2, 1024, lds2, ctx->stream>>>(
+        marginal_split256_kernel<R, false, 1><<<grid2, 1024, lds2, ctx->stream>>>(
             N, M, agpl_cdiv(N, NT), Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag, mu0, (const h8 *)W_hi,
             (const h8 *)W_lo, alpha, mu_out, var_out);
     } else {
@@ -574,16 +583,26 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
     if (N == 0) return AGPL_OK;
     if (!Phi_hi || !Phi_lo || !resid || !U_hi || !U_lo || !v || !mu_out || !var_out)
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    constexpr int R = 4;
-    const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    // tuning knob: AGPL_MARGINAL_STAGE = <ring slots R><16-deep slices per stage KU>.  Measured at C2 on one box:
+    // 41 9.73 ms, 31 9.84, 21 9.91, 22 9.33 (two slices per barrier, one 64 KB stage in flight) -> default 22
+    static const int cfg = getenv("AGPL_MARGINAL_STAGE") ? atoi(getenv("AGPL_MARGINAL_STAGE")) : 22;
     dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
     int32_t rc = agpl_timing_begin(ctx, 0);
     if (rc) return rc;
-    marginal_split256_kernel<R, true><<<grid2, 1024, lds2, ctx->stream>>>(
-        N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
-        (const h8 *)U_lo, v, mu_out, var_out);
+#define AGPL_LAUNCH_M256(R_, KU_)                                                                                    \
+    do {                                                                                                             \
+        const size_t lds2 = (size_t)(R_) * (KU_) * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);                 \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R_, true, KU_>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                   \
+        marginal_split256_kernel<R_, true, KU_><<<grid2, 1024, lds2, ctx->stream>>>(                                 \
+            N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,  \
+            (const h8 *)U_lo, v, mu_out, var_out);                                                                   \
+    } while (0)
+    if (cfg == 41) AGPL_LAUNCH_M256(4, 1);
+    else if (cfg == 31) AGPL_LAUNCH_M256(3, 1);
+    else if (cfg == 21) AGPL_LAUNCH_M256(2, 1);
+    else AGPL_LAUNCH_M256(2, 2);
+#undef AGPL_LAUNCH_M256
     AGPL_LAUNCH_CHECK(ctx);
     return agpl_timing_end(ctx, 0);
 }
