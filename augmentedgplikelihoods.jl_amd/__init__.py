@@ -19,7 +19,7 @@ from ._ffi import AGPLError, ArgumentError, DomainError, PosDefException, build
 from .likelihoods import (BernoulliLikelihood, CategoricalLikelihood, HeteroscedasticGaussianLikelihood,
                           LaplaceLikelihood, NegativeBinomialLikelihood, PoissonLikelihood, StudentTLikelihood,
                           nlatent)
-from .operators import (AuxPosterior, Context, TupleVector, aug_loglik_unsupported, auglik_potential,
+from .operators import (AuxPosterior, Context, TupleVector, aug_loglik, aux_prior_logpdf, auglik_potential,
                         auglik_potential_and_precision, auglik_precision, aux_kldivergence, aux_posterior,
                         aux_posterior_, aux_sample, aux_sample_, default_context, expected_auglik_potential,
                         expected_auglik_potential_and_precision, expected_auglik_precision, expected_logtilt,
@@ -36,7 +36,7 @@ __all__ = [
     "init_aux_variables", "init_aux_posterior", "aux_sample", "aux_sample_", "aux_posterior", "aux_posterior_",
     "auglik_potential", "auglik_precision", "auglik_potential_and_precision",
     "expected_auglik_potential", "expected_auglik_precision", "expected_auglik_potential_and_precision",
-    "logtilt", "expected_logtilt", "aux_kldivergence", "rand_polyagamma",
+    "logtilt", "expected_logtilt", "aux_kldivergence", "aug_loglik", "aux_prior_logpdf", "rand_polyagamma",
     "SparseCAVI", "SparseGibbs", "DenseGibbs", "se_features", "whiten_features", "synth_xy", "shard_range",
     "exchange_natural_parameters",
 ]

@@ -341,7 +341,61 @@ __device__ __forceinline__ double digamma_(double x) {
            f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f / 132.0))));
 }
 
-enum { RED_LOGTILT = 0, RED_EXPECTED_LOGTILT = 1, RED_KL = 2 };
+// logpdf(PolyaGamma(b, c), x) -- polyagamma.jl:37-91: exponential tilt + (b-1) log 2 - (log 2pi + 3 log x) / 2 + the
+// log of the 101-term alternating series (n = 0, 2, .., 200), evaluated in the log domain (logsumexp) for x < 1e-2
+// exactly as the reference does.  The running product prod_{m<=n} (1 + (b-1)/m) is carried along; the log-domain
+// branch makes two passes over the terms (maximum, then sum) instead of materialising them.
+__device__ __forceinline__ double log1mexp_(double x) { // LogExpFunctions.log1mexp, x < 0
+    return x < -kLogTwo ? log1p(-exp(x)) : log(-expm1(x));
+}
+__device__ double pg_log_series_term(double x, double b, int n, double logprod) {
+    const double Rn = 2.0 * n + b;
+    const double log_c_nb = log(n + b) - log(n + 1.0) + log(2.0 / Rn + 1.0);
+    const double log_inner = log1mexp_(log_c_nb + ((Rn + 1.0) / (-2.0 * x)));
+    return (n == 0 ? 0.0 : logprod) + log(Rn) + Rn * Rn / (-8.0 * x) + log_inner;
+}
+__device__ double pg_logpdf(double b, double c, double x) {
+    if (b == 0.0) return x == 0.0 ? 0.0 : -__builtin_inf();
+    const double ext = b * logcosh_(c / 2.0) - c * c * x / 2.0 + (b - 1.0) * kLogTwo - (kLog2Pi + 3.0 * log(x)) / 2.0;
+    if (x < 1e-2) {
+        double mx = -__builtin_inf(), logprod = 0.0;
+        int m = 0;
+        for (int n = 0; n <= 200; n += 2) {
+            while (m < n) {
+                m += 1;
+                logprod += log(1.0 + (b - 1.0) / m);
+            }
+            const double t = pg_log_series_term(x, b, n, logprod);
+            mx = t > mx ? t : mx;
+        }
+        double ssum = 0.0;
+        logprod = 0.0;
+        m = 0;
+        for (int n = 0; n <= 200; n += 2) {
+            while (m < n) {
+                m += 1;
+                logprod += log(1.0 + (b - 1.0) / m);
+            }
+            ssum += exp(pg_log_series_term(x, b, n, logprod) - mx);
+        }
+        return ext + mx + log(ssum);
+    }
+    double prod = 1.0, acc = 0.0;
+    int m = 0;
+    for (int n = 0; n <= 200; n += 2) {
+        while (m < n) {
+            m += 1;
+            prod *= 1.0 + (b - 1.0) / m;
+        }
+        const double Rn = 2.0 * n + b;
+        const double c_nb = ((n + b) / (n + 1.0)) * (2.0 / Rn + 1.0);
+        acc += (n == 0 ? 1.0 : prod) * Rn * exp(Rn * Rn / (-8.0 * x)) * (1.0 - c_nb * exp((Rn + 1.0) / (-2.0 * x)));
+    }
+    if (!(acc > 2.2250738585072014e-308)) acc = 2.2250738585072014e-308; // max(s, floatmin)
+    return ext + log(acc);
+}
+
+enum { RED_LOGTILT = 0, RED_EXPECTED_LOGTILT = 1, RED_KL = 2, RED_AUX_PRIOR_LOGPDF = 3, RED_AUG_LOGLIK = 4 };
 
 struct RedArgs {
     const void *y;
@@ -352,9 +406,33 @@ struct RedArgs {
     const double *var; // var
 };
 
+__device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A);
+
+// logdensity_def(aux_prior(lik, y), Omega) per point -- the second half of aug_loglik (generic.jl:48-50).
+// PG(1, 0) bernoulli.jl:9-11 ; PG(y + r, 0) negativebinomial.jl:14-18 ; Gamma(nu/2, scale 2 sigma^2/nu) studentt.jl:91.
+// The categorical / Poisson priors go through the reference's broken logdensity_def and the others are
+// never evaluated by it: unsupported here.
+__device__ double aux_prior_logpdf_term(const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
+    const double *omega = A.a1;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC:
+        return pg_logpdf(1.0, 0.0, omega[i]);
+    case AGPL_LIK_NEGBINOMIAL:
+        return pg_logpdf((double)((const int32_t *)A.y)[i] + lik.p[0], 0.0, omega[i]);
+    case AGPL_LIK_STUDENTT: {
+        const double a = lik.p[0] / 2.0, th = lik.p[1] * lik.p[1] / a;
+        return -lgamma(a) - a * log(th) + (a - 1.0) * log(omega[i]) - omega[i] / th;
+    }
+    default:
+        return __builtin_nan("");
+    }
+}
+
 __device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
     const int L = lik.nlatent;
     const double nanv = __builtin_nan("");
+    if (mode == RED_AUX_PRIOR_LOGPDF) return aux_prior_logpdf_term(lik, i, A);
+    if (mode == RED_AUG_LOGLIK) return red_term(RED_LOGTILT, lik, i, A) + aux_prior_logpdf_term(lik, i, A);
     if (mode == RED_LOGTILT) {
         const double *omega = A.a1, *f = A.f;
         switch (lik.kind) {
@@ -522,6 +600,11 @@ int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t
                   "(categorical.jl:165-170); use the bijective link");
     if (lik->kind == AGPL_LIK_HETEROGAUSS)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "heteroscedastic ELBO terms are not split in the reference");
+    if ((mode == RED_AUX_PRIOR_LOGPDF || mode == RED_AUG_LOGLIK) && lik->kind != AGPL_LIK_BERNOULLI_LOGISTIC &&
+        lik->kind != AGPL_LIK_NEGBINOMIAL && lik->kind != AGPL_LIK_STUDENTT)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
+                  "aug_loglik / the aux-prior log-density is available for the Bernoulli, negative-binomial and "
+                  "Student-t likelihoods (the reference's logdensity_def of the other priors is broken or absent)");
     if (n <= 0) {
         *out_host = 0.0;
         return AGPL_OK;
@@ -689,6 +772,16 @@ extern "C" int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t
                                 const double *omega, const int64_t *n_aux, const double *f, double *out_host) {
     RedArgs A{y, omega, nullptr, n_aux, f, nullptr};
     return run_reduction(ctx, RED_LOGTILT, lik, n, A, out_host);
+}
+extern "C" int32_t agpl_aux_prior_logpdf(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                         const double *omega, double *out_host) {
+    RedArgs A{y, omega, nullptr, nullptr, nullptr, nullptr};
+    return run_reduction(ctx, RED_AUX_PRIOR_LOGPDF, lik, n, A, out_host);
+}
+extern "C" int32_t agpl_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                   const double *omega, const int64_t *n_aux, const double *f, double *out_host) {
+    RedArgs A{y, omega, nullptr, n_aux, f, nullptr};
+    return run_reduction(ctx, RED_AUG_LOGLIK, lik, n, A, out_host);
 }
 extern "C" int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                                          const double *q1, const double *q2, const double *mu, const double *var,

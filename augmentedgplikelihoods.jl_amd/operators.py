@@ -369,6 +369,33 @@ def logtilt(lik, Ω: TupleVector, y, f, ctx: Context | None = None) -> float:
     return out.value
 
 
+def aug_loglik(lik, Ω: TupleVector, y, f, ctx: Context | None = None) -> float:
+    """aug_loglik(lik, Ω, y, f) = logtilt + logdensity_def(aux_prior(lik, y), Ω) -- src/generic.jl:48-50
+    (Bernoulli, negative binomial, Student-t)."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    f = _prep(f, torch.float64, "f")
+    y = _prep_y(lik, y, torch.float64)
+    out = C.c_double()
+    d = lik.desc()
+    nn = Ω.n if lik.kind in _HAS_N else None
+    ctx.call("agpl_aug_loglik", C.byref(d), C.c_int64(_npoints(lik, f)), _ptr(y), _ptr(_prep(Ω.ω, torch.float64, "ω")),
+             _ptr(nn), _ptr(f), C.byref(out))
+    return out.value
+
+
+def aux_prior_logpdf(lik, Ω: TupleVector, y, ctx: Context | None = None) -> float:
+    """logdensity_def(aux_prior(lik, y), Ω): the second term of aug_loglik."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    y = _prep_y(lik, y, torch.float64)
+    ω = _prep(Ω.ω, torch.float64, "ω")
+    out = C.c_double()
+    d = lik.desc()
+    ctx.call("agpl_aux_prior_logpdf", C.byref(d), C.c_int64(ω.numel()), _ptr(y), _ptr(ω), C.byref(out))
+    return out.value
+
+
 def expected_logtilt(lik, qΩ: AuxPosterior, y, qf, ctx: Context | None = None) -> float:
     """expected_logtilt(lik, qΩ, y, qf) -- src/api.jl:219-223."""
     torch = _torch()
@@ -401,8 +428,3 @@ def aux_kldivergence(lik, qΩ: AuxPosterior, y, ctx: Context | None = None) -> f
     ctx.call("agpl_aux_kldivergence", C.byref(d), C.c_int64(q1.shape[0]), _ptr(y), _ptr(q1), _ptr(q2), C.byref(out))
     return out.value
 
-
-def aug_loglik_unsupported(*_a, **_k):
-    """aug_loglik (src/generic.jl:48-50) needs the Pólya-Gamma density series (polyagamma.jl:37-91), which the
-    reference itself advises against using (docs/src/index.md:190-191); it is outside the device path."""
-    raise _ffi.AGPLError(_ffi.ERR_UNSUPPORTED, "aug_loglik is not part of the device path (SURVEY.md 8f-4)")

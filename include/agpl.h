@@ -131,6 +131,16 @@ AGPL_API int32_t agpl_expected_potential_precision(agpl_ctx *ctx, const agpl_lik
  * logtilt generic.jl:40-46 ; expected_logtilt api.jl:219-223 ; aux_kldivergence generic.jl:56-62.  */
 AGPL_API int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                      const double *omega, const int64_t *n_aux, const double *f, double *out_host);
+/* agpl_aug_loglik: aug_loglik(lik, Omega, y, f) = logtilt + logdensity_def(aux_prior(lik, y), Omega), src/generic.jl:48-50;
+ *   the PG prior density is the 101-term series of src/SpecialDistributions/polyagamma.jl:37-91 (log-domain for
+ *   omega < 1e-2), evaluated per point in float64.  agpl_aux_prior_logpdf is the second term alone.
+ *   Bernoulli (bernoulli.jl:9-11), negative binomial (negativebinomial.jl:14-18), Student-t (studentt.jl:91);
+ *   AGPL_ERR_UNSUPPORTED for the others (the reference's own logdensity_def of those priors is broken or absent,
+ *   SURVEY.md Appendix B).                                                                                      */
+AGPL_API int32_t agpl_aux_prior_logpdf(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                       const double *omega, double *out_host);
+AGPL_API int32_t agpl_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                 const double *omega, const int64_t *n_aux, const double *f, double *out_host);
 AGPL_API int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                               const double *q1, const double *q2, const double *mu,
                               const double *var, double *out_host);

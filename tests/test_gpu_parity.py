@@ -139,6 +139,15 @@ def test_aux_sample_matches_oracle(A, ctx, oracle, name):
     if name not in ("hetero",):
         lt = A.logtilt(lik, Om, dev(y), dev(f), ctx=ctx)
         assert lt == pytest.approx(O.logtilt(olik, y, ref["omega"], f, ref.get("n")), rel=1e-11)
+    if name in ("bernoulli", "negbin", "negbin_real", "studentt"):
+        # aug_loglik = logtilt + log-density of the aux prior at the draw (generic.jl:48-50; PG series polyagamma.jl:37-91)
+        al = A.aug_loglik(lik, Om, dev(y), dev(f), ctx=ctx)
+        assert al == pytest.approx(O.aug_loglik(olik, y, ref["omega"], f), rel=1e-10)
+        pl = A.aux_prior_logpdf(lik, Om, dev(y), ctx=ctx)
+        assert pl == pytest.approx(O.aux_prior_logpdf(olik, y, ref["omega"]), rel=1e-10)
+    elif name != "hetero":
+        with pytest.raises(A.AGPLError):
+            A.aug_loglik(lik, Om, dev(y), dev(f), ctx=ctx)
 
 
 def test_sampler_is_reproducible_and_sweep_dependent(A, ctx):
@@ -887,3 +896,17 @@ def test_gaussian_factor_reports_indefinite_matrix(A, ctx):
         ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()),
                  C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
                  C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+
+
+def test_pg_logpdf_series_both_branches(A, ctx, oracle):
+    """The aux-prior log-density at omega on both sides of the reference's x < 1e-2 switch to the log-domain series
+    (polyagamma.jl:49-54), Bernoulli prior PG(1, 0), against the oracle's restatement point by point."""
+    om = np.concatenate([10.0 ** np.linspace(-3.5, -2.001, 40), 10.0 ** np.linspace(-1.999, 0.7, 60)])
+    lik = A.BernoulliLikelihood()
+    y = np.zeros(om.size, dtype=np.uint8)
+    for i in range(om.size):
+        Om = A.TupleVector(ω=dev(om[i:i + 1]))
+        got = A.aux_prior_logpdf(lik, Om, dev(y[i:i + 1]), ctx=ctx)
+        ref = oracle.pg_logpdf(1.0, 0.0, om[i])
+        # device libm vs glibc on arguments of magnitude 1e2..1e4 (R_n^2 / 8x): a few 1e-11 relative
+        assert got == pytest.approx(ref, rel=5e-10, abs=1e-10), (om[i], got, ref)
