@@ -398,7 +398,7 @@ __global__ void split_prep_kernel(int64_t N, int64_t Npad, int L, const float *_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t l = i / Npad, n = i - l * Npad;
         const bool in = n < N;
-        sg[i] = in ? kPsiScale * sqrtf(gamma[l * N + n]) : 0.f;
+        sg[i] = in ? kPsiScale * sqrtf(fmaxf(gamma[l * N + n], 0.f)) : 0.f; // gamma >= 0 by construction (TestUtils.jl:88)
         bp[i] = in ? beta[l * N + n] : 0.f;
     }
 }
