@@ -73,6 +73,46 @@ __global__ void copy_kernel(int64_t n, const double *__restrict__ a, double *__r
         b[i] = a[i];
 }
 
+// or_info: info[0] |= info[1] (keeps the first failing block's flag across the blocked factorisation)
+__global__ void or_info_kernel(rocblas_int *info, int block_start) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && info[1] != 0 && info[0] == 0) info[0] = block_start + info[1];
+}
+
+// Lower Cholesky (column-major view, in place) of an N x N float64 matrix as a right-looking blocked factorisation on
+// rocBLAS level-3 calls: rocsolver_dpotrf on 2048-wide diagonal blocks, one dtrsm per panel and the trailing lower
+// block-triangle updated one block column at a time by dgemm.  rocSOLVER's own dpotrf runs this size at 16-30 TF/s
+// float64 on the MI355X; this arrangement measured 38 TF/s at N = 32768 (tools/scratch/blocked_chol.py), identical
+// to 5e-15.  info[0] = 0 or 1-based index of the first non-positive pivot, as potrf.
+int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
+    constexpr int64_t nb = 2048;
+    AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), ctx->stream));
+    AGPL_ROCBLAS(ctx, rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
+    const double one = 1.0, mone = -1.0;
+    for (int64_t k = 0; k < N; k += nb) {
+        const int64_t e = k + nb < N ? k + nb : N, w = e - k;
+        double *Akk = A + k + k * N;
+        AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)w, Akk, (rocblas_int)N, info + 1));
+        or_info_kernel<<<1, 64, 0, ctx->stream>>>(info, (int)k);
+        AGPL_LAUNCH_CHECK(ctx);
+        if (e == N) break;
+        const int64_t m = N - e;
+        double *A21 = A + e + k * N;
+        // A21 <- A21 L11^-T
+        AGPL_ROCBLAS(ctx, rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
+                                        rocblas_diagonal_non_unit, (rocblas_int)m, (rocblas_int)w, &one, Akk,
+                                        (rocblas_int)N, A21, (rocblas_int)N));
+        // trailing lower block-triangle: A[j:, j:je] -= A[j:, k:e] A[j:je, k:e]'
+        for (int64_t j = e; j < N; j += nb) {
+            const int64_t je = j + nb < N ? j + nb : N;
+            AGPL_ROCBLAS(ctx, rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose,
+                                            (rocblas_int)(N - j), (rocblas_int)(je - j), (rocblas_int)w, &mone,
+                                            A + j + k * N, (rocblas_int)N, A + j + k * N, (rocblas_int)N, &one,
+                                            A + j + j * N, (rocblas_int)N));
+        }
+    }
+    return AGPL_OK;
+}
+
 } // namespace
 
 extern "C" int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A, double *L_out) {
@@ -89,7 +129,12 @@ extern "C" int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A
     rc = agpl_ws2_reserve(ctx, 32768);
     if (rc) return rc;
     rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + 16384);
-    AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)N, L_out, (rocblas_int)N, info));
+    if (N >= 8192) {
+        rc = blocked_potrf(ctx, h, N, L_out, info);
+        if (rc) return rc;
+    } else {
+        AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)N, L_out, (rocblas_int)N, info));
+    }
     rocblas_int hinfo = 0;
     AGPL_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -138,7 +183,12 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     rc = agpl_ws2_reserve(ctx, 32768);
     if (rc) return rc;
     rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + 16384);
-    AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)N, B_work, (rocblas_int)N, info));
+    if (N >= 8192) {
+        rc = blocked_potrf(ctx, h, N, B_work, info);
+        if (rc) return rc;
+    } else {
+        AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)N, B_work, (rocblas_int)N, info));
+    }
     AGPL_ROCBLAS(ctx, rocsolver_dpotrs(h, rocblas_fill_lower, (rocblas_int)N, 1, B_work, (rocblas_int)N, r,
                                        (rocblas_int)N));
     // 5. f = f0 + K (D^1/2 s)

@@ -910,3 +910,24 @@ def test_pg_logpdf_series_both_branches(A, ctx, oracle):
         ref = oracle.pg_logpdf(1.0, 0.0, om[i])
         # device libm vs glibc on arguments of magnitude 1e2..1e4 (R_n^2 / 8x): a few 1e-11 relative
         assert got == pytest.approx(ref, rel=5e-10, abs=1e-10), (om[i], got, ref)
+
+
+def test_dense_cholesky_blocked_route(A, ctx):
+    """agpl_dense_cholesky above its blocking threshold (N >= 8192; N not a multiple of the 2048 block) against
+    torch.linalg.cholesky in float64, and the potrf-style failure report for an indefinite input."""
+    import ctypes as C
+
+    N = 8192 + 1000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.sort(torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 40 - 20).values
+    K = torch.exp(-0.5 * ((x[:, None] - x[None, :]) / 0.05) ** 2)
+    K.diagonal().add_(1e-3)
+    Lk = torch.empty_like(K)
+    ctx.call("agpl_dense_cholesky", C.c_int64(N), C.c_void_p(K.data_ptr()), C.c_void_p(Lk.data_ptr()))
+    ref = torch.linalg.cholesky(K)
+    got = torch.triu(Lk).T  # column-major lower triangle = row-major upper
+    assert (got - ref).abs().max().item() < 1e-11
+    Kbad = K.clone()
+    Kbad[5000, 5000] = -1.0
+    with pytest.raises(A.PosDefException):
+        ctx.call("agpl_dense_cholesky", C.c_int64(N), C.c_void_p(Kbad.data_ptr()), C.c_void_p(Lk.data_ptr()))
