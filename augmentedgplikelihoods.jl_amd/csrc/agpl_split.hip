@@ -341,18 +341,26 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         __builtin_amdgcn_s_barrier();
-        if (t + R - 1 < T) AGPL_DMA_ISSUE(t + R - 1);
         // rows 128..255 of the block are zero for the block's first 8 slices (strictly lower part of W');
         // FACTOR: rows 0..127 are zero for its last 8 slices (strictly upper part of U)
-        if (FACTOR ? !(!(wr >> 1) && ks >= rb * 16 + 8) : !((wr >> 1) && ks < rb * 16 + 8)) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot + u * 8 * 4096);
-                const h8 ah0 = st[fa], ah1 = st[fa + 32], bh0 = st[fb], bh1 = st[fb + 32];
+        const bool act = FACTOR ? !(!(wr >> 1) && ks >= rb * 16 + 8) : !((wr >> 1) && ks < rb * 16 + 8);
+        // The DMA for stage t + R - 1 (into the slot read in iteration t - 1) is issued AFTER the first four MFMAs: its
+        // issue cost (~100 cycles per piece with 16 waves issuing at once) then overlaps matrix work instead of
+        // delaying the first MFMA of every wave behind the barrier.
+        h8 ah0, ah1, bh0, bh1;
+        {
+            const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
+            if (act) {
+                ah0 = st[fa]; ah1 = st[fa + 32]; bh0 = st[fb]; bh1 = st[fb + 32];
                 acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
                 acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
                 acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
                 acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + R - 1 < T) AGPL_DMA_ISSUE(t + R - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (act) {
                 const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
                 acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
                 acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
@@ -363,6 +371,27 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
                 acc[0][1] = mfma16(al0, bh1, acc[0][1]);
                 acc[1][0] = mfma16(al1, bh0, acc[1][0]);
                 acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int u = 1; u < KU; ++u) {
+                const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot + u * 8 * 4096);
+                const h8 a0 = st[fa], a1 = st[fa + 32], b0 = st[fb], b1 = st[fb + 32];
+                acc[0][0] = mfma16(a0, b0, acc[0][0]);
+                acc[0][1] = mfma16(a0, b1, acc[0][1]);
+                acc[1][0] = mfma16(a1, b0, acc[1][0]);
+                acc[1][1] = mfma16(a1, b1, acc[1][1]);
+                const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
+                acc[0][0] = mfma16(a0, bl0, acc[0][0]);
+                acc[0][1] = mfma16(a0, bl1, acc[0][1]);
+                acc[1][0] = mfma16(a1, bl0, acc[1][0]);
+                acc[1][1] = mfma16(a1, bl1, acc[1][1]);
+                const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
+                acc[0][0] = mfma16(al0, b0, acc[0][0]);
+                acc[0][1] = mfma16(al0, b1, acc[0][1]);
+                acc[1][0] = mfma16(al1, b0, acc[1][0]);
+                acc[1][1] = mfma16(al1, b1, acc[1][1]);
             }
         }
         ks += KU;
