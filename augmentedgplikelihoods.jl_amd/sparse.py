@@ -88,14 +88,26 @@ def shard_range(N: int, rank: int, world: int):
     return rank * N // world, (rank + 1) * N // world
 
 
-def exchange_natural_parameters(G, g, group=None):
+def natural_parameter_buffers(L, M, device):
+    """(flat, G, g): G [L, M, M] and g [L, M] float64 as views of ONE flat buffer, so that the exchange step of a
+    sweep is a single collective of L (M^2 + M) doubles."""
+    torch = _torch()
+    flat = torch.zeros(L * M * M + L * M, dtype=torch.float64, device=device)
+    return flat, flat[: L * M * M].view(L, M, M), flat[L * M * M:].view(L, M)
+
+
+def exchange_natural_parameters(G, g, group=None, flat=None):
     """The one exchange step of a sweep: sum the per-rank partials of the M x M natural-parameter
     accumulators over the ranks that shard N (torch.distributed all-reduce; backend "nccl" = RCCL over
-    xGMI on the GPU box, "gloo" in the CPU tests).  float64 on the wire; in place."""
+    xGMI on the GPU box, "gloo" in the CPU tests).  float64 on the wire; in place.  ``flat``: the buffer G and g are
+    views of (natural_parameter_buffers) -- one collective instead of two."""
     if group is None:
         return G, g
     import torch.distributed as dist
 
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return G, g
     dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
     return G, g
@@ -148,8 +160,7 @@ class SparseCAVI:
                           _ptr(self.Phi_lo))
             self.W_hi = torch.empty(L * M * M, dtype=torch.float16, device=dev)
             self.W_lo = torch.empty(L * M * M, dtype=torch.float16, device=dev)
-        self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
-        self.g = torch.zeros((L, M), dtype=f64, device=dev)
+        self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
         if self.factor:
             # q(v) is carried as (U, v): S = U'U = I, m = U'v = 0 at the start (script.jl:41-42)
@@ -213,7 +224,7 @@ class SparseCAVI:
 
     def exchange(self):
         """Sum (G, g) over the ranks that shard N; every rank then performs the identical M x M update."""
-        exchange_natural_parameters(self.G, self.g, self.group)
+        exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
 
     def update(self):
         """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the factor form
@@ -331,8 +342,7 @@ class SparseGibbs:
         dev = self.Phi.device
         L, M = self.L, self.M
         f64 = torch.float64
-        self.G = torch.zeros((L, M, M), dtype=f64, device=dev)
-        self.g = torch.zeros((L, M), dtype=f64, device=dev)
+        self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.v = torch.empty((L, M), dtype=f64, device=dev)
         self.m = torch.empty((L, M), dtype=f64, device=dev)
         self.sweep_index = 0
@@ -357,7 +367,7 @@ class SparseGibbs:
                       _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))
 
     def exchange(self):
-        exchange_natural_parameters(self.G, self.g, self.group)
+        exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
 
     def sweep(self):
         self.accumulate()

@@ -38,6 +38,11 @@ def _worker(rank, world, port, N, M, q):
         G, g = O.cavi_pass(olik, Phi, kd, y, -S, m)
         Gt, gt = torch.from_numpy(G.copy()), torch.from_numpy(g.copy())
         A.exchange_natural_parameters(Gt, gt, dist.group.WORLD)
+        # the single-collective form the sweep drivers use: G and g as views of one flat buffer
+        flat, Gf, gf = A.sparse.natural_parameter_buffers(1, M, "cpu")
+        Gf.copy_(torch.from_numpy(G)); gf.copy_(torch.from_numpy(g))
+        A.exchange_natural_parameters(Gf, gf, dist.group.WORLD, flat=flat)
+        assert torch.equal(Gf, Gt) and torch.equal(gf, gt)
         Sn, mn = O.gaussian_update(Gt.numpy(), gt.numpy())
         q.put((rank, i0, i1, x[:3].tolist(), Gt.numpy(), gt.numpy(), Sn, mn))
     finally:
