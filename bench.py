@@ -136,6 +136,12 @@ def main():
     import ctypes as C
 
     _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
+    # used to land in one random sweep of the timed loop: collect now, keep the collector off while timing
+    import gc
+
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     trace = os.environ.get("AGPL_BENCH_TRACE")  # debug: per-step wall times ("1" adds a sync per step)
     step_times = []
@@ -151,6 +157,7 @@ def main():
     t_loop = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if trace:
         print(f"[trace] loop {1e3 * t_loop:.2f} ms, loop + final barrier {1e3 * dt:.2f} ms "
               f"steps {[round(1e3 * t, 2) for t in step_times]}", file=sys.stderr)
