@@ -22,6 +22,8 @@
 //
 // Output convention = rocSOLVER's (so agpl_pack_factor_split and the S / m accessors are shared with the library
 // route): U[a][b] (b <= a) at A[b * M + a]; the other triangle of A is left untouched.
+#include <cstdlib>
+
 #include "agpl_common.h"
 
 namespace {
@@ -70,23 +72,47 @@ __device__ __forceinline__ void mac_2x1(const double *__restrict__ Uop, const do
     }
 }
 
+// spin (one lane) until *p >= target, acquire at agent scope; bounded: a lost partner must not hang the device
+__device__ __forceinline__ bool spin_until_ge(unsigned *p, unsigned target) {
+    for (int it = 0; it < (1 << 21); ++it) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+
+// NW = 1: the whole factorisation in one workgroup.  NW > 1: NW workgroups per latent share the update tiles of every
+// block step.  Workgroup 0 runs the serial spine (stage, block factor + inverse, panel / U rows), publishes P | X_k'
+// (M rows of 32 doubles) through global memory and a `ready` counter; all NW workgroups take their share of the
+// 32 x 16 update tiles and bump a `done` counter; workgroup 0 waits for it before staging block k + 1.  Release =
+// barrier (all stores drained) + one lane's agent-scope atomic, acquire = agent-scope atomic load (invalidates the
+// CU's L1) + barrier.
+// The launch is 8 NW workgroups wide and only those with blockIdx.x % 8 == 0 work: the dispatcher deals workgroups
+// round-robin to the 8 XCDs, so the cooperating ones share one L2.
+template <int NW>
 __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__restrict__ Gall,
                                                          const double *__restrict__ gall,
                                                          const double *__restrict__ eta0all, double *__restrict__ Tall,
                                                          double *__restrict__ Aall, double *__restrict__ vall,
                                                          float *__restrict__ v32all, double *__restrict__ logdet,
-                                                         int *__restrict__ info) {
+                                                         int *__restrict__ info, double *__restrict__ PXg_all,
+                                                         unsigned *__restrict__ sync_all) {
+    if (NW > 1 && (blockIdx.x & 7)) return;
+    const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *PX = sm;                 // [M][FP]: rows 0..Mp-1 = P, rows Mp..M-1 = X_k' (one row per column c of U)
     double *Ds = PX + (size_t)M * FP; // [32][FP] diagonal block being eliminated, then the identity's elimination
     double *Rs = Ds + FB * FP;       // [32][FP] the identity block being eliminated alongside
     double *Wf = Rs + FB * FP;       // [32][FP] W = R_kk^-1
     __shared__ int bad;
+    __shared__ int lost;
     __shared__ double ldsum;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = blockIdx.x;
+    const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
+    double *PXg = PXg_all + (size_t)l * M * FB;            // NW > 1: P | X_k' of the current block step
+    unsigned *ready = sync_all + 2 * l, *done = ready + 1; // NW > 1: block steps published / tile shares finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -94,91 +120,113 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 
     if (tid == 0) {
         bad = 0;
+        lost = 0;
         ldsum = 0.0;
     }
     // T (lower triangle) = I + G
-    for (int idx = tid; idx < M * M; idx += 1024) {
-        const int i = idx / M, j = idx - i * M;
-        if (j <= i) T[idx] = G[idx] + (i == j ? 1.0 : 0.0);
-    }
+    if (wg == 0)
+        for (int idx = tid; idx < M * M; idx += 1024) {
+            const int i = idx / M, j = idx - i * M;
+            if (j <= i) T[idx] = G[idx] + (i == j ? 1.0 : 0.0);
+        }
     __syncthreads();
 
     for (int k = 0; k < nb; ++k) {
         const int kb = k * FB;
         const int Mp = M - kb - FB; // trailing rows
         const int ncx = kb + FB;    // columns of U that rows kb.. can touch
-        // ---- stage the diagonal block and the raw panel
-        {
-            const int r = tid >> 5, c = tid & 31;
-            Ds[r * FP + c] = c <= r ? T[(size_t)(kb + r) * M + kb + c] : 0.0;
-        }
-        for (int idx = tid; idx < Mp * FB; idx += 1024) {
-            const int ip = idx >> 5, m = idx & 31;
-            PX[(size_t)ip * FP + m] = T[(size_t)(kb + FB + ip) * M + kb + m];
-        }
-        // rows kb..kb+31 of the eliminated identity, one LDS row per column c (block (k,k) is still the identity)
-        for (int idx = tid; idx < ncx * FB; idx += 1024) {
-            const int c = idx >> 5, q = idx & 31;
-            PX[(size_t)(Mp + c) * FP + q] = c < kb ? A[(size_t)c * M + kb + q] : (c - kb == q ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
-        //      column c: column c of the working block D and row c of the eliminated identity Y are final since step
-        //      c - 1, and step c only writes columns > c of D and rows > c of Y.
-        //         R[r][c] = D[r][c] / sqrt(D[c][c]);   D[r][cc] -= R[r][c] R[cc][c]   (cc > c)
-        //         W[c][:] = Y[c][:] / R[c][c];         Y[r][:]  -= R[r][c] W[c][:]    (r > c)
-        {
-            const int r = tid >> 5, cc = tid & 31;
-            double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
-            Y[r * FP + cc] = r == cc ? 1.0 : 0.0;
-            for (int c = 0; c < FB; ++c) {
+        if (wg == 0) {
+            if (NW > 1 && k > 0) {
+                // every workgroup's tiles of step k - 1 (they touch the block and panel staged next) are finished
+                if (tid == 0 && !spin_until_ge(done, (unsigned)(NW * k))) lost = 1;
                 __syncthreads();
-                const double piv = Ds[c * FP + c];
-                // 1 / R[c][c]: v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle sqrt + divide
-                // sequences: this is the serial spine of the whole factorisation (32 dependent steps per block)
-                double rs = __builtin_amdgcn_rsq(piv);
-                rs = rs * (1.5 - 0.5 * piv * rs * rs);
-                rs = rs * (1.5 - 0.5 * piv * rs * rs);
-                const double lrc = Ds[r * FP + c] * rs; // R[r][c]   (r >= c)
-                if (cc > c && r >= cc) Ds[r * FP + cc] -= lrc * (Ds[cc * FP + c] * rs);
-                const double wc = Y[c * FP + cc] * rs;  // W[c][cc]
-                if (r == c) Wf[c * FP + cc] = wc;
-                if (r > c) Y[r * FP + cc] -= lrc * wc;
-                if (tid == 0) {
-                    ldsum += log(piv); // = 2 log R_cc
-                    if (!(piv > 0.0)) bad = kb + c + 1;
+                if (lost) break;
+            }
+        // ---- stage the diagonal block and the raw panel
+            {
+                const int r = tid >> 5, c = tid & 31;
+                Ds[r * FP + c] = c <= r ? T[(size_t)(kb + r) * M + kb + c] : 0.0;
+            }
+            for (int idx = tid; idx < Mp * FB; idx += 1024) {
+                const int ip = idx >> 5, m = idx & 31;
+                PX[(size_t)ip * FP + m] = T[(size_t)(kb + FB + ip) * M + kb + m];
+            }
+            // rows kb..kb+31 of the eliminated identity, one LDS row per column c (block (k,k) is still the identity)
+            for (int idx = tid; idx < ncx * FB; idx += 1024) {
+                const int c = idx >> 5, q = idx & 31;
+                PX[(size_t)(Mp + c) * FP + q] = c < kb ? A[(size_t)c * M + kb + q] : (c - kb == q ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
+            //      column c: column c of the working block D and row c of the eliminated identity Y are final since step
+            //      c - 1, and step c only writes columns > c of D and rows > c of Y.
+            //         R[r][c] = D[r][c] / sqrt(D[c][c]);   D[r][cc] -= R[r][c] R[cc][c]   (cc > c)
+            //         W[c][:] = Y[c][:] / R[c][c];         Y[r][:]  -= R[r][c] W[c][:]    (r > c)
+            {
+                const int r = tid >> 5, cc = tid & 31;
+                double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
+                Y[r * FP + cc] = r == cc ? 1.0 : 0.0;
+                for (int c = 0; c < FB; ++c) {
+                    __syncthreads();
+                    const double piv = Ds[c * FP + c];
+                    // 1 / R[c][c]: v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle sqrt + divide
+                    // sequences: this is the serial spine of the whole factorisation (32 dependent steps per block)
+                    double rs = __builtin_amdgcn_rsq(piv);
+                    rs = rs * (1.5 - 0.5 * piv * rs * rs);
+                    rs = rs * (1.5 - 0.5 * piv * rs * rs);
+                    const double lrc = Ds[r * FP + c] * rs; // R[r][c]   (r >= c)
+                    if (cc > c && r >= cc) Ds[r * FP + cc] -= lrc * (Ds[cc * FP + c] * rs);
+                    const double wc = Y[c * FP + cc] * rs;  // W[c][cc]
+                    if (r == c) Wf[c * FP + cc] = wc;
+                    if (r > c) Y[r * FP + cc] -= lrc * wc;
+                    if (tid == 0) {
+                        ldsum += log(piv); // = 2 log R_cc
+                        if (!(piv > 0.0)) bad = kb + c + 1;
+                    }
                 }
             }
-        }
-        __syncthreads();
-        // ---- every row of PX times W':  P[i'][c] = sum_m Araw[i'][m] W[c][m]  (panel of R below the block) and
-        //      X_k'[c][m] = sum_q RHS[kb+q][c] W[m][q]  (rows kb..kb+31 of U, final).  Wave w owns rows 32 w..32 w + 31
-        //      and nobody else touches them: in place without a barrier between its reads and its writes.
-        if (wave * 32 < M) {
-            d4 acc[2][2];
+            __syncthreads();
+            // ---- every row of PX times W':  P[i'][c] = sum_m Araw[i'][m] W[c][m]  (panel of R below the block) and
+            //      X_k'[c][m] = sum_q RHS[kb+q][c] W[m][q]  (rows kb..kb+31 of U, final).  Wave w owns rows 32 w..32 w + 31
+            //      and nobody else touches them: in place without a barrier between its reads and its writes.
+            if (wave * 32 < M) {
+                d4 acc[2][2];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+                for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
-            double *rows = PX + (size_t)wave * 32 * FP;
-            macro_mac(rows, Wf, lane, acc);
-            const bool xrows = wave * 32 >= Mp; // Mp % 32 == 0: a wave's rows are all P rows or all X rows
+                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+                double *rows = PX + (size_t)wave * 32 * FP;
+                macro_mac(rows, Wf, lane, acc);
+                const bool xrows = wave * 32 >= Mp; // Mp % 32 == 0: a wave's rows are all P rows or all X rows
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+                for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
+                    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * ti + 4 * r + (lane >> 4), m = 16 * tj + (lane & 15);
-                        const double val = acc[ti][tj][r];
-                        rows[i * FP + m] = val;
-                        if (xrows) {
-                            const int c = wave * 32 + i - Mp;
-                            if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // (the other triangle of A is not ours)
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + 4 * r + (lane >> 4), m = 16 * tj + (lane & 15);
+                            const double val = acc[ti][tj][r];
+                            rows[i * FP + m] = val;
+                            if (xrows) {
+                                const int c = wave * 32 + i - Mp;
+                                if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // (the other triangle of A is not ours)
+                            }
                         }
-                    }
+            }
+            __syncthreads();
+            if (NW > 1) {
+                // publish P | X_k' (the LDS rows without their padding) and the step counter
+                for (int idx = tid; idx < M * FB; idx += 1024) PXg[idx] = PX[(size_t)(idx >> 5) * FP + (idx & 31)];
+                __syncthreads(); // every wave's stores have left the CU (vmcnt(0) + barrier; the L1 is write-through)
+                if (tid == 0) __hip_atomic_store(ready, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (tid == 0 && !spin_until_ge(ready, (unsigned)(k + 1))) lost = 1;
+            __syncthreads();
+            if (lost) break;
+            for (int idx = tid; idx < M * FB; idx += 1024) PX[(size_t)(idx >> 5) * FP + (idx & 31)] = PXg[idx];
+            __syncthreads();
         }
-        __syncthreads();
         if (Mp > 0) {
             // ---- 32 x 16 wave tiles: (a) T[i][j] -= P_i . P_j over the lower block triangle (16 wb <= 32 ub + 31);
             //                          (b) RHS[i][c] -= X_k'[c] . P_i for every 32-column block cb (U is column-major:
@@ -189,7 +237,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             const int ntile_a = nbp * (nbp + 1), ntile_b = ncb * 2 * nbp;
             const unsigned lo_ = (unsigned)(lane >> 4) * (unsigned)M + (unsigned)(lane & 15);
             int ub = 0;
-            for (int w = wave; w < ntile_a + ntile_b; w += 16) {
+            for (int w = wg * 16 + wave; w < ntile_a + ntile_b; w += NW * 16) {
                 d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
                 if (w < ntile_a) {
                     while ((ub + 1) * (ub + 2) <= w) ++ub;
@@ -227,7 +275,22 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 }
             }
         }
+        if (NW > 1) {
+            __syncthreads(); // as above: one lane's agent-scope release then covers the whole workgroup's stores
+            if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();
+        }
+    }
+    if (NW > 1) {
+        if (wg != 0) return;
+        // U is complete once every workgroup has finished the last step's tiles
+        if (tid == 0 && !lost && !spin_until_ge(done, (unsigned)(NW * nb))) lost = 1;
         __syncthreads();
+        if (lost) {
+            if (tid == 0) info[l] = -1; // a partner workgroup never arrived: reported as an internal error by the host
+            return;
+        }
     }
 
     // ---- v = U (g + eta0):  v[a] = sum_{b <= a} A[b * M + a] r[b].  Wave w takes b = w, w + 16, ...; lanes run along
@@ -261,15 +324,40 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 
 } // namespace
 
-// internal: fused factorisation (M % 32 == 0, M <= 512); T_work / A_work [L][M][M] float64, info [L] int (device)
+// internal: fused factorisation (M % 32 == 0, M <= 512); T_work / A_work [L][M][M] float64, info [L] int (device),
+// coop_work: L * (M * 32 doubles) + 2 L unsigned for the cooperating form (may be null: single workgroup)
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
-                          int *info_dev) {
+                          int *info_dev, void *coop_work) {
     const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    factor_kernel<<<(unsigned)L, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
-                                                           info_dev);
+    // AGPL_FACTOR_WGS = 1 | 4 | 8 cooperating workgroups per latent.  Measured at M = 512: 0.91 / 0.82 / 0.96 ms -- two
+    // agent-scope hand-offs and a 131 KB operand copy per block step eat most of what the shared tiles save, so the
+    // single-workgroup form stays the default; the cooperating form is the base for a look-ahead version (spine of
+    // step k + 1 overlapping the non-critical tiles of step k).
+    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 1;
+    const int nw = coop_work ? nw_env : 1;
+    if (nw == 8 || nw == 4) {
+        double *PXg = (double *)coop_work;
+        unsigned *sync = (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * M * FB);
+        AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 2 * (size_t)L, ctx->stream));
+        dim3 grid((unsigned)(8 * nw), (unsigned)L);
+        if (nw == 8) {
+            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            factor_kernel<8><<<grid, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
+                                                               info_dev, PXg, sync);
+        } else {
+            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            factor_kernel<4><<<grid, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
+                                                               info_dev, PXg, sync);
+        }
+    } else {
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        factor_kernel<1><<<(unsigned)L, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,
+                                                                  logdet_out, info_dev, nullptr, nullptr);
+    }
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

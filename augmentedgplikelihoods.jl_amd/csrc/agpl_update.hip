@@ -246,7 +246,7 @@ extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, c
                                           void *U_lo);
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
-                          int *info_dev);
+                          int *info_dev, void *coop_work);
 
 // I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
 // pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
@@ -260,11 +260,13 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
     if (M <= 512 && M % 32 == 0 && !use_lib) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
         const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
-        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes);
+        const size_t coop_bytes = sizeof(double) * (size_t)L * M * 32 + 1024;
+        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         double *T = (double *)((char *)ctx->ws2 + info_off + 1024);
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info);
+        void *coop = (char *)ctx->ws2 + info_off + 1024 + mat_bytes;
+        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info, coop);
         if (rc) return rc;
         if (U_hi) {
             rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
@@ -273,10 +275,13 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
         int hinfo[64];
         AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
         AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < L; ++i)
+        for (int i = 0; i < L; ++i) {
+            if (hinfo[i] < 0)
+                AGPL_FAIL(ctx, AGPL_ERR_HIP, "factor kernel: a cooperating workgroup never arrived (latent %d)", i);
             if (hinfo[i] != 0)
                 AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot block at row %d)",
                           i, (int)hinfo[i] - 1);
+        }
         return AGPL_OK;
     }
     rocblas_handle h;
@@ -462,13 +467,15 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
         const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
         const size_t info_off = 16384;
-        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512);
+        const size_t coop_bytes = sizeof(double) * (size_t)L * M * 32 + 1024;
+        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         char *p = (char *)ctx->ws2 + info_off + 1024;
         double *T = (double *)p, *A = (double *)(p + mat_bytes);
         double *vf = (double *)(p + 2 * mat_bytes), *z = (double *)(p + 2 * mat_bytes + vec_bytes);
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A, vf, nullptr, nullptr, info);
+        void *coop = p + 2 * mat_bytes + 2 * vec_bytes + 512;
+        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A, vf, nullptr, nullptr, info, coop);
         if (rc) return rc;
         rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
         if (rc) return rc;
@@ -480,8 +487,10 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
         AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < L; ++i)
             if (hinfo[i] != 0)
-                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot at row %d)", i,
-                          (int)hinfo[i] - 1);
+                AGPL_FAIL(ctx, hinfo[i] < 0 ? AGPL_ERR_HIP : AGPL_ERR_NOT_POSDEF,
+                          hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
+                                       : "I + G is not positive definite (latent %d, pivot at row %d)",
+                          i, (int)hinfo[i] - 1);
         return AGPL_OK;
     }
     rocblas_handle h;
