@@ -931,3 +931,65 @@ def test_dense_cholesky_blocked_route(A, ctx):
     Kbad[5000, 5000] = -1.0
     with pytest.raises(A.PosDefException):
         ctx.call("agpl_dense_cholesky", C.c_int64(N), C.c_void_p(Kbad.data_ptr()), C.c_void_p(Lk.data_ptr()))
+
+
+@pytest.mark.timeout(600)
+def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
+    """BASELINE config C2 at its full size (Bernoulli, N = 1e7, M = 512) on the path bench.py ships (split-float16
+    contractions, factor-form marginals) -- sizes the oracle cannot reach, so size-independent properties:
+      * G exactly symmetric, the sweep bitwise reproducible from the same state;
+      * tr G = sum_n gamma_n |phi_n|^2 and g = Phi beta against float64 torch reductions over the same gamma, beta;
+      * additivity over N: G(all) = G(first half) + G(second half) (the sharding identity of the multi-GPU sweep);
+      * first-sweep marginals in closed form (S = I, m = 0: mu = 0, var = d + |phi|^2 = 1 for a unit-variance kernel);
+      * gamma = tanh(c/2)/(2c) in (0, 1/4] and finite everywhere."""
+    import ctypes as C
+
+    N, M = 10_000_000, 512
+    lik = A.BernoulliLikelihood()
+    x, y = A.synth_xy(lik, SEED, 0, N, ctx=ctx)
+    z = np.linspace(-10, 10, M)
+    ell = 1.5 * (z[1] - z[0])
+    Kzz = np.exp(-0.5 * ((z[:, None] - z[None, :]) / ell) ** 2)
+    _, Linv = A.sparse.whitening_matrix(Kzz, 1e-8)
+    Kzx = A.se_features(x, dev(z), ell, ctx=ctx)
+    Phi = A.whiten_features(Kzx, Linv, ctx=ctx)
+    del Kzx
+    kd = A.sparse.nystrom_residual(Phi, torch.ones(N, device="cuda"), ctx=ctx)
+
+    def make(sl=slice(None)):
+        return A.SparseCAVI(lik, Phi[sl], kd[sl], y[sl], ctx=ctx, keep_points=True,
+                            marginal_precision="f16x2-factor", accumulate_precision="f16x2")
+
+    try:
+        cavi = make()
+        mu, var = cavi.marginals()  # S = I, m = 0
+        assert mu.abs().max().item() == 0.0
+        assert (var - 1.0).abs().max().item() < 2e-5  # k_nn = 1: d + |phi|^2 recombined in float32
+        cavi.accumulate()
+        G1, g1 = cavi.G.clone(), cavi.g.clone()
+        assert torch.equal(G1, G1.transpose(1, 2))
+        gam, bet = cavi.gamma[0], cavi.beta[0]
+        assert torch.isfinite(gam).all() and (gam > 0).all() and (gam <= 0.25).all()
+        # trace and g against float64 reductions, in chunks (no N x M float64 temporary)
+        tr = 0.0
+        gref = torch.zeros(M, dtype=torch.float64, device="cuda")
+        for i0 in range(0, N, 1_000_000):
+            P = Phi[i0:i0 + 1_000_000].double()
+            tr += (gam[i0:i0 + 1_000_000].double() * (P * P).sum(1)).sum().item()
+            gref += P.T @ bet[i0:i0 + 1_000_000].double()
+        assert torch.diagonal(G1[0]).sum().item() == pytest.approx(tr, rel=2e-6)
+        assert relmax(host(g1[0]), host(gref)) < 2e-6
+        cavi.accumulate()  # same state: bitwise identical
+        assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
+        del cavi
+        h = N // 2
+        parts = []
+        for sl in (slice(0, h), slice(h, N)):
+            c = make(sl)
+            c.accumulate()
+            parts.append((c.G.clone(), c.g.clone()))
+            del c
+        assert relmax(host(parts[0][0] + parts[1][0]), host(G1)) < 2e-6
+        assert relmax(host(parts[0][1] + parts[1][1]), host(g1)) < 2e-6
+    finally:
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
