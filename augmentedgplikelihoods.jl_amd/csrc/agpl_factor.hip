@@ -158,30 +158,46 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             }
             __syncthreads();
             // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
-            //      column c: column c of the working block D and row c of the eliminated identity Y are final since step
-            //      c - 1, and step c only writes columns > c of D and rows > c of Y.
-            //         R[r][c] = D[r][c] / sqrt(D[c][c]);   D[r][cc] -= R[r][c] R[cc][c]   (cc > c)
-            //         W[c][:] = Y[c][:] / R[c][c];         Y[r][:]  -= R[r][c] W[c][:]    (r > c)
+            //      PAIR of columns (c, c + 1): columns c, c + 1 of the working block D and rows c, c + 1 of the
+            //      eliminated identity Y are final since the previous step, and this step only writes columns > c + 1
+            //      of D and rows > c + 1 of Y.  Every thread rebuilds the two pivots and its own entries of R from D:
+            //         R[r][c] = D[r][c] / sqrt(D[c][c]),  R[r][c+1] = (D[r][c+1] - R[r][c] R[c+1][c]) / R[c+1][c+1]
+            //         D[r][cc] -= R[r][c] R[cc][c] + R[r][c+1] R[cc][c+1]                              (cc > c + 1)
+            //         W[c][:] = Y[c][:] / R[c][c],  W[c+1][:] = (Y[c+1][:] - R[c+1][c] W[c][:]) / R[c+1][c+1]
+            //         Y[r][:] -= R[r][c] W[c][:] + R[r][c+1] W[c+1][:]                                 (r > c + 1)
+            //      The reciprocal pivots are v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle
+            //      sqrt + divide sequences: these 16 dependent steps per block are the serial spine of the factorisation.
             {
                 const int r = tid >> 5, cc = tid & 31;
                 double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
                 Y[r * FP + cc] = r == cc ? 1.0 : 0.0;
-                for (int c = 0; c < FB; ++c) {
+                for (int c = 0; c < FB; c += 2) {
                     __syncthreads();
-                    const double piv = Ds[c * FP + c];
-                    // 1 / R[c][c]: v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle sqrt + divide
-                    // sequences: this is the serial spine of the whole factorisation (32 dependent steps per block)
-                    double rs = __builtin_amdgcn_rsq(piv);
-                    rs = rs * (1.5 - 0.5 * piv * rs * rs);
-                    rs = rs * (1.5 - 0.5 * piv * rs * rs);
-                    const double lrc = Ds[r * FP + c] * rs; // R[r][c]   (r >= c)
-                    if (cc > c && r >= cc) Ds[r * FP + cc] -= lrc * (Ds[cc * FP + c] * rs);
-                    const double wc = Y[c * FP + cc] * rs;  // W[c][cc]
-                    if (r == c) Wf[c * FP + cc] = wc;
-                    if (r > c) Y[r * FP + cc] -= lrc * wc;
+                    const double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
+                    double r0 = __builtin_amdgcn_rsq(p0);
+                    r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
+                    r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
+                    const double l10 = b10 * r0;          // R[c+1][c]
+                    const double p1 = d11 - l10 * l10;    // the second pivot
+                    double r1 = __builtin_amdgcn_rsq(p1);
+                    r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1);
+                    r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1); // 1 / R[c+1][c+1]
+                    const double lr0 = Ds[r * FP + c] * r0;                          // R[r][c]     (r >= c)
+                    const double lr1 = (Ds[r * FP + c + 1] - lr0 * l10) * r1;        // R[r][c+1]   (r >= c + 1)
+                    if (cc > c + 1 && r >= cc) {
+                        const double lc0 = Ds[cc * FP + c] * r0;
+                        const double lc1 = (Ds[cc * FP + c + 1] - lc0 * l10) * r1;
+                        Ds[r * FP + cc] -= lr0 * lc0 + lr1 * lc1;
+                    }
+                    const double w0 = Y[c * FP + cc] * r0;                           // W[c][cc]
+                    const double w1 = (Y[(c + 1) * FP + cc] - l10 * w0) * r1;        // W[c+1][cc]
+                    if (r == c) Wf[c * FP + cc] = w0;
+                    if (r == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                    if (r > c + 1) Y[r * FP + cc] -= lr0 * w0 + lr1 * w1;
                     if (tid == 0) {
-                        ldsum += log(piv); // = 2 log R_cc
-                        if (!(piv > 0.0)) bad = kb + c + 1;
+                        ldsum += log(p0) + log(p1); // = 2 log R_cc + 2 log R_c+1,c+1
+                        if (!(p0 > 0.0)) bad = kb + c + 1;
+                        else if (!(p1 > 0.0)) bad = kb + c + 2;
                     }
                 }
             }

@@ -4,6 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import agpl_amd as A
+from agpl_amd import _ffi
+if os.environ.get("AGPL_LIB_AB"):
+    _ffi.LIB_PATH = os.environ["AGPL_LIB_AB"]
 
 M = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctx = A.Context(0, seed=1)
