@@ -182,3 +182,30 @@ extern "C" int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_
     ctx->ev[which].clear();
     return AGPL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// agpl_allreduce_nat: the one exchange step of an N-sharded sweep for hosts that drive RCCL themselves (the Python
+// host uses torch.distributed, whose "nccl" backend is the same RCCL).  librccl is resolved at the first call
+// (dlopen by SONAME: the instance already in the process if there is one), so libagpl.so carries no load-time
+// dependency on it.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+
+extern "C" int32_t agpl_allreduce_nat(agpl_ctx *ctx, void *rccl_comm, double *buf, int64_t count) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (!rccl_comm || !buf || count < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    if (count == 0) return AGPL_OK;
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "librccl is not available: %s", dlerror());
+        fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "ncclAllReduce not found in librccl");
+    }
+    // ncclFloat64 = 8, ncclSum = 0 (rccl.h); in place, on the context's stream
+    const int rc = fn(buf, buf, (size_t)count, 8, 0, rccl_comm, ctx->stream);
+    if (rc != 0) AGPL_FAIL(ctx, AGPL_ERR_HIP, "ncclAllReduce failed: ncclResult_t %d", rc);
+    return AGPL_OK;
+}

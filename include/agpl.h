@@ -298,6 +298,12 @@ AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc 
                                              const void *U_lo, const float *v, double *G_out, double *g_out,
                                              float *c_out, float *gamma_out, float *beta_out);
 
+/* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
+ *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
+ *   context's stream.  For hosts that own their communicator (the Julia / C++ callers of INTEGRATION.md); the
+ *   Python host reaches the same RCCL through torch.distributed.  librccl is loaded at the first call.          */
+AGPL_API int32_t agpl_allreduce_nat(agpl_ctx *ctx, void *rccl_comm, double *buf, int64_t count);
+
 /* agpl_set_accumulate_precision: which kernel agpl_accumulate / agpl_cavi_pass(_split) / agpl_gibbs_pass use for
  *   G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default), 1 = split-float16 MFMA (psi = sqrt(gamma) phi is
  *   split into hi/lo float16 while staging; 3 float16 products per float32 product; needs gamma >= 0 and

@@ -993,3 +993,38 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
         assert relmax(host(parts[0][1] + parts[1][1]), host(g1)) < 2e-6
     finally:
         ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+
+
+@pytest.mark.timeout(120)
+def test_allreduce_nat_on_a_one_rank_rccl_communicator(A, ctx):
+    """agpl_allreduce_nat with a communicator the caller owns (ncclCommInitRank through the process's librccl, one
+    rank): the in-place float64 sum over one rank is the identity and the call returns AGPL_OK; a null communicator
+    is an ArgumentError.  (The multi-rank sum is RCCL's; the two-rank sweep is covered through torch.distributed.)"""
+    import ctypes as C
+
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl not loadable in this process")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        M = 256
+        flat, G, g = A.sparse.natural_parameter_buffers(1, M, "cuda")
+        flat.copy_(torch.arange(flat.numel(), dtype=torch.float64, device="cuda") * 0.5 - 3.0)
+        ref = flat.clone()
+        ctx.call("agpl_allreduce_nat", comm, C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()))
+        torch.cuda.synchronize()
+        assert torch.equal(flat, ref)
+        with pytest.raises(A.ArgumentError):
+            ctx.call("agpl_allreduce_nat", C.c_void_p(0), C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()))
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
