@@ -74,9 +74,9 @@ __device__ __forceinline__ void mac_2x1(const double *__restrict__ Uop, const do
 
 // spin (one lane) until *p >= target, acquire at agent scope; bounded: a lost partner must not hang the device
 __device__ __forceinline__ bool spin_until_ge(unsigned *p, unsigned target) {
-    for (int it = 0; it < (1 << 21); ++it) {
+    for (int it = 0; it < (1 << 22); ++it) {
         if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(1);
     }
     return false;
 }
@@ -89,7 +89,14 @@ __device__ __forceinline__ bool spin_until_ge(unsigned *p, unsigned target) {
 // CU's L1) + barrier.
 // The launch is 8 NW workgroups wide and only those with blockIdx.x % 8 == 0 work: the dispatcher deals workgroups
 // round-robin to the 8 XCDs, so the cooperating ones share one L2.
-template <int NW>
+//
+// LA (look-ahead, NW = 2): workgroup 0 runs ONLY the spine, workgroup 1 ONLY the tiles, and the two overlap: the tiles
+// that the next spine step reads -- the first trailing 32 columns of T (next diagonal block and panel) and the next 32
+// rows of the eliminated identity -- are done first and signalled through `crit`; the spine of step k + 1 then runs
+// while the remaining tiles of step k finish.  Every T / U location is updated by workgroup 1 alone across steps, so
+// no other hand-off is needed; P | X_k' travels through two alternating global buffers (buffer k & 1 is rewritten at
+// step k + 2, by when workgroup 1 has loaded it: it signalled crit(k) after doing so).
+template <int NW, bool LA>
 __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__restrict__ Gall,
                                                          const double *__restrict__ gall,
                                                          const double *__restrict__ eta0all, double *__restrict__ Tall,
@@ -111,8 +118,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
-    double *PXg = PXg_all + (size_t)l * M * FB;            // NW > 1: P | X_k' of the current block step
-    unsigned *ready = sync_all + 2 * l, *done = ready + 1; // NW > 1: block steps published / tile shares finished
+    double *PXg0 = PXg_all + (size_t)l * 2 * M * FB;       // NW > 1: P | X_k' of a block step (LA: two buffers)
+    unsigned *ready = sync_all + 4 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -137,8 +144,9 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
         const int ncx = kb + FB;    // columns of U that rows kb.. can touch
         if (wg == 0) {
             if (NW > 1 && k > 0) {
-                // every workgroup's tiles of step k - 1 (they touch the block and panel staged next) are finished
-                if (tid == 0 && !spin_until_ge(done, (unsigned)(NW * k))) lost = 1;
+                // every workgroup's tiles of step k - 1 (they touch the block and panel staged next) are finished;
+                // look-ahead: only the critical ones need to be
+                if (tid == 0 && !spin_until_ge(LA ? crit : done, (unsigned)(LA ? (NW - 1) * k : NW * k))) lost = 1;
                 __syncthreads();
                 if (lost) break;
             }
@@ -232,14 +240,17 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             __syncthreads();
             if (NW > 1) {
                 // publish P | X_k' (the LDS rows without their padding) and the step counter
+                double *PXg = PXg0 + (LA ? (size_t)(k & 1) * M * FB : 0);
                 for (int idx = tid; idx < M * FB; idx += 1024) PXg[idx] = PX[(size_t)(idx >> 5) * FP + (idx & 31)];
                 __syncthreads(); // every wave's stores have left the CU (vmcnt(0) + barrier; the L1 is write-through)
                 if (tid == 0) __hip_atomic_store(ready, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
+            if (LA && Mp == 0) break; // the last block step has no tiles
             if (tid == 0 && !spin_until_ge(ready, (unsigned)(k + 1))) lost = 1;
             __syncthreads();
             if (lost) break;
+            const double *PXg = PXg0 + (LA ? (size_t)(k & 1) * M * FB : 0);
             for (int idx = tid; idx < M * FB; idx += 1024) PX[(size_t)(idx >> 5) * FP + (idx & 31)] = PXg[idx];
             __syncthreads();
         }
@@ -252,12 +263,18 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             const int nbp = Mp / 32, ncb = ncx / 32;
             const int ntile_a = nbp * (nbp + 1), ntile_b = ncb * 2 * nbp;
             const unsigned lo_ = (unsigned)(lane >> 4) * (unsigned)M + (unsigned)(lane & 15);
+            for (int pass = 0; pass < (LA ? 2 : 1); ++pass) {
+            if (LA && wg == 0) break; // look-ahead: the spine workgroup does no tiles
             int ub = 0;
-            for (int w = wg * 16 + wave; w < ntile_a + ntile_b; w += NW * 16) {
+            for (int w = (LA ? 0 : wg * 16) + wave; w < ntile_a + ntile_b; w += (LA ? 1 : NW) * 16) {
                 d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
                 if (w < ntile_a) {
                     while ((ub + 1) * (ub + 2) <= w) ++ub;
                     const int wb = w - ub * (ub + 1); // 16-column block, 0 .. 2 ub + 1
+                    if (LA && (wb < 2) != (pass == 0)) continue; // pass 0: the next diagonal block and panel
+                    // look-ahead with several tile workgroups: a location keeps its owner across steps (absolute
+                    // 32-row / 16-column block coordinates), so no workgroup ever waits for another one's update
+                    if (LA && NW > 2 && (k + 1 + ub + 2 * (k + 1) + wb) % (NW - 1) != wg - 1) continue;
                     double *tp = T + (size_t)(kb + FB + 32 * ub) * M + kb + FB + 16 * wb;
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
@@ -275,6 +292,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 } else {
                     const int wbi = w - ntile_a;
                     const int cb = wbi / (2 * nbp), ib = wbi - cb * 2 * nbp; // 32 columns c x 16 rows i
+                    if (LA && (ib < 2) != (pass == 0)) continue; // pass 0: the next 32 rows of the eliminated identity
+                    if (LA && NW > 2 && (cb + 2 * (k + 1) + ib) % (NW - 1) != wg - 1) continue;
                     double *ap = A + (size_t)(32 * cb) * M + kb + FB + 16 * ib;
                     const bool fresh = 32 * cb >= kb; // column block k: nothing eliminated into it yet
 #pragma unroll
@@ -290,8 +309,18 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                             ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
                 }
             }
+            if (LA && pass == 0) {
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(crit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            }
         }
-        if (NW > 1) {
+        if (LA) {
+            if (wg != 0) {
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (NW > 1) {
             __syncthreads(); // as above: one lane's agent-scope release then covers the whole workgroup's stores
             if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     if (NW > 1) {
         if (wg != 0) return;
         // U is complete once every workgroup has finished the last step's tiles
-        if (tid == 0 && !lost && !spin_until_ge(done, (unsigned)(NW * nb))) lost = 1;
+        if (tid == 0 && !lost && (!LA || nb > 1) && !spin_until_ge(done, (unsigned)(LA ? (NW - 1) * (nb - 1) : NW * nb))) lost = 1;
         __syncthreads();
         if (lost) {
             if (tid == 0) info[l] = -1; // a partner workgroup never arrived: reported as an internal error by the host
@@ -341,39 +370,33 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 } // namespace
 
 // internal: fused factorisation (M % 32 == 0, M <= 512); T_work / A_work [L][M][M] float64, info [L] int (device),
-// coop_work: L * (M * 32 doubles) + 2 L unsigned for the cooperating form (may be null: single workgroup)
+// coop_work: L * (2 * M * 32 doubles) + 4 L unsigned for the multi-workgroup forms (may be null: single workgroup)
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work) {
     const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
-    // AGPL_FACTOR_WGS = 1 | 4 | 8 cooperating workgroups per latent.  Measured at M = 512: 0.91 / 0.82 / 0.96 ms -- two
-    // agent-scope hand-offs and a 131 KB operand copy per block step eat most of what the shared tiles save, so the
-    // single-workgroup form stays the default; the cooperating form is the base for a look-ahead version (spine of
-    // step k + 1 overlapping the non-critical tiles of step k).
-    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 1;
+    // AGPL_FACTOR_WGS = 1 | 2 | 3 | 5 | 4 | 8 workgroups per latent.  2, 3, 5 = look-ahead (one spine workgroup + 1, 2,
+    // 4 tile workgroups);
+    // 4, 8 = the tiles of every step shared, hand-offs at step boundaries.  Measured at M = 512: see DESIGN.md 4.5.
+    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 3;
     const int nw = coop_work ? nw_env : 1;
-    if (nw == 8 || nw == 4) {
-        double *PXg = (double *)coop_work;
-        unsigned *sync = (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * M * FB);
-        AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 2 * (size_t)L, ctx->stream));
-        dim3 grid((unsigned)(8 * nw), (unsigned)L);
-        if (nw == 8) {
-            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<8>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            factor_kernel<8><<<grid, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
-                                                               info_dev, PXg, sync);
-        } else {
-            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            factor_kernel<4><<<grid, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out,
-                                                               info_dev, PXg, sync);
-        }
-    } else {
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        factor_kernel<1><<<(unsigned)L, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,
-                                                                  logdet_out, info_dev, nullptr, nullptr);
-    }
+    double *PXg = (double *)coop_work;
+    unsigned *sync = coop_work ? (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * 2 * M * FB) : nullptr;
+    if (nw > 1) AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 4 * (size_t)L, ctx->stream));
+#define AGPL_LAUNCH_FACTOR(NW_, LA_, GRID_)                                                                          \
+    do {                                                                                                             \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<NW_, LA_>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+        factor_kernel<NW_, LA_><<<GRID_, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,    \
+                                                                   logdet_out, info_dev, PXg, sync);                 \
+    } while (0)
+    if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L));
+    else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L));
+    else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L));
+    else if (nw == 4) AGPL_LAUNCH_FACTOR(4, false, dim3(32, (unsigned)L));
+    else if (nw == 8) AGPL_LAUNCH_FACTOR(8, false, dim3(64, (unsigned)L));
+    else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L));
+#undef AGPL_LAUNCH_FACTOR
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

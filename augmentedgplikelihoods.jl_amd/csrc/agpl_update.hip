@@ -313,7 +313,7 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
     if (M <= 512 && M % 32 == 0 && !use_lib) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
         const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
-        const size_t coop_bytes = sizeof(double) * (size_t)L * M * 32 + 1024;
+        const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * M * 32 + 1024;
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
@@ -520,7 +520,7 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
         const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
         const size_t info_off = 16384;
-        const size_t coop_bytes = sizeof(double) * (size_t)L * M * 32 + 1024;
+        const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * M * 32 + 1024;
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
