@@ -768,7 +768,8 @@ def test_cavi_with_split_f16_both_passes_matches_oracle(A, ctx, oracle, name, N,
 
 
 # ------------------------------------------------------------------------------- factor (one-pass) marginal form
-@pytest.mark.parametrize("N,M,L", [(1000, 256, 1), (4099, 512, 1), (257, 256, 2), (70001, 256, 1)])
+@pytest.mark.parametrize("N,M,L", [(1000, 256, 1), (4099, 512, 1), (257, 256, 2), (70001, 256, 1), (3001, 768, 1),
+                                   (2000, 1024, 1)])
 def test_factor_marginals_against_float64(A, ctx, N, M, L):
     """agpl_gaussian_factor + agpl_marginals_factor_split against float64 numpy: with I + G = R R', U = R^-1,
     var = (k - |phi|^2) + |U phi|^2 and mu = mu0 + (U g)'(U phi) must equal k - phi'(I - S)phi and mu0 + m'phi."""
