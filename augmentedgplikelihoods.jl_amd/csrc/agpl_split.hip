@@ -347,11 +347,15 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
         // The DMA for stage t + R - 1 (into the slot read in iteration t - 1) is issued AFTER the first four MFMAs: its
         // issue cost (~100 cycles per piece with 16 waves issuing at once) then overlaps matrix work instead of
         // delaying the first MFMA of every wave behind the barrier.
-        h8 ah0, ah1, bh0, bh1;
+        // Fragment reads run one MFMA group ahead of their use (the lo parts of B are read with the hi parts, the lo
+        // parts of A and the next slice's hi parts while the previous group's MFMAs execute): the compiler's counted
+        // lgkmcnt waits then leave the LDS latency behind matrix work instead of in front of every group.
         {
             const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
+            h8 ah0, ah1, bh0, bh1, bl0, bl1;
             if (act) {
                 ah0 = st[fa]; ah1 = st[fa + 32]; bh0 = st[fb]; bh1 = st[fb + 32];
+                bl0 = st[256 + fb]; bl1 = st[256 + fb + 32];
                 acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
                 acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
                 acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
@@ -361,37 +365,33 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
             if (t + R - 1 < T) AGPL_DMA_ISSUE(t + R - 1);
             __builtin_amdgcn_sched_barrier(0);
             if (act) {
-                const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
-                acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-                acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
-                acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
-                acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
-                const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
-                acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-                acc[0][1] = mfma16(al0, bh1, acc[0][1]);
-                acc[1][0] = mfma16(al1, bh0, acc[1][0]);
-                acc[1][1] = mfma16(al1, bh1, acc[1][1]);
-            }
-        }
-        if (act) {
 #pragma unroll
-            for (int u = 1; u < KU; ++u) {
-                const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot + u * 8 * 4096);
-                const h8 a0 = st[fa], a1 = st[fa + 32], b0 = st[fb], b1 = st[fb + 32];
-                acc[0][0] = mfma16(a0, b0, acc[0][0]);
-                acc[0][1] = mfma16(a0, b1, acc[0][1]);
-                acc[1][0] = mfma16(a1, b0, acc[1][0]);
-                acc[1][1] = mfma16(a1, b1, acc[1][1]);
-                const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32];
-                acc[0][0] = mfma16(a0, bl0, acc[0][0]);
-                acc[0][1] = mfma16(a0, bl1, acc[0][1]);
-                acc[1][0] = mfma16(a1, bl0, acc[1][0]);
-                acc[1][1] = mfma16(a1, bl1, acc[1][1]);
-                const h8 al0 = st[256 + fa], al1 = st[256 + fa + 32];
-                acc[0][0] = mfma16(al0, b0, acc[0][0]);
-                acc[0][1] = mfma16(al0, b1, acc[0][1]);
-                acc[1][0] = mfma16(al1, b0, acc[1][0]);
-                acc[1][1] = mfma16(al1, b1, acc[1][1]);
+                for (int u = 0; u < KU; ++u) {
+                    const h8 *su = st + u * 8 * 256;
+                    const h8 al0 = su[256 + fa], al1 = su[256 + fa + 32];
+                    // the next slice's hi parts and lo(B), read before this slice's last two groups are issued
+                    h8 nah0, nah1, nbh0, nbh1, nbl0, nbl1;
+                    if (u + 1 < KU) {
+                        const h8 *sn = su + 8 * 256;
+                        nah0 = sn[fa]; nah1 = sn[fa + 32]; nbh0 = sn[fb]; nbh1 = sn[fb + 32];
+                        nbl0 = sn[256 + fb]; nbl1 = sn[256 + fb + 32];
+                    }
+                    acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
+                    acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+                    acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
+                    acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
+                    acc[0][0] = mfma16(al0, bh0, acc[0][0]);
+                    acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+                    acc[1][0] = mfma16(al1, bh0, acc[1][0]);
+                    acc[1][1] = mfma16(al1, bh1, acc[1][1]);
+                    if (u + 1 < KU) {
+                        ah0 = nah0; ah1 = nah1; bh0 = nbh0; bh1 = nbh1; bl0 = nbl0; bl1 = nbl1;
+                        acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
+                        acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+                        acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
+                        acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
+                    }
+                }
             }
         }
         ks += KU;
