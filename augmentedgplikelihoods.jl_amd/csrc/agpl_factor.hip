@@ -379,7 +379,9 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     // 4 tile workgroups);
     // 4, 8 = the tiles of every step shared, hand-offs at step boundaries.  Measured at M = 512: see DESIGN.md 4.5.
     static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 3;
-    const int nw = coop_work ? nw_env : 1;
+    // the multi-workgroup forms spin on their partners: every working workgroup must be resident at once (one per CU,
+    // the 150 KB of LDS see to that), so they are used only while L * NW stays well inside the 256 CUs
+    const int nw = (coop_work && (int64_t)L * nw_env <= 128) ? nw_env : 1;
     double *PXg = (double *)coop_work;
     unsigned *sync = coop_work ? (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * 2 * M * FB) : nullptr;
     if (nw > 1) AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 4 * (size_t)L, ctx->stream));
