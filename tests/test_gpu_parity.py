@@ -861,10 +861,11 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
     assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
 
 
-@pytest.mark.parametrize("M,L", [(128, 1), (512, 2), (1024, 1)])
-def test_gaussian_factor_with_prior_term_and_both_routes(A, ctx, M, L):
-    """agpl_gaussian_factor with eta0: v = U (g + eta0); the fused kernel (M <= 512) and the rocSOLVER route (M = 1024)
-    satisfy the same identities: U'U = (I+G)^-1, U'v = (I+G)^-1 (g + eta0), log det."""
+@pytest.mark.parametrize("M,L", [(128, 1), (512, 2), (640, 3), (1024, 1), (1024, 2), (1536, 1)])
+def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
+    """agpl_gaussian_factor with eta0: v = U (g + eta0); the fused kernel (M <= 512), the two-block form around it
+    (512 < M <= 1024) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
+    U'v = (I+G)^-1 (g + eta0), log det."""
     import ctypes as C
 
     rng = np.random.default_rng(M + L)
@@ -886,11 +887,13 @@ def test_gaussian_factor_with_prior_term_and_both_routes(A, ctx, M, L):
         assert host(ld)[l] == pytest.approx(np.linalg.slogdet(np.eye(M) + G[l])[1], rel=1e-12)
 
 
-def test_gaussian_factor_reports_indefinite_matrix(A, ctx):
+@pytest.mark.parametrize("M,first_bad", [(256, 0), (1024, 0), (1024, 700)])
+def test_gaussian_factor_reports_indefinite_matrix(A, ctx, M, first_bad):
     import ctypes as C
 
-    M = 256
-    G = -2.0 * np.eye(M)[None]  # I + G = -I
+    d = np.zeros(M)
+    d[first_bad:] = -2.0  # I + G = diag(1, ..., 1, -1, ..., -1): either block of the two-block form must report it
+    G = np.diag(d)[None]
     dG, dg = dev(G), dev(np.zeros((1, M)))
     Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
     with pytest.raises(A.PosDefException):
