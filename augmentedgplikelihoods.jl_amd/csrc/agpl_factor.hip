@@ -130,12 +130,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
         lost = 0;
         ldsum = 0.0;
     }
-    // T (lower triangle) = I + G
-    if (wg == 0)
-        for (int idx = tid; idx < M * M; idx += 1024) {
-            const int i = idx / M, j = idx - i * M;
-            if (j <= i) T[idx] = G[idx] + (i == j ? 1.0 : 0.0);
-        }
+    // T holds the updated trailing matrix; nothing has been updated before step 0, whose reads therefore come straight
+    // from G (+ I): no M x M copy up front
     __syncthreads();
 
     for (int k = 0; k < nb; ++k) {
@@ -151,18 +147,36 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 if (lost) break;
             }
         // ---- stage the diagonal block and the raw panel
+            //      (PX rows Mp.. = rows kb..kb+31 of the eliminated identity, one LDS row per column c; block (k,k) is
+            //      still the identity).  All of a thread's loads are issued before the first LDS store: one round trip
+            //      to L2 instead of one per element.
             {
+                const double *Tsrc = k == 0 ? G : T;
+                const double dadd = k == 0 ? 1.0 : 0.0;
                 const int r = tid >> 5, c = tid & 31;
-                Ds[r * FP + c] = c <= r ? T[(size_t)(kb + r) * M + kb + c] : 0.0;
-            }
-            for (int idx = tid; idx < Mp * FB; idx += 1024) {
-                const int ip = idx >> 5, m = idx & 31;
-                PX[(size_t)ip * FP + m] = T[(size_t)(kb + FB + ip) * M + kb + m];
-            }
-            // rows kb..kb+31 of the eliminated identity, one LDS row per column c (block (k,k) is still the identity)
-            for (int idx = tid; idx < ncx * FB; idx += 1024) {
-                const int c = idx >> 5, q = idx & 31;
-                PX[(size_t)(Mp + c) * FP + q] = c < kb ? A[(size_t)c * M + kb + q] : (c - kb == q ? 1.0 : 0.0);
+                const double dval = Tsrc[(size_t)(kb + r) * M + kb + c];
+                // thread (r, c) takes element c of rows r, r + 32, ...: row block u is all P rows (u < nbp0), all rows of
+                // U already eliminated into (u - nbp0 < k) or the identity block (u - nbp0 == k): uniform branches
+                const int nbp0 = Mp / 32;
+                const unsigned toff = (unsigned)((kb + FB + r) * M + kb + c), aoff = (unsigned)(r * M + kb + c);
+                // (8 loads in flight per thread: 16 would spill under the 128-VGPR cap)
+#pragma unroll 1
+                for (int u0 = 0; u0 < nb; u0 += 8) {
+                    double tmp[8];
+#pragma unroll
+                    for (int uu = 0; uu < 8; ++uu) {
+                        const int u = u0 + uu;
+                        tmp[uu] = 0.0;
+                        if (u < nbp0) tmp[uu] = Tsrc[toff + (unsigned)(u * 32 * M)];
+                        else if (u - nbp0 < k) tmp[uu] = A[aoff + (unsigned)((u - nbp0) * 32 * M)];
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < 8; ++uu) {
+                        const int u = u0 + uu;
+                        if (u < nb) PX[(size_t)(u * 32 + r) * FP + c] = (u - nbp0 == k && r == c) ? 1.0 : tmp[uu];
+                    }
+                }
+                Ds[r * FP + c] = c < r ? dval : (c == r ? dval + dadd : 0.0);
             }
             __syncthreads();
             // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
@@ -203,7 +217,9 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     if (r == c + 1) Wf[(c + 1) * FP + cc] = w1;
                     if (r > c + 1) Y[r * FP + cc] -= lr0 * w0 + lr1 * w1;
                     if (tid == 0) {
-                        ldsum += log(p0) + log(p1); // = 2 log R_cc + 2 log R_c+1,c+1
+                        // the pivots go to the padding column of PX (log det at the end, off the serial path)
+                        PX[(size_t)(kb + c) * FP + FB] = p0;
+                        PX[(size_t)(kb + c + 1) * FP + FB] = p1;
                         if (!(p0 > 0.0)) bad = kb + c + 1;
                         else if (!(p1 > 0.0)) bad = kb + c + 2;
                     }
@@ -251,7 +267,17 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             __syncthreads();
             if (lost) break;
             const double *PXg = PXg0 + (LA ? (size_t)(k & 1) * M * FB : 0);
-            for (int idx = tid; idx < M * FB; idx += 1024) PX[(size_t)(idx >> 5) * FP + (idx & 31)] = PXg[idx];
+#pragma unroll 1
+            for (int i0 = tid; i0 < M * FB; i0 += 8 * 1024) { // 8 loads in flight per thread
+                double tmp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tmp[u] = PXg[min(i0 + u * 1024, M * FB - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * 1024;
+                    if (idx < M * FB) PX[(size_t)(idx >> 5) * FP + (idx & 31)] = tmp[u];
+                }
+            }
             __syncthreads();
         }
         if (Mp > 0) {
@@ -275,11 +301,13 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     // look-ahead with several tile workgroups: a location keeps its owner across steps (absolute
                     // 32-row / 16-column block coordinates), so no workgroup ever waits for another one's update
                     if (LA && NW > 2 && (k + 1 + ub + 2 * (k + 1) + wb) % (NW - 1) != wg - 1) continue;
-                    double *tp = T + (size_t)(kb + FB + 32 * ub) * M + kb + FB + 16 * wb;
+                    const size_t to = (size_t)(kb + FB + 32 * ub) * M + kb + FB + 16 * wb;
+                    double *tp = T + to;
+                    const double *tsrc = (k == 0 ? G : T) + to;
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) old[ti][r] = tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                        for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
                     mac_2x1(PX + (size_t)ub * 32 * FP, PX + (size_t)wb * 16 * FP, lane, acc);
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
@@ -287,7 +315,9 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                         for (int r = 0; r < 4; ++r) {
                             const int ip = 32 * ub + 16 * ti + 4 * r + (lane >> 4), jp = 16 * wb + (lane & 15);
                             // (elements above the diagonal of a diagonal tile were read too: inside T, unused)
-                            if (jp <= ip) tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                            if (jp <= ip)
+                                tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] =
+                                    old[ti][r] - acc[ti][r] + (k == 0 && jp == ip ? 1.0 : 0.0);
                         }
                 } else {
                     const int wbi = w - ntile_a;
@@ -338,6 +368,15 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
         }
     }
 
+    // ---- log det(I + G) = sum of the log pivots (fixed order: lanes of wave 0 over a stride, then a shuffle tree)
+    if (wave == 0) {
+        double acc = 0.0;
+        for (int i = lane; i < M; i += 64) acc += log(PX[(size_t)i * FP + FB]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) ldsum = acc;
+    }
+    __syncthreads();
     // ---- v = U (g + eta0):  v[a] = sum_{b <= a} A[b * M + a] r[b].  Wave w takes b = w, w + 16, ...; lanes run along
     //      a (coalesced); the 16 partial sums of an a are combined in wave order (fixed order: reproducible)
     {
