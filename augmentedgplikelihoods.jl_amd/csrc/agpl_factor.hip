@@ -26,6 +26,20 @@
 
 #include "agpl_common.h"
 
+#ifdef AGPL_FTRACE
+// debug build only (tools/scratch/ftrace.py): wall-clock stamps of the phases of every block step, per workgroup
+__device__ unsigned long long g_ftrace[8 * 16 * 8];
+#define AGPL_TS(id_)                                                                                                  \
+    do {                                                                                                              \
+        if (tid == 0 && blockIdx.y == 0) g_ftrace[(wg * 16 + k) * 8 + (id_)] = wall_clock64();                         \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int agpl_debug_ftrace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ftrace), sizeof(g_ftrace));
+}
+#else
+#define AGPL_TS(id_)
+#endif
+
 namespace {
 
 constexpr int FB = 32;      // block size
@@ -43,6 +57,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // columns of both LDS operands (row pitch FP).  v_mfma_f64_16x16x4_f64 (layout probed on gfx950, tools/scratch):
 // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
 // D[4 r + (l >> 4)][l & 15].
+// VTRI: Vop is lower triangular (Vop[w][m] = 0 for m > w): its first 16 rows end at column 15, so the tj = 0 products
+// of the upper half of the columns are skipped (24 MFMAs instead of 32).
+template <bool VTRI>
 __device__ __forceinline__ void macro_mac(const double *__restrict__ Uop, const double *__restrict__ Vop, int lane,
                                           d4 (&acc)[2][2]) {
     const int off = (lane & 15) * FP + (lane >> 4);
@@ -50,10 +67,13 @@ __device__ __forceinline__ void macro_mac(const double *__restrict__ Uop, const 
 #pragma unroll
     for (int kk = 0; kk < FB / 4; ++kk) {
         const double a0 = u[4 * kk], a1 = u[16 * FP + 4 * kk];
-        const double b0 = v[4 * kk], b1 = v[16 * FP + 4 * kk];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        const double b1 = v[16 * FP + 4 * kk];
+        if (!VTRI || kk < FB / 8) {
+            const double b0 = v[4 * kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        }
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
 }
@@ -107,7 +127,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     if (NW > 1 && (blockIdx.x & 7)) return;
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *PX = sm;                 // [M][FP]: rows 0..Mp-1 = P, rows Mp..M-1 = X_k' (one row per column c of U)
+    double *PX = sm;                 // [M][FP]: row c < ncx = X_k'[c] (column c of U), row g >= ncx = P of global row g
     double *Ds = PX + (size_t)M * FP; // [32][FP] diagonal block being eliminated, then the identity's elimination
     double *Rs = Ds + FB * FP;       // [32][FP] the identity block being eliminated alongside
     double *Wf = Rs + FB * FP;       // [32][FP] W = R_kk^-1
@@ -135,17 +155,23 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     __syncthreads();
 
     for (int k = 0; k < nb; ++k) {
+        // the thread and lane indices pass through an empty asm once per block step: without it every address that
+        // depends on them is hoisted out of this loop as an invariant and the kernel spills ~100 VGPRs
+        int tk = tid, ln = lane;
+        asm volatile("" : "+v"(tk), "+v"(ln));
         const int kb = k * FB;
         const int Mp = M - kb - FB; // trailing rows
         const int ncx = kb + FB;    // columns of U that rows kb.. can touch
         if (wg == 0) {
-            if (NW > 1 && k > 0) {
-                // every workgroup's tiles of step k - 1 (they touch the block and panel staged next) are finished;
-                // look-ahead: only the critical ones need to be
-                if (tid == 0 && !spin_until_ge(LA ? crit : done, (unsigned)(LA ? (NW - 1) * k : NW * k))) lost = 1;
+            AGPL_TS(0);
+            if (!LA && NW > 1 && k > 0) {
+                // every workgroup's tiles of step k - 1 (they touch the block and panel staged next) are finished
+                if (tk == 0 && !spin_until_ge(done, (unsigned)(NW * k))) lost = 1;
                 __syncthreads();
                 if (lost) break;
             }
+            AGPL_TS(1);
+            if (!LA || k == 0) { // look-ahead: block k > 0 is already in LDS, updated by this workgroup at step k - 1
         // ---- stage the diagonal block and the raw panel
             //      (PX rows Mp.. = rows kb..kb+31 of the eliminated identity, one LDS row per column c; block (k,k) is
             //      still the identity).  All of a thread's loads are issued before the first LDS store: one round trip
@@ -153,11 +179,10 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             {
                 const double *Tsrc = k == 0 ? G : T;
                 const double dadd = k == 0 ? 1.0 : 0.0;
-                const int r = tid >> 5, c = tid & 31;
+                const int r = tk >> 5, c = tk & 31;
                 const double dval = Tsrc[(size_t)(kb + r) * M + kb + c];
-                // thread (r, c) takes element c of rows r, r + 32, ...: row block u is all P rows (u < nbp0), all rows of
-                // U already eliminated into (u - nbp0 < k) or the identity block (u - nbp0 == k): uniform branches
-                const int nbp0 = Mp / 32;
+                // thread (r, c) takes element c of rows r, r + 32, ...: row block u is all rows of U already eliminated
+                // into (u < k), the identity block (u == k) or all P rows (u > k): uniform branches
                 const unsigned toff = (unsigned)((kb + FB + r) * M + kb + c), aoff = (unsigned)(r * M + kb + c);
                 // (8 loads in flight per thread: 16 would spill under the 128-VGPR cap)
 #pragma unroll 1
@@ -167,18 +192,20 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     for (int uu = 0; uu < 8; ++uu) {
                         const int u = u0 + uu;
                         tmp[uu] = 0.0;
-                        if (u < nbp0) tmp[uu] = Tsrc[toff + (unsigned)(u * 32 * M)];
-                        else if (u - nbp0 < k) tmp[uu] = A[aoff + (unsigned)((u - nbp0) * 32 * M)];
+                        if (u > k) tmp[uu] = Tsrc[toff + (unsigned)((u - k - 1) * 32 * M)];
+                        else if (u < k) tmp[uu] = A[aoff + (unsigned)(u * 32 * M)];
                     }
 #pragma unroll
                     for (int uu = 0; uu < 8; ++uu) {
                         const int u = u0 + uu;
-                        if (u < nb) PX[(size_t)(u * 32 + r) * FP + c] = (u - nbp0 == k && r == c) ? 1.0 : tmp[uu];
+                        if (u < nb) PX[(size_t)(u * 32 + r) * FP + c] = (u == k && r == c) ? 1.0 : tmp[uu];
                     }
                 }
                 Ds[r * FP + c] = c < r ? dval : (c == r ? dval + dadd : 0.0);
             }
             __syncthreads();
+            }
+            AGPL_TS(2);
             // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
             //      PAIR of columns (c, c + 1): columns c, c + 1 of the working block D and rows c, c + 1 of the
             //      eliminated identity Y are final since the previous step, and this step only writes columns > c + 1
@@ -189,13 +216,22 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             //         Y[r][:] -= R[r][c] W[c][:] + R[r][c+1] W[c+1][:]                                 (r > c + 1)
             //      The reciprocal pivots are v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle
             //      sqrt + divide sequences: these 16 dependent steps per block are the serial spine of the factorisation.
+            //      Thread (r, cc) keeps D[r][cc] and Y[r][cc] in registers and every LDS read of a step is issued
+            //      up front, unconditionally (a read inside a branch exposes its latency after the pivot chains); LDS
+            //      only carries what other threads need next: columns c + 2, c + 3 of D and rows c + 2, c + 3 of Y.
             {
-                const int r = tid >> 5, cc = tid & 31;
+                const int r = tk >> 5, cc = tk & 31;
                 double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
-                Y[r * FP + cc] = r == cc ? 1.0 : 0.0;
+                double dreg = Ds[r * FP + cc];
+                double yreg = r == cc ? 1.0 : 0.0;
+                Y[r * FP + cc] = yreg;
+#pragma unroll
                 for (int c = 0; c < FB; c += 2) {
                     __syncthreads();
                     const double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
+                    const double dr0 = Ds[r * FP + c], dr1 = Ds[r * FP + c + 1];    // D[r][c], D[r][c+1]
+                    const double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];    // D[cc][c], D[cc][c+1]
+                    const double y0 = Y[c * FP + cc], y1 = Y[(c + 1) * FP + cc];
                     double r0 = __builtin_amdgcn_rsq(p0);
                     r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
                     r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
@@ -204,19 +240,22 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     double r1 = __builtin_amdgcn_rsq(p1);
                     r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1);
                     r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1); // 1 / R[c+1][c+1]
-                    const double lr0 = Ds[r * FP + c] * r0;                          // R[r][c]     (r >= c)
-                    const double lr1 = (Ds[r * FP + c + 1] - lr0 * l10) * r1;        // R[r][c+1]   (r >= c + 1)
-                    if (cc > c + 1 && r >= cc) {
-                        const double lc0 = Ds[cc * FP + c] * r0;
-                        const double lc1 = (Ds[cc * FP + c + 1] - lc0 * l10) * r1;
-                        Ds[r * FP + cc] -= lr0 * lc0 + lr1 * lc1;
-                    }
-                    const double w0 = Y[c * FP + cc] * r0;                           // W[c][cc]
-                    const double w1 = (Y[(c + 1) * FP + cc] - l10 * w0) * r1;        // W[c+1][cc]
+                    const double lr0 = dr0 * r0;                  // R[r][c]     (r >= c)
+                    const double lr1 = (dr1 - lr0 * l10) * r1;    // R[r][c+1]   (r >= c + 1)
+                    const double lc0 = x0 * r0;                   // R[cc][c]
+                    const double lc1 = (x1 - lc0 * l10) * r1;     // R[cc][c+1]
+                    const double w0 = y0 * r0;                    // W[c][cc]
+                    const double w1 = (y1 - l10 * w0) * r1;       // W[c+1][cc]
+                    const double dd = lr0 * lc0 + lr1 * lc1, dy = lr0 * w0 + lr1 * w1;
+                    dreg -= (cc > c + 1 && r >= cc) ? dd : 0.0;
+                    yreg -= r > c + 1 ? dy : 0.0;
                     if (r == c) Wf[c * FP + cc] = w0;
                     if (r == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                    if (r > c + 1) Y[r * FP + cc] -= lr0 * w0 + lr1 * w1;
-                    if (tid == 0) {
+                    if (c + 2 < FB) {
+                        if (cc == c + 2 || cc == c + 3) Ds[r * FP + cc] = dreg;
+                        if (r == c + 2 || r == c + 3) Y[r * FP + cc] = yreg;
+                    }
+                    if (tk == 0) {
                         // the pivots go to the padding column of PX (log det at the end, off the serial path)
                         PX[(size_t)(kb + c) * FP + FB] = p0;
                         PX[(size_t)(kb + c + 1) * FP + FB] = p1;
@@ -226,6 +265,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 }
             }
             __syncthreads();
+            AGPL_TS(3);
             // ---- every row of PX times W':  P[i'][c] = sum_m Araw[i'][m] W[c][m]  (panel of R below the block) and
             //      X_k'[c][m] = sum_q RHS[kb+q][c] W[m][q]  (rows kb..kb+31 of U, final).  Wave w owns rows 32 w..32 w + 31
             //      and nobody else touches them: in place without a barrier between its reads and its writes.
@@ -236,39 +276,101 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
                 double *rows = PX + (size_t)wave * 32 * FP;
-                macro_mac(rows, Wf, lane, acc);
-                const bool xrows = wave * 32 >= Mp; // Mp % 32 == 0: a wave's rows are all P rows or all X rows
+                macro_mac<true>(rows, Wf, ln, acc); // W is lower triangular
+                const bool xrows = wave * 32 < ncx; // a wave's rows are all X rows or all P rows
+                const bool p0rows = LA && wave * 32 == ncx; // the first 32 rows of P: a copy for the look-ahead update
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int i = 16 * ti + 4 * r + (lane >> 4), m = 16 * tj + (lane & 15);
+                            const int i = 16 * ti + 4 * r + (ln >> 4), m = 16 * tj + (ln & 15);
                             const double val = acc[ti][tj][r];
                             rows[i * FP + m] = val;
+                            if (p0rows) Rs[i * FP + m] = val;
                             if (xrows) {
-                                const int c = wave * 32 + i - Mp;
+                                const int c = wave * 32 + i;
                                 if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // (the other triangle of A is not ours)
                             }
                         }
             }
             __syncthreads();
-            if (NW > 1) {
+            AGPL_TS(4);
+            if (NW > 1 && (!LA || Mp >= 2 * FB)) {
                 // publish P | X_k' (the LDS rows without their padding) and the step counter
                 double *PXg = PXg0 + (LA ? (size_t)(k & 1) * M * FB : 0);
-                for (int idx = tid; idx < M * FB; idx += 1024) PXg[idx] = PX[(size_t)(idx >> 5) * FP + (idx & 31)];
+                for (int idx = tk; idx < M * FB; idx += 1024) PXg[idx] = PX[(size_t)(idx >> 5) * FP + (idx & 31)];
                 __syncthreads(); // every wave's stores have left the CU (vmcnt(0) + barrier; the L1 is write-through)
-                if (tid == 0) __hip_atomic_store(ready, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == 0) __hip_atomic_store(ready, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            AGPL_TS(5);
+            if (LA && Mp > 0) {
+                // ---- look-ahead on the spine: apply THIS step's update to the next block column of T (diagonal block
+                //      k + 1 and the panel below it) and to the next 32 rows of the eliminated identity, straight into
+                //      the LDS layout of step k + 1.  Their updates of steps < k came from the tile workgroups, which
+                //      never touch them again (they work two block columns ahead); those of step k - 1 are the tiles
+                //      they do first and count in `crit` -- a whole spine step ago, so this wait is normally over.
+                const int nbp = Mp / 32, ncb = ncx / 32; // nbp + ncb = nb - 1 <= 15 row blocks: one wave each
+                if (k > 0) {
+                    if (tk == 0 && !spin_until_ge(crit, (unsigned)((NW - 1) * k))) lost = 1;
+                    __syncthreads();
+                    if (lost) break;
+                }
+                AGPL_TS(6);
+                // wave w < nbp: rows 32 w.. of P against the first 32 rows of P (their copy in Rs), old values from T,
+                // result = rows of the next diagonal block (w = 0, into Ds) or of the next raw panel (in place: the
+                // same LDS rows, which only this wave reads).  Wave nbp + cb: rows 32 cb.. of X_k' against the same,
+                // old values from U (column-major), result = the next raw rows of the eliminated identity, in place.
+                if (wave < nbp + ncb) {
+                    const bool ta = wave < nbp;
+                    const int hb = ta ? wave : wave - nbp;
+                    const double *oldp = ta ? (k == 0 ? G : T) + (size_t)(kb + FB + 32 * hb) * M + kb + FB
+                                            : A + (size_t)(32 * hb) * M + kb + FB;
+                    const bool zero_old = !ta && 32 * hb >= kb; // column block k of U: nothing eliminated into it yet
+                    const bool tri = ta && hb == 0;
+                    double *rowsU = tri ? Rs : PX + (size_t)(ta ? ncx + 32 * hb : 32 * hb) * FP;
+                    double *dst = tri ? Ds : rowsU;
+                    const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+                    d4 acc[2][2], old[2][2];
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj) {
+                            acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                old[ti][tj][r] = oldp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
+                        }
+                    macro_mac<false>(rowsU, Rs, ln, acc);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * ti + 4 * r + (ln >> 4), j = 16 * tj + (ln & 15);
+                                double val = (zero_old ? 0.0 : old[ti][tj][r]) - acc[ti][tj][r];
+                                if (tri) val = j < i ? val : (j == i ? val + (k == 0 ? 1.0 : 0.0) : 0.0); // T = I + G
+                                dst[i * FP + j] = val;
+                            }
+                }
+                // block (k + 1, k + 1) of the eliminated identity is still the identity
+                // (rows ncx.. of PX held the first 32 rows of P: the waves above read their copy in Rs)
+                PX[(size_t)(ncx + (tk >> 5)) * FP + (tk & 31)] = (tk >> 5) == (tk & 31) ? 1.0 : 0.0;
+                __syncthreads();
+                AGPL_TS(7);
             }
         } else {
-            if (LA && Mp == 0) break; // the last block step has no tiles
-            if (tid == 0 && !spin_until_ge(ready, (unsigned)(k + 1))) lost = 1;
+            if (LA && Mp < 2 * FB) break; // the tile workgroups work two block columns ahead of the spine
+            AGPL_TS(0);
+            if (tk == 0 && !spin_until_ge(ready, (unsigned)(k + 1))) lost = 1;
             __syncthreads();
             if (lost) break;
+            AGPL_TS(1);
             const double *PXg = PXg0 + (LA ? (size_t)(k & 1) * M * FB : 0);
 #pragma unroll 1
-            for (int i0 = tid; i0 < M * FB; i0 += 8 * 1024) { // 8 loads in flight per thread
+            for (int i0 = tk; i0 < M * FB; i0 += 8 * 1024) { // 8 loads in flight per thread
                 double tmp[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) tmp[u] = PXg[min(i0 + u * 1024, M * FB - 1)];
@@ -279,16 +381,17 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 }
             }
             __syncthreads();
+            AGPL_TS(2);
         }
         if (Mp > 0) {
             // ---- 32 x 16 wave tiles: (a) T[i][j] -= P_i . P_j over the lower block triangle (16 wb <= 32 ub + 31);
             //                          (b) RHS[i][c] -= X_k'[c] . P_i for every 32-column block cb (U is column-major:
             //                              the lanes of a result run along i).
-            // The old values are loaded first (uniform tile origin + one 32-bit lane offset): their latency hides
+            // The old values are loaded first (uniform tile origin + one 32-bit ln offset): their latency hides
             // behind the 16 MFMAs.
             const int nbp = Mp / 32, ncb = ncx / 32;
             const int ntile_a = nbp * (nbp + 1), ntile_b = ncb * 2 * nbp;
-            const unsigned lo_ = (unsigned)(lane >> 4) * (unsigned)M + (unsigned)(lane & 15);
+            const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
             for (int pass = 0; pass < (LA ? 2 : 1); ++pass) {
             if (LA && wg == 0) break; // look-ahead: the spine workgroup does no tiles
             int ub = 0;
@@ -297,7 +400,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 if (w < ntile_a) {
                     while ((ub + 1) * (ub + 2) <= w) ++ub;
                     const int wb = w - ub * (ub + 1); // 16-column block, 0 .. 2 ub + 1
-                    if (LA && (wb < 2) != (pass == 0)) continue; // pass 0: the next diagonal block and panel
+                    if (LA && wb < 2) continue;                  // the next block column is the spine's own
+                    if (LA && (wb < 4) != (pass == 0)) continue; // pass 0: the block column the spine takes next step
                     // look-ahead with several tile workgroups: a location keeps its owner across steps (absolute
                     // 32-row / 16-column block coordinates), so no workgroup ever waits for another one's update
                     if (LA && NW > 2 && (k + 1 + ub + 2 * (k + 1) + wb) % (NW - 1) != wg - 1) continue;
@@ -308,12 +412,12 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
-                    mac_2x1(PX + (size_t)ub * 32 * FP, PX + (size_t)wb * 16 * FP, lane, acc);
+                    mac_2x1(PX + (size_t)(ncx + 32 * ub) * FP, PX + (size_t)(ncx + 16 * wb) * FP, ln, acc);
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int ip = 32 * ub + 16 * ti + 4 * r + (lane >> 4), jp = 16 * wb + (lane & 15);
+                            const int ip = 32 * ub + 16 * ti + 4 * r + (ln >> 4), jp = 16 * wb + (ln & 15);
                             // (elements above the diagonal of a diagonal tile were read too: inside T, unused)
                             if (jp <= ip)
                                 tp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] =
@@ -322,7 +426,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                 } else {
                     const int wbi = w - ntile_a;
                     const int cb = wbi / (2 * nbp), ib = wbi - cb * 2 * nbp; // 32 columns c x 16 rows i
-                    if (LA && (ib < 2) != (pass == 0)) continue; // pass 0: the next 32 rows of the eliminated identity
+                    if (LA && ib < 2) continue;                  // (the same for the rows of the eliminated identity)
+                    if (LA && (ib < 4) != (pass == 0)) continue;
                     if (LA && NW > 2 && (cb + 2 * (k + 1) + ib) % (NW - 1) != wg - 1) continue;
                     double *ap = A + (size_t)(32 * cb) * M + kb + FB + 16 * ib;
                     const bool fresh = 32 * cb >= kb; // column block k: nothing eliminated into it yet
@@ -331,7 +436,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
-                    mac_2x1(PX + (size_t)(Mp + 32 * cb) * FP, PX + (size_t)ib * 16 * FP, lane, acc);
+                    mac_2x1(PX + (size_t)(32 * cb) * FP, PX + (size_t)(ncx + 16 * ib) * FP, ln, acc);
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -341,18 +446,20 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             }
             if (LA && pass == 0) {
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(crit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == 0) __hip_atomic_fetch_add(crit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                AGPL_TS(3);
             }
             }
         }
         if (LA) {
             if (wg != 0) {
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                AGPL_TS(4);
             }
         } else if (NW > 1) {
-            __syncthreads(); // as above: one lane's agent-scope release then covers the whole workgroup's stores
-            if (tid == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads(); // as above: one ln's agent-scope release then covers the whole workgroup's stores
+            if (tk == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __syncthreads();
         }
@@ -360,7 +467,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     if (NW > 1) {
         if (wg != 0) return;
         // U is complete once every workgroup has finished the last step's tiles
-        if (tid == 0 && !lost && (!LA || nb > 1) && !spin_until_ge(done, (unsigned)(LA ? (NW - 1) * (nb - 1) : NW * nb))) lost = 1;
+        if (tid == 0 && !lost && (!LA || nb > 2) && !spin_until_ge(done, (unsigned)(LA ? (NW - 1) * (nb - 2) : NW * nb))) lost = 1;
         __syncthreads();
         if (lost) {
             if (tid == 0) info[l] = -1; // a partner workgroup never arrived: reported as an internal error by the host
