@@ -110,12 +110,16 @@ __device__ __forceinline__ bool spin_until_ge(unsigned *p, unsigned target) {
 // The launch is 8 NW workgroups wide and only those with blockIdx.x % 8 == 0 work: the dispatcher deals workgroups
 // round-robin to the 8 XCDs, so the cooperating ones share one L2.
 //
-// LA (look-ahead, NW = 2): workgroup 0 runs ONLY the spine, workgroup 1 ONLY the tiles, and the two overlap: the tiles
-// that the next spine step reads -- the first trailing 32 columns of T (next diagonal block and panel) and the next 32
-// rows of the eliminated identity -- are done first and signalled through `crit`; the spine of step k + 1 then runs
-// while the remaining tiles of step k finish.  Every T / U location is updated by workgroup 1 alone across steps, so
-// no other hand-off is needed; P | X_k' travels through two alternating global buffers (buffer k & 1 is rewritten at
-// step k + 2, by when workgroup 1 has loaded it: it signalled crit(k) after doing so).
+// LA (look-ahead; NW = 2, 3, 5): workgroup 0 runs ONLY the spine, the other NW - 1 ONLY tiles, two block columns
+// ahead of it.  At step k the spine factors block k, forms P | X_k' and publishes them, then applies this step's update
+// itself -- in LDS, straight into the layout of step k + 1 -- to the next block column of T (diagonal block k + 1 and
+// its panel) and to the next 32 rows of the eliminated identity.  The tile workgroups update everything from block
+// column k + 2 on; the block column the spine will take over at step k + 1 comes first and is counted in `crit`, which
+// the spine reads a whole step later: no round trip through another workgroup sits on the spine's path (measured:
+// 29 -> 20 us per block step).  A T / U location is updated by one tile workgroup until the spine takes it over
+// (ownership by absolute block coordinates), so no other hand-off is needed; P | X_k' travels through two alternating
+// global buffers (buffer k & 1 is rewritten at step k + 2, by when every tile workgroup has loaded it: it counted
+// crit(k) after doing so).
 template <int NW, bool LA>
 __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__restrict__ Gall,
                                                          const double *__restrict__ gall,
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                     for (int uu = 0; uu < 8; ++uu) {
                         const int u = u0 + uu;
                         tmp[uu] = 0.0;
-                        if (u > k) tmp[uu] = Tsrc[toff + (unsigned)((u - k - 1) * 32 * M)];
+                        if (u > k && u < nb) tmp[uu] = Tsrc[toff + (unsigned)((u - k - 1) * 32 * M)];
                         else if (u < k) tmp[uu] = A[aoff + (unsigned)(u * 32 * M)];
                     }
 #pragma unroll
@@ -215,52 +219,74 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             //         W[c][:] = Y[c][:] / R[c][c],  W[c+1][:] = (Y[c+1][:] - R[c+1][c] W[c][:]) / R[c+1][c+1]
             //         Y[r][:] -= R[r][c] W[c][:] + R[r][c+1] W[c+1][:]                                 (r > c + 1)
             //      The reciprocal pivots are v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle
-            //      sqrt + divide sequences: these 16 dependent steps per block are the serial spine of the factorisation.
-            //      Thread (r, cc) keeps D[r][cc] and Y[r][cc] in registers and every LDS read of a step is issued
-            //      up front, unconditionally (a read inside a branch exposes its latency after the pivot chains); LDS
-            //      only carries what other threads need next: columns c + 2, c + 3 of D and rows c + 2, c + 3 of Y.
+            //      sqrt + divide sequences, the two of a step from independent chains: these 16 dependent steps per
+            //      block are the serial spine of the factorisation.
+            //      A step is bound by instruction issue (about 120 instructions per wave, most of them the two
+            //      reciprocal-pivot chains every wave repeats; 4 waves per SIMD), so only waves 0..7 work here: thread
+            //      (rq, cc) keeps D and Y of rows rq and rq + 16 at column cc in registers, written branch-free (masks,
+            //      not branches: a read inside a branch exposes its latency after the chains).  LDS only carries what
+            //      other threads need next: columns c + 2, c + 3 of D and rows c + 2, c + 3 of Y.
             {
-                const int r = tk >> 5, cc = tk & 31;
+                const bool act = tk < 512;
+                const int cc = tk & 31, rq = (tk >> 5) & 15;
                 double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
-                double dreg = Ds[r * FP + cc];
-                double yreg = r == cc ? 1.0 : 0.0;
-                Y[r * FP + cc] = yreg;
+                double d0 = Ds[rq * FP + cc], d1 = Ds[(rq + 16) * FP + cc];
+                double y0r = rq == cc ? 1.0 : 0.0, y1r = rq + 16 == cc ? 1.0 : 0.0;
+                Y[(tk >> 5) * FP + cc] = (tk >> 5) == cc ? 1.0 : 0.0;
 #pragma unroll
                 for (int c = 0; c < FB; c += 2) {
                     __syncthreads();
-                    const double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
-                    const double dr0 = Ds[r * FP + c], dr1 = Ds[r * FP + c + 1];    // D[r][c], D[r][c+1]
-                    const double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];    // D[cc][c], D[cc][c+1]
-                    const double y0 = Y[c * FP + cc], y1 = Y[(c + 1) * FP + cc];
-                    double r0 = __builtin_amdgcn_rsq(p0);
-                    r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
-                    r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
-                    const double l10 = b10 * r0;          // R[c+1][c]
-                    const double p1 = d11 - l10 * l10;    // the second pivot
-                    double r1 = __builtin_amdgcn_rsq(p1);
-                    r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1);
-                    r1 = r1 * (1.5 - 0.5 * p1 * r1 * r1); // 1 / R[c+1][c+1]
-                    const double lr0 = dr0 * r0;                  // R[r][c]     (r >= c)
-                    const double lr1 = (dr1 - lr0 * l10) * r1;    // R[r][c+1]   (r >= c + 1)
-                    const double lc0 = x0 * r0;                   // R[cc][c]
-                    const double lc1 = (x1 - lc0 * l10) * r1;     // R[cc][c+1]
-                    const double w0 = y0 * r0;                    // W[c][cc]
-                    const double w1 = (y1 - l10 * w0) * r1;       // W[c+1][cc]
-                    const double dd = lr0 * lc0 + lr1 * lc1, dy = lr0 * w0 + lr1 * w1;
-                    dreg -= (cc > c + 1 && r >= cc) ? dd : 0.0;
-                    yreg -= r > c + 1 ? dy : 0.0;
-                    if (r == c) Wf[c * FP + cc] = w0;
-                    if (r == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                    if (c + 2 < FB) {
-                        if (cc == c + 2 || cc == c + 3) Ds[r * FP + cc] = dreg;
-                        if (r == c + 2 || r == c + 3) Y[r * FP + cc] = yreg;
-                    }
-                    if (tk == 0) {
-                        // the pivots go to the padding column of PX (log det at the end, off the serial path)
-                        PX[(size_t)(kb + c) * FP + FB] = p0;
-                        PX[(size_t)(kb + c + 1) * FP + FB] = p1;
-                        if (!(p0 > 0.0)) bad = kb + c + 1;
-                        else if (!(p1 > 0.0)) bad = kb + c + 2;
+                    if (act) {
+                        double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
+                        double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];       // D[cc][c], D[cc][c+1]
+                        double ya = Y[c * FP + cc], yb = Y[(c + 1) * FP + cc];
+                        double a0 = Ds[rq * FP + c], a1 = Ds[rq * FP + c + 1];       // D[rq][c], D[rq][c+1]
+                        double e0 = Ds[(rq + 16) * FP + c], e1 = Ds[(rq + 16) * FP + c + 1];
+                        // (every read above is issued before the first use: the asm keeps them out of later branches)
+                        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(ya), "+v"(yb), "+v"(a0), "+v"(a1), "+v"(e0), "+v"(e1));
+                        // both reciprocal pivots from independent chains: with det = D[c][c] D[c+1][c+1] - D[c+1][c]^2,
+                        // the second pivot is det / D[c][c] and 1 / R[c+1][c+1] = rsqrt(det) sqrt(D[c][c])
+                        const double det = __builtin_fma(d11, p0, -(b10 * b10));
+                        double r0 = __builtin_amdgcn_rsq(p0), rd = __builtin_amdgcn_rsq(det);
+                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
+                        rd = rd * (1.5 - 0.5 * det * rd * rd);
+                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
+                        rd = rd * (1.5 - 0.5 * det * rd * rd);
+                        const double l10 = b10 * r0;          // R[c+1][c]
+                        const double r1 = rd * (p0 * r0);     // 1 / R[c+1][c+1]
+                        const double p1 = det * (r0 * r0);    // the second pivot
+                        const double lc0 = x0 * r0;                   // R[cc][c]
+                        const double lc1 = (x1 - lc0 * l10) * r1;     // R[cc][c+1]
+                        const double w0 = ya * r0;                    // W[c][cc]
+                        const double w1 = (yb - l10 * w0) * r1;       // W[c+1][cc]
+                        const double la0 = a0 * r0, la1 = (a1 - la0 * l10) * r1; // R[rq][c], R[rq][c+1]
+                        const double le0 = e0 * r0, le1 = (e1 - le0 * l10) * r1; // R[rq+16][c], R[rq+16][c+1]
+                        // masks instead of branches (rows above the block being eliminated hold finite leftovers)
+                        const double md0 = (cc > c + 1 && rq >= cc) ? 1.0 : 0.0, md1 = (cc > c + 1 && rq + 16 >= cc) ? 1.0 : 0.0;
+                        const double my0 = rq > c + 1 ? 1.0 : 0.0, my1 = rq + 16 > c + 1 ? 1.0 : 0.0;
+                        d0 -= md0 * (la0 * lc0 + la1 * lc1);
+                        d1 -= md1 * (le0 * lc0 + le1 * lc1);
+                        y0r -= my0 * (la0 * w0 + la1 * w1);
+                        y1r -= my1 * (le0 * w0 + le1 * w1);
+                        if (rq == c) Wf[c * FP + cc] = w0;
+                        if (rq == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                        if (rq + 16 == c) Wf[c * FP + cc] = w0;
+                        if (rq + 16 == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                        if (c + 2 < FB) {
+                            if (cc == c + 2 || cc == c + 3) {
+                                Ds[rq * FP + cc] = d0;
+                                Ds[(rq + 16) * FP + cc] = d1;
+                            }
+                            if (rq == c + 2 || rq == c + 3) Y[rq * FP + cc] = y0r;
+                            if (rq + 16 == c + 2 || rq + 16 == c + 3) Y[(rq + 16) * FP + cc] = y1r;
+                        }
+                        if (tk == 0) {
+                            // the pivots go to the padding column of PX (log det at the end, off the serial path)
+                            PX[(size_t)(kb + c) * FP + FB] = p0;
+                            PX[(size_t)(kb + c + 1) * FP + FB] = p1;
+                            if (!(p0 > 0.0)) bad = kb + c + 1;
+                            else if (!(p1 > 0.0)) bad = kb + c + 2;
+                        }
                     }
                 }
             }
@@ -521,10 +547,10 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work) {
     const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
-    // AGPL_FACTOR_WGS = 1 | 2 | 3 | 5 | 4 | 8 workgroups per latent.  2, 3, 5 = look-ahead (one spine workgroup + 1, 2,
-    // 4 tile workgroups);
-    // 4, 8 = the tiles of every step shared, hand-offs at step boundaries.  Measured at M = 512: see DESIGN.md 4.5.
-    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 3;
+    // AGPL_FACTOR_WGS = 1 | 2 | 3 | 5 | 4 | 8 workgroups per latent.  2, 3, 5 (default) = look-ahead (one spine workgroup
+    // + 1, 2, 4 tile workgroups); 4, 8 = the tiles of every step shared, hand-offs at step boundaries.  Measured at
+    // M = 512: see DESIGN.md 4.5.
+    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 5;
     // the multi-workgroup forms spin on their partners: every working workgroup must be resident at once (one per CU,
     // the 150 KB of LDS see to that), so they are used only while L * NW stays well inside the 256 CUs
     const int nw = (coop_work && (int64_t)L * nw_env <= 128) ? nw_env : 1;

@@ -444,7 +444,6 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
     const bool active = !(DIAG && wr < wc);
-    const bool need01 = !(DIAG && wr == wc); // the 32 x 32 block above the diagonal of a diagonal wave tile is never read
     constexpr int PQ = DIAG ? 2 : 4; // points per thread
     const int panel = DIAG ? 0 : (wave >> 1);
     const int plane = wave & 1;
@@ -550,17 +549,17 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
             const h8v *I = reinterpret_cast<const h8v *>(smem_raw + buf * kStageBytes);
             const h8v ah0 = I[fa], ah1 = I[fa + 8], bh0 = I[fb], bh1 = I[fb + 8];
             acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-            if (need01) acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
             acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
             acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
             const h8v bl0 = I[kImgSlots + fb], bl1 = I[kImgSlots + fb + 8];
             acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-            if (need01) acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
             acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
             acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
             const h8v al0 = I[kImgSlots + fa], al1 = I[kImgSlots + fa + 8];
             acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-            if (need01) acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
             acc[1][0] = mfma16(al1, bh0, acc[1][0]);
             acc[1][1] = mfma16(al1, bh1, acc[1][1]);
         }

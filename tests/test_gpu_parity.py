@@ -715,6 +715,35 @@ def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M,
     assert np.array_equal(host(G), G1)
 
 
+@pytest.mark.parametrize("N,M", [(1_000_003, 512), (2_500_000, 256)])
+def test_split_accumulate_with_every_cu_shared(A, ctx, split_accumulate, N, M):
+    """Enough slices that four accumulation workgroups share every CU (the sizes above leave one per CU): a kernel
+    variant that passed all of them produced a wrong g here.  Reference: float64 torch reductions in chunks."""
+    import ctypes as C
+
+    gen = torch.Generator(device="cuda").manual_seed(N)
+    Phi = torch.randn((N, M), device="cuda", generator=gen) * 0.1
+    gamma = torch.rand((1, N), device="cuda", generator=gen) * 0.25
+    beta = torch.randn((1, N), device="cuda", generator=gen)
+    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
+    args = (C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(Phi.data_ptr()), C.c_void_p(beta.data_ptr()),
+            C.c_void_p(gamma.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()))
+    ctx.call("agpl_accumulate", *args)
+    G1, g1 = G.clone(), g.clone()
+    Gr = torch.zeros((M, M), dtype=torch.float64, device="cuda")
+    gr = torch.zeros(M, dtype=torch.float64, device="cuda")
+    for i0 in range(0, N, 500_000):
+        P = Phi[i0:i0 + 500_000].double()
+        Gr += (P * gamma[0, i0:i0 + 500_000].double()[:, None]).T @ P
+        gr += P.T @ beta[0, i0:i0 + 500_000].double()
+    assert ((G1[0] - Gr).abs().max() / Gr.abs().max()).item() < 2e-6
+    assert ((g1[0] - gr).abs().max() / gr.abs().max()).item() < 2e-6
+    for _ in range(3):  # and bitwise reproducible under the same load
+        ctx.call("agpl_accumulate", *args)
+        assert torch.equal(G, G1) and torch.equal(g, g1)
+
+
 def test_split_accumulate_wide_dynamic_range(A, ctx, oracle, split_accumulate):
     """gamma spanning 1e-6..1e2 and features spanning 1e-4..3: psi = 2^8 sqrt(gamma) phi stays inside the
     float16 normal range for |sqrt(gamma) phi| in [2^-11, 2^8); smaller terms lose relative, not absolute, accuracy."""

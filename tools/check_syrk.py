@@ -4,6 +4,9 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import agpl_amd as A
+from agpl_amd import _ffi
+if os.environ.get("AGPL_LIB_AB"):
+    _ffi.LIB_PATH = os.environ["AGPL_LIB_AB"]
 N, M = int(sys.argv[1]), int(sys.argv[2])
 ctx = A.Context(0, seed=1)
 ctx.call("agpl_set_accumulate_precision", C.c_int32(int(os.environ.get("AGPL_ASPLIT", "0"))))
@@ -14,9 +17,14 @@ bet = torch.randn((1, N), device="cuda", generator=g)
 G = torch.empty((1, M, M), dtype=torch.float64, device="cuda"); gg = torch.empty((1, M), dtype=torch.float64, device="cuda")
 ctx.call("agpl_accumulate", C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(Phi.data_ptr()), C.c_void_p(bet.data_ptr()),
          C.c_void_p(gam.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(gg.data_ptr()))
-P = Phi.double()
-Gr = (P * gam[0].double()[:, None]).t() @ P
-gr = P.t() @ bet[0].double()
+Gr = torch.zeros((M, M), dtype=torch.float64, device="cuda"); gr = torch.zeros(M, dtype=torch.float64, device="cuda")
+for i0 in range(0, N, 1000000):
+    P = Phi[i0:i0 + 1000000].double()
+    Gr += (P * gam[0, i0:i0 + 1000000].double()[:, None]).t() @ P
+    gr += P.t() @ bet[0, i0:i0 + 1000000].double()
+dg = (gg[0] - gr).abs()
+top = torch.topk(dg, 5)
+print("top |dg|:", [(int(i), float(v)) for v, i in zip(top.values, top.indices)], "max|g|", gr.abs().max().item())
 print("abl", os.environ.get("AGPL_ABL", "0"), "relG", ((G[0] - Gr).abs().max() / Gr.abs().max()).item(), "relg", ((gg[0] - gr).abs().max() / gr.abs().max()).item())
 if os.environ.get("AGPL_DUMP"):
     E = (G[0] - Gr).abs()
