@@ -307,6 +307,32 @@ def main():
         out["parity"] = {"max_rel_dG": dG, "max_rel_dg": dg, "points": ns, "sweeps": 3, "tolerance": 1e-5,
                          "pass": bool(dG < 1e-5 and dg < 1e-5)}
 
+    # ---- full-size self-check (N = 1 only): the accumulation of the timed object at the measured size and load,
+    #      against float64 torch reductions over the same gamma, beta (a slice cannot see load-dependent faults)
+    if world == 1 and not args.no_parity:
+        cavi.gamma = torch.empty((L, n_loc), dtype=torch.float32, device="cuda")
+        cavi.beta = torch.empty((L, n_loc), dtype=torch.float32, device="cuda")
+        cavi.c = torch.empty((n_loc,) if L == 1 else (n_loc, L), dtype=torch.float32, device="cuda")
+        cavi.accumulate()
+        torch.cuda.synchronize()
+        step = max(1, (1 << 29) // Mp)
+        rel_g = rel_tr = 0.0
+        for l in range(L):
+            tr = torch.zeros((), dtype=torch.float64, device="cuda")
+            gref = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+            for i0 in range(0, n_loc, step):
+                P = Phi[i0:i0 + step].double()
+                tr += (cavi.gamma[l, i0:i0 + step].double() * (P * P).sum(1)).sum()
+                gref += P.T @ cavi.beta[l, i0:i0 + step].double()
+            rel_g = max(rel_g, float(((cavi.g[l] - gref).abs().max() / gref.abs().max().clamp_min(1e-300)).item()))
+            rel_tr = max(rel_tr, float(((torch.diagonal(cavi.G[l]).sum() - tr).abs() / tr.abs().clamp_min(1e-300)).item()))
+            del P
+        sym = bool(torch.equal(cavi.G, cavi.G.transpose(1, 2)))
+        out["full_size_check"] = {"points": n_loc, "max_rel_dg": rel_g, "rel_d_trace_G": rel_tr, "G_symmetric": sym,
+                                  "reference": "float64 torch reductions over the exported gamma, beta",
+                                  "tolerance": 2e-6, "pass": bool(rel_g < 2e-6 and rel_tr < 2e-6 and sym)}
+        cavi.gamma = cavi.beta = cavi.c = None
+
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------------
     if world == 1 and not args.no_cpu:
         from oracle import oracle as O
