@@ -1,0 +1,60 @@
+"""bench.py's output contract on a small workload: one JSON line with the driver's keys, the roofline and
+cpu_baseline objects, the oracle parity slice and the full-size self-check -- single process, and two ranks sharing
+the one GPU (gloo hook) through the same launcher line the driver uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_single_gpu_small_workload():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, "bench.py", "--points", "300000", "--inducing", "256", "--steps", "3",
+                        "--warmup", "1", "--cpu-sample", "20000"], cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d), sorted(KEYS - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "sweeps/s" and d["vs_baseline"] is None and d["data"].startswith("synthetic")
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
+    rf = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+    assert d["parity"]["pass"] and d["parity"]["max_rel_dG"] < 1e-5 and d["parity"]["max_rel_dg"] < 1e-5
+    fc = d["full_size_check"]
+    assert fc["pass"] and fc["points"] == 300000 and fc["G_symmetric"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_two_ranks_through_the_driver_launcher():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, AGPL_BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", "bench.py", "--gpus", "2",
+                        "--points", "300000", "--inducing", "256", "--steps", "3", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=550, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
