@@ -57,7 +57,7 @@ def main():
                     help="total observations (sharded over ranks)")
     ap.add_argument("--m", "--inducing", dest="m", type=int, default=512, help="inducing points")
     ap.add_argument("--lik", default="bernoulli")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="points of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
@@ -348,11 +348,35 @@ def main():
         S, m = O.gaussian_update(G, g)
         t_cpu = time.perf_counter() - t0
         cpu_value = 1.0 / (t_cpu * (n_loc / ns))
+        note = (f"1 sweep of the float64 oracle (OpenMP, scalar per-point loops) on the first {ns} of the {N} points, "
+                f"{t_cpu:.2f} s; value extrapolated linearly in N (labelled extrapolation)")
+        extra = {}
+        if L == 1:
+            # the same sweep with its two contractions through the host BLAS (numpy / OpenBLAS, float64) -- what the
+            # reference's dense algebra runs on -- and the per-point operators through the oracle's vector entry
+            # points; checked against the oracle's pass on the sample, and the faster of the two is `value`
+            S0, m0 = np.tile(np.eye(Mp), (1, 1, 1)), np.zeros((1, Mp))
+            t0 = time.perf_counter()
+            P = Ph.astype(np.float64)
+            q = np.einsum("ij,ij->i", P @ (-S0[0]), P)
+            mu_b, var_b = P @ m0[0], kh - q
+            q1, q2, _ = O.aux_posterior(olik, yh, mu_b, var_b)
+            bt, gm = O.expected_potential_precision(olik, yh, q1, q2)
+            Gb = (P * gm[0][:, None]).T @ P
+            gb = P.T @ bt[0]
+            Sb, mb = O.gaussian_update(Gb[None], gb[None])
+            t_blas = time.perf_counter() - t0
+            ok = bool(np.abs(Gb - G[0]).max() <= 1e-9 * np.abs(G).max() and np.abs(gb - g[0]).max() <= 1e-9 * np.abs(g).max())
+            blas_value = 1.0 / (t_blas * (n_loc / ns))
+            extra = {"oracle_openmp_value": cpu_value, "blas_twin_value": blas_value, "blas_twin_matches_oracle": ok}
+            if ok and blas_value > cpu_value:
+                cpu_value = blas_value
+                note = (f"1 sweep on the first {ns} of the {N} points with the two contractions through numpy/OpenBLAS "
+                        f"(float64) and the oracle's per-point operators, {t_blas:.2f} s (the oracle's own scalar pass: "
+                        f"{t_cpu:.2f} s; both agree to 1e-9); value extrapolated linearly in N (labelled extrapolation)")
         out["cpu_baseline"] = {
-            "value": cpu_value, "unit": "sweeps/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"1 sweep of the float64 oracle (OpenMP) on the first {ns} of the {N} points, "
-                      f"{t_cpu:.2f} s; value extrapolated linearly in N (labelled extrapolation)",
-            "gpu_over_cpu": round(value / cpu_value, 1)}
+            "value": cpu_value, "unit": "sweeps/s", "cores": O.num_threads(), "kind": "port", "sample": note,
+            "gpu_over_cpu": round(value / cpu_value, 1), **extra}
     print(json.dumps(out), flush=True)
 
 
