@@ -890,7 +890,8 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
     assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
 
 
-@pytest.mark.parametrize("M,L", [(128, 1), (512, 2), (640, 3), (1024, 1), (1024, 2), (1536, 1)])
+@pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (352, 1), (512, 2), (544, 1), (640, 3), (1024, 1),
+                                 (1024, 2), (1536, 1), (256, 30)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
     """agpl_gaussian_factor with eta0: v = U (g + eta0); the fused kernel (M <= 512), the two-block form around it
     (512 < M <= 1024) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
