@@ -32,8 +32,18 @@ struct agpl_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // deferred outcome of the last agpl_gaussian_factor_async: info words in pinned host memory, ready once the event
+    // has passed (agpl_pending_resolve waits for the event only, not for work enqueued behind it)
+    bool pend = false;
+    int pend_n = 0;          // info words (L, or 2 L for the two-block form)
+    int pend_latents = 0;
+    int *pend_host = nullptr; // hipHostMalloc, 128 ints
+    hipEvent_t pend_ev = nullptr;
     char err[512] = {0};
 };
+
+// reports (and clears) the deferred outcome of the last asynchronous factorisation; AGPL_OK when none is pending
+int32_t agpl_pending_resolve(agpl_ctx *ctx);
 
 // RAII-less helpers: record a start event now, and the matching stop event after the launch
 int32_t agpl_timing_begin(agpl_ctx *ctx, int which);

@@ -41,6 +41,8 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
+    if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
+    if (ctx->pend_ev) (void)hipEventDestroy(ctx->pend_ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return AGPL_OK;
@@ -65,7 +67,7 @@ extern "C" int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed) {
 extern "C" int32_t agpl_ctx_synchronize(agpl_ctx *ctx) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return AGPL_OK;
+    return agpl_pending_resolve(ctx); // also the place where a deferred factorisation failure surfaces
 }
 
 extern "C" const char *agpl_last_error(const agpl_ctx *ctx) { return ctx ? ctx->err : "null context"; }

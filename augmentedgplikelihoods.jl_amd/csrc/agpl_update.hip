@@ -348,7 +348,7 @@ __global__ void two_block_assemble_kernel(int M, int m1, const double *__restric
 
 int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                   const double *eta0, double *A_work, double *v_out, float *v32_out,
-                                  double *logdet_out, int *hinfo /* [2 L] host */) {
+                                  double *logdet_out, int **info_dev /* [2 L] device */) {
     rocblas_handle h;
     int32_t rc = get_handle(ctx, &h);
     if (rc) return rc;
@@ -402,10 +402,43 @@ int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const dou
     two_block_assemble_kernel<<<gridM, 128, 0, ctx->stream>>>(M, m1, A1, A2, v1, v2, ld1, ld2, A_work, v_out, v32_out,
                                                               logdet_out);
     AGPL_LAUNCH_CHECK(ctx);
-    AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * 2 * L, hipMemcpyDeviceToHost, ctx->stream));
+    *info_dev = info;
     return AGPL_OK;
 }
 } // namespace
+
+int32_t agpl_pending_resolve(agpl_ctx *ctx) {
+    if (!ctx->pend) return AGPL_OK;
+    ctx->pend = false;
+    AGPL_HIP(ctx, hipEventSynchronize(ctx->pend_ev));
+    const int L = ctx->pend_latents;
+    for (int i = 0; i < ctx->pend_n; ++i) {
+        const int info = ctx->pend_host[i];
+        if (info < 0)
+            AGPL_FAIL(ctx, AGPL_ERR_HIP, "factor kernel: a cooperating workgroup never arrived (latent %d)", i % L);
+        if (info != 0)
+            AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot block at row %d)", i % L,
+                      info - 1 + (i < L ? 0 : 512));
+    }
+    return AGPL_OK;
+}
+
+// the info words of a factorisation that was just enqueued: copied to pinned host memory behind it, checked by
+// agpl_pending_resolve
+static int32_t pending_arm(agpl_ctx *ctx, const int *info_dev, int n, int L) {
+    if (!ctx->pend_host) AGPL_HIP(ctx, hipHostMalloc((void **)&ctx->pend_host, sizeof(int) * 128, hipHostMallocDefault));
+    if (!ctx->pend_ev) AGPL_HIP(ctx, hipEventCreateWithFlags(&ctx->pend_ev, hipEventDisableTiming));
+    AGPL_HIP(ctx, hipMemcpyAsync(ctx->pend_host, info_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipEventRecord(ctx->pend_ev, ctx->stream));
+    ctx->pend = true;
+    ctx->pend_n = n;
+    ctx->pend_latents = L;
+    return AGPL_OK;
+}
+
+static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                       const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
+                                       void *U_lo, double *logdet_out, bool *armed);
 
 // I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
 // pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
@@ -413,8 +446,35 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
                                         const double *eta0, double *A_work, double *v_out, float *v32_out,
                                         void *U_hi, void *U_lo, double *logdet_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    bool armed = false;
+    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, U_hi, U_lo, logdet_out, &armed);
+    if (rc) return rc;
+    return agpl_pending_resolve(ctx);
+}
+
+// The same, without waiting: the outcome (AGPL_ERR_NOT_POSDEF, ...) is reported by the next agpl_cavi_pass_factor_split
+// (after it has enqueued its own kernels -- the host never idles the GPU between the update and the next pass),
+// agpl_gaussian_factor[_async] or agpl_ctx_synchronize on this context.  Everything enqueued behind a failed
+// factorisation computes on NaNs; nothing is lost but the timing of the report.
+extern "C" int32_t agpl_gaussian_factor_async(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                              const double *eta0, double *A_work, double *v_out, float *v32_out,
+                                              void *U_hi, void *U_lo, double *logdet_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    bool armed = false;
+    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, U_hi, U_lo, logdet_out, &armed);
+    if (rc) return rc;
+    return armed ? AGPL_OK : agpl_pending_resolve(ctx);
+}
+
+static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                       const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
+                                       void *U_lo, double *logdet_out, bool *armed) {
     if (M <= 0 || L <= 0 || L > 64 || !G || !g || !A_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if ((U_hi == nullptr) != (U_lo == nullptr)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "U_hi and U_lo go together");
+    {
+        const int32_t rp = agpl_pending_resolve(ctx); // the previous factorisation's outcome, before its slot is reused
+        if (rp) return rp;
+    }
     static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
     if (M <= 512 && M % 32 == 0 && !use_lib) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
@@ -431,34 +491,22 @@ extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, con
             rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
             if (rc) return rc;
         }
-        int hinfo[64];
-        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < L; ++i) {
-            if (hinfo[i] < 0)
-                AGPL_FAIL(ctx, AGPL_ERR_HIP, "factor kernel: a cooperating workgroup never arrived (latent %d)", i);
-            if (hinfo[i] != 0)
-                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot block at row %d)",
-                          i, (int)hinfo[i] - 1);
-        }
+        rc = pending_arm(ctx, info, L, L);
+        if (rc) return rc;
+        *armed = true;
         return AGPL_OK;
     }
     if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16 && !use_lib) {
-        int hinfo[32];
-        int32_t rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, logdet_out, hinfo);
+        int *info2 = nullptr;
+        int32_t rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, logdet_out, &info2);
         if (rc) return rc;
         if (U_hi) {
             rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
             if (rc) return rc;
         }
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < 2 * L; ++i) {
-            if (hinfo[i] < 0)
-                AGPL_FAIL(ctx, AGPL_ERR_HIP, "factor kernel: a cooperating workgroup never arrived (latent %d)", i % L);
-            if (hinfo[i] != 0)
-                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot block at row %d)",
-                          i % L, (int)hinfo[i] - 1 + (i < L ? 0 : 512));
-        }
+        rc = pending_arm(ctx, info2, 2 * L, L);
+        if (rc) return rc;
+        *armed = true;
         return AGPL_OK;
     }
     rocblas_handle h;
@@ -783,5 +831,8 @@ extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_des
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    if (rc) return rc;
+    // everything of this pass is enqueued: now is the free moment to look at the outcome of the factorisation before it
+    return agpl_pending_resolve(ctx);
 }

@@ -193,6 +193,7 @@ class SparseCAVI:
         row-major (rocSOLVER leaves U in the column-major lower triangle)."""
         if not self.factor:
             return self._S
+        self.check()
         Ut = _torch().triu(self.A_work)
         return Ut @ Ut.transpose(1, 2)
 
@@ -200,6 +201,7 @@ class SparseCAVI:
     def m(self):
         if not self.factor:
             return self._m
+        self.check()
         return (_torch().triu(self.A_work) @ self.v.unsqueeze(-1)).squeeze(-1)
 
     def accumulate(self):
@@ -230,7 +232,9 @@ class SparseCAVI:
         """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the factor form
         keeps U = chol(I + G)^-1 and v = U g (S = U'U, m = U'v) and packs the images of U."""
         if self.factor:
-            self.ctx.call("agpl_gaussian_factor", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
+            # enqueue only: a failed factorisation surfaces in the next accumulate() (once its kernels are queued),
+            # in check(), or when S / m / elbo() are read -- the host never idles the GPU between update and pass
+            self.ctx.call("agpl_gaussian_factor_async", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
                           C.c_void_p(0), _ptr(self.A_work), _ptr(self.v), _ptr(self.alpha), _ptr(self.W_hi),
                           _ptr(self.W_lo), C.c_void_p(0))
             return
@@ -244,9 +248,14 @@ class SparseCAVI:
         self.update()
         self.nsweeps += 1
 
+    def check(self):
+        """Wait for the stream and raise what a deferred factorisation has to report (PosDefException, ...)."""
+        self.ctx.synchronize()
+
     def run(self, niter: int = 10):
         for _ in range(niter):
             self.sweep()
+        self.check()
         return self.m, self.S
 
     def elbo(self):

@@ -156,6 +156,7 @@ def main():
             print(f"[trace] step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
     t_loop = time.perf_counter() - t0
     barrier()
+    cavi.check()  # inside the timed region: the last sweep's deferred factorisation outcome (raises if it failed)
     dt = time.perf_counter() - t0
     gc.enable()
     if trace:

@@ -287,6 +287,14 @@ AGPL_API int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, cons
 AGPL_API int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                       const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
                                       void *U_lo, double *logdet_out);
+/* The same without waiting for the outcome: a failed factorisation (AGPL_ERR_NOT_POSDEF, ...) is reported by the next
+ * agpl_cavi_pass_factor_split -- after that call has enqueued its own kernels, so the host never idles the GPU between
+ * the update and the next pass of a sweep loop (examples/bernoulli/script.jl:34-38) --, by the next
+ * agpl_gaussian_factor[_async], or by agpl_ctx_synchronize on this context.  Work enqueued behind a failed
+ * factorisation computes on NaNs; only the moment of the report moves. */
+AGPL_API int32_t agpl_gaussian_factor_async(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                      const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
+                                      void *U_lo, double *logdet_out);
 AGPL_API int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo);
 AGPL_API int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
                                              const void *Phi_lo, const float *resid, const float *mu0,

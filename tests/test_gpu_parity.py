@@ -932,6 +932,54 @@ def test_gaussian_factor_reports_indefinite_matrix(A, ctx, M, first_bad):
                  C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
 
 
+def test_gaussian_factor_async_defers_the_report(A, ctx):
+    """agpl_gaussian_factor_async returns before the outcome is known; a failed factorisation is reported by the next
+    synchronisation point of the context (here agpl_ctx_synchronize), once, and the context is usable afterwards."""
+    import ctypes as C
+
+    M = 256
+    d = np.zeros(M)
+    d[100:] = -2.0
+    dG, dg = dev(np.diag(d)[None]), dev(np.zeros((1, M)))
+    Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    args = (C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(0),
+            C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+    ctx.call("agpl_gaussian_factor_async", *args)  # no exception yet
+    with pytest.raises(A.PosDefException):
+        ctx.synchronize()
+    ctx.synchronize()  # reported once
+    good = dev(np.zeros((1, M, M)))
+    ctx.call("agpl_gaussian_factor_async", C.c_int32(M), C.c_int32(1), C.c_void_p(good.data_ptr()),
+             C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
+             C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+    ctx.synchronize()
+    assert np.allclose(np.triu(host(Aw)[0]), np.eye(M))
+    # a pending failure is also reported by the next factorisation on the context, before it starts
+    ctx.call("agpl_gaussian_factor_async", *args)
+    with pytest.raises(A.PosDefException):
+        ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(1), C.c_void_p(good.data_ptr()),
+                 C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
+                 C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+
+
+def test_cavi_factor_form_reports_a_failed_update(A, ctx):
+    """SparseCAVI in the factor form defers the outcome of its M x M update to the next pass: a state that makes
+    I + G indefinite (planted directly in G) must still raise -- at the next sweep or at check()."""
+    N, M = 2000, 256
+    rng = np.random.default_rng(3)
+    Phi = dev(_features(rng, N, M))
+    kd = torch.ones(N, device="cuda")
+    y = dev((rng.random(N) < 0.5).astype(np.uint8))
+    cavi = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision="f16x2-factor",
+                        accumulate_precision="f16x2")
+    cavi.sweep()
+    cavi.check()
+    cavi.G.copy_(-3.0 * torch.eye(M, dtype=torch.float64, device="cuda")[None])
+    cavi.update()  # enqueued, not yet reported
+    with pytest.raises(A.PosDefException):
+        cavi.check()
+
+
 def test_pg_logpdf_series_both_branches(A, ctx, oracle):
     """The aux-prior log-density at omega on both sides of the reference's x < 1e-2 switch to the log-domain series
     (polyagamma.jl:49-54), Bernoulli prior PG(1, 0), against the oracle's restatement point by point."""
