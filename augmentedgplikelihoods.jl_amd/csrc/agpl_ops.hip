@@ -2,6 +2,7 @@
 // (expected_)auglik_{potential,precision}, and the ELBO N-reductions.  HBM-bound streaming kernels
 // (the PG sampler is transcendental-heavy: see DESIGN.md for its measured fraction of the HBM roof).
 #include <math.h>
+#include <cstdlib>
 
 #include "agpl_common.h"
 #include "agpl_random.h"
@@ -896,38 +897,98 @@ int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int
     return AGPL_OK;
 }
 
+// The per-point half of the Gibbs point pass: lane `lane` of a wave owns point base + lane, whose noiseless projection(s)
+// sit in fS[lane * Lf + l]; f = projection + sqrt(d) eps (+ mu0), then aux_sample! and the sampled potential / precision.
+template <int KIND>
+__device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int64_t N, int64_t base, int lane, int np,
+                                                    int Lf, int Lo, const float *__restrict__ kdiag,
+                                                    const float *__restrict__ mu0, const void *yv, uint64_t seed,
+                                                    uint32_t sweep, double *fS, double *omS, int64_t *nnS,
+                                                    float *__restrict__ gamma, float *__restrict__ beta,
+                                                    double *__restrict__ f_out, double *__restrict__ omega_out,
+                                                    int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out,
+                                                    int *__restrict__ bad) {
+    const int64_t i = base + lane;
+    if (lane < np) {
+        Philox g;
+        g.init(seed, (uint64_t)i, sweep);
+        const double kd = (double)kdiag[i];
+        const double sd = sqrt(kd > 0.0 ? kd : 0.0); // a float32 Nystrom residual can round below zero
+        for (int l = 0; l < Lf; ++l) {
+            double f = fS[lane * Lf + l] + sd * g.normal();
+            if (mu0) f += (double)mu0[(int64_t)l * N + i];
+            fS[lane * Lf + l] = f;
+            if (f_out) f_out[i * Lf + l] = f;
+        }
+        uint32_t nt = 0;
+        sample_point<KIND>(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+        if (nuni_out) nuni_out[i] = g.nuni;
+        // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
+        switch (KIND) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC:
+            beta[i] = ((const uint8_t *)yv)[i] ? 0.5f : -0.5f;
+            gamma[i] = (float)omS[lane];
+            break;
+        case AGPL_LIK_NEGBINOMIAL:
+            beta[i] = (float)(((double)((const int32_t *)yv)[i] - lik.p[0]) / 2.0);
+            gamma[i] = (float)omS[lane];
+            break;
+        case AGPL_LIK_STUDENTT:
+            beta[i] = (float)(((const double *)yv)[i] * omS[lane]);
+            gamma[i] = (float)omS[lane];
+            break;
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ:
+            for (int k = 0; k < Lf; ++k) {
+                beta[(int64_t)k * N + i] =
+                    (float)(((double)((const uint8_t *)yv)[i * Lf + k] - (double)nnS[lane * Lo + k]) / 2.0);
+                gamma[(int64_t)k * N + i] = (float)omS[lane * Lo + k];
+            }
+            break;
+        case AGPL_LIK_POISSON:
+            beta[i] = (float)(((double)((const int32_t *)yv)[i] - (double)nnS[lane]) / 2.0);
+            gamma[i] = (float)omS[lane];
+            break;
+        case AGPL_LIK_LAPLACE:
+            beta[i] = (float)(2.0 * omS[lane] * ((const double *)yv)[i]);
+            gamma[i] = (float)(2.0 * omS[lane]);
+            break;
+        case AGPL_LIK_HETEROGAUSS: {
+            const double il = lik.p[0] * logistic(fS[lane * 2 + 1]);
+            beta[i] = (float)(((const double *)yv)[i] * il);
+            gamma[i] = (float)il;
+            beta[N + i] = (float)((0.5 - (double)nnS[lane]) / 2.0);
+            gamma[N + i] = (float)omS[lane];
+        } break;
+        default:
+            break;
+        }
+        if (omega_out)
+            for (int k = 0; k < Lo; ++k) omega_out[i * Lo + k] = omS[lane * Lo + k];
+        if (n_out)
+            for (int k = 0; k < Lo; ++k) n_out[i * Lo + k] = nnS[lane * Lo + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Gibbs pass, per-point half (sparse form of examples/bernoulli/script.jl:81-84):
+// Gibbs point pass (agpl_gibbs_pass; sparse form of examples/bernoulli/script.jl:81-84):
 //   f_il = mu0_il + phi_i' v_l + sqrt(kdiag_i) eps_il      (the draw of f given v under the sparse model)
 //   Omega_i ~ aux_full_conditional(lik, y_i, f_i)           (aux_sample!, same per-point Philox stream)
 //   beta_i, gamma_i = auglik_potential / auglik_precision   (float32, [L][N], feed agpl_accumulate)
-// HBM-bound: one read of Phi (N*M*4 B).  One wave per 64-point chunk: the wave first forms the 64 x L
-// projections phi_i' v_l cooperatively (16 lanes per point, 4 points per round; lane q owns features 4q..,
-// 4q+64..: float4 loads, float64 products/sums in a fixed order, xor-butterfly 8..1), then every lane samples
-// its own point.  One kernel instantiation per likelihood keeps the sampler's register footprint down.
-// The float64 summation order is part of the contract (the CPU check reproduces it bit for bit).
-// LDS: v [L][M] doubles + per-wave scratch (f, omega, n) [64][L].
+// Two kernels around N * L doubles of scratch.  gibbs_project_kernel streams Phi once: one wave per 64-point chunk,
+// 16 lanes per point form phi_i' v in float64 in a fixed order (lane q owns features 4q.., 4q+64..; xor butterfly
+// 8,4,2,1 -- the order is part of the contract, the CPU check reproduces it bit for bit).  gibbs_sample_kernel<KIND>
+// then gives every lane its own point (one instantiation per likelihood keeps the sampler's register footprint down).
+// Fused into one kernel (the first form) the sampler's ~255 VGPRs held the streaming half at one wave per SIMD:
+// 6.2 ms at C2 against 4.9 ms for the pair.
 // ------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
-    agpl_lik_dev lik, int64_t N, int M, const float *__restrict__ Phi, const float *__restrict__ kdiag,
-    const float *__restrict__ mu0, const void *yv, const double *__restrict__ v, uint64_t seed, uint32_t sweep,
-    float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out,
-    int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
+__global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, int Lf, const float *__restrict__ Phi,
+                                                            const double *__restrict__ v, double *__restrict__ proj) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int Lf = lik.nlatent;
-    const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
-    double *v_s = sh;                                   // [Lf][M]
+    double *v_s = sh; // [Lf][M]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *fS = sh + (size_t)Lf * M + (size_t)wave * 64 * (Lf + 2 * Lo); // [64][Lf]
-    double *omS = fS + 64 * Lf;                                            // [64][Lo]
-    int64_t *nnS = reinterpret_cast<int64_t *>(omS + 64 * Lo);             // [64][Lo]
     for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
     __syncthreads();
-
-    // projection geometry: 16 lanes per point, 4 points per wave-round.  Lane q = lane & 15 of a group owns
-    // features 4q.., 4q+64.., ...; the 16 partial sums are combined by an xor butterfly 8,4,2,1.
-    // (This float64 summation order is the contract the CPU check reproduces.)
     const int q = lane & 15, grp = lane >> 4;
     const int64_t nchunks = (N + 63) >> 6;
     for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
@@ -940,7 +1001,7 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
             for (int l = 0; l < Lf; ++l) {
                 const double *vl = v_s + (size_t)l * M;
                 double acc = 0.0;
-#pragma unroll 4
+#pragma unroll 8
                 for (int a = q << 2; a < M; a += 64) {
                     const float4 x = *reinterpret_cast<const float4 *>(row + a);
                     acc += (double)x.x * vl[a];
@@ -950,108 +1011,80 @@ __global__ __launch_bounds__(256) void gibbs_project_sample_kernel(
                 }
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-                if (q == 0 && p < np) fS[p * Lf + l] = acc;
+                if (q == 0 && p < np) proj[(base + p) * Lf + l] = acc;
             }
         }
-        // every lane now owns one point
-        const int64_t i = base + lane;
-        if (lane < np) {
-            Philox g;
-            g.init(seed, (uint64_t)i, sweep);
-            const double kd = (double)kdiag[i];
-            const double sd = sqrt(kd > 0.0 ? kd : 0.0); // a float32 Nystrom residual can round below zero
-            for (int l = 0; l < Lf; ++l) {
-                double f = fS[lane * Lf + l] + sd * g.normal();
-                if (mu0) f += (double)mu0[(int64_t)l * N + i];
-                fS[lane * Lf + l] = f;
-                if (f_out) f_out[i * Lf + l] = f;
-            }
-            uint32_t nt = 0;
-            sample_point<KIND>(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
-            if (nuni_out) nuni_out[i] = g.nuni;
-            // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
-            switch (KIND) {
-            case AGPL_LIK_BERNOULLI_LOGISTIC:
-                beta[i] = ((const uint8_t *)yv)[i] ? 0.5f : -0.5f;
-                gamma[i] = (float)omS[lane];
-                break;
-            case AGPL_LIK_NEGBINOMIAL:
-                beta[i] = (float)(((double)((const int32_t *)yv)[i] - lik.p[0]) / 2.0);
-                gamma[i] = (float)omS[lane];
-                break;
-            case AGPL_LIK_STUDENTT:
-                beta[i] = (float)(((const double *)yv)[i] * omS[lane]);
-                gamma[i] = (float)omS[lane];
-                break;
-            case AGPL_LIK_CATEGORICAL:
-            case AGPL_LIK_CATEGORICAL_BIJ:
-                for (int k = 0; k < Lf; ++k) {
-                    beta[(int64_t)k * N + i] =
-                        (float)(((double)((const uint8_t *)yv)[i * Lf + k] - (double)nnS[lane * Lo + k]) / 2.0);
-                    gamma[(int64_t)k * N + i] = (float)omS[lane * Lo + k];
-                }
-                break;
-            case AGPL_LIK_POISSON:
-                beta[i] = (float)(((double)((const int32_t *)yv)[i] - (double)nnS[lane]) / 2.0);
-                gamma[i] = (float)omS[lane];
-                break;
-            case AGPL_LIK_LAPLACE:
-                beta[i] = (float)(2.0 * omS[lane] * ((const double *)yv)[i]);
-                gamma[i] = (float)(2.0 * omS[lane]);
-                break;
-            case AGPL_LIK_HETEROGAUSS: {
-                const double il = lik.p[0] * logistic(fS[lane * 2 + 1]);
-                beta[i] = (float)(((const double *)yv)[i] * il);
-                gamma[i] = (float)il;
-                beta[N + i] = (float)((0.5 - (double)nnS[lane]) / 2.0);
-                gamma[N + i] = (float)omS[lane];
-            } break;
-            default:
-                break;
-            }
-            if (omega_out)
-                for (int k = 0; k < Lo; ++k) omega_out[i * Lo + k] = omS[lane * Lo + k];
-            if (n_out)
-                for (int k = 0; k < Lo; ++k) n_out[i * Lo + k] = nnS[lane * Lo + k];
-        }
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gibbs_sample_kernel(
+    agpl_lik_dev lik, int64_t N, const double *__restrict__ proj, const float *__restrict__ kdiag,
+    const float *__restrict__ mu0, const void *yv, uint64_t seed, uint32_t sweep, float *__restrict__ gamma,
+    float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
+    uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int Lf = lik.nlatent;
+    const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *fS = sh + (size_t)wave * 64 * (Lf + 2 * Lo);       // [64][Lf]
+    double *omS = fS + 64 * Lf;                                 // [64][Lo]
+    int64_t *nnS = reinterpret_cast<int64_t *>(omS + 64 * Lo);  // [64][Lo]
+    const int64_t nchunks = (N + 63) >> 6;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+        const int64_t base = chunk << 6;
+        const int np = (int)((N - base) < 64 ? (N - base) : 64);
+        if (lane < np)
+            for (int l = 0; l < Lf; ++l) fS[lane * Lf + l] = proj[(base + lane) * Lf + l];
+        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, sweep, fS, omS, nnS, gamma, beta,
+                                  f_out, omega_out, n_out, nuni_out, bad);
     }
 }
 
 int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
                                          const float *kdiag, const float *mu0, const void *y, const double *v,
                                          uint32_t sweep, float *gamma, float *beta, double *f_out,
-                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad) {
+                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad,
+                                         double *proj_work /* N * L doubles of scratch */) {
     const int Lf = ld.nlatent;
     const int Lo = ld.kind == AGPL_LIK_HETEROGAUSS ? 1 : ld.nlatent;
-    const size_t lds = sizeof(double) * ((size_t)Lf * M + 4 * 64 * (size_t)(Lf + 2 * Lo));
-    if (lds > 160 * 1024)
+    if (sizeof(double) * (size_t)Lf * M > 160 * 1024)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "Gibbs pass: L * M = %d x %d does not fit the LDS working set", Lf, M);
     int64_t nb = agpl_cdiv(agpl_cdiv(N, 64), 4);
     if (nb > 256 * 8) nb = 256 * 8;
     int32_t rc = agpl_timing_begin(ctx, 2);
     if (rc) return rc;
-#define AGPL_LAUNCH_GIBBS(K)                                                                                         \
-    case K:                                                                                                          \
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_sample_kernel<K>),           \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-        gibbs_project_sample_kernel<K><<<(unsigned)nb, 256, lds, ctx->stream>>>(                                     \
-            ld, N, M, Phi, kdiag, mu0, y, v, ctx->seed, sweep, gamma, beta, f_out, omega_out, n_out, nuni_out, bad); \
+    if (!proj_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "Gibbs point pass: no projection scratch");
+    {
+        const size_t lds_p = sizeof(double) * (size_t)Lf * M, lds_s = sizeof(double) * 4 * 64 * (size_t)(Lf + 2 * Lo);
+        int64_t nbp = agpl_cdiv(agpl_cdiv(N, 64), 4);
+        if (nbp > 256 * 16) nbp = 256 * 16;
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        gibbs_project_kernel<<<(unsigned)nbp, 256, lds_p, ctx->stream>>>(N, M, Lf, Phi, v, proj_work);
+        AGPL_LAUNCH_CHECK(ctx);
+#define AGPL_LAUNCH_GIBBS_S(K)                                                                                        \
+    case K:                                                                                                           \
+        gibbs_sample_kernel<K><<<(unsigned)nb, 256, lds_s, ctx->stream>>>(ld, N, proj_work, kdiag, mu0, y, ctx->seed, \
+                                                                           sweep, gamma, beta, f_out, omega_out,     \
+                                                                           n_out, nuni_out, bad);                    \
         break;
-    switch (ld.kind) {
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_BERNOULLI_LOGISTIC)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_NEGBINOMIAL)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_STUDENTT)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_CATEGORICAL)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_CATEGORICAL_BIJ)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_POISSON)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_LAPLACE)
-        AGPL_LAUNCH_GIBBS(AGPL_LIK_HETEROGAUSS)
-    default:
-        break;
+        switch (ld.kind) {
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_BERNOULLI_LOGISTIC)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_NEGBINOMIAL)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_STUDENTT)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_CATEGORICAL)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_CATEGORICAL_BIJ)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_POISSON)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_LAPLACE)
+            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_HETEROGAUSS)
+        default:
+            break;
+        }
+#undef AGPL_LAUNCH_GIBBS_S
+        AGPL_LAUNCH_CHECK(ctx);
+        return agpl_timing_end(ctx, 2);
     }
-#undef AGPL_LAUNCH_GIBBS
-    AGPL_LAUNCH_CHECK(ctx);
-    return agpl_timing_end(ctx, 2);
 }
 
 // z_a = standard normal from the stream (seed, a, sweep): the randn!(...) of the Gaussian conditional draw

@@ -22,7 +22,8 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
 int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
                                          const float *kdiag, const float *mu0, const void *y, const double *v,
                                          uint32_t sweep, float *gamma, float *beta, double *f_out,
-                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad);
+                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad,
+                                         double *proj_work);
 int32_t agpl_launch_randn(agpl_ctx *ctx, int64_t n, uint32_t sweep, double *out);
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
 
@@ -630,8 +631,10 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     char *base = (char *)ctx->ws;
     float *gam = (float *)(base + slab);
     float *bet = (float *)(base + slab + vec);
+    // the slab region (>= 16 L N bytes) is free until the accumulation starts: it lends the N x L doubles of the
+    // projections between the two kernels of the point pass
     rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
-                                          n_out, nuni_out, bad);
+                                          n_out, nuni_out, bad, (double *)base);
     if (rc) return rc;
     rc = agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
     if (rc) return rc;

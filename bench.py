@@ -276,7 +276,7 @@ def main():
         proj_ms = pms / max(pcnt, 1)
         out["gibbs"] = {
             "sweeps_per_s": round(1.0 / tg, 3), "ms_per_sweep": round(tg * 1e3, 3),
-            "point_pass": {"kernel": "gibbs_project_sample_kernel", "avg_ms": round(proj_ms, 3), "bound": "hbm",
+            "point_pass": {"kernel": "gibbs_project_kernel + gibbs_sample_kernel", "avg_ms": round(proj_ms, 3), "bound": "hbm",
                            "algorithmic_bytes": n_loc * (Mp * 4 + 16),
                            "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000},
             "sampler": {"kernel": "aux_sample_kernel", "avg_ms": round(samp_ms, 4), "bound": "hbm (by contract)",
