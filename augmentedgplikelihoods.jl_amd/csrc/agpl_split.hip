@@ -342,8 +342,10 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
         }
         __builtin_amdgcn_s_barrier();
         // rows 128..255 of the block are zero for the block's first 8 slices (strictly lower part of W');
-        // FACTOR: rows 0..127 are zero for its last 8 slices (strictly upper part of U)
-        const bool act = FACTOR ? !(!(wr >> 1) && ks >= rb * 16 + 8) : !((wr >> 1) && ks < rb * 16 + 8);
+        // FACTOR: U is lower triangular, so this wave's rows 64 wr .. 64 wr + 63 of the block are zero from slice
+        // 16 rb + 4 (wr + 1) on (KU divides 4: a stage is skipped whole).  The four waves of a SIMD have the four
+        // values of wr, so every SIMD sheds the same share of the diagonal block's products.
+        const bool act = FACTOR ? ks < rb * 16 + 4 * (wr + 1) : !((wr >> 1) && ks < rb * 16 + 8);
         // The DMA for stage t + R - 1 (into the slot read in iteration t - 1) is issued AFTER the first four MFMAs: its
         // issue cost (~100 cycles per piece with 16 waves issuing at once) then overlaps matrix work instead of
         // delaying the first MFMA of every wave behind the barrier.
