@@ -190,8 +190,12 @@ def main():
     # flops the kernels actually execute (padded M, 128-row blocks): the marginal pass visits block pairs cb >= rb
     # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
     nbk = Mp // 128
-    executed = ((1.0 + 1.0 / nbk) * L * n_loc * Mp * Mp, (nbk + 1.0) / nbk * L * n_loc * Mp * Mp)
     msplit = args.marginal in ("f16x2", "f16x2-factor")
+    # factor-form marginal kernel on 256-tiles: a wave (64 rows) stops at its own diagonal -> (1 + 64 / M) M^2 per point;
+    # accumulation: lower tile pairs only, and the wave above the diagonal of a diagonal tile idles -> (nb + 1/2) / nb
+    ex_m = (1.0 + 64.0 / Mp) if (args.marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
+    ex_s = (nbk + 0.5) / nbk
+    executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
     names = (("marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
              "syrk_split_kernel" if args.accumulate == "f16x2" else "syrk_kernel")
     # split-float16 kernels issue 3 float16 MFMA products (hi hi + hi lo + lo hi) per float32-equivalent product

@@ -33,10 +33,10 @@ def test_bench_line_single_gpu_small_workload():
     assert KEYS <= set(d), sorted(KEYS - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "sweeps/s" and d["vs_baseline"] is None and d["data"].startswith("synthetic")
-    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=2e-3)
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
-    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and 0 < rf["frac"] < 1
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=1e-4) and 0 < rf["frac"] < 1  # 4 decimals
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
     assert d["parity"]["pass"] and d["parity"]["max_rel_dG"] < 1e-5 and d["parity"]["max_rel_dg"] < 1e-5
