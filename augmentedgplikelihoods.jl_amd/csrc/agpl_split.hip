@@ -451,23 +451,28 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
     }
 #undef AGPL_DMA_ISSUE
 
+    // the lane indices are re-derived here: kept live across the loop they are what the 128-VGPR cap spills
+    // (3 dwords per thread = 0.5 GB of scratch traffic per launch at C2)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li_e = lane_e & 31, lk_e = lane_e >> 5, tid_e = wave * 64 + lane_e;
+
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         qacc[jj] += __shfl_xor(qacc[jj], 32);
         macc[jj] += __shfl_xor(macc[jj], 32);
     }
-    if (lk == 0) {
-        qred[wr * NT2 + wc * 64 + li] = qacc[0];
-        qred[wr * NT2 + wc * 64 + 32 + li] = qacc[1];
-        mred[wr * NT2 + wc * 64 + li] = macc[0];
-        mred[wr * NT2 + wc * 64 + 32 + li] = macc[1];
+    if (lk_e == 0) {
+        qred[wr * NT2 + wc * 64 + li_e] = qacc[0];
+        qred[wr * NT2 + wc * 64 + 32 + li_e] = qacc[1];
+        mred[wr * NT2 + wc * 64 + li_e] = macc[0];
+        mred[wr * NT2 + wc * 64 + 32 + li_e] = macc[1];
     }
     __syncthreads();
-    if (tid < NT2) {
-        const int64_t n = n0 + tid;
+    if (tid_e < NT2) {
+        const int64_t n = n0 + tid_e;
         if (n < N) {
-            float q = (qred[tid] + qred[NT2 + tid]) + (qred[2 * NT2 + tid] + qred[3 * NT2 + tid]);
-            float m = (mred[tid] + mred[NT2 + tid]) + (mred[2 * NT2 + tid] + mred[3 * NT2 + tid]);
+            float q = (qred[tid_e] + qred[NT2 + tid_e]) + (qred[2 * NT2 + tid_e] + qred[3 * NT2 + tid_e]);
+            float m = (mred[tid_e] + mred[NT2 + tid_e]) + (mred[2 * NT2 + tid_e] + mred[3 * NT2 + tid_e]);
             if (mu0) m += mu0[(int64_t)l * N + n];
             mu_out[(int64_t)l * N + n] = m;
             var_out[(int64_t)l * N + n] = FACTOR ? kdiag[n] + q : kdiag[n] - q;
