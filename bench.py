@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
-PMC_PROFILE = "r01_pmc_traffic_c2_v11.json"  # HBM bytes per launch of the split-float16 kernels (separate --pmc passes)
+PMC_PROFILE = "r01_pmc_traffic_c2_v18.json"  # HBM bytes per launch of the split-float16 kernels (separate --pmc passes)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 
 

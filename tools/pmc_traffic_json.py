@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/r01_pmc_traffic_*.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see profiles/README.md).
+Usage: pmc_traffic_json.py <fetch_dir> <write_dir> <kernel_stats.csv> <out.json>"""
+import collections, csv, glob, json, re, sys
+
+def means(root, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+KNOWN = ("marginal_split256_kernel", "syrk_split_kernel", "reduce_slab_kernel", "gibbs_project_kernel",
+         "gibbs_sample_kernel", "factor_kernel")
+
+
+def short(n):
+    for k in KNOWN:  # (template instantiations arrive mangled)
+        if k in n:
+            return k
+    return n[:40]
+
+fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
+avg = {}
+for r in csv.DictReader(open(sys.argv[3])):
+    avg.setdefault(short(r["Name"]), float(r["AverageNs"]) / 1e6)
+N, M = 10_000_000, 512
+alg = {"marginal_split256_kernel": N * M * 4, "syrk_split_kernel": N * M * 4, "gibbs_project_kernel": N * (M * 4 + 8),
+       "gibbs_sample_kernel": N * 24, "reduce_slab_kernel": None}
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-cpu "
+               "--no-parity at C2 (bernoulli N=1e7 M=512). FETCH_SIZE is reported in KiB and doubled per "
+               "MI355X_MICROARCH.md 'HBM' (16 B/lane coalesced reads report 1/2; calibrated on reduce_slab_kernel: "
+               "1.60 GB of slabs read); WRITE_SIZE (KiB) is taken as is.",
+       "config": {"lik": "bernoulli", "N": N, "M": M, "L": 1}, "kernels": {}}
+for k in KNOWN:
+    if k not in fetch:
+        continue
+    fb, wb = fetch[k] * 1024 * 2, write.get(k, 0.0) * 1024
+    out["kernels"][k] = {"fetch_size_kib_raw": fetch[k], "fetch_bytes_corrected": fb, "write_bytes": wb,
+                         "algorithmic_bytes": alg.get(k), "avg_ms": round(avg.get(k, float("nan")), 4),
+                         "traffic_bytes": fb + wb}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
