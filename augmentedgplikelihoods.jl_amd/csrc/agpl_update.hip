@@ -347,6 +347,15 @@ __global__ void two_block_assemble_kernel(int M, int m1, const double *__restric
     }
 }
 
+// bytes of ctx->ws2 the two-block form uses (from its start): callers that keep their own arrays behind it reserve
+// the sum first, so that the reservation inside cannot move the buffer
+size_t two_block_ws2_bytes(int32_t L) {
+    const size_t blk = sizeof(double) * (size_t)L * 512 * 512;
+    const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * 512 * 32 + 1024;
+    const size_t vec = (sizeof(double) * (size_t)L * 512 + 255) & ~(size_t)255;
+    return 16384 + 1024 + 9 * blk + coop_bytes + 6 * vec;
+}
+
 int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                   const double *eta0, double *A_work, double *v_out, float *v32_out,
                                   double *logdet_out, int **info_dev /* [2 L] device */) {
@@ -357,7 +366,7 @@ int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const dou
     const size_t info_off = 16384, blk = sizeof(double) * (size_t)L * m1 * m1;
     const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * m1 * 32 + 1024;
     const size_t vec = (sizeof(double) * (size_t)L * m1 + 255) & ~(size_t)255;
-    rc = agpl_ws2_reserve(ctx, info_off + 1024 + 9 * blk + coop_bytes + 6 * vec);
+    rc = agpl_ws2_reserve(ctx, two_block_ws2_bytes(L));
     if (rc) return rc;
     int *info = (int *)((char *)ctx->ws2 + info_off); // [2 L]
     char *p = (char *)ctx->ws2 + info_off + 1024;
@@ -719,6 +728,34 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
                           hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
                                        : "I + G is not positive definite (latent %d, pivot at row %d)",
                           i, (int)hinfo[i] - 1);
+        return AGPL_OK;
+    }
+    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16 && !use_lib) {
+        // the same with the two-block factorisation (agpl_gaussian_factor's 512 < M <= 1024 route)
+        const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
+        const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
+        const size_t own = (two_block_ws2_bytes(L) + 255) & ~(size_t)255;
+        int32_t rc = agpl_ws2_reserve(ctx, own + mat_bytes + 2 * vec_bytes + 256);
+        if (rc) return rc;
+        char *p = (char *)ctx->ws2 + own;
+        double *A = (double *)p, *vf = (double *)(p + mat_bytes), *z = (double *)(p + mat_bytes + vec_bytes);
+        int *info2 = nullptr;
+        rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A, vf, nullptr, nullptr, &info2);
+        if (rc) return rc;
+        rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
+        if (rc) return rc;
+        dim3 gd((unsigned)agpl_cdiv(M, 4), (unsigned)L);
+        factor_draw_kernel<<<gd, 256, 0, ctx->stream>>>(M, A, vf, z, v_out, m_out);
+        AGPL_LAUNCH_CHECK(ctx);
+        int hinfo[32];
+        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info2, sizeof(int) * 2 * L, hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2 * L; ++i)
+            if (hinfo[i] != 0)
+                AGPL_FAIL(ctx, hinfo[i] < 0 ? AGPL_ERR_HIP : AGPL_ERR_NOT_POSDEF,
+                          hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
+                                       : "I + G is not positive definite (latent %d, pivot at row %d)",
+                          i % L, (int)hinfo[i] - 1 + (hinfo[i] > 0 && i >= L ? 512 : 0));
         return AGPL_OK;
     }
     rocblas_handle h;

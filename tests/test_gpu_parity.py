@@ -511,11 +511,13 @@ def test_gibbs_pass_matches_oracle(A, ctx, oracle, name):
     assert relmax(host(g), gr) < 5e-6
 
 
-def test_gibbs_draw_v_matches_oracle(A, ctx, oracle):
+@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 640), (1, 1024), (1, 1280)])
+def test_gibbs_draw_v_matches_oracle(A, ctx, oracle, L, M):
+    """All three routes of the conditional draw: the one-launch factor kernel (M <= 512), the two-block form around
+    it (M <= 1024) and rocSOLVER (beyond)."""
     import ctypes as C
 
-    rng = np.random.default_rng(23)
-    L, M = 2, 256
+    rng = np.random.default_rng(23 + M)
     B = rng.normal(size=(L, M, 2 * M)) * 0.3
     G = B @ B.transpose(0, 2, 1)
     g = rng.normal(size=(L, M))
