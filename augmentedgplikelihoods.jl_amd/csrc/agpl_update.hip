@@ -181,6 +181,13 @@ __global__ void factor_clean_kernel(int M, const double *__restrict__ A, double 
 }
 } // namespace
 
+namespace {
+size_t two_block_ws2_bytes(int32_t L);
+int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                  const double *eta0, double *A_work, double *v_out, float *v32_out,
+                                  double *logdet_out, int **info_dev);
+} // namespace
+
 static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                     const double *eta0, double *S_out, double *m_out, float *Wpack_out,
                                     float *alpha_out, double *logdet_dev) {
@@ -192,16 +199,21 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
     const size_t info_off = 16384; // ws2 head is used by the reductions
     static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
-    if (M <= 512 && M % 32 == 0 && L <= 64 && !use_lib) {
-        // one-launch factorisation (agpl_factor.hip): U = chol(I + G)^-1, then S = U'U as one float64 GEMM -- 1.1 ms
-        // against 3.4 ms for the ~300 launches of potrf + potri
-        rc = agpl_ws2_reserve(ctx, info_off + 1024 + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + 1024);
+    const bool two = M > 512;
+    if ((M <= 512 || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64 && !use_lib) {
+        // one-launch factorisation (agpl_factor.hip; two block rows of it for 512 < M <= 1024): U = chol(I + G)^-1,
+        // then S = U'U as one float64 GEMM -- 1.1 ms at M = 512 against 3.4 ms for the ~300 launches of potrf + potri
+        const size_t own = two ? ((two_block_ws2_bytes(L) + 255) & ~(size_t)255) : info_off + 1024;
+        rc = agpl_ws2_reserve(ctx, own + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + 1024);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
-        char *p = (char *)ctx->ws2 + info_off + 1024;
+        char *p = (char *)ctx->ws2 + own;
         double *T = (double *)p, *Aw = (double *)(p + mat_bytes), *Uz = (double *)(p + 2 * mat_bytes);
         double *S = S_out ? S_out : (double *)(p + 3 * mat_bytes);
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, nullptr);
+        if (two)
+            rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, Aw, nullptr, nullptr, logdet_dev, &info);
+        else
+            rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, nullptr);
         if (rc) return rc;
         dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
         factor_clean_kernel<<<grid, 128, 0, ctx->stream>>>(M, Aw, Uz);
@@ -224,12 +236,15 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
             AGPL_LAUNCH_CHECK(ctx);
         }
         int hinfo[64];
-        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
+        const int ni = two ? 2 * L : L;
+        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * ni, hipMemcpyDeviceToHost, ctx->stream));
         AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < L; ++i)
+        for (int i = 0; i < ni; ++i)
             if (hinfo[i] != 0)
-                AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + G is not positive definite (latent %d, pivot at row %d)", i,
-                          (int)hinfo[i] - 1);
+                AGPL_FAIL(ctx, hinfo[i] < 0 ? AGPL_ERR_HIP : AGPL_ERR_NOT_POSDEF,
+                          hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
+                                       : "I + G is not positive definite (latent %d, pivot at row %d)",
+                          i % L, (int)hinfo[i] - 1 + (hinfo[i] > 0 && i >= L ? 512 : 0));
         return AGPL_OK;
     }
     rc = agpl_ws2_reserve(ctx, info_off + sizeof(rocblas_int) * 2 * (size_t)L + 256 + (S_out ? 0 : mat_bytes));

@@ -333,10 +333,11 @@ def test_accumulate_linearity_at_scale(A, ctx):
     assert host(torch.diagonal(Ga[0]).sum()) == pytest.approx(tr, rel=1e-6)
 
 
-def test_gaussian_update_against_lapack(A, ctx, oracle):
-    rng = np.random.default_rng(11)
-    L, M = 2, 256
-    B = rng.normal(size=(L, M, 3 * M))
+@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 768), (1, 1024), (1, 1152)])
+def test_gaussian_update_against_lapack(A, ctx, oracle, L, M):
+    """S, m against LAPACK on all three routes: factor kernel (M <= 512), its two-block form (M <= 1024), rocSOLVER."""
+    rng = np.random.default_rng(11 + M)
+    B = rng.normal(size=(L, M, 3 * M)) / np.sqrt(M / 256.0)
     G = B @ B.transpose(0, 2, 1)
     g = rng.normal(size=(L, M))
     S = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
