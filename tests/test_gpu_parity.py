@@ -588,6 +588,28 @@ def test_dense_gibbs_step_matches_oracle(A, ctx, oracle, name):
         assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max())
 
 
+@pytest.mark.timeout(600)
+def test_dense_gibbs_step_blocked_routes_match_oracle(A, ctx, oracle):
+    """The same step above the blocking threshold (N >= 8192, not a multiple of the 2048 block): blocked Cholesky and
+    blocked triangular solves on the device against the numpy chain."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)["studentt"]
+    N = 8192 + 300
+    rng = np.random.default_rng(37)
+    x = np.sort(rng.uniform(-400, 400, size=N))
+    K = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 2.0) ** 2) + 1e-3 * np.eye(N)
+    y = gen_y(O, olik, N, rng)
+    dctx = A.Context(0, seed=99)
+    dg = A.DenseGibbs(lik, dev(K), dev(y), ctx=dctx)
+    Lk = np.linalg.cholesky(K)
+    f = np.zeros(N)
+    for sweep in range(2):
+        dg.sweep()
+        f, d = O.dense_gibbs_step(olik, K, Lk, y, f, seed=99, sweep=sweep)
+        assert np.allclose(host(dg.omega), d["omega"], rtol=1e-6)
+        assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max())
+
+
 def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
     """aug_elbo (examples/bernoulli/script.jl:65-70) on the device against the float64 oracle evaluation, and the
     CAVI property the reference's commented-out test was after: the ELBO does not decrease across sweeps."""
