@@ -107,8 +107,9 @@ __device__ __forceinline__ bool spin_until_ge(unsigned *p, unsigned target) {
 // 32 x 16 update tiles and bump a `done` counter; workgroup 0 waits for it before staging block k + 1.  Release =
 // barrier (all stores drained) + one lane's agent-scope atomic, acquire = agent-scope atomic load (invalidates the
 // CU's L1) + barrier.
-// The launch is 8 NW workgroups wide and only those with blockIdx.x % 8 == 0 work: the dispatcher deals workgroups
-// round-robin to the 8 XCDs, so the cooperating ones share one L2.
+// The launch is 8 NW workgroups wide per latent and only those with blockIdx.x % 8 == latent % 8 work: the dispatcher
+// deals workgroups round-robin to the 8 XCDs by linear id, so the cooperating ones of a latent share one L2 and the
+// latents spread over the XCDs (all on XCD 0, the first form, put the 50 workgroups of a 10-latent update on 32 CUs).
 //
 // LA (look-ahead; NW = 2, 3, 5): workgroup 0 runs ONLY the spine, the other NW - 1 ONLY tiles, two block columns
 // ahead of it.  At step k the spine factors block k, forms P | X_k' and publishes them, then applies this step's update
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                                                          float *__restrict__ v32all, double *__restrict__ logdet,
                                                          int *__restrict__ info, double *__restrict__ PXg_all,
                                                          unsigned *__restrict__ sync_all) {
-    if (NW > 1 && (blockIdx.x & 7)) return;
+    if (NW > 1 && (blockIdx.x & 7) != (blockIdx.y & 7)) return; // latent l works on XCD l % 8 (see the launch)
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *PX = sm;                 // [M][FP]: row c < ncx = X_k'[c] (column c of U), row g >= ncx = P of global row g
@@ -552,8 +553,15 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     // M = 512: see DESIGN.md 4.5.
     static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 5;
     // the multi-workgroup forms spin on their partners: every working workgroup must be resident at once (one per CU,
-    // the 150 KB of LDS see to that), so they are used only while L * NW stays well inside the 256 CUs
-    const int nw = (coop_work && (int64_t)L * nw_env <= 128) ? nw_env : 1;
+    // the 150 KB of LDS see to that).  Latent l runs on XCD l % 8 (32 CUs each), so ceil(L / 8) latents share an XCD:
+    // the widest look-ahead form that keeps their workgroups within 24 CUs is used, else one workgroup per latent
+    int nw = 1;
+    if (coop_work) {
+        const int per_xcd = (L + 7) / 8;
+        if (per_xcd * nw_env <= 24) nw = nw_env;
+        else if (nw_env == 5 && per_xcd * 3 <= 24) nw = 3;
+        else if ((nw_env == 5 || nw_env == 3) && per_xcd * 2 <= 24) nw = 2;
+    }
     double *PXg = (double *)coop_work;
     unsigned *sync = coop_work ? (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * 2 * M * FB) : nullptr;
     if (nw > 1) AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 4 * (size_t)L, ctx->stream));
