@@ -81,6 +81,7 @@ AGPL_API int32_t agpl_ctx_destroy(agpl_ctx *ctx);
  * non-blocking stream; NULL = the device's default (null) stream */
 AGPL_API int32_t agpl_ctx_set_stream(agpl_ctx *ctx, void *hip_stream);
 AGPL_API int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed);
+/* waits for the context's stream; also returns what an agpl_gaussian_factor_async still has to report */
 AGPL_API int32_t agpl_ctx_synchronize(agpl_ctx *ctx);
 AGPL_API const char *agpl_last_error(const agpl_ctx *ctx);
 AGPL_API int32_t agpl_version(void);
