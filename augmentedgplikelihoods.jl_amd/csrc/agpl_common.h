@@ -15,6 +15,8 @@ struct rocblas_handle_s; // fwd (rocblas_handle is a pointer to an opaque struct
 struct agpl_ctx {
     int device = 0;
     uint64_t seed = 0;
+    int64_t point_offset = 0; // global index of local point 0 (agpl_ctx_set_point_offset): per-point Philox streams
+                              // are keyed on point_offset + i, so that N sharded over ranks draws what one rank would
     hipStream_t stream = nullptr;
     bool own_stream = false;
     void *rocblas = nullptr; // rocblas_handle, created lazily by agpl_update.hip

@@ -64,6 +64,13 @@ extern "C" int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed) {
     return AGPL_OK;
 }
 
+extern "C" int32_t agpl_ctx_set_point_offset(agpl_ctx *ctx, int64_t i0) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (i0 < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "point offset %lld < 0", (long long)i0);
+    ctx->point_offset = i0;
+    return AGPL_OK;
+}
+
 extern "C" int32_t agpl_ctx_synchronize(agpl_ctx *ctx) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));

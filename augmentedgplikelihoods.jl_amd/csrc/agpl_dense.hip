@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void build_b_kernel(int64_t N, const double *_
     }
 }
 
-// f0 = mu0 + (L_K z1) ; r = beta / sqrt(gamma) - sqrt(gamma) f0 - z2
+// f0 = mu0 + (L_K z1) ; r = beta / sqrt(gamma) - sqrt(gamma) f0 - z2.  gamma_i = 0 happens (Poisson: y_i = 0 and a
+// drawn n_i = 0 give omega_i = PG(0, c) = 0) and implies beta_i = 0: row i of B is then e_i and D^1/2 zeroes that
+// component of the solve on output, so beta / sqrt(gamma) := 0 there is exact, not a patch.
 __global__ void prep_rhs_kernel(int64_t N, const double *__restrict__ mu0, const double *__restrict__ lz,
                                 const double *__restrict__ beta, const double *__restrict__ gamma,
                                 const double *__restrict__ z2, double *__restrict__ f0, double *__restrict__ r) {
@@ -61,7 +63,7 @@ __global__ void prep_rhs_kernel(int64_t N, const double *__restrict__ mu0, const
     const double f = lz[i] + (mu0 ? mu0[i] : 0.0);
     const double sg = sqrt(gamma[i]);
     f0[i] = f;
-    r[i] = beta[i] / sg - sg * f - z2[i];
+    r[i] = (sg > 0.0 ? beta[i] / sg : 0.0) - sg * f - z2[i];
 }
 // t = sqrt(gamma) .* s
 __global__ void scale_kernel(int64_t N, const double *__restrict__ gamma, double *__restrict__ s) {
@@ -241,5 +243,60 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (hinfo != 0)
         AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + D^1/2 K D^1/2 is not positive definite (potrf info = %d)", (int)hinfo);
+    return AGPL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// agpl_probe_mfma_f64: the float64 matrix rate this device sustains (the local hardware guide gives no FP64 MFMA
+// peak: "measure, don't assume") -- v_mfma_f64_16x16x4_f64 issued back to back on four independent
+// accumulators by one wave per SIMD of every CU, on non-trivial operands; 2 * 16 * 16 * 4 flop per instruction.
+// ------------------------------------------------------------------------------------------------
+namespace {
+typedef double d4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_f64_probe_kernel(int iters, double *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    double a = 1.0 + 1e-3 * lane, b = 1.0 - 1e-3 * lane;
+    d4v c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+        }
+        a = -a; // keeps the sums bounded and the operands changing
+    }
+    const d4v s = c0 + c1 + c2 + c3;
+    if (s[0] + s[1] + s[2] + s[3] == 1.2345e300) sink[0] = s[0]; // never true: keeps the chain alive
+}
+} // namespace
+
+extern "C" int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (iters <= 0 || !tflops_host) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    int32_t rc = agpl_ws2_reserve(ctx, 4096);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    AGPL_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount; // one 4-wave workgroup per CU = one wave per SIMD
+    hipEvent_t e0, e1;
+    AGPL_HIP(ctx, hipEventCreate(&e0));
+    AGPL_HIP(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) { // first launch warms the clocks; report the fastest of the rest
+        AGPL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        mfma_f64_probe_kernel<<<blocks, 256, 0, ctx->stream>>>(iters, (double *)ctx->ws2);
+        AGPL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        AGPL_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        AGPL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    AGPL_LAUNCH_CHECK(ctx);
+    const double flop = (double)blocks * 4.0 * (double)iters * 16.0 * (2.0 * 16 * 16 * 4);
+    *tflops_host = flop / ((double)best * 1e-3) / 1e12;
     return AGPL_OK;
 }

@@ -128,8 +128,12 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                                                          double *__restrict__ Aall, double *__restrict__ vall,
                                                          float *__restrict__ v32all, double *__restrict__ logdet,
                                                          int *__restrict__ info, double *__restrict__ PXg_all,
-                                                         unsigned *__restrict__ sync_all) {
+                                                         unsigned *__restrict__ sync_all, int rescue) {
     if (NW > 1 && (blockIdx.x & 7) != (blockIdx.y & 7)) return; // latent l works on XCD l % 8 (see the launch)
+    // rescue launch (NW = 1, queued behind every multi-workgroup launch): redo latent l alone iff the cooperative
+    // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
+    // untouched inputs, so the result is the one the cooperative launch would have produced
+    if (NW == 1 && rescue && info[blockIdx.x] != -1) return;
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *PX = sm;                 // [M][FP]: row c < ncx = X_k'[c] (column c of U), row g >= ncx = P of global row g
@@ -565,19 +569,25 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     double *PXg = (double *)coop_work;
     unsigned *sync = coop_work ? (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * 2 * M * FB) : nullptr;
     if (nw > 1) AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 4 * (size_t)L, ctx->stream));
-#define AGPL_LAUNCH_FACTOR(NW_, LA_, GRID_)                                                                          \
+#define AGPL_LAUNCH_FACTOR(NW_, LA_, GRID_, RESCUE_)                                                                         \
     do {                                                                                                             \
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<NW_, LA_>),                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
         factor_kernel<NW_, LA_><<<GRID_, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,    \
-                                                                   logdet_out, info_dev, PXg, sync);                 \
+                                                                   logdet_out, info_dev, PXg, sync, RESCUE_);        \
     } while (0)
-    if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L));
-    else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L));
-    else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L));
-    else if (nw == 4) AGPL_LAUNCH_FACTOR(4, false, dim3(32, (unsigned)L));
-    else if (nw == 8) AGPL_LAUNCH_FACTOR(8, false, dim3(64, (unsigned)L));
-    else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L));
+    if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L), 0);
+    else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L), 0);
+    else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L), 0);
+    else if (nw == 4) AGPL_LAUNCH_FACTOR(4, false, dim3(32, (unsigned)L), 0);
+    else if (nw == 8) AGPL_LAUNCH_FACTOR(8, false, dim3(64, (unsigned)L), 0);
+    else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 0);
+    AGPL_LAUNCH_CHECK(ctx);
+    // The multi-workgroup forms are plain launches that assume their partners co-resident (true when this process has
+    // the device to itself: per_xcd * nw <= 24 CUs of an XCD's 32).  Should other work hold those CUs for longer than
+    // the bounded spin, the spine reports info = -1 and the rescue launch behind it redoes that latent in one workgroup,
+    // in stream order and without the host; otherwise it exits at once (~2 us per update).
+    if (nw > 1) AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 1);
 #undef AGPL_LAUNCH_FACTOR
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, in
                                                             const double *__restrict__ f,
                                                             double *__restrict__ omega,
                                                             int64_t *__restrict__ nout, uint64_t seed,
-                                                            uint32_t sweep, uint32_t *__restrict__ nuni_out,
+                                                            uint64_t i0, uint32_t sweep,
+                                                            uint32_t *__restrict__ nuni_out,
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
     const int Lf = lik.nlatent;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, in
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         Philox g;
-        g.init(seed, (uint64_t)i, sweep);
+        g.init(seed, i0 + (uint64_t)i, sweep);
         uint32_t nt = 0;
         sample_point<KIND>(lik, g, i, yv, f + i * Lf, omega + i * Lo, nout ? nout + i * Lo : nullptr, nt, bad);
         if (nuni_out) nuni_out[i] = g.nuni;
@@ -652,7 +653,8 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
 #define AGPL_LAUNCH_AUX(K)                                                                                     \
     case K:                                                                                                    \
         aux_sample_kernel<K><<<grid_for(n), kBlock, 0, ctx->stream>>>(ld, n, y, f, omega_out, n_out, ctx->seed,   \
-                                                                      sweep, nuni_out, nterms_out, bad);       \
+                                                                      (uint64_t)ctx->point_offset, sweep,      \
+                                                                      nuni_out, nterms_out, bad);              \
         break;
     switch (ld.kind) {
         AGPL_LAUNCH_AUX(AGPL_LIK_BERNOULLI_LOGISTIC)
@@ -903,7 +905,7 @@ template <int KIND>
 __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int64_t N, int64_t base, int lane, int np,
                                                     int Lf, int Lo, const float *__restrict__ kdiag,
                                                     const float *__restrict__ mu0, const void *yv, uint64_t seed,
-                                                    uint32_t sweep, double *fS, double *omS, int64_t *nnS,
+                                                    uint64_t i0, uint32_t sweep, double *fS, double *omS, int64_t *nnS,
                                                     float *__restrict__ gamma, float *__restrict__ beta,
                                                     double *__restrict__ f_out, double *__restrict__ omega_out,
                                                     int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out,
@@ -911,7 +913,7 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
     const int64_t i = base + lane;
     if (lane < np) {
         Philox g;
-        g.init(seed, (uint64_t)i, sweep);
+        g.init(seed, i0 + (uint64_t)i, sweep);
         const double kd = (double)kdiag[i];
         const double sd = sqrt(kd > 0.0 ? kd : 0.0); // a float32 Nystrom residual can round below zero
         for (int l = 0; l < Lf; ++l) {
@@ -1020,8 +1022,8 @@ __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, in
 template <int KIND>
 __global__ __launch_bounds__(256) void gibbs_sample_kernel(
     agpl_lik_dev lik, int64_t N, const double *__restrict__ proj, const float *__restrict__ kdiag,
-    const float *__restrict__ mu0, const void *yv, uint64_t seed, uint32_t sweep, float *__restrict__ gamma,
-    float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
+    const float *__restrict__ mu0, const void *yv, uint64_t seed, uint64_t i0, uint32_t sweep,
+    float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
     uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int Lf = lik.nlatent;
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(256) void gibbs_sample_kernel(
         const int np = (int)((N - base) < 64 ? (N - base) : 64);
         if (lane < np)
             for (int l = 0; l < Lf; ++l) fS[lane * Lf + l] = proj[(base + lane) * Lf + l];
-        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, sweep, fS, omS, nnS, gamma, beta,
+        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, i0, sweep, fS, omS, nnS, gamma, beta,
                                   f_out, omega_out, n_out, nuni_out, bad);
     }
 }
@@ -1066,8 +1068,9 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
 #define AGPL_LAUNCH_GIBBS_S(K)                                                                                        \
     case K:                                                                                                           \
         gibbs_sample_kernel<K><<<(unsigned)nb, 256, lds_s, ctx->stream>>>(ld, N, proj_work, kdiag, mu0, y, ctx->seed, \
-                                                                           sweep, gamma, beta, f_out, omega_out,     \
-                                                                           n_out, nuni_out, bad);                    \
+                                                                           (uint64_t)ctx->point_offset, sweep, gamma, \
+                                                                           beta, f_out, omega_out, n_out, nuni_out,  \
+                                                                           bad);                                     \
         break;
         switch (ld.kind) {
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_BERNOULLI_LOGISTIC)

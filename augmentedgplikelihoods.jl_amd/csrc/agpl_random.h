@@ -2,7 +2,7 @@
 //
 // One Philox4x32-10 stream per (context seed, point index, sweep): a lane owns its stream, so a sweep
 // is reproducible for any launch geometry and resumable from (seed, sweep) alone.  Uniform -> double
-// conversion, randexp and randn are fixed transforms of the stream (53-bit open-interval uniform,
+// conversion, randexp and randn are fixed transforms of the stream (52-bit open-interval uniform,
 // inversion, cosine Box-Muller) so that a float64 host evaluation of the same formulas consumes the
 // stream identically.
 //
@@ -58,15 +58,16 @@ struct Philox {
         c0 += 1u;
         pos = 0;
     }
-    // uniform in the open interval (0,1), 53 random bits
+    // uniform in the open interval (0,1): (k + 1/2) 2^-52 for a 52-bit k -- every value is exact in float64
+    // (k + 1/2 needs 53 bits), so neither 0 nor 1 can come out of the rounding of the conversion
     __device__ __forceinline__ double u01() {
         if (pos >= 4) refill();
         uint32_t w0, w1;
         if (pos == 0) { w0 = b0; w1 = b1; } else { w0 = b2; w1 = b3; }
         pos += 2;
         nuni += 1u;
-        uint64_t k = ((uint64_t)(w0 >> 5) << 26) | (uint64_t)(w1 >> 6);
-        return ((double)k + 0.5) * 0x1.0p-53;
+        uint64_t k = ((uint64_t)(w0 >> 6) << 26) | (uint64_t)(w1 >> 6);
+        return ((double)k + 0.5) * 0x1.0p-52;
     }
     __device__ __forceinline__ double exp1() { return -log(u01()); }
     __device__ __forceinline__ double normal() {

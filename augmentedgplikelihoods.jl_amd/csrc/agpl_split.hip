@@ -480,6 +480,176 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// marginal_factor16_kernel: the factor form of marginal_split256_kernel (same 256 x 256 tile, same images, same LDS-DMA
+// ring of two 64 KB stages of two 16-deep slices) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
+// A stage's two slices ARE the 32-deep reduction of one instruction: lane l reads row (l & 15) of k-group l >> 4
+// (= slice (l >> 5), plane (l >> 4) & 1 of the 4 KB blocks -- no image changes).  Per flop the 16 x 16 shape moves half
+// the accumulator registers through the matrix pipe; on a chip that holds its clock down under float16 MFMA load
+// (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15x the FLOP/s of the 32 x 32 loop at equal cycles per flop)
+// that is what pays.  Same fragment bytes per flop: a wave's 64 x 64 tile reads 16 fragments per 48 instructions.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(1024, 1) void marginal_factor16_kernel(
+    int64_t N, int M, int64_t ntiles128, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
+    const float *__restrict__ resid, const float *__restrict__ mu0, const h8 *__restrict__ Wh,
+    const h8 *__restrict__ Wl, const float *__restrict__ v_all, float *__restrict__ mu_out,
+    float *__restrict__ var_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int R = 2, KU = 2;
+    constexpr int kSlot = KU * 8 * 4096;
+    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // M floats (v)
+    float *qred = alpha_s + M;                                         // 4 x 256
+    float *mred = qred + 4 * NT2;                                      // 4 x 256
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..15
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l = blockIdx.y;
+    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
+    const int64_t tile2 = blockIdx.x;
+    const int64_t n0 = tile2 * NT2;
+
+    const int ia = wave >> 2, qd = wave & 3;
+    const int64_t t128 = 2 * tile2 + (ia >> 1) < ntiles128 ? 2 * tile2 + (ia >> 1) : ntiles128 - 1;
+    const h8 *a_src = ((ia & 1) ? Wl : Wh) + ((int64_t)l * nb + (ia >> 1)) * nks * 256 + qd * 64 + lane;
+    const h8 *b_src = ((ia & 1) ? Pl : Ph) + t128 * nks * 256 + qd * 64 + lane;
+    const int dma_off = ia * 4096 + qd * 1024;
+
+    const float *vv = v_all + (int64_t)l * M;
+    for (int a = tid; a < M; a += 1024) alpha_s[a] = vv[a];
+
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float macc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int T = 8 * nb2 * (nb2 + 1) / KU; // stages: 16 (rb + 1) slices per 256-row block rb
+    int irb = 0, iks = 0;                   // issue pointer
+    typedef __attribute__((address_space(3))) void lds_void;
+#define AGPL_DMA16_ISSUE(t_)                                                                                \
+    do {                                                                                                    \
+        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
+        _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                                 \
+            __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks + u_) * 256,          \
+                                             (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);                \
+            __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256,                             \
+                                             (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0);     \
+        }                                                                                                   \
+        iks += KU;                                                                                          \
+        if (iks == 16 * (irb + 1)) {                                                                        \
+            ++irb;                                                                                          \
+            iks = 0;                                                                                        \
+        }                                                                                                   \
+    } while (0)
+
+    if (0 < T) AGPL_DMA16_ISSUE(0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment indices (16-byte units within a stage): k-group g = lane >> 4 -> slice g >> 1 (2048 units apart), plane
+    // g & 1 (128 units apart); row = sub-tile base + 16 i + (lane & 15)
+    const int kg = lane >> 4;
+    const int fbase = (kg >> 1) * 2048 + (kg & 1) * 128 + (lane & 15);
+    const int fa = fbase + (wr >> 1) * 512 + (wr & 1) * 64;        // A block (wr >> 1): hi, lo at +256
+    const int fb = fbase + 1024 + (wc >> 1) * 512 + (wc & 1) * 64; // B tile (wc >> 1)
+
+    int rb = 0, ks = 0; // consume pointer
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
+        __builtin_amdgcn_s_barrier();
+        // U is lower triangular: this wave's rows 64 wr .. 64 wr + 63 of block rb are zero from slice 16 rb + 4 (wr + 1)
+        const bool act = ks < rb * 16 + 4 * (wr + 1);
+        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
+        h8 ah[4], al[4];
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ah[i] = st[fa + 16 * i];
+            const h8 bh0 = st[fb], bl0 = st[256 + fb];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bh0, acc[i][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) AGPL_DMA16_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bl0, acc[i][0]);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const h8 bh = st[fb + 16 * j], bl = st[256 + fb + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j - 1] = mfma32(al[i], j == 1 ? bh0 : st[fb + 16 * (j - 1)], acc[i][j - 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bh, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bl, acc[i][j]);
+            }
+            {
+                const h8 bh3 = st[fb + 48];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][3] = mfma32(al[i], bh3, acc[i][3]);
+            }
+        } else {
+            if (t + 1 < T) AGPL_DMA16_ISSUE(t + 1);
+        }
+        ks += KU;
+        if (ks == 16 * (rb + 1)) {
+            // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n]; lane rows a = 16 i + 4 kg + 0..3
+            const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * kg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 16 * i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t0 = acc[i][j][0], t1 = acc[i][j][1], t2 = acc[i][j][2], t3 = acc[i][j][3];
+                    qacc[j] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+                    macc[j] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            ++rb;
+            ks = 0;
+        }
+    }
+#undef AGPL_DMA16_ISSUE
+
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int tid_e = wave * 64 + lane_e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qacc[j] += __shfl_xor(qacc[j], 16);
+        qacc[j] += __shfl_xor(qacc[j], 32);
+        macc[j] += __shfl_xor(macc[j], 16);
+        macc[j] += __shfl_xor(macc[j], 32);
+    }
+    if (lane_e < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qred[wr * NT2 + wc * 64 + 16 * j + lane_e] = qacc[j];
+            mred[wr * NT2 + wc * 64 + 16 * j + lane_e] = macc[j];
+        }
+    }
+    __syncthreads();
+    if (tid_e < NT2) {
+        const int64_t n = n0 + tid_e;
+        if (n < N) {
+            float q = (qred[tid_e] + qred[NT2 + tid_e]) + (qred[2 * NT2 + tid_e] + qred[3 * NT2 + tid_e]);
+            float m = (mred[tid_e] + mred[NT2 + tid_e]) + (mred[2 * NT2 + tid_e] + mred[3 * NT2 + tid_e]);
+            if (mu0) m += mu0[(int64_t)l * N + n];
+            mu_out[(int64_t)l * N + n] = m;
+            var_out[(int64_t)l * N + n] = resid[n] + q;
+        }
+    }
+}
+
 // U = R^-1 as rocSOLVER leaves it: column-major lower triangle of A, i.e. U[a][b] = A[b * M + a] for b <= a
 // (the other triangle of A still holds I + G and is never read) -> blocked hi / lo images of U
 __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
@@ -634,7 +804,14 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
             N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,  \
             (const h8 *)U_lo, v, mu_out, var_out);                                                                   \
     } while (0)
-    if (cfg == 41) AGPL_LAUNCH_M256(4, 1);
+    if (cfg == 16) {
+        const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor16_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        marginal_factor16_kernel<<<grid2, 1024, lds2, ctx->stream>>>(N, M, agpl_cdiv(N, NT), (const h8 *)Phi_hi,
+                                                                     (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
+                                                                     (const h8 *)U_lo, v, mu_out, var_out);
+    } else if (cfg == 41) AGPL_LAUNCH_M256(4, 1);
     else if (cfg == 31) AGPL_LAUNCH_M256(3, 1);
     else if (cfg == 21) AGPL_LAUNCH_M256(2, 1);
     else AGPL_LAUNCH_M256(2, 2);

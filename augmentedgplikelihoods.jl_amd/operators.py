@@ -38,6 +38,7 @@ class Context:
         self._bound = None
         self.seed = seed
         self.sweep = 0
+        self.point_offset = 0
 
     def bind(self):
         """Enqueue on torch's current stream for this device."""
@@ -51,6 +52,20 @@ class Context:
         _ffi.check(self._h, _ffi.lib().agpl_ctx_set_seed(self._h, C.c_uint64(seed)))
         self.seed = seed
         self.sweep = 0
+
+    def next_sweep(self) -> int:
+        """The next unused draw counter of this context (the ``sweep`` word of every Philox stream key).  Every
+        sampler entry point -- aux_sample, rand_polyagamma, SparseGibbs, DenseGibbs -- takes its indices from here,
+        so two users of one Context never replay each other's streams."""
+        s = self.sweep
+        self.sweep += 1
+        return s
+
+    def set_point_offset(self, i0: int):
+        """Global index of this rank's local point 0: per-point streams are keyed (seed, i0 + i, sweep), so N sharded
+        over ranks (same seed everywhere) draws what a single process would (agpl_ctx_set_point_offset)."""
+        _ffi.check(self._h, _ffi.lib().agpl_ctx_set_point_offset(self._h, C.c_int64(i0)))
+        self.point_offset = i0
 
     def synchronize(self):
         _ffi.check(self._h, _ffi.lib().agpl_ctx_synchronize(self.bind()))
@@ -177,8 +192,7 @@ def rand_polyagamma(b: float, c: float, out, ctx: Context | None = None, sweep: 
     torch = _torch()
     ctx = ctx or default_context()
     if sweep is None:
-        sweep = ctx.sweep
-        ctx.sweep += 1
+        sweep = ctx.next_sweep()
     n = out.numel()
     nuni = torch.empty(n, dtype=torch.int32, device=out.device) if stats else None
     nterms = torch.empty(n, dtype=torch.int32, device=out.device) if stats else None
@@ -201,8 +215,7 @@ def aux_sample_(Ω: TupleVector, lik, y, f, ctx: Context | None = None, sweep: i
         raise TypeError("Ω.ω must be a contiguous float64 CUDA tensor")
     nn = Ω.n if lik.kind in _HAS_N else None
     if sweep is None:
-        sweep = ctx.sweep
-        ctx.sweep += 1
+        sweep = ctx.next_sweep()
     nuni = torch.empty(n, dtype=torch.int32, device=f.device) if stats else None
     nterms = torch.empty(n, dtype=torch.int32, device=f.device) if stats else None
     d = lik.desc()

@@ -328,11 +328,14 @@ class SparseGibbs:
         v | Ω    ~ N(m, S), S = (I + G)^-1, m = S g,  G = Phi Diag(γ(Ω)) Phi', g = Phi β(Ω)   (agpl_gibbs_draw_v)
 
     N is sharded over ``group`` exactly as in SparseCAVI: (G, g) are all-reduced, every rank draws the identical v
-    (same Philox key / counter).  Real-valued y must be float64 here (the Gibbs operators are Float64).
+    (same Philox key / counter: every rank's Context must carry the same seed and be at the same draw counter).
+    ``point_offset`` = global index of this rank's first point (``shard_range(N, rank, world)[0]``): the per-point
+    streams are keyed on the GLOBAL point index, so the sharded chain is the single-process chain.
+    Real-valued y must be float64 here (the Gibbs operators are Float64).
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 accumulate_precision: str = "f32"):
+                 accumulate_precision: str = "f32", point_offset: int = 0):
         torch = _torch()
         self.ctx = ctx or default_context()
         if accumulate_precision not in ("f32", "f16x2"):
@@ -354,26 +357,38 @@ class SparseGibbs:
         self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.v = torch.empty((L, M), dtype=f64, device=dev)
         self.m = torch.empty((L, M), dtype=f64, device=dev)
-        self.sweep_index = 0
+        self.point_offset = int(point_offset)
+        if group is not None and self.point_offset == 0:
+            import torch.distributed as dist
+
+            if dist.get_rank(group) != 0:
+                raise _ffi.ArgumentError(-1, "SparseGibbs(group=...) needs point_offset = the global index of this "
+                                             "rank's first point on every rank but the first")
+        self.sweep_index = None  # draw counter of the sweep in flight (taken from the Context)
         self.f = self.omega = self.n = None
         if keep_points:
             Lo = 1 if lik.kind == 7 else L
             self.f = torch.empty((self.N, L), dtype=f64, device=dev)
             self.omega = torch.empty((self.N, Lo), dtype=f64, device=dev)
             self.n = torch.zeros((self.N, Lo), dtype=torch.int64, device=dev)
+        self.sweep_index = self.ctx.next_sweep()
         self.draw()  # G = 0, g = 0: v ~ N(0, I), the prior draw (script.jl:89 `f = randn(N)`)
 
     def draw(self):
+        """v ~ N(m, S) on the streams (seed, l M + a, sweep_index | 2^31): identical on every rank."""
         self.ctx.call("agpl_gibbs_draw_v", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
                       C.c_void_p(0), C.c_uint32(self.sweep_index), _ptr(self.v), _ptr(self.m))
-        self.sweep_index += 1
 
     def accumulate(self):
+        """Point pass of one sweep on the streams (seed, point_offset + i, sweep_index)."""
         d = self.lik.desc()
+        self.sweep_index = self.ctx.next_sweep()
+        self.ctx.set_point_offset(self.point_offset)
         self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
         self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
                       _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))
+        self.ctx.set_point_offset(0)
 
     def exchange(self):
         exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
@@ -414,14 +429,14 @@ class DenseGibbs:
                   else _prep(f0, torch.float64, "f0").clone())
         self.omega = torch.empty(self.N, dtype=torch.float64, device=dev)
         self.n = torch.zeros(self.N, dtype=torch.int64, device=dev) if lik.kind == 5 else None
-        self.sweep_index = 0
+        self.sweep_index = None
 
     def sweep(self):
         d = self.lik.desc()
+        self.sweep_index = self.ctx.next_sweep()
         self.ctx.call("agpl_dense_gibbs_step", C.byref(d), C.c_int64(self.N), _ptr(self.K), _ptr(self.Lk),
                       _ptr(self.mu0), _ptr(self.y), _ptr(self.f), _ptr(self.B), C.c_uint32(self.sweep_index),
                       _ptr(self.omega), _ptr(self.n))
-        self.sweep_index += 1
         return self.f
 
     def run(self, nsamples: int = 200):

@@ -10,13 +10,24 @@ All inputs are resident in HBM before the timed region.
 
 N is a fixed total sharded over ranks (strong scaling), with one RCCL all-reduce of (G, g) per sweep.
 
+At N = 1 the same JSON line also carries (each skippable by a --no-... flag):
+  "m1024"  the north-star target configuration (Bernoulli, N = 1e7, M = 1024) with the same timed-loop discipline,
+           its own roofline and a 10-sweep parity slice;
+  "gibbs"  the Gibbs half on the resident workload (point pass, PG sampler rates for Bernoulli AND NegBin r = 15);
+  "parity" 10 sweeps on a 20 000-point slice against the oracle; "full_size_check"; "cpu_baseline";
+  "c5"     BASELINE configs[4]: StudentT full-rank Gibbs step at N = 65 536 (float64; library N^3).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000000] [--m 512] [--lik bernoulli]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import ctypes as C
+import datetime
+import gc
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,8 +37,9 @@ sys.path.insert(0, ROOT)
 
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
-PMC_PROFILE = "r01_pmc_traffic_c2_v18.json"  # HBM bytes per launch of the split-float16 kernels (separate --pmc passes)
-PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense
+PMC_PROFILE = "r02_pmc_traffic_c2.json"  # HBM bytes per launch of the two contraction kernels (separate --pmc passes)
+RENDEZVOUS_TIMEOUT_S = 300  # a rank that cannot join (or whose first collective hangs) exits non-zero after this
 
 
 def make_lik(A, name):
@@ -47,6 +59,211 @@ def make_olik(O, name):
             "categorical": lambda: O.categorical(np.zeros(10))}[name]()
 
 
+def build_workload(A, ctx, lik, i0, n_loc, M):
+    """Setup (untimed): synthetic data, K_ZX, whitening, Nystrom residual -- all on device."""
+    import torch
+
+    x, y = A.synth_xy(lik, SEED, i0, n_loc, ctx=ctx)
+    z = np.linspace(-10.0, 10.0, M)
+    ell = 1.5 * (z[1] - z[0])
+    Kzz = np.exp(-0.5 * ((z[:, None] - z[None, :]) / ell) ** 2)
+    _, Linv = A.sparse.whitening_matrix(Kzz, 1e-8)
+    Kzx = A.se_features(x, torch.from_numpy(z).cuda(), ell, ctx=ctx)
+    Phi = A.whiten_features(Kzx, Linv, ctx=ctx)
+    del Kzx
+    kd = A.sparse.nystrom_residual(Phi, torch.ones(n_loc, device="cuda"), ctx=ctx)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return y, Phi, kd
+
+
+def read_timing(ctx, which):
+    from agpl_amd import _ffi
+
+    ms, cnt = C.c_double(), C.c_int64()
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
+    return ms.value, cnt.value
+
+
+def timed_sweeps(ctx, cavi, steps, warmup, barrier):
+    """W untimed sweeps, then exactly K sweeps bracketed by barrier + synchronize on both sides; the deferred outcome of
+    the last factorisation is read inside the timed region.  Returns (seconds, per-kernel hipEvent timings)."""
+    from agpl_amd import _ffi
+
+    for _ in range(warmup):
+        cavi.sweep()
+    barrier()
+    _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
+    # used to land in one random sweep of the timed loop: collect now, keep the collector off while timing
+    gc.collect()
+    gc.disable()
+    trace = os.environ.get("AGPL_BENCH_TRACE")  # debug: per-step wall times
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        cavi.sweep()
+        if trace:
+            print(f"[trace] step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
+    barrier()
+    cavi.check()  # inside the timed region: the last sweep's deferred factorisation outcome (raises if it failed)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    kt = [read_timing(ctx, 0), read_timing(ctx, 1)]
+    _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+    return dt, kt
+
+
+def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N, traffic_key=None):
+    """Roofline of the dominant kernel from the in-library hipEvent timings.  Algorithmic flops per launch
+    (SURVEY.md 8d): marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)."""
+    flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
+    nbk = Mp // 128
+    msplit = marginal in ("f16x2", "f16x2-factor")
+    # executed flops: factor-form marginal kernel -- a wave (64 rows) stops at its own diagonal -> (1 + 64 / M) M^2 per
+    # point; accumulation -- lower tile pairs only, the sub-tile above the diagonal of a diagonal tile idles
+    ex_m = (1.0 + 64.0 / Mp) if (marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
+    ex_s = (nbk + 0.5) / nbk
+    executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
+    names = (("marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
+             "syrk_split_kernel" if accumulate == "f16x2" else "syrk_kernel")
+    mult = (3.0 if msplit else 1.0, 3.0 if accumulate == "f16x2" else 1.0)
+    peaks = (PEAK_F16_MFMA_TFLOPS if msplit else PEAK_F32_MFMA_TFLOPS,
+             PEAK_F16_MFMA_TFLOPS if accumulate == "f16x2" else PEAK_F32_MFMA_TFLOPS)
+    per = []
+    for (ms, cnt), fl, ex, nm, mu, pk in zip(kt, flops, executed, names, mult, peaks):
+        avg = ms / max(cnt, 1)
+        per.append({"kernel": nm, "avg_ms": round(avg, 4), "launches": cnt,
+                    "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
+                    "mfma_dtype": "f16 (hi/lo split, x3 products)" if mu == 3.0 else "f32",
+                    "executed_mfma_tflops": round(mu * ex / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
+                    "peak_tflops": pk,
+                    "executed_frac_of_peak": round(mu * ex / (avg * 1e-3) / 1e12 / pk, 4) if avg > 0 else None})
+    dom = 0 if kt[0][0] >= kt[1][0] else 1
+    achieved = per[dom]["algorithmic_tflops"]
+    # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
+    # the committed summary is attached when it was collected on exactly this configuration, else null.
+    traffic = None
+    if traffic_key is not None and world == 1:
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as fh:
+                pm = json.load(fh)
+            if pm["config"] == traffic_key:
+                traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")
+        except Exception:
+            traffic = None
+    return {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": peaks[dom], "unit": "TFLOP/s",
+            "frac": round(achieved / peaks[dom], 4) if achieved else None,
+            "mfma_products_per_algorithmic_product": mult[dom],
+            "traffic": traffic, "traffic_source": "profiles/" + PMC_PROFILE if traffic else None, "kernels": per,
+            "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
+
+
+def parity_slice(A, ctx, lik, likname, Phi, kd, y, marginal, accumulate, nsweeps=10, ns=20_000):
+    """GPU vs oracle on a slice of the same workload: `nsweeps` full CAVI sweeps (10), natural parameters
+    compared at the end (and after the first sweep)."""
+    import torch
+    from oracle import oracle as O
+
+    olik = make_olik(O, likname)
+    ns = min(ns, Phi.shape[0])
+    Mp, L = Phi.shape[1], A.nlatent(lik)
+    Phi_s, kd_s, y_s = Phi[:ns].contiguous(), kd[:ns].contiguous(), y[:ns].contiguous()
+    cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx, marginal_precision=marginal, accumulate_precision=accumulate)
+    Ph, kh, yh = Phi_s.cpu().numpy(), kd_s.cpu().numpy().astype(np.float64), y_s.cpu().numpy()
+    if lik.ykind == "real":
+        yh = yh.astype(np.float64)
+    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
+    first = None
+    for it in range(nsweeps):
+        cs.sweep()
+        G, g = O.cavi_pass(olik, Ph, kh, yh, -S, m)
+        S, m = O.gaussian_update(G, g)
+        if it == 0:
+            torch.cuda.synchronize()
+            first = (float(np.abs(cs.G.cpu().numpy() - G).max() / np.abs(G).max()),
+                     float(np.abs(cs.g.cpu().numpy() - g).max() / np.abs(g).max()))
+    cs.check()
+    dG = float(np.abs(cs.G.cpu().numpy() - G).max() / np.abs(G).max())
+    dg = float(np.abs(cs.g.cpu().numpy() - g).max() / np.abs(g).max())
+    return {"max_rel_dG": dG, "max_rel_dg": dg, "after_first_sweep": {"max_rel_dG": first[0], "max_rel_dg": first[1]},
+            "points": ns, "sweeps": nsweeps, "tolerance": 1e-5,
+            "pass": bool(max(dG, dg, first[0], first[1]) < 1e-5)}
+
+
+def m1024_leg(A, ctx, args):
+    """BASELINE.json north_star's target configuration: Bernoulli-logistic CAVI, N = 1e7, M = 1024, 1 GPU -- same
+    timed-loop discipline as the headline value, its own roofline, and a 10-sweep parity slice."""
+    import torch
+
+    lik = make_lik(A, "bernoulli")
+    N, M = args.m1024_n, 1024
+    t0 = time.time()
+    y, Phi, kd = build_workload(A, ctx, lik, 0, N, M)
+    Mp = Phi.shape[1]
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2-factor", accumulate_precision="f16x2")
+    t_setup = time.time() - t0
+    steps = max(3, min(args.steps, 6))
+    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
+    ms = dt / steps * 1e3
+    out = {"config": {"workload": f"bernoulli-logistic SVGP CAVI sweep, N={N}, M={M}, L=1, 1 GPU", "N": N, "M": M, "L": 1,
+                      "marginal_pass": "f16x2-factor", "accumulate_pass": "f16x2"},
+           "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": 1,
+           "roofline": roofline_of(kt, 1, N, M, Mp, "f16x2-factor", "f16x2", ms, 1, N), "setup_s": round(t_setup, 2)}
+    del cavi
+    if not args.no_parity:
+        out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2")
+    del Phi, kd, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def c5_leg(A, args):
+    """BASELINE configs[4]: StudentTLikelihood Gibbs path, aug_sample (Gamma) + the full-rank N = 65 536 conditional
+    solve of examples/studentt/script.jl (gibbs_sample, :76-87 of the bernoulli example), float64.  The N^3 work is
+    rocSOLVER / rocBLAS calls in a blocked arrangement (labelled "library"); the rate is priced against
+    the float64 MFMA rate measured by the library's own probe kernel on this device."""
+    import torch
+    from agpl_amd import _ffi
+
+    N = args.c5_n
+    ctx = A.Context(0, seed=SEED)
+    lik = A.StudentTLikelihood(3.5, 2.0)  # examples/studentt/script.jl:17-19
+    x, y32 = A.synth_xy(lik, SEED, 0, N, ctx=ctx)
+    x, order = torch.sort(x)
+    y = y32.to(torch.float64)[order].contiguous()
+    K = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    for r0 in range(0, N, 4096):  # row blocks: no N x N temporaries
+        blk = K[r0:min(N, r0 + 4096)]
+        torch.sub(x[r0:r0 + 4096, None], x[None, :], out=blk)
+        blk.div_(2.0).pow_(2).mul_(-0.5).exp_()  # with_lengthscale(SqExponentialKernel(), 2.0), script.jl:15
+    K.diagonal().add_(1e-6)  # LatentGP(gp, lik, 1e-6), script.jl:18
+    dg = A.DenseGibbs(lik, K, y, ctx=ctx)
+    dg.sweep()
+    torch.cuda.synchronize()
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dg.sweep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    peak = C.c_double()
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f64(ctx.bind(), C.c_int32(4096), C.byref(peak)))
+    tf = N ** 3 / 3 / dt / 1e12
+    out = {"config": {"workload": f"StudentT(3.5, 2.0) full-rank Gibbs step, N={N}, SE kernel lengthscale 2.0, jitter 1e-6"},
+           "value": round(1.0 / dt, 4), "unit": "sweeps/s", "ms_per_step": round(dt * 1e3, 1), "steps": steps, "dtype": "f64",
+           "n3_work": "library (rocSOLVER dpotrf on 2048-blocks + rocBLAS dtrsm/dgemm, blocked by agpl_dense.hip)",
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s (N^3/3 per sweep, float64)",
+                        "peak": round(peak.value, 1), "peak_source": "agpl_probe_mfma_f64: v_mfma_f64_16x16x4_f64 "
+                        "back-to-back on every SIMD, measured on this device in this run",
+                        "frac": round(tf / peak.value, 4) if peak.value > 0 else None},
+           "f_finite": bool(torch.isfinite(dg.f).all().item()),
+           "hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+    del dg, K
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,12 +278,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--no-m1024", action="store_true", help="skip the north-star target leg (Bernoulli N=1e7 M=1024)")
+    ap.add_argument("--m1024-n", type=int, default=10_000_000)
+    ap.add_argument("--no-c5", action="store_true", help="skip the full-rank StudentT Gibbs leg (BASELINE configs[4])")
+    ap.add_argument("--c5-n", type=int, default=65_536)
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
     ap.add_argument("--marginal", default="auto", choices=["auto", "f32", "f16x2", "f16x2-factor"],
                     help="marginal pass: f32-input MFMA, split-float16 MFMA (3 f16 products per f32 product), or its "
                          "one-pass factor form (needs padded M %% 256 == 0; auto picks it when it applies)")
     args = ap.parse_args()
+    default_config = (args.n, args.m, args.lik) == (10_000_000, 512, "bernoulli")
 
     import torch
 
@@ -83,17 +305,41 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
+    watchdog = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # A rank that never arrives (or a first collective that hangs) must end the job with a non-zero exit instead of
+        # stalling the node: the rendezvous and every collective carry a timeout, and a watchdog thread ends THIS
+        # process (os._exit: no re-exec, nothing started from a process that has touched the GPU) if the first
+        # all-reduce has not completed in time.
+        tmo = datetime.timedelta(seconds=int(os.environ.get("AGPL_BENCH_TIMEOUT_S", RENDEZVOUS_TIMEOUT_S)))
+
+        def _expired():
+            print(f"[bench rank {rank}] rendezvous / first all-reduce did not complete in {tmo}: exiting 3",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(tmo.total_seconds(), _expired)
+        watchdog.daemon = True
+        watchdog.start()
         if single_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
+                                    device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
+        probe = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(probe, group=group)  # the first collective builds the communicator: under the watchdog
+        torch.cuda.synchronize()
+        if probe.item() != world:
+            print(f"[bench rank {rank}] first all-reduce returned {probe.item()} != {world}", file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog.cancel()
 
     import agpl_amd as A
+    from agpl_amd import _ffi
 
     ctx = A.Context(local_rank, seed=SEED)
     lik = make_lik(A, args.lik)
@@ -101,19 +347,8 @@ def main():
     i0, i1 = A.shard_range(N, rank, world)
     n_loc = i1 - i0
 
-    # ---- setup (untimed): synthetic data, K_ZX, whitening, Nystrom residual -- all on device ----------------
     t_setup = time.time()
-    x, y = A.synth_xy(lik, SEED, i0, n_loc, ctx=ctx)
-    z = np.linspace(-10.0, 10.0, M)
-    ell = 1.5 * (z[1] - z[0])
-    Kzz = np.exp(-0.5 * ((z[:, None] - z[None, :]) / ell) ** 2)
-    _, Linv = A.sparse.whitening_matrix(Kzz, 1e-8)
-    Kzx = A.se_features(x, torch.from_numpy(z).cuda(), ell, ctx=ctx)
-    Phi = A.whiten_features(Kzx, Linv, ctx=ctx)
-    del Kzx
-    kd = A.sparse.nystrom_residual(Phi, torch.ones(n_loc, device="cuda"), ctx=ctx)
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+    y, Phi, kd = build_workload(A, ctx, lik, i0, n_loc, M)
     t_setup = time.time() - t_setup
     Mp = Phi.shape[1]
 
@@ -129,45 +364,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        cavi.sweep()
-    barrier()
-    from agpl_amd import _ffi
-    import ctypes as C
-
-    _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
-    # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
-    # used to land in one random sweep of the timed loop: collect now, keep the collector off while timing
-    import gc
-
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    trace = os.environ.get("AGPL_BENCH_TRACE")  # debug: per-step wall times ("1" adds a sync per step)
-    step_times = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        cavi.sweep()
-        if trace == "1":
-            torch.cuda.synchronize()
-        if trace == "3":
-            step_times.append(time.perf_counter() - ts)
-        elif trace:
-            print(f"[trace] step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
-    t_loop = time.perf_counter() - t0
-    barrier()
-    cavi.check()  # inside the timed region: the last sweep's deferred factorisation outcome (raises if it failed)
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if trace:
-        print(f"[trace] loop {1e3 * t_loop:.2f} ms, loop + final barrier {1e3 * dt:.2f} ms "
-              f"steps {[round(1e3 * t, 2) for t in step_times]}", file=sys.stderr)
-    kt = []
-    for which in (0, 1):
-        ms, cnt = C.c_double(), C.c_int64()
-        _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
-        kt.append((ms.value, cnt.value))
-    _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+    dt, kt = timed_sweeps(ctx, cavi, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
 
@@ -178,60 +375,13 @@ def main():
         dist.destroy_process_group()
         if rank != 0:
             return
-        # the single-GPU extra legs (Gibbs, parity slice, CPU baseline) are reported at N = 1 only
-        args.no_gibbs = args.no_cpu = args.no_parity = True
+        # the single-GPU extra legs (Gibbs, parity slice, CPU baseline, M = 1024, C5) are reported at N = 1 only
+        args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = True
 
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
-
-    # ---- roofline of the dominant kernel (hipEvents inside libagpl.so around each launch) --------------------
-    # algorithmic flops per launch: marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)
-    flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
-    # flops the kernels actually execute (padded M, 128-row blocks): the marginal pass visits block pairs cb >= rb
-    # only; the accumulation computes the nb (nb + 1) / 2 lower tile pairs in full (diagonal tiles redundantly)
-    nbk = Mp // 128
-    msplit = args.marginal in ("f16x2", "f16x2-factor")
-    # factor-form marginal kernel on 256-tiles: a wave (64 rows) stops at its own diagonal -> (1 + 64 / M) M^2 per point;
-    # accumulation: lower tile pairs only, and the wave above the diagonal of a diagonal tile idles -> (nb + 1/2) / nb
-    ex_m = (1.0 + 64.0 / Mp) if (args.marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
-    ex_s = (nbk + 0.5) / nbk
-    executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
-    names = (("marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
-             "syrk_split_kernel" if args.accumulate == "f16x2" else "syrk_kernel")
-    # split-float16 kernels issue 3 float16 MFMA products (hi hi + hi lo + lo hi) per float32-equivalent product
-    # and are priced against the dense float16 peak; the f32-input kernels against the f32 MFMA peak
-    mult = (3.0 if msplit else 1.0, 3.0 if args.accumulate == "f16x2" else 1.0)
-    peaks = (PEAK_F16_MFMA_TFLOPS if msplit else PEAK_F32_MFMA_TFLOPS,
-             PEAK_F16_MFMA_TFLOPS if args.accumulate == "f16x2" else PEAK_F32_MFMA_TFLOPS)
-    per = []
-    for (ms, cnt), fl, ex, nm, mu, pk in zip(kt, flops, executed, names, mult, peaks):
-        avg = ms / max(cnt, 1)
-        per.append({"kernel": nm, "avg_ms": round(avg, 4), "launches": cnt,
-                    "algorithmic_tflops": round(fl / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
-                    "mfma_dtype": "f16 (hi/lo split, x3 products)" if mu == 3.0 else "f32",
-                    "executed_mfma_tflops": round(mu * ex / (avg * 1e-3) / 1e12, 2) if avg > 0 else None,
-                    "peak_tflops": pk,
-                    "executed_frac_of_peak": round(mu * ex / (avg * 1e-3) / 1e12 / pk, 4) if avg > 0 else None})
-    dom = 0 if kt[0][0] >= kt[1][0] else 1
-    achieved = per[dom]["algorithmic_tflops"]
-    # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
-    # the committed summary is attached when it was collected on exactly this configuration, else null.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as fh:
-            pm = json.load(fh)
-        if pm["config"] == {"lik": args.lik, "N": N, "M": M, "L": L} and world == 1:
-            traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")  # null until a PMC pass of this kernel is committed
-    except Exception:
-        traffic = None
-    # achieved = ALGORITHMIC (float32-equivalent) flops per launch / launch duration; peak = dense MFMA peak of the
-    # dtype the kernel issues.  For a split-float16 kernel the scheme's own ceiling in these terms is peak / 3.
-    roofline = {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": peaks[dom],
-                "unit": "TFLOP/s", "frac": round(achieved / peaks[dom], 4) if achieved else None,
-                "mfma_products_per_algorithmic_product": mult[dom],
-                "traffic": traffic, "traffic_source": "profiles/" + PMC_PROFILE if traffic else None,
-                "kernels": per,
-                "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
+    roofline = roofline_of(kt, L, n_loc, M, Mp, args.marginal, args.accumulate, ms_per_step, world, N,
+                           traffic_key={"lik": args.lik, "N": N, "M": M, "L": L})
 
     out = {
         "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",
@@ -249,11 +399,6 @@ def main():
 
     # ---- Gibbs half on the same resident workload (extra legs, not the headline value) ------------------------
     if not args.no_gibbs:
-        def read_timing(which):
-            ms, cnt = C.c_double(), C.c_int64()
-            _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
-            return ms.value, cnt.value
-
         yg = y.to(torch.float64) if lik.ykind == "real" else y
         gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None, accumulate_precision=args.accumulate)
         for _ in range(2):
@@ -266,51 +411,61 @@ def main():
             gib.sweep()
         torch.cuda.synchronize()
         tg = (time.perf_counter() - t0) / nsw
-        pms, pcnt = read_timing(2)
-        read_timing(1)
-        # standalone aux_sample! (src/generic.jl:5-12) at the marginal means: the PG sampler kernel alone
-        f64 = cavi.marginals()[0].to(torch.float64).t().contiguous() if L > 1 else cavi.marginals()[0][0].to(torch.float64)
-        Om = A.aux_sample(lik, yg, f64, ctx=ctx, sweep=1)
-        for sw in range(3):
-            A.aux_sample_(Om, lik, yg, f64, ctx=ctx, sweep=2 + sw)
-        sms, scnt = read_timing(3)
-        _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
-        bytes_pt = {"bernoulli": 16, "negbin": 20, "studentt": 24, "categorical": L * (8 + 1 + 8 + 8)}[args.lik]
-        samp_ms = sms / max(scnt, 1)
+        pms, pcnt = read_timing(ctx, 2)
+        read_timing(ctx, 1)
         proj_ms = pms / max(pcnt, 1)
         out["gibbs"] = {
             "sweeps_per_s": round(1.0 / tg, 3), "ms_per_sweep": round(tg * 1e3, 3),
             "point_pass": {"kernel": "gibbs_project_kernel + gibbs_sample_kernel", "avg_ms": round(proj_ms, 3), "bound": "hbm",
                            "algorithmic_bytes": n_loc * (Mp * 4 + 16),
-                           "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000},
-            "sampler": {"kernel": "aux_sample_kernel", "avg_ms": round(samp_ms, 4), "bound": "hbm (by contract)",
-                        "algorithmic_bytes_per_point": bytes_pt, "draws_per_s": round(n_loc / (samp_ms * 1e-3), 0),
-                        "achieved_GBps": round(n_loc * bytes_pt / (samp_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
-                        "frac": round(n_loc * bytes_pt / (samp_ms * 1e-3) / 8e12, 4)}}
-        del gib, Om, f64
+                           "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000}}
+        del gib
 
-    # ---- parity leg: a slice of the same workload, GPU vs oracle, 3 sweeps -----------------------------------
+        # standalone aux_sample! (src/generic.jl:5-12) at the marginal means: the PG sampler kernel alone, for the
+        # bench likelihood and for NegBin r = 15, whose b = y + r PG(1, c) draws per point are the
+        # load-balance case; PG(1) draws/s = sum_i floor(b_i) / kernel time
+        def sampler_leg(slik, sname, ys, nd):
+            f64 = (cavi.marginals()[0].to(torch.float64).t().contiguous() if A.nlatent(slik) > 1
+                   else cavi.marginals()[0][0].to(torch.float64))[:nd].contiguous()
+            Om = A.aux_sample(slik, ys, f64, ctx=ctx)
+            for _ in range(3):
+                A.aux_sample_(Om, slik, ys, f64, ctx=ctx)
+            sms, scnt = read_timing(ctx, 3)
+            sms /= max(scnt, 1)
+            Ls = A.nlatent(slik)
+            bytes_pt = {"bernoulli": 16, "negbin": 20, "studentt": 24, "categorical": Ls * (8 + 1 + 8 + 8)}[sname]
+            if sname == "bernoulli":
+                pg1 = nd
+            elif sname == "negbin":
+                pg1 = int(ys.to(torch.int64).sum().item()) + 15 * nd
+            else:
+                pg1 = None
+            leg = {"kernel": "aux_sample_kernel", "likelihood": sname, "points": nd, "avg_ms": round(sms, 4),
+                   "bound": "hbm (by contract)", "algorithmic_bytes_per_point": bytes_pt,
+                   "points_per_s": round(nd / (sms * 1e-3), 0),
+                   "achieved_GBps": round(nd * bytes_pt / (sms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
+                   "frac": round(nd * bytes_pt / (sms * 1e-3) / 8e12, 4)}
+            if pg1 is not None:
+                leg["pg1_draws_per_s"] = round(pg1 / (sms * 1e-3), 0)
+            return leg
+
+        yg = y.to(torch.float64) if lik.ykind == "real" else y
+        read_timing(ctx, 3)
+        out["gibbs"]["sampler"] = sampler_leg(lik, args.lik, yg, n_loc)
+        out["gibbs"]["sampler"]["draws_per_s"] = out["gibbs"]["sampler"]["points_per_s"]
+        if args.lik == "bernoulli":
+            nlik = make_lik(A, "negbin")
+            nd = min(n_loc, 4_000_000)
+            _, yn = A.synth_xy(nlik, SEED, i0, nd, ctx=ctx, want_x=False)
+            out["gibbs"]["sampler_negbin"] = sampler_leg(nlik, "negbin", yn, nd)
+            a, b = out["gibbs"]["sampler"].get("pg1_draws_per_s"), out["gibbs"]["sampler_negbin"].get("pg1_draws_per_s")
+            out["gibbs"]["negbin_over_bernoulli_pg1_rate"] = round(b / a, 3) if a and b else None
+            del yn
+        _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+
+    # ---- parity leg: a slice of the same workload, GPU vs oracle, 10 sweeps ---------------------
     if not args.no_parity:
-        from oracle import oracle as O
-
-        olik = make_olik(O, args.lik)
-        ns = min(20_000, n_loc)
-        Phi_s, kd_s, y_s = Phi[:ns].contiguous(), kd[:ns].contiguous(), y[:ns].contiguous()
-        cs = A.SparseCAVI(lik, Phi_s, kd_s, y_s, ctx=ctx, marginal_precision=args.marginal,
-                           accumulate_precision=args.accumulate)
-        Ph, kh, yh = Phi_s.cpu().numpy(), kd_s.cpu().numpy().astype(np.float64), y_s.cpu().numpy()
-        if lik.ykind == "real":
-            yh = yh.astype(np.float64)
-        S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
-        for _ in range(3):
-            cs.sweep()
-            G, g = O.cavi_pass(olik, Ph, kh, yh, -S, m)
-            S, m = O.gaussian_update(G, g)
-        torch.cuda.synchronize()
-        dG = float(np.abs(cs.G.cpu().numpy() - G).max() / np.abs(G).max())
-        dg = float(np.abs(cs.g.cpu().numpy() - g).max() / np.abs(g).max())
-        out["parity"] = {"max_rel_dG": dG, "max_rel_dg": dg, "points": ns, "sweeps": 3, "tolerance": 1e-5,
-                         "pass": bool(dG < 1e-5 and dg < 1e-5)}
+        out["parity"] = parity_slice(A, ctx, lik, args.lik, Phi, kd, y, args.marginal, args.accumulate)
 
     # ---- full-size self-check (N = 1 only): the accumulation of the timed object at the measured size and load,
     #      against float64 torch reductions over the same gamma, beta (a slice cannot see load-dependent faults)
@@ -325,10 +480,10 @@ def main():
         for l in range(L):
             tr = torch.zeros((), dtype=torch.float64, device="cuda")
             gref = torch.zeros(Mp, dtype=torch.float64, device="cuda")
-            for i0 in range(0, n_loc, step):
-                P = Phi[i0:i0 + step].double()
-                tr += (cavi.gamma[l, i0:i0 + step].double() * (P * P).sum(1)).sum()
-                gref += P.T @ cavi.beta[l, i0:i0 + step].double()
+            for j0 in range(0, n_loc, step):
+                P = Phi[j0:j0 + step].double()
+                tr += (cavi.gamma[l, j0:j0 + step].double() * (P * P).sum(1)).sum()
+                gref += P.T @ cavi.beta[l, j0:j0 + step].double()
             rel_g = max(rel_g, float(((cavi.g[l] - gref).abs().max() / gref.abs().max().clamp_min(1e-300)).item()))
             rel_tr = max(rel_tr, float(((torch.diagonal(cavi.G[l]).sum() - tr).abs() / tr.abs().clamp_min(1e-300)).item()))
             del P
@@ -379,9 +534,38 @@ def main():
                 note = (f"1 sweep on the first {ns} of the {N} points with the two contractions through numpy/OpenBLAS "
                         f"(float64) and the oracle's per-point operators, {t_blas:.2f} s (the oracle's own scalar pass: "
                         f"{t_cpu:.2f} s; both agree to 1e-9); value extrapolated linearly in N (labelled extrapolation)")
+            del P
+        try:
+            with open("/proc/cpuinfo") as fh:
+                phys = {ln.split(":")[1].strip() for ln in fh if ln.startswith("physical id")}
+            sockets = len(phys) or None
+        except Exception:
+            sockets = None
         out["cpu_baseline"] = {
-            "value": cpu_value, "unit": "sweeps/s", "cores": O.num_threads(), "kind": "port", "sample": note,
+            "value": cpu_value, "unit": "sweeps/s", "cores": O.num_threads(), "sockets": sockets, "kind": "port",
+            "sample": note, "julia": "unavailable (no julia on PATH; bench/julia_ref.jl runs the literal reference "
+                                     "operators where it is)",
             "gpu_over_cpu": round(value / cpu_value, 1), **extra}
+        del Ph, kh, yh
+
+    # ---- the other configurations the driver should see (N = 1, default C2 run only) ------------------------
+    if world == 1 and default_config and not (args.no_m1024 and args.no_c5):
+        del cavi, Phi, kd, y
+        gc.collect()
+        torch.cuda.empty_cache()
+        if not args.no_m1024:
+            try:
+                out["m1024"] = m1024_leg(A, ctx, args)
+                if "cpu_baseline" in out and out["cpu_baseline"].get("blas_twin_value"):
+                    # CPU cost of a sweep scales with M^2 at fixed N (both contractions): the M = 512 sample x 4
+                    out["m1024"]["gpu_over_cpu_estimate"] = round(out["m1024"]["value"] / (out["cpu_baseline"]["value"] / 4.0), 1)
+            except Exception as e:  # an extra leg must not take the headline line down with it
+                out["m1024"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_c5:
+            try:
+                out["c5"] = c5_leg(A, args)
+            except Exception as e:
+                out["c5"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
 
 

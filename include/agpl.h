@@ -81,6 +81,11 @@ AGPL_API int32_t agpl_ctx_destroy(agpl_ctx *ctx);
  * non-blocking stream; NULL = the device's default (null) stream */
 AGPL_API int32_t agpl_ctx_set_stream(agpl_ctx *ctx, void *hip_stream);
 AGPL_API int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed);
+/* global index of this context's local point 0 (default 0).  The per-point Philox streams of agpl_aux_sample and
+ * agpl_gibbs_pass are keyed (seed, point_offset + i, sweep): a rank that owns points [i0, i1) of N sharded
+ * observations sets i0 here and, with the same seed on every rank, draws exactly what one process
+ * holding all N points would (agpl_gibbs_draw_v is unaffected: every rank must draw the identical v).           */
+AGPL_API int32_t agpl_ctx_set_point_offset(agpl_ctx *ctx, int64_t i0);
 /* waits for the context's stream; also returns what an agpl_gaussian_factor_async still has to report */
 AGPL_API int32_t agpl_ctx_synchronize(agpl_ctx *ctx);
 AGPL_API const char *agpl_last_error(const agpl_ctx *ctx);
@@ -235,6 +240,11 @@ AGPL_API int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A, 
 AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, const double *K,
                                        const double *Lk, const double *mu0, const void *y, double *f_inout,
                                        double *B_work, uint32_t sweep, double *omega_out, int64_t *n_out);
+
+/* agpl_probe_mfma_f64: measured float64 MFMA rate of this device [TFLOP/s] (v_mfma_f64_16x16x4_f64 back to back on
+ *   every SIMD for `iters` x 16 instructions per wave): the peak bench.py prices the C5 Cholesky against
+ *   ("FP64 peak is not in the local guide -- measure, don't assume").  Synchronous.              */
+AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host);
 
 /* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
  * pair is recorded on the context's stream around every launch of the marginal (which = 0), the

@@ -101,8 +101,8 @@ static void rng_init(agplo_rng *g, uint64_t seed, uint64_t stream, uint32_t swee
     g->nuni = 0;
 }
 
-/* uniform in (0,1), 53 random bits, never 0 or 1 (Julia's rand() is [0,1); the open interval only
- * removes the measure-zero log(0)). */
+/* uniform in (0,1): (k + 1/2) 2^-52 with 52 random bits -- exact in float64, never 0 or 1 (Julia's rand() is
+ * [0,1) on a 2^-52 grid; the half-step shift only removes log(0)). */
 static double rng_u01(agplo_rng *g) {
     if (g->pos >= 4) {
         agplo_philox4x32_10(g->ctr, g->key, g->buf);
@@ -112,8 +112,8 @@ static double rng_u01(agplo_rng *g) {
     uint32_t w0 = g->buf[g->pos], w1 = g->buf[g->pos + 1];
     g->pos += 2;
     g->nuni += 1u;
-    uint64_t k = ((uint64_t)(w0 >> 5) << 26) | (uint64_t)(w1 >> 6);
-    return ((double)k + 0.5) * 0x1.0p-53;
+    uint64_t k = ((uint64_t)(w0 >> 6) << 26) | (uint64_t)(w1 >> 6);
+    return ((double)k + 0.5) * 0x1.0p-52;
 }
 
 /* randexp(rng): Exp(1) by inversion (Julia uses a ziggurat; distribution identical). */
@@ -493,6 +493,11 @@ static double cat_sum_theta(const agplo_lik *lik) { /* :16-20 */
 /* (categorical [L,N], poisson/heterogauss [N]) or NULL.                                       */
 /* nuni_out (u32[N], optional): uniforms consumed per point; nterms_out: summed series index.   */
 /* ------------------------------------------------------------------------------------------ */
+/* Global index of local point 0 for the per-point streams of agplo_aux_sample / agplo_gibbs_points (the twin of
+ * agpl_ctx_set_point_offset: a shard [i0, i1) of N points draws on the streams (seed, i0 + i, sweep)). */
+static int64_t g_point_offset = 0;
+AGPLO_API void agplo_set_point_offset(int64_t i0) { g_point_offset = i0; }
+
 AGPLO_API int agplo_aux_sample(const agplo_lik *lik, int64_t n, const void *yv, const double *f,
                                double *omega, int64_t *nout, uint64_t seed, uint32_t sweep,
                                uint32_t *nuni_out, uint32_t *nterms_out) {
@@ -501,7 +506,7 @@ AGPLO_API int agplo_aux_sample(const agplo_lik *lik, int64_t n, const void *yv, 
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t i = 0; i < n; ++i) {
         agplo_rng g;
-        rng_init(&g, seed, (uint64_t)i, sweep);
+        rng_init(&g, seed, (uint64_t)(g_point_offset + i), sweep);
         uint32_t nt = 0;
         switch (lik->kind) {
         case LIK_BERNOULLI_LOGISTIC: /* bernoulli.jl:13-15  PG(1,|f|) */
@@ -1211,7 +1216,7 @@ AGPLO_API int agplo_gibbs_points(const agplo_lik *lik, int64_t N, int M, const f
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t i = 0; i < N; ++i) {
         agplo_rng g;
-        rng_init(&g, seed, (uint64_t)i, sweep);
+        rng_init(&g, seed, (uint64_t)(g_point_offset + i), sweep);
         double sd = sqrt(kdiag[i] > 0.0 ? kdiag[i] : 0.0); /* a float32 Nystrom residual can round below zero */
         double *fi = f_out + i * Lf;
         for (int l = 0; l < Lf; ++l) {

@@ -108,6 +108,7 @@ def lib():
             ("agplo_approx_expected_logistic_f32", C.c_float, [C.c_float, C.c_float]),
             ("agplo_synth_fstar", d, [d]),
             ("agplo_num_threads", C.c_int, []),
+            ("agplo_set_point_offset", None, [C.c_int64]),
         ]:
             f = getattr(_lib, name)
             f.restype, f.argtypes = res, args
@@ -201,8 +202,9 @@ def _ycast(lik: Lik, y):
     return np.ascontiguousarray(y, dtype=lik.ydtype())
 
 
-def aux_sample(lik: Lik, y, f, seed, sweep=0, stats=False):
-    """aux_sample! src/generic.jl:5-12.  Returns dict(omega=..., n=...)."""
+def aux_sample(lik: Lik, y, f, seed, sweep=0, stats=False, i0=0):
+    """aux_sample! src/generic.jl:5-12.  Returns dict(omega=..., n=...).  ``i0``: global index of point 0 (the
+    per-point streams are keyed on i0 + i, as agpl_ctx_set_point_offset)."""
     f = _f64(f)
     y = _ycast(lik, y)
     n = f.size // lik.nlatent
@@ -215,8 +217,10 @@ def aux_sample(lik: Lik, y, f, seed, sweep=0, stats=False):
     nu = np.zeros(n, dtype=np.uint32)
     nt = np.zeros(n, dtype=np.uint32)
     lc = lik.c()
+    lib().agplo_set_point_offset(C.c_int64(i0))
     rc = lib().agplo_aux_sample(C.byref(lc), C.c_int64(n), _p(y), _p(f), _p(omega), _p(nn),
                                 C.c_uint64(seed), C.c_uint32(sweep), _p(nu), _p(nt))
+    lib().agplo_set_point_offset(C.c_int64(0))
     if rc != 0:
         raise ValueError(f"oracle aux_sample failed rc={rc}")
     out = {"omega": omega}
@@ -363,8 +367,9 @@ def randn(seed, stream0, sweep, n):
     return out
 
 
-def gibbs_pass(lik: Lik, Phi, kdiag, y, v, seed, sweep, mu0=None):
-    """Per-point half of a sparse Gibbs sweep + accumulation.  Returns G, g and the per-point draws."""
+def gibbs_pass(lik: Lik, Phi, kdiag, y, v, seed, sweep, mu0=None, i0=0):
+    """Per-point half of a sparse Gibbs sweep + accumulation.  Returns G, g and the per-point draws.
+    ``i0``: global index of point 0 (stream key = i0 + i)."""
     Phi = np.ascontiguousarray(Phi, dtype=np.float32)
     N, M = Phi.shape
     Lf = lik.nlatent
@@ -378,9 +383,11 @@ def gibbs_pass(lik: Lik, Phi, kdiag, y, v, seed, sweep, mu0=None):
     beta = np.empty((Lf, N), dtype=np.float32)
     gamma = np.empty((Lf, N), dtype=np.float32)
     lc = lik.c()
+    lib().agplo_set_point_offset(C.c_int64(i0))
     rc = lib().agplo_gibbs_points(C.byref(lc), C.c_int64(N), C.c_int(M), _p(Phi), _p(_f64(kdiag)), _p(_f64(mu0)),
                                   _p(y), _p(v), C.c_uint64(seed), C.c_uint32(sweep), _p(f), _p(omega), _p(nn),
                                   _p(nuni), _p(beta), _p(gamma))
+    lib().agplo_set_point_offset(C.c_int64(0))
     if rc != 0:
         raise ValueError(f"oracle gibbs_points failed rc={rc}")
     G, g = accumulate(Phi, beta.astype(np.float64), gamma.astype(np.float64))
@@ -419,7 +426,10 @@ def dense_gibbs_step(lik: Lik, K, Lk, y, f, seed, sweep, mu0=None):
     z = randn(seed, 0, (sweep | 0x80000000) & 0xFFFFFFFF, 2 * N)
     f0 = Lk @ z[:N] + (0.0 if mu0 is None else mu0)
     sg = np.sqrt(gamma)
-    r = beta / sg - sg * f0 - z[N:]
+    # gamma_i = 0 (Poisson: y_i = 0 and a drawn n_i = 0 give omega_i = PG(0, c) = 0) implies beta_i = 0: row i of B is
+    # e_i and D^1/2 zeroes the component on output, so 0 is the exact value of beta / sqrt(gamma) there
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(sg > 0, beta / sg, 0.0) - sg * f0 - z[N:]
     B = np.eye(N) + sg[:, None] * K * sg[None, :]
     s = sla.cho_solve(sla.cho_factor(B, lower=True), r)
     return f0 + K @ (sg * s), d

@@ -95,3 +95,71 @@ def test_two_rank_sharded_sweep_matches_single_process(oracle):
     # identical on every rank, bit for bit -> identical update, no broadcast
     assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
     assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])
+
+
+def _gibbs_worker(rank, world, port, N, M, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import agpl_amd as A
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = 20240807
+        olik = O.negbinomial(15.0)
+        i0, i1 = A.shard_range(N, rank, world)
+        x = O.synth_x(seed, i0, i1 - i0)
+        y = O.synth_y(olik, seed, i0, i1 - i0)
+        z = np.linspace(-10, 10, M)
+        Phi = O.se_kernel_f32(x, z, 1.5 * (z[1] - z[0]))
+        kd = np.full(i1 - i0, 0.3)
+        v, _ = O.gibbs_draw_v(np.zeros((1, M, M)), np.zeros((1, M)), seed=seed, sweep=0)  # same key on every rank
+        # the shard's point pass on the GLOBAL point streams (agpl_ctx_set_point_offset / SparseGibbs(point_offset=i0))
+        G, g, pts = O.gibbs_pass(olik, Phi, kd, y, v, seed=seed, sweep=1, i0=i0)
+        flat, Gf, gf = A.sparse.natural_parameter_buffers(1, M, "cpu")
+        Gf.copy_(torch.from_numpy(G)); gf.copy_(torch.from_numpy(g))
+        A.exchange_natural_parameters(Gf, gf, dist.group.WORLD, flat=flat)
+        v1, _ = O.gibbs_draw_v(Gf.numpy(), gf.numpy(), seed=seed, sweep=1)
+        q.put((rank, i0, i1, pts["f"], pts["omega"], pts["nuni"], Gf.numpy().copy(), v, v1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_gibbs_sweep_is_the_single_process_sweep(oracle):
+    """The N-sharded Gibbs sweep: per-point streams keyed on the global point index, the inducing draw
+    on the same key everywhere -- the shards' f, omega and uniforms-consumed concatenate to the single-process arrays
+    bit for bit, the reduced G matches to float64 round-off, and every rank draws the identical v."""
+    import torch.multiprocessing as mp
+
+    O = oracle
+    N, M, world = 3001, 32, 2
+    port = 29400 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gibbs_worker, args=(r, world, port, N, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seed = 20240807
+    olik = O.negbinomial(15.0)
+    x, y = O.synth_x(seed, 0, N), O.synth_y(olik, seed, 0, N)
+    z = np.linspace(-10, 10, M)
+    Phi = O.se_kernel_f32(x, z, 1.5 * (z[1] - z[0]))
+    v, _ = O.gibbs_draw_v(np.zeros((1, M, M)), np.zeros((1, M)), seed=seed, sweep=0)
+    G, g, pts = O.gibbs_pass(olik, Phi, np.full(N, 0.3), y, v, seed=seed, sweep=1)
+    assert np.array_equal(res[0][7], v) and np.array_equal(res[1][7], v)
+    assert np.array_equal(np.concatenate([res[0][3], res[1][3]]), pts["f"])
+    assert np.array_equal(np.concatenate([res[0][4], res[1][4]]), pts["omega"])
+    assert np.array_equal(np.concatenate([res[0][5], res[1][5]]), pts["nuni"])  # integer bookkeeping: bit-exact
+    # a rank keyed on LOCAL indices (the round-1 defect) would replay rank 0's streams on rank 1
+    n1 = res[1][2] - res[1][1]
+    assert not np.array_equal(res[0][5][:n1], res[1][5])
+    assert np.allclose(res[0][6], G, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][8], res[1][8])

@@ -370,3 +370,129 @@ def test_dense_gibbs_step_is_an_exact_draw_from_the_reference_conditional(oracle
     mu_ref, Sigma_ref = O.dense_conditional(K, beta, gamma, mu0)
     assert np.allclose(mean, mu_ref, rtol=1e-7, atol=1e-9)
     assert np.allclose(cov, Sigma_ref, rtol=1e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# Tightening what can be tightened on the unpinned oracle: constructions that do not share a
+# line of code with the oracle's samplers.
+# ------------------------------------------------------------------------------------------------
+def _pg_from_definition(b, c, n, rng, terms=400):
+    """PG(b, c) straight from its definition (Polson, Scott & Windle 2013, eq. 2; the law polyagamma.jl:1-20 documents):
+    omega = 1/(2 pi^2) sum_k g_k / ((k - 1/2)^2 + c^2 / (4 pi^2)),  g_k ~ Gamma(b, 1) iid -- numpy's Gamma sampler, numpy's
+    bit generator, truncated after `terms` terms with the tail replaced by its mean (relative tail mass ~ 1/(pi^2 terms))."""
+    k = np.arange(1, terms + 1)
+    den = (k - 0.5) ** 2 + c * c / (4 * np.pi ** 2)
+    g = rng.gamma(b, 1.0, size=(n, terms))
+    ktail = np.arange(terms + 1, 200_000)
+    tail = b * np.sum(1.0 / ((ktail - 0.5) ** 2 + c * c / (4 * np.pi ** 2)))
+    return (g / den).sum(1) / (2 * np.pi ** 2) + tail / (2 * np.pi ** 2)
+
+
+@pytest.mark.parametrize("b,c", [(1, 0.0), (1, 2.0), (3, 0.0), (3, 2.5), (3, 3.2), (1.2, 3.2), (1, 9.0), (2, 60.0)])
+def test_rand_pg_against_independent_construction_from_the_definition(oracle, b, c):
+    """Two-sample test of the oracle's Devroye sampler (polyagamma.jl:121-257 restated) against the infinite-Gamma-sum
+    definition of the law: the six (b, c) pairs of the reference's own test (test/SpecialDistributions/polyagamma.jl:30)
+    plus c = 9 and c = 60 (both truncated-inverse-Gaussian branches)."""
+    n = 20_000
+    x = oracle.rand_pg(b, c, n, seed=1234)
+    ref = _pg_from_definition(b, c, n, np.random.default_rng(4321))
+    mean = b / (2 * c) * np.tanh(c / 2) if c else b / 4
+    assert ref.mean() == pytest.approx(mean, rel=0.02)  # the construction itself is sound
+    assert stats.ks_2samp(x, ref).pvalue > 1e-3
+    assert abs(x.mean() - ref.mean()) < 5 * np.sqrt((x.var() + ref.var()) / n)
+    assert x.var() == pytest.approx(ref.var(), rel=0.1)
+
+
+def test_negative_multinomial_counts_against_numpy_construction(oracle):
+    """The categorical Gibbs counts (negativemultinomial.jl:35-45: theta ~ Gamma(x0 = 1, 1/p0 - 1), n_k ~ Poisson(p_k
+    theta / (1 - p0))) against a numpy construction of NegativeMultinomial(1, p): marginally n_k ~ Geometric-type
+    NegBin(1, p0 / (p0 + p_k)) and sum_k n_k ~ NegBin(1, p0); two-sample chi-square on the pooled counts."""
+    O = oracle
+    L = 4
+    lik = O.categorical(np.array([0.1, -0.2, 0.3, 0.0]))
+    f = np.array([0.4, -1.0, 0.2, 1.3])
+    n = 40_000
+    fs = np.tile(f, (n, 1))
+    y = np.zeros((n, L), dtype=np.uint8)
+    d = O.aux_sample(lik, y, fs, seed=77)
+    counts = d["n"]
+    theta = np.exp(lik.logtheta[:L]) if hasattr(lik, "logtheta") else np.exp(np.array([0.1, -0.2, 0.3, 0.0]))
+    p = theta / theta.sum() / (1 + np.exp(-f))
+    p0 = 1 - p.sum()
+    rng = np.random.default_rng(99)
+    th = rng.gamma(1.0, 1 / p0 - 1, size=n)
+    ref = rng.poisson(p[None, :] * th[:, None] / (1 - p0))
+    for k in range(L):
+        hi = int(max(counts[:, k].max(), ref[:, k].max()))
+        a = np.bincount(counts[:, k], minlength=hi + 1).astype(float)
+        b = np.bincount(ref[:, k], minlength=hi + 1).astype(float)
+        keep = (a + b) > 10
+        chi = ((a[keep] - b[keep]) ** 2 / (a[keep] + b[keep])).sum()
+        assert chi < stats.chi2(keep.sum()).ppf(0.9999), k
+        # closed form: E n_k = x0 p_k / p0 (negativemultinomial.jl:54)
+        assert counts[:, k].mean() == pytest.approx(p[k] / p0, rel=0.05)
+    tot = counts.sum(1)
+    assert tot.mean() == pytest.approx((1 - p0) / p0, rel=0.05)
+    assert stats.ks_2samp(tot, ref.sum(1)).pvalue > 1e-3
+
+
+def test_oracle_pins_pass_under_address_and_ub_sanitizers():
+    """The plain-C restatement built with -fsanitize=address,undefined (oracle/Makefile, libagpl_oracle_asan.so) runs
+    the sampler / operator / sweep entry points in a child process with the sanitizer runtime preloaded: any
+    out-of-bounds access, use-after-free or undefined shift / overflow in the checker aborts the child."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "libagpl_oracle_asan.so"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan_rt = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(asan_rt):
+        pytest.skip("no libasan runtime in this image")
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as O
+import ctypes as C
+O._lib = None
+O.build = lambda force=False: os.path.join(%r, "oracle", "libagpl_oracle_asan.so")
+rng = np.random.default_rng(3)
+n = 300
+for lik in (O.bernoulli(), O.negbinomial(15.0), O.negbinomial(5.5), O.studentt(3.0, 1.5), O.poisson(10.0), O.laplace(1.0),
+            O.categorical(np.zeros(3)), O.categorical(np.zeros(3), bijective=True), O.heterogauss(5.0)):
+    L = lik.nlatent
+    f = rng.normal(size=(n, L)) if L > 1 else rng.normal(size=n)
+    if lik.kind == O.BERNOULLI:
+        y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    elif lik.kind in (O.NEGBINOMIAL, O.POISSON):
+        y = rng.poisson(3.0, size=n).astype(np.int32)
+    elif lik.kind in (O.CATEGORICAL, O.CATEGORICAL_BIJ):
+        K = L + (1 if lik.kind == O.CATEGORICAL_BIJ else 0)
+        y = (rng.integers(0, K, size=n)[:, None] == np.arange(L)[None, :]).astype(np.uint8)
+    else:
+        y = rng.normal(size=n)
+    d = O.aux_sample(lik, y, f, seed=5, sweep=2, stats=True, i0=7)
+    mu = rng.normal(size=f.shape); var = rng.uniform(0.1, 1.0, size=f.shape)
+    q1, q2, q3 = O.aux_posterior(lik, y, mu, var)
+    O.expected_potential_precision(lik, y, q1, q2, mu_g=(mu[:, 1] if lik.kind == O.HETEROGAUSS else None))
+    O.potential_precision(lik, y, d["omega"], d.get("n"), fg=(f if lik.kind == O.HETEROGAUSS else None))
+    O.aux_kl(lik, y, q1, q2) if lik.kind != O.CATEGORICAL else None
+    M = 32
+    Phi = (rng.normal(size=(n, M)) * 0.3).astype(np.float32)
+    O.cavi_pass(lik, Phi, np.full(n, 0.5), y, -np.tile(np.eye(M), (L, 1, 1)) * 0.5, np.zeros((L, M)))
+    O.gibbs_pass(lik, Phi, np.full(n, 0.5), y, rng.normal(size=(L, M)), seed=5, sweep=1, i0=11)
+O.rand_pg(1.2, 3.2, 500, seed=1); O.rand_pg(3, 0.0, 500, seed=1); O.rand_gamma(0.3, 1.0, 500, seed=1)
+O.rand_poisson(0.7, 500, seed=1); O.rand_poisson(40.0, 500, seed=1); O.rand_invgaussian(0.5, 0.5, 500, seed=1)
+O.synth_y(O.negbinomial(15.0), 1, 3, 200); O.synth_x(1, 0, 10)
+[O.pg_logpdf(1, 2.0, x) for x in (1e-4, 0.01, 0.3, 5.0)]
+print("ASAN_RUN_OK")
+""" % (root, root)
+    env = dict(os.environ, LD_PRELOAD=asan_rt + (":" + ubsan_rt if os.path.exists(ubsan_rt) else ""),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ASAN_RUN_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
