@@ -19,6 +19,8 @@
 // LDS images: [k][row] with the row index contiguous (conflict-free ds_read_b32: lanes 0-31 read
 // consecutive rows at k, lanes 32-63 at k+1), except the Phi operand of marginal_kernel whose k index
 // is the contiguous one in memory: image [point][17] (odd pitch -> conflict-free).
+#include <cstdlib>
+
 #include "agpl_common.h"
 
 namespace {
@@ -655,6 +657,281 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
 
 size_t syrk_split_lds_bytes() { return 2 * kStageBytes; }
 
+// ------------------------------------------------------------------------------------------------
+// syrk_strip_kernel: the split-float16 accumulation with ONE 1024-thread workgroup (16 waves) per CU that owns up to
+// sixteen 64 x 64 sub-tiles of G drawn from at most FOUR staged 128-row panels, instead of four independent 4-wave
+// workgroups owning one 128 x 128 tile (two panels) each.  What that buys at M = 512 (lower triangle = 10 tiles):
+//   * panel stagings (global -> registers -> scale, split to hi / lo float16 -> LDS) per 4096-point slice: 9 instead of
+//     16 -- the L2 -> CU bytes AND the v_fma_mix conversions drop by 44 % (round 1 measured the next stage's loads at 26 %
+//     and conversion + LDS stores + barriers at 19 % of syrk_split_kernel);
+//   * a stage is 32 points: 24 MFMAs per wave between two barriers instead of 12;
+//   * workgroups that walk the same slices advance through the same stage indices at the same pace (every type has
+//     ~16 sub-tiles and 3-4 panels), so the re-reads of a panel by another workgroup type hit L2 more often.
+// The decomposition is a host-built plan (syrk_strip_plan): workgroup TYPES, each a list of <= 4 panel instances
+// (panel index, slice offset: a type that needs < 3 panels replicates itself over 2 or 4 slices) and <= 16 sub-tile
+// entries (A instance + 64-row half, B instance + half, output unit, position); per super-slice (4 slices) a list of
+// (type, first slice) entries.  M = 512:  T0 = {(3,0) (3,1) (3,2) (3,3)}  panels 3,0,1,2;  T1 = {(2,0) (2,1) (2,2) (0,0)}
+// panels 2,0,1;  T2 = {(1,0) (1,1)} x 2 slices: 5 workgroups per 2 slices, all of 14-15 active sub-tiles.
+// Staging, images, scaling and slabs are those of syrk_split_kernel (the [plane][slot][8 halves] image with
+// slot(r) = (r & 3) 36 + (r >> 2), here 4 planes of 8 points): wave w stages (instance w >> 2, plane w & 3) -- 16 values
+// per thread from 4 coalesced float4 loads, 8 ds_write_b64 -- and g = Phi beta rides the staging registers of the
+// instance that is the row panel of a diagonal unit.  Same f32 accumulation length (one slab per unit and slice),
+// same fixed-order float64 reduction behind it: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStripPlanes = 4;                        // 8 points each: a stage is 32 points
+constexpr int kSImgSlots = kStripPlanes * 148;         // 16-byte slots per image (hi or lo of one panel instance)
+constexpr int kSImgBytes = kSImgSlots * 16;            // 9472
+constexpr int kSStageBytes = 4 * 2 * kSImgBytes;       // 4 instances x (hi | lo) = 75776
+constexpr int kTypeWords = 16 + 16 * 8;                // plan words per workgroup type
+constexpr int kSuper = 4;                              // slices per super-slice (lcm of the replications 1, 2, 4)
+
+// PP = true (shipped): the two halves of the workgroup (waves 0-7, 8-15: two waves of each on every SIMD) run half a
+// stage out of phase -- while one half multiplies stage st out of LDS, the other converts and stores its share of
+// stage st + 1, then they swap (two barriers per stage).  In lock step (PP = false) every wave converts at the same
+// time and the matrix pipe idles meanwhile: measured 8.47 ms against 8.11 ms for syrk_split_kernel at C2, whose four
+// independent workgroups per CU drift apart and overlap by themselves.
+template <bool PP>
+__global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
+                                                             const float *__restrict__ Phi,
+                                                             const float *__restrict__ sg_all,
+                                                             const float *__restrict__ bp_all,
+                                                             float *__restrict__ slabG, float *__restrict__ slabg,
+                                                             const int *__restrict__ plan, int ntypes, int nE,
+                                                             int nsuper) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsuper8 = (nsuper + 7) / 8;
+    const int per_l = nE * nsuper8 * 8;
+    const int l = blockIdx.x / per_l;
+    const int rem = blockIdx.x - l * per_l;
+    const int xcd = rem & 7, jj_ = rem >> 3;
+    const int e = jj_ % nE;
+    const int sup = (jj_ / nE) * 8 + xcd;
+    if (sup >= nsuper) return;
+    const int *ent = plan + ntypes * kTypeWords + 2 * e;
+    const int *ty = plan + ent[0] * kTypeWords;
+    const int s0 = sup * kSuper + ent[1];
+    if (s0 >= nsplit) return;
+    const int npan = ty[1];
+    const int nb = M / BS;
+
+    // ---- this wave's staging job: instance q, plane h
+    const int q = wave >> 2, plane = wave & 3;
+    const int sq = s0 + ty[6 + q];
+    const bool stager = q < npan && sq < nsplit;
+    const int64_t nbeg_q = (int64_t)sq * kChunk;
+    int64_t nend_q = nbeg_q + kChunk;
+    if (nend_q > N) nend_q = N;
+    const int nstage_q = stager ? (int)((nend_q - nbeg_q + 31) / 32) : 0;
+    const int plast_q = (int)(nend_q - 1 - nbeg_q);
+    const bool gjob = stager && ty[10 + q] != 0;
+    // the longest instance sets the loop length (instances differ only when one of them is the last, short slice)
+    int nstage = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int si = s0 + ty[6 + i];
+        if (i < npan && si < nsplit) {
+            int64_t b = (int64_t)si * kChunk, en = b + kChunk;
+            if (en > N) en = N;
+            const int ns = (int)((en - b + 31) / 32);
+            nstage = ns > nstage ? ns : nstage;
+        }
+    }
+
+    const int half = lane & 1, fq = lane >> 1;
+    const int p0 = 8 * plane + 4 * half; // first of this thread's 4 points within the stage
+    const unsigned colofs4 = (unsigned)(ty[2 + q] * BS + (fq << 2)) * 4u; // byte offset of the thread's 4 features in a row
+    const char *sbase = reinterpret_cast<const char *>(Phi + nbeg_q * (int64_t)M);
+    const unsigned rowpitch = (unsigned)M * 4u;
+    // wave-uniform bases + one per-lane byte offset (the thread's 4 points within a stage)
+    const char *sgs = reinterpret_cast<const char *>(sg_all + (int64_t)l * Npad + nbeg_q);
+    const char *bps = reinterpret_cast<const char *>(bp_all + (int64_t)l * Npad + nbeg_q);
+    const char *zeros = reinterpret_cast<const char *>(sg_all + (int64_t)l * Npad + (Npad - 32)); // 32 zeros past every slice
+    const unsigned p0b = (unsigned)p0 * 4u;
+    const unsigned dst0 = (unsigned)(q * 2 * kSImgBytes + plane * 148 * 16 + fq * 16 + (p0 & 7) * 2);
+
+    // ---- this wave's sub-tile
+    const int *sub = ty + 16 + 8 * wave;
+    const int qa = sub[1], ra = sub[2], qb = sub[3], rb_ = sub[4];
+    const bool active = wave < ty[14] && sub[0] != 0 && (s0 + ty[6 + qa]) < nsplit;
+    const int li = lane & 31, lk = lane >> 5;
+    const int fslot = lk * 148 + (li & 3) * 36 + (li >> 2);
+    const int fa = qa * 2 * kSImgSlots + fslot + ra * 16;
+    const int fb = qb * 2 * kSImgSlots + fslot + rb_ * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 x[4];
+    float4 sv, bv;
+
+#define AGPL_ST_LOAD(st_)                                                                          \
+    do {                                                                                           \
+        if (stager) {                                                                              \
+            const int stq_ = (st_) < nstage_q ? (st_) : nstage_q - 1;                              \
+            const bool in_ = (st_) < nstage_q;                                                     \
+            /* rows past the slice end are clamped to its last point (their scale is 0) */        \
+            _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
+                int r_ = stq_ * 32 + p0 + k_;                                                      \
+                r_ = r_ < plast_q ? r_ : plast_q;                                                  \
+                x[k_] = *reinterpret_cast<const float4 *>(sbase + (size_t)r_ * rowpitch + colofs4); \
+            }                                                                                      \
+            sv = *reinterpret_cast<const float4 *>((in_ ? sgs + stq_ * 128 : zeros) + p0b);        \
+            if (gjob) bv = *reinterpret_cast<const float4 *>((in_ ? bps + stq_ * 128 : zeros) + p0b); \
+        }                                                                                          \
+    } while (0)
+#define AGPL_ST_STORE(buf_, gkeep_)                                                                \
+    do {                                                                                           \
+        if (stager) {                                                                              \
+            unsigned char *dst_ = smem_raw + (buf_) * kSStageBytes + dst0;                         \
+            if (gjob) {                                                                            \
+                const float b0_ = bv.x * (gkeep_), b1_ = bv.y * (gkeep_), b2_ = bv.z * (gkeep_),   \
+                            b3_ = bv.w * (gkeep_);                                                 \
+                gacc[0] += (b0_ * x[0].x + b1_ * x[1].x) + (b2_ * x[2].x + b3_ * x[3].x);          \
+                gacc[1] += (b0_ * x[0].y + b1_ * x[1].y) + (b2_ * x[2].y + b3_ * x[3].y);          \
+                gacc[2] += (b0_ * x[0].z + b1_ * x[1].z) + (b2_ * x[2].z + b3_ * x[3].z);          \
+                gacc[3] += (b0_ * x[0].w + b1_ * x[1].w) + (b2_ * x[2].w + b3_ * x[3].w);          \
+            }                                                                                      \
+            uint2 h_, l_;                                                                          \
+            AGPL_SPLIT2("v", x[0].x, sv.x, x[1].x, sv.y, h_.x, l_.x);                              \
+            AGPL_SPLIT2("v", x[2].x, sv.z, x[3].x, sv.w, h_.y, l_.y);                              \
+            *reinterpret_cast<uint2 *>(dst_ + 0 * 36 * 16) = h_;                                   \
+            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 0 * 36 * 16) = l_;                      \
+            AGPL_SPLIT2("v", x[0].y, sv.x, x[1].y, sv.y, h_.x, l_.x);                              \
+            AGPL_SPLIT2("v", x[2].y, sv.z, x[3].y, sv.w, h_.y, l_.y);                              \
+            *reinterpret_cast<uint2 *>(dst_ + 1 * 36 * 16) = h_;                                   \
+            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 1 * 36 * 16) = l_;                      \
+            AGPL_SPLIT2("v", x[0].z, sv.x, x[1].z, sv.y, h_.x, l_.x);                              \
+            AGPL_SPLIT2("v", x[2].z, sv.z, x[3].z, sv.w, h_.y, l_.y);                              \
+            *reinterpret_cast<uint2 *>(dst_ + 2 * 36 * 16) = h_;                                   \
+            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 2 * 36 * 16) = l_;                      \
+            AGPL_SPLIT2("v", x[0].w, sv.x, x[1].w, sv.y, h_.x, l_.x);                              \
+            AGPL_SPLIT2("v", x[2].w, sv.z, x[3].w, sv.w, h_.y, l_.y);                              \
+            *reinterpret_cast<uint2 *>(dst_ + 3 * 36 * 16) = h_;                                   \
+            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 3 * 36 * 16) = l_;                      \
+        }                                                                                          \
+    } while (0)
+
+#define AGPL_ST_MFMA(buf_)                                                                         \
+    do {                                                                                           \
+        if (active) {                                                                              \
+            const h8v *I = reinterpret_cast<const h8v *>(smem_raw + (buf_) * kSStageBytes);        \
+            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                     \
+                const int o = s2 * 2 * 148;                                                        \
+                const h8v ah0 = I[fa + o], ah1 = I[fa + o + 8], bh0 = I[fb + o], bh1 = I[fb + o + 8]; \
+                acc[0][0] = mfma16(ah0, bh0, acc[0][0]);                                           \
+                acc[0][1] = mfma16(ah0, bh1, acc[0][1]);                                           \
+                acc[1][0] = mfma16(ah1, bh0, acc[1][0]);                                           \
+                acc[1][1] = mfma16(ah1, bh1, acc[1][1]);                                           \
+                const h8v bl0 = I[kSImgSlots + fb + o], bl1 = I[kSImgSlots + fb + o + 8];          \
+                acc[0][0] = mfma16(ah0, bl0, acc[0][0]);                                           \
+                acc[0][1] = mfma16(ah0, bl1, acc[0][1]);                                           \
+                acc[1][0] = mfma16(ah1, bl0, acc[1][0]);                                           \
+                acc[1][1] = mfma16(ah1, bl1, acc[1][1]);                                           \
+                const h8v al0 = I[kSImgSlots + fa + o], al1 = I[kSImgSlots + fa + o + 8];          \
+                acc[0][0] = mfma16(al0, bh0, acc[0][0]);                                           \
+                acc[0][1] = mfma16(al0, bh1, acc[0][1]);                                           \
+                acc[1][0] = mfma16(al1, bh0, acc[1][0]);                                           \
+                acc[1][1] = mfma16(al1, bh1, acc[1][1]);                                           \
+            }                                                                                      \
+        }                                                                                          \
+    } while (0)
+
+    AGPL_ST_LOAD(0);
+    AGPL_ST_STORE(0, 1.f);
+    if (PP) {
+        // Ping-pong without a role branch in the loop: BOTH halves run  C(st) | barrier | S(st + 1 + second) | barrier
+        // (C = loads of the stage stored next + multiply stage st, S = convert + store); the second half (waves 8-15)
+        // merely starts with one extra store step, so it is always half a stage behind:
+        //     first  half:          C0 | S1 | C1 | S2 | C2 | ...        (+ one closing barrier)
+        //     second half:     S1 | C0 | S2 | C1 | S3 | ...
+        // Stage k lives in buffer k & 1; S(k) of the second half rewrites the buffer both halves have finished reading
+        // one half-step earlier.  s_barrier counts arrivals, not program points, so the extra step pairs up correctly.
+#define AGPL_ST_BAR()                                              \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
+        __builtin_amdgcn_s_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
+    } while (0)
+        const int second = wave >= 8 ? 1 : 0;
+        if (second) AGPL_ST_LOAD(1 < nstage ? 1 : 0);
+        AGPL_ST_BAR();
+        if (second) {
+            AGPL_ST_STORE(1, 1 < nstage ? 1.f : 0.f);
+            AGPL_ST_BAR();
+        }
+        for (int st = 0; st < nstage; ++st) {
+            const int ld = st + 1 + second;
+            AGPL_ST_LOAD(ld < nstage ? ld : nstage - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            AGPL_ST_MFMA(st & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            AGPL_ST_BAR();
+            AGPL_ST_STORE(ld & 1, ld < nstage ? 1.f : 0.f);
+            AGPL_ST_BAR();
+        }
+        if (!second) AGPL_ST_BAR();
+#undef AGPL_ST_BAR
+    } else {
+        __syncthreads();
+        for (int st = 0; st < nstage; ++st) {
+            const int buf = st & 1;
+            const bool more = st + 1 < nstage;
+            AGPL_ST_LOAD(more ? st + 1 : st); // unconditional, as in syrk_split_body (a conditional load stalls the MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+            AGPL_ST_MFMA(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            AGPL_ST_STORE(buf ^ 1, more ? 1.f : 0.f);
+            __syncthreads();
+        }
+    }
+#undef AGPL_ST_MFMA
+#undef AGPL_ST_LOAD
+#undef AGPL_ST_STORE
+
+    if (active) {
+        const int unit = sub[5], wr = sub[6], wc = sub[7];
+        const int ss = s0 + ty[6 + qa];
+        float *slab = slabG + (((int64_t)l * npairs + unit) * nsplit + ss) * (int64_t)(BS * BS);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wr * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const int col = wc * 64 + j2 * 32 + li;
+                    slab[row * BS + col] = acc[ii][j2][r] * kPsiUnscale;
+                }
+    }
+    // g: lanes (2 fq, 2 fq + 1) hold the two point halves of features 4 fq ..; the instance's 4 planes are waves 4 q ..
+    float *gw = reinterpret_cast<float *>(smem_raw); // [16 waves][128] (the stage images are dead: last barrier passed)
+    if (gjob) {
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) gacc[e2] += __shfl_xor(gacc[e2], 1);
+        if (half == 0) {
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) gw[wave * 128 + 4 * fq + e2] = gacc[e2];
+        }
+    }
+    __syncthreads();
+    if (gjob && plane == 0) {
+        const float *g4 = gw + wave * 128; // planes = waves 4 q .. 4 q + 3 (this wave is 4 q)
+        for (int f = lane; f < BS; f += 64)
+            slabg[(((int64_t)l * nb + ty[2 + q]) * nsplit + sq) * BS + f] =
+                (g4[f] + g4[128 + f]) + (g4[256 + f] + g4[384 + f]);
+    }
+}
+
+size_t syrk_strip_lds_bytes() { return 2 * kSStageBytes; }
+
+
 size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT + 128); }
 
 // Fixed-order float64 reduction of the f32 slabs, two levels (HBM-bound streaming, 16 B per lane):
@@ -774,9 +1051,154 @@ __global__ void reduce_g_kernel(int M, int ngroup, const double *__restrict__ pa
 
 inline int syrk_nsplit(int64_t N) { return (int)agpl_cdiv(N, kChunk); }
 
+// ------------------------------------------------------------------------------------------------
+// syrk_strip_plan: host-side decomposition of the lower triangle of G (nb x nb units of 128 x 128; a unit on the
+// diagonal needs 3 of its 4 sub-tiles of 64 x 64) into workgroup types of <= 16 sub-tiles over <= 4 panel instances.
+//   1. every block row bi is cut into chunks: {diagonal unit + up to 3 nearest off-diagonal units} (panels bi + 3),
+//      then runs of up to 3 off-diagonal units (panels bi + 3);
+//   2. small chunks are merged into the chunk that fills its 16 sub-tile slots best while the union of panels stays
+//      <= 4 (smallest chunk first; deterministic tie-break by index);
+//   3. a type with P <= 2 panels and <= 8 sub-tiles runs r = 2 (or 4) slices at once (r P <= 4, r sub-tiles <= 16).
+// Words per type: [0] r, [1] instances, [2..5] panel, [6..9] slice offset, [10..13] g flag, [14] sub-tiles, then 16 x
+// {active, A instance, A half, B instance, B half, unit, wr, wc}; then the per-super-slice entry list (type, slice).
+// ------------------------------------------------------------------------------------------------
+struct StripChunk {
+    std::vector<std::pair<int, int>> units; // (bi, bj), bj <= bi
+    std::vector<int> panels;
+    int subtiles() const {
+        int n = 0;
+        for (auto &u : units) n += u.first == u.second ? 3 : 4;
+        return n;
+    }
+};
+
+static void strip_add_panel(std::vector<int> &ps, int p) {
+    for (int x : ps)
+        if (x == p) return;
+    ps.push_back(p);
+}
+
+static std::vector<int> syrk_strip_plan(int nb, int *ntypes_out, int *nE_out) {
+    std::vector<StripChunk> ch;
+    for (int bi = nb - 1; bi >= 0; --bi) {
+        int c = bi - 1;
+        StripChunk first;
+        first.units.push_back({bi, bi});
+        strip_add_panel(first.panels, bi);
+        for (int k = 0; k < 3 && c >= 0; ++k, --c) {
+            first.units.push_back({bi, c});
+            strip_add_panel(first.panels, c);
+        }
+        ch.push_back(first);
+        while (c >= 0) {
+            StripChunk nx;
+            strip_add_panel(nx.panels, bi);
+            for (int k = 0; k < 3 && c >= 0; ++k, --c) {
+                nx.units.push_back({bi, c});
+                strip_add_panel(nx.panels, c);
+            }
+            ch.push_back(nx);
+        }
+    }
+    // merge: smallest unfinished chunk into the partner that gives the fullest workgroup
+    std::vector<char> done(ch.size(), 0);
+    for (;;) {
+        int a = -1;
+        for (int i = 0; i < (int)ch.size(); ++i)
+            if (!done[i] && ch[i].subtiles() < 12 && (a < 0 || ch[i].subtiles() < ch[a].subtiles())) a = i;
+        if (a < 0) break;
+        int best_b = -1, best_fill = 0;
+        for (int b = 0; b < (int)ch.size(); ++b) {
+            if (b == a) continue;
+            const int fill = ch[a].subtiles() + ch[b].subtiles();
+            if (fill > 16 || fill <= best_fill) continue;
+            std::vector<int> un = ch[b].panels;
+            for (int p : ch[a].panels) strip_add_panel(un, p);
+            if ((int)un.size() > 4) continue;
+            best_fill = fill;
+            best_b = b;
+        }
+        if (best_b < 0) {
+            done[a] = 1; // no partner: it will run replicated over slices if it is small enough
+            continue;
+        }
+        for (auto &u : ch[a].units) ch[best_b].units.push_back(u);
+        for (int p : ch[a].panels) strip_add_panel(ch[best_b].panels, p);
+        done[best_b] = 0;
+        ch.erase(ch.begin() + a);
+        done.erase(done.begin() + a);
+    }
+    std::vector<int> words;
+    std::vector<int> reps;
+    for (auto &c : ch) {
+        const int P = (int)c.panels.size(), S = c.subtiles();
+        int r = 1;
+        while (2 * r * P <= 4 && 2 * r * S <= 16 && 2 * r <= kSuper) r *= 2;
+        reps.push_back(r);
+        std::vector<int> w(kTypeWords, 0);
+        w[0] = r;
+        w[1] = r * P;
+        for (int i = 0; i < r; ++i)
+            for (int k = 0; k < P; ++k) {
+                w[2 + i * P + k] = c.panels[k];
+                w[6 + i * P + k] = i;
+            }
+        int ns = 0;
+        for (int i = 0; i < r; ++i)
+            for (auto &u : c.units) {
+                int ia = -1, ib = -1;
+                for (int k = 0; k < P; ++k) {
+                    if (c.panels[k] == u.first) ia = i * P + k;
+                    if (c.panels[k] == u.second) ib = i * P + k;
+                }
+                const bool diag = u.first == u.second;
+                if (diag) w[10 + ia] = 1;
+                for (int wr = 0; wr < 2; ++wr)
+                    for (int wc = 0; wc < 2; ++wc) {
+                        if (diag && wr < wc) continue;
+                        int *sb = &w[16 + 8 * ns++];
+                        sb[0] = 1;
+                        sb[1] = ia;
+                        sb[2] = wr;
+                        sb[3] = ib;
+                        sb[4] = wc;
+                        sb[5] = u.first * (u.first + 1) / 2 + u.second;
+                        sb[6] = wr;
+                        sb[7] = wc;
+                    }
+            }
+        w[14] = ns;
+        words.insert(words.end(), w.begin(), w.end());
+    }
+    int nE = 0;
+    for (int t = 0; t < (int)ch.size(); ++t)
+        for (int k = 0; k < kSuper; k += reps[t]) {
+            words.push_back(t);
+            words.push_back(k);
+            ++nE;
+        }
+    *ntypes_out = (int)ch.size();
+    *nE_out = nE;
+    return words;
+}
+
+
 } // namespace
 
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
+
+// test hook (not part of the operator ABI): the strip plan for nb block rows, as the device reads it
+extern "C" __attribute__((visibility("default"))) int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap,
+                                                                                int32_t *ntypes, int32_t *nentries) {
+    if (nb <= 0 || !out || !ntypes || !nentries) return -1;
+    int nt = 0, ne = 0;
+    const std::vector<int> w = syrk_strip_plan(nb, &nt, &ne);
+    if ((int)w.size() > cap) return -(int32_t)w.size();
+    for (size_t i = 0; i < w.size(); ++i) out[i] = w[i];
+    *ntypes = nt;
+    *nentries = ne;
+    return (int32_t)w.size();
+}
 
 extern "C" int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L) {
     if (N <= 0 || M <= 0 || M % BS || L <= 0) return 0;
@@ -841,7 +1263,9 @@ static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
     o.partG = al(o.slabg + sizeof(float) * (size_t)((int64_t)L * o.nb * o.ns * BS));
     o.partg = al(o.partG + sizeof(double) * (size_t)(L * o.npairs * o.ng * BS * BS));
     o.sgam = al(o.partg + sizeof(double) * (size_t)((int64_t)L * o.nb * o.ng * BS));
-    o.total = al(o.sgam + 2 * sizeof(float) * (size_t)((int64_t)L * ((N + 15) & ~(int64_t)15))); // padded 2^8 sqrt(gamma) | beta
+    // padded 2^8 sqrt(gamma) | beta: N rounded up to a 32-point stage + one stage of zeros (syrk_strip_kernel reads it
+    // for the stages a shorter slice of its workgroup no longer has)
+    o.total = al(o.sgam + 2 * sizeof(float) * (size_t)((int64_t)L * (((N + 31) & ~(int64_t)31) + 32)));
     return o;
 }
 
@@ -862,12 +1286,51 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
     if (ctx->accumulate_split) {
-        const int64_t Npad = (N + 15) & ~(int64_t)15;
+        const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         float *sg = (float *)((char *)slab_mem + lo.sgam);
         float *bp = sg + (int64_t)L * Npad;
         split_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, sg, bp);
-        syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
-            N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg);
+        // AGPL_SYRK = tile (default) | strip | pp.  Round-2 A/B on one box, ms per launch tile / strip / pp: C2 8.18 / 8.50 /
+        // 8.02; N/8 1.19 / 1.37 / 1.21; M = 1024 27.0 / 30.5 / 30.3; C4 2.60 / 3.02 / 2.55 -- and the PMC pass showed the
+        // strip forms FETCH MORE (40.8 GB against 36.7 GB at C2: their workgroup types do not stay in step, so a panel
+        // staged by two types is fetched twice; the tile kernel's ten workgroups per slice share L2 better).  A wash in
+        // time and worse in traffic: the tile kernel stays the default, the strip forms stay selectable.
+        const char *form = getenv("AGPL_SYRK");
+        const bool tile_form = !form || !strcmp(form, "tile");
+        if (tile_form) {
+            syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
+                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg);
+        } else {
+            if (ctx->strip_nb != nb) {
+                int nt = 0, ne = 0;
+                const std::vector<int> w = syrk_strip_plan(nb, &nt, &ne);
+                AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->strip_plan) AGPL_HIP(ctx, hipFree(ctx->strip_plan));
+                ctx->strip_plan = nullptr;
+                ctx->strip_nb = 0;
+                AGPL_HIP(ctx, hipMalloc((void **)&ctx->strip_plan, sizeof(int) * w.size()));
+                AGPL_HIP(ctx, hipMemcpy(ctx->strip_plan, w.data(), sizeof(int) * w.size(), hipMemcpyHostToDevice));
+                ctx->strip_nb = nb;
+                ctx->strip_ntypes = nt;
+                ctx->strip_nE = ne;
+            }
+            const int nsuper = (ns + kSuper - 1) / kSuper;
+            const int64_t nwg2 = (int64_t)L * ctx->strip_nE * ((nsuper + 7) / 8) * 8;
+            if (nwg2 > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
+            if (form && !strcmp(form, "strip")) { // lock-step form, kept for A/B runs
+                AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_strip_lds_bytes()));
+                syrk_strip_kernel<false><<<(unsigned)nwg2, 1024, syrk_strip_lds_bytes(), ctx->stream>>>(
+                    N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes,
+                    ctx->strip_nE, nsuper);
+            } else {
+                AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_strip_lds_bytes()));
+                syrk_strip_kernel<true><<<(unsigned)nwg2, 1024, syrk_strip_lds_bytes(), ctx->stream>>>(
+                    N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes,
+                    ctx->strip_nE, nsuper);
+            }
+        }
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
