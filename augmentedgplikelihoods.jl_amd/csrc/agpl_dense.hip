@@ -279,24 +279,31 @@ extern "C" int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tfl
     if (rc) return rc;
     hipDeviceProp_t prop;
     AGPL_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int blocks = prop.multiProcessorCount; // one 4-wave workgroup per CU = one wave per SIMD
     hipEvent_t e0, e1;
     AGPL_HIP(ctx, hipEventCreate(&e0));
     AGPL_HIP(ctx, hipEventCreate(&e1));
-    float best = 1e30f;
-    for (int rep = 0; rep < 4; ++rep) { // first launch warms the clocks; report the fastest of the rest
-        AGPL_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        mfma_f64_probe_kernel<<<blocks, 256, 0, ctx->stream>>>(iters, (double *)ctx->ws2);
-        AGPL_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        AGPL_HIP(ctx, hipEventSynchronize(e1));
-        float ms = 0.f;
-        AGPL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-        if (rep > 0 && ms < best) best = ms;
+    double best_tf = 0.0;
+    // 1, 2 and 4 waves per SIMD (4-wave workgroups, 1 / 2 / 4 per CU): the rate a wave alone cannot reach because of the
+    // instruction's dependent-issue latency shows up with more waves; the best of the three is the device's rate
+    for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
+        const int blocks = prop.multiProcessorCount * per_cu;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) { // first launch warms the clocks; the fastest of the rest counts
+            AGPL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+            mfma_f64_probe_kernel<<<blocks, 256, 0, ctx->stream>>>(iters, (double *)ctx->ws2);
+            AGPL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            AGPL_HIP(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            AGPL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double flop = (double)blocks * 4.0 * (double)iters * 16.0 * (2.0 * 16 * 16 * 4);
+        const double tf = flop / ((double)best * 1e-3) / 1e12;
+        if (tf > best_tf) best_tf = tf;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     AGPL_LAUNCH_CHECK(ctx);
-    const double flop = (double)blocks * 4.0 * (double)iters * 16.0 * (2.0 * 16 * 16 * 4);
-    *tflops_host = flop / ((double)best * 1e-3) / 1e12;
+    *tflops_host = best_tf;
     return AGPL_OK;
 }

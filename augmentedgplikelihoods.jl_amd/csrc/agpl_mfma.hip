@@ -1187,8 +1187,8 @@ static std::vector<int> syrk_strip_plan(int nb, int *ntypes_out, int *nE_out) {
 
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
 
-// test hook (not part of the operator ABI): the strip plan for nb block rows, as the device reads it
-extern "C" __attribute__((visibility("default"))) int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap,
+// test hook (include/agpl.h): the strip plan for nb block rows, as the device reads it
+extern "C" int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap,
                                                                                 int32_t *ntypes, int32_t *nentries) {
     if (nb <= 0 || !out || !ntypes || !nentries) return -1;
     int nt = 0, ne = 0;

@@ -21,69 +21,198 @@ inline int grid_for(int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// aux_sample!  src/generic.jl:5-12 ; one lane per point, per-lane Philox stream (seed, i, sweep)
-// sample_point draws Omega_i from aux_full_conditional(lik, y_i, f_i); f / om / nn point at the point's own
+// aux_sample!  src/generic.jl:5-12.  A wave owns 64 consecutive points; lane = point for everything drawn on the
+// point's main Philox stream (seed, i, sweep).  The PG(1, c) draws -- b_i = y_i + r of them for a negative-binomial
+// point, n_ik + y_ik per latent for the categorical / Poisson families (polyagamma.jl:129-134 draw_sum) -- live on
+// sub-streams (agpl_random.h) and are dealt across the lanes of the wave: an exclusive prefix sum of floor(b) over the
+// wave numbers the draws, lane l takes draws l, l + 64, ..., finds each one's owner by bisection, runs the Devroye
+// sampler (polyagamma.jl:225-257) with the owner's hoisted (z, K, r), and leaves the value in LDS where the owner adds
+// its own draws up left to right (the order of the sequential draw_sum loop: bit-identical sums).  With one lane per point the wave waited
+// for its largest b (NegBin r = 15: PG(1) draws at 0.66 of the Bernoulli rate, round-1 bench).
+// sample_point_wave is called by all 64 lanes (valid = the lane has a point); f / om / nn point at the lane's own
 // latent values (global memory for agpl_aux_sample, LDS scratch for the Gibbs pass).
 // ------------------------------------------------------------------------------------------------
+struct PgWaveScratch {
+    double draws[256]; // one chunk of dealt draws
+    double par[64][3]; // owner's (z, K, r)
+    int off[65];       // exclusive prefix sums of floor(b); off[64] = total
+    unsigned nuni[64], nterms[64];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order: only the compiler must not move accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: lane only helps)
+__device__ inline double pg_int_sum_wave(PgWaveScratch *scr, int lane, const Philox &g, uint32_t sub_base, int tb,
+                                         double c, uint32_t &nuni, uint32_t &nterms) {
+    if (tb > 0) {
+        Pg1Params p;
+        p.set(c);
+        scr->par[lane][0] = p.z;
+        scr->par[lane][1] = p.K;
+        scr->par[lane][2] = p.r;
+    }
+    scr->nuni[lane] = 0u;
+    scr->nterms[lane] = 0u;
+    int incl = tb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const int off = incl - tb;
+    const int T = __shfl(incl, 63);
+    scr->off[lane] = off;
+    if (lane == 63) scr->off[64] = T;
+    wave_lds_sync();
+    const uint64_t my_index = (uint64_t)g.c2 | ((uint64_t)(g.c3 & 0xFFu) << 32); // lanes = consecutive points
+    double acc = 0.0;
+    for (int cb = 0; cb < T; cb += 256) {
+        for (int r = 0; r < 4; ++r) {
+            const int t = cb + 64 * r + lane;
+            if (t < T) {
+                int lo = 0, hi = 63; // owner = last lane whose first draw is <= t (lanes without draws share an offset
+                while (lo < hi) {    // with their successor and are skipped by "last")
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (scr->off[mid] <= t) lo = mid;
+                    else hi = mid - 1;
+                }
+                const uint64_t oi = my_index - (uint64_t)lane + (uint64_t)lo;
+                Philox s = g;
+                s.c0 = 0;
+                s.c2 = (uint32_t)oi;
+                s.c3 = (uint32_t)(oi >> 32) + ((sub_base + (uint32_t)(t - scr->off[lo])) << 8);
+                s.pos = 4;
+                s.nuni = 0;
+                Pg1Params p;
+                p.z = scr->par[lo][0];
+                p.K = scr->par[lo][1];
+                p.r = scr->par[lo][2];
+                uint32_t nt = 0;
+                scr->draws[t - cb] = sample_pg1(s, p, nt);
+                atomicAdd(&scr->nuni[lo], s.nuni);
+                atomicAdd(&scr->nterms[lo], nt);
+            }
+        }
+        wave_lds_sync();
+        const int a0 = off > cb ? off : cb, a1 = (off + tb) < (cb + 256) ? (off + tb) : (cb + 256);
+        for (int t = a0; t < a1; ++t) acc += scr->draws[t - cb];
+        wave_lds_sync();
+    }
+    nuni += scr->nuni[lane];
+    nterms += scr->nterms[lane];
+    return acc;
+}
+
+// rand(PolyaGamma(b, c)) for the lane's point, integer part dealt across the wave: the same value, uniforms consumed and
+// series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all 64 lanes.
+__device__ inline double pg_point_wave(PgWaveScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
+                                       double c, uint32_t &nterms) {
+    const bool ok = valid && (b >= 0.0) && (fabs(c) < __builtin_inf()) && (b < 65535.0);
+    const int tb = ok ? (int)floor(b) : 0;
+    const uint32_t base = 1u + ((uint32_t)latent << 16);
+    double acc = pg_int_sum_wave(scr, lane, g, base, tb, c, g.nuni, nterms);
+    if (!valid) return 0.0;
+    if (!ok) return __builtin_nan("");
+    if (b == 0.0) return 0.0;
+    const double res = b - (double)tb;
+    if (res != 0.0) {
+        Philox s = g.sub(base + kSubResidual);
+        acc += rand_gamma_sum(s, c, res);
+        g.nuni += s.nuni;
+    }
+    return acc;
+}
+
 template <int KIND>
-__device__ inline void sample_point(const agpl_lik_dev &lik, Philox &g, int64_t i, const void *yv, const double *f,
-                                    double *om, int64_t *nn, uint32_t &nt, int *bad) {
+__device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch *scr, int lane, bool valid, Philox &g,
+                                         int64_t i, const void *yv, const double *f, double *om, int64_t *nn,
+                                         uint32_t &nt, int *bad) {
     const int L = lik.nlatent;
     switch (KIND) { // compile-time: each kernel instantiation carries one likelihood's sampler only
-    case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15
-        om[0] = rand_pg_int(g, 1, fabs(f[0]), nt);
+    case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15: one draw per point, nothing to deal
+        if (valid) om[0] = rand_pg_int(g, 1, fabs(f[0]), nt);
         break;
     case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
         const int32_t *y = (const int32_t *)yv;
-        om[0] = rand_pg(g, (double)y[i] + lik.p[0], fabs(f[0]), nt);
+        const double b = valid ? (double)y[i] + lik.p[0] : 0.0, c = valid ? fabs(f[0]) : 0.0;
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        if (valid) om[0] = w;
     } break;
     case AGPL_LIK_STUDENTT: { // studentt.jl:46-48
-        const double *y = (const double *)yv;
-        double nu = lik.p[0], sg = lik.p[1];
-        double d = y[i] - f[0];
-        double scale = 2.0 / (nu / (sg * sg) + d * d);
-        om[0] = scale * rand_gamma(g, (nu + 1.0) / 2.0);
+        if (valid) {
+            const double *y = (const double *)yv;
+            double nu = lik.p[0], sg = lik.p[1];
+            double d = y[i] - f[0];
+            double scale = 2.0 / (nu / (sg * sg) + d * d);
+            om[0] = scale * rand_gamma(g, (nu + 1.0) / 2.0);
+        }
     } break;
     case AGPL_LIK_CATEGORICAL:
     case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:72-78, polyagammanegativemultinomial.jl:27-31,
                                      // negativemultinomial.jl:35-45
         const uint8_t *y = (const uint8_t *)yv;
-        double sp = 0.0;
-        for (int k = 0; k < L; ++k) sp += exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
-        double p0 = 1.0 - sp;
-        if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
-            atomicOr(bad, 1);
-            break;
+        bool good = valid;
+        if (valid) {
+            double sp = 0.0;
+            for (int k = 0; k < L; ++k) sp += exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+            double p0 = 1.0 - sp;
+            if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
+                atomicOr(bad, 1);
+                good = false;
+            } else {
+                double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
+                for (int k = 0; k < L; ++k) {
+                    double pk = exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+                    double lam = pk * theta / (1.0 - p0);
+                    nn[k] = rand_poisson(g, lam);
+                }
+            }
         }
-        double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
-        for (int k = 0; k < L; ++k) {
-            double pk = exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
-            double lam = pk * theta / (1.0 - p0);
-            nn[k] = rand_poisson(g, lam);
+        for (int k = 0; k < L; ++k) { // L is wave-uniform: every lane deals for every latent
+            const double b = good ? (double)(nn[k] + (int64_t)y[i * L + k]) : 0.0, c = good ? fabs(f[k]) : 0.0;
+            const double w = pg_point_wave(scr, lane, good, g, k, b, c, nt);
+            if (good) om[k] = w;
         }
-        for (int k = 0; k < L; ++k)
-            om[k] = rand_pg(g, (double)(nn[k] + (int64_t)y[i * L + k]), fabs(f[k]), nt);
     } break;
     case AGPL_LIK_POISSON: { // poisson.jl:26-28, polyagammapoisson.jl:23-27
         const int32_t *y = (const int32_t *)yv;
-        double lam = lik.p[0] * logistic(-f[0]);
-        int64_t n1 = rand_poisson(g, lam);
-        nn[0] = n1;
-        om[0] = rand_pg(g, (double)(n1 + y[i]), fabs(f[0]), nt);
+        double b = 0.0, c = 0.0;
+        if (valid) {
+            double lam = lik.p[0] * logistic(-f[0]);
+            int64_t n1 = rand_poisson(g, lam);
+            nn[0] = n1;
+            b = (double)(n1 + y[i]);
+            c = fabs(f[0]);
+        }
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        if (valid) om[0] = w;
     } break;
     case AGPL_LIK_LAPLACE: { // laplace.jl:40-42
-        const double *y = (const double *)yv;
-        double beta = lik.p[0];
-        double lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
-        om[0] = rand_invgaussian(g, 1.0 / (2.0 * beta * fabs(y[i] - f[0])), 2.0 * lam);
+        if (valid) {
+            const double *y = (const double *)yv;
+            double beta = lik.p[0];
+            double lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
+            om[0] = rand_invgaussian(g, 1.0 / (2.0 * beta * fabs(y[i] - f[0])), 2.0 * lam);
+        }
     } break;
     case AGPL_LIK_HETEROGAUSS: { // heteroscedasticgaussian.jl:28-32
         const double *y = (const double *)yv;
-        double ff = f[0], gg = f[1];
-        double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
-        int64_t n1 = rand_poisson(g, lam);
-        nn[0] = n1;
-        om[0] = rand_pg(g, 0.5 + (double)n1, fabs(gg), nt);
+        double b = 0.0, c = 0.0;
+        if (valid) {
+            double ff = f[0], gg = f[1];
+            double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
+            int64_t n1 = rand_poisson(g, lam);
+            nn[0] = n1;
+            b = 0.5 + (double)n1;
+            c = fabs(gg);
+        }
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        if (valid) om[0] = w;
     } break;
     default:
         break;
@@ -99,16 +228,24 @@ __global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, in
                                                             uint32_t *__restrict__ nuni_out,
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
+    __shared__ PgWaveScratch scratch[kBlock / 64];
     const int Lf = lik.nlatent;
     const int Lo = lik.kind == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nchunks = (n + 63) >> 6;
+    for (int64_t chunk = (int64_t)blockIdx.x * (kBlock / 64) + wave; chunk < nchunks;
+         chunk += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t i = (chunk << 6) + lane;
+        const bool valid = i < n;
         Philox g;
         g.init(seed, i0 + (uint64_t)i, sweep);
         uint32_t nt = 0;
-        sample_point<KIND>(lik, g, i, yv, f + i * Lf, omega + i * Lo, nout ? nout + i * Lo : nullptr, nt, bad);
-        if (nuni_out) nuni_out[i] = g.nuni;
-        if (nterms_out) nterms_out[i] = nt;
+        sample_point_wave<KIND>(lik, &scratch[wave], lane, valid, g, i, yv, f + i * Lf, omega + i * Lo,
+                                nout ? nout + i * Lo : nullptr, nt, bad);
+        if (valid) {
+            if (nuni_out) nuni_out[i] = g.nuni;
+            if (nterms_out) nterms_out[i] = nt;
+        }
     }
 }
 
@@ -121,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void rand_pg_kernel(double b, double c, int
         Philox g;
         g.init(seed, (uint64_t)i, sweep);
         uint32_t nt = 0;
-        out[i] = rand_pg(g, b, c, nt);
+        out[i] = rand_pg(g, 0, b, c, nt);
         if (nuni_out) nuni_out[i] = g.nuni;
         if (nterms_out) nterms_out[i] = nt;
     }
@@ -905,15 +1042,18 @@ template <int KIND>
 __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int64_t N, int64_t base, int lane, int np,
                                                     int Lf, int Lo, const float *__restrict__ kdiag,
                                                     const float *__restrict__ mu0, const void *yv, uint64_t seed,
-                                                    uint64_t i0, uint32_t sweep, double *fS, double *omS, int64_t *nnS,
+                                                    uint64_t i0, uint32_t sweep, PgWaveScratch *scr, double *fS, double *omS,
+                                                    int64_t *nnS,
                                                     float *__restrict__ gamma, float *__restrict__ beta,
                                                     double *__restrict__ f_out, double *__restrict__ omega_out,
                                                     int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out,
                                                     int *__restrict__ bad) {
     const int64_t i = base + lane;
-    if (lane < np) {
-        Philox g;
-        g.init(seed, i0 + (uint64_t)i, sweep);
+    const bool valid = lane < np;
+    Philox g;
+    g.init(seed, i0 + (uint64_t)i, sweep);
+    uint32_t nt = 0;
+    if (valid) {
         const double kd = (double)kdiag[i];
         const double sd = sqrt(kd > 0.0 ? kd : 0.0); // a float32 Nystrom residual can round below zero
         for (int l = 0; l < Lf; ++l) {
@@ -922,8 +1062,9 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
             fS[lane * Lf + l] = f;
             if (f_out) f_out[i * Lf + l] = f;
         }
-        uint32_t nt = 0;
-        sample_point<KIND>(lik, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+    }
+    sample_point_wave<KIND>(lik, scr, lane, valid, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+    if (valid) {
         if (nuni_out) nuni_out[i] = g.nuni;
         // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
         switch (KIND) {
@@ -1026,6 +1167,7 @@ __global__ __launch_bounds__(256) void gibbs_sample_kernel(
     float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
     uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
+    __shared__ PgWaveScratch scratch[4];
     const int Lf = lik.nlatent;
     const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1038,7 +1180,8 @@ __global__ __launch_bounds__(256) void gibbs_sample_kernel(
         const int np = (int)((N - base) < 64 ? (N - base) : 64);
         if (lane < np)
             for (int l = 0; l < Lf; ++l) fS[lane * Lf + l] = proj[(base + lane) * Lf + l];
-        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, i0, sweep, fS, omS, nnS, gamma, beta,
+        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, i0, sweep, &scratch[wave], fS, omS, nnS, gamma,
+                                  beta,
                                   f_out, omega_out, n_out, nuni_out, bad);
     }
 }

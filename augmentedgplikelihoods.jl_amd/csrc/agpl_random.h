@@ -1,7 +1,11 @@
 // agpl_random.h -- per-lane counter RNG and the scalar samplers of the Gibbs half, device side.
 //
-// One Philox4x32-10 stream per (context seed, point index, sweep): a lane owns its stream, so a sweep
-// is reproducible for any launch geometry and resumable from (seed, sweep) alone.  Uniform -> double
+// One Philox4x32-10 stream per (context seed, point index, sweep), so a sweep is reproducible for any launch
+// geometry and resumable from (seed, sweep) alone.  Every PG(1, c) draw of a point lives on a SUB-STREAM of the
+// point's stream (counter word 3 = (point index >> 32) in its low 8 bits, sub-stream id above: draw j of latent k has
+// id 1 + (k << 16) + j, the residual Gamma series id 1 + (k << 16) + 0xFFFF, id 0 is the main stream): the
+// b = y + r draws of a negative-binomial point are independent work items that the kernels deal across the lanes of
+// a wave (pg_int_sum_wave, agpl_ops.hip) and sum left to right in draw order -- the order of the sequential draw_sum loop (polyagamma.jl:129-134).  Uniform -> double
 // conversion, randexp and randn are fixed transforms of the stream (52-bit open-interval uniform,
 // inversion, cosine Box-Muller) so that a float64 host evaluation of the same formulas consumes the
 // stream identically.
@@ -41,6 +45,15 @@ struct Philox {
         c3 = (uint32_t)(stream >> 32);
         pos = 4;
         nuni = 0;
+    }
+    // sub-stream `id` of this point's stream (same key, sweep and point; fresh counter)
+    __device__ __forceinline__ Philox sub(uint32_t id) const {
+        Philox s = *this;
+        s.c0 = 0;
+        s.c3 = (c3 & 0xFFu) + (id << 8);
+        s.pos = 4;
+        s.nuni = 0;
+        return s;
     }
     __device__ __forceinline__ void refill() {
         uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, q0 = k0, q1 = k1;
@@ -227,31 +240,47 @@ __device__ inline double rand_gamma_sum(Philox &g, double c, double e) {
     return inv2pi2 * acc;
 }
 
-// rand(PolyaGamma(b,c)) polyagamma.jl:121-154
-__device__ inline double rand_pg(Philox &g, double b, double c, uint32_t &nterms) {
+constexpr uint32_t kSubResidual = 0xFFFFu;
+
+// rand(PolyaGamma(b,c)) polyagamma.jl:121-154, one lane doing all of a point's draws: draw j of `latent` on sub-stream
+// 1 + (latent << 16) + j, the residual series on 1 + (latent << 16) + 0xFFFF; uniforms consumed are added to g.nuni.
+__device__ inline double rand_pg(Philox &g, int latent, double b, double c, uint32_t &nterms) {
     // NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin or
-    // throw its DomainError from a(n, 0), polyagamma.jl:175)
-    if (!(b >= 0.0) || !(fabs(c) < __builtin_inf())) return __builtin_nan("");
+    // throw its DomainError from a(n, 0), polyagamma.jl:175); b >= 65535 would leave the sub-stream id space
+    if (!(b >= 0.0) || !(fabs(c) < __builtin_inf()) || !(b < 65535.0)) return __builtin_nan("");
     if (b == 0.0) return 0.0;
-    if (b < 1.0) return rand_gamma_sum(g, c, b);
-    long tb = (long)floor(b);
-    Pg1Params p;
-    p.set(c);
+    const long tb = (long)floor(b);
+    const uint32_t base = 1u + ((uint32_t)latent << 16);
     double acc = 0.0;
-    for (long i = 0; i < tb; ++i) acc += sample_pg1(g, p, nterms);
-    double res = b - (double)tb;
+    if (tb > 0) {
+        Pg1Params p;
+        p.set(c);
+        for (long j = 0; j < tb; ++j) {
+            Philox s = g.sub(base + (uint32_t)j);
+            acc += sample_pg1(s, p, nterms);
+            g.nuni += s.nuni;
+        }
+    }
+    const double res = b - (double)tb;
     if (res == 0.0) return acc;
-    return acc + rand_gamma_sum(g, c, res);
+    Philox s = g.sub(base + kSubResidual);
+    acc += rand_gamma_sum(s, c, res);
+    g.nuni += s.nuni;
+    return acc;
 }
 
 // draw_sum(rng, PolyaGamma{<:Integer}) polyagamma.jl:129-134 for a compile-time-integer b (Bernoulli: b = 1):
-// identical draws to rand_pg(g, b, c, .) without carrying the non-integer Gamma-series code.
+// identical draws to rand_pg(g, 0, b, c, .) without carrying the non-integer Gamma-series code.
 __device__ inline double rand_pg_int(Philox &g, int b, double c, uint32_t &nterms) {
     if (!(fabs(c) < __builtin_inf())) return __builtin_nan("");
     Pg1Params p;
     p.set(c);
     double acc = 0.0;
-    for (int i = 0; i < b; ++i) acc += sample_pg1(g, p, nterms);
+    for (int j = 0; j < b; ++j) {
+        Philox s = g.sub(1u + (uint32_t)j);
+        acc += sample_pg1(s, p, nterms);
+        g.nuni += s.nuni;
+    }
     return acc;
 }
 

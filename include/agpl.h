@@ -246,6 +246,13 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *   ("FP64 peak is not in the local guide -- measure, don't assume").  Synchronous.              */
 AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host);
 
+/* agpl_debug_strip_plan: the host-built decomposition the strip form of the split accumulation executes (AGPL_SYRK =
+ *   strip | pp, agpl_mfma.hip syrk_strip_plan), for `nb` block rows of 128 features, as the device reads it: `ntypes`
+ *   workgroup types of 144 words each, then `nentries` (type, first slice) pairs per super-slice of 4 slices.  Host
+ *   only (no GPU needed; ctx-free): what tests/test_strip_plan.py checks.  Returns the number of words (or minus the
+ *   number needed when `cap` is too small).                                                                         */
+AGPL_API int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap, int32_t *ntypes, int32_t *nentries);
+
 /* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
  * pair is recorded on the context's stream around every launch of the marginal (which = 0), the
  * accumulation (which = 1), the Gibbs per-point (which = 2) and the aux_sample (which = 3) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel

@@ -292,20 +292,41 @@ static double rand_gamma_sum(agplo_rng *g, double c, double e) {
     return inv2pi2 * acc;
 }
 
-/* rand(PolyaGamma(b,c)) polyagamma.jl:121-154.  Integer-valued b follows draw_sum{<:Integer}
- * (:129-134); real b follows :137-154 (identical draws when the residual is zero). */
-static double rand_pg(agplo_rng *g, double b, double c, uint32_t *nterms) {
+/* rand(PolyaGamma(b, c)) polyagamma.jl:121-154: draw_sum of floor(b) PG(1, c) draws (:129-134) plus, for real b, the
+ * truncated Gamma series on the residual (:137-154; identical draws when the residual is zero).
+ * STREAM LAYOUT (shared bit for bit with agpl_random.h): every PG(1, c) draw lives on a SUB-STREAM of its point's
+ * Philox stream -- counter word 3 carries (point index >> 32) in its low 8 bits and the sub-stream id above them;
+ * draw j of latent k uses id 1 + (k << 16) + j, the residual series id 1 + (k << 16) + 0xFFFF; id 0 is the point's
+ * main stream (noise, Gamma / Poisson / inverse-Gaussian draws).  The draws of one point are therefore independent
+ * work items (the device deals them across the lanes of a wave), summed left to right in draw order, residual last. */
+#define AGPLO_SUB_RESIDUAL 0xFFFFu
+static void rng_sub(const agplo_rng *g, uint32_t id, agplo_rng *s) {
+    *s = *g;
+    s->ctr[0] = 0;
+    s->ctr[3] = (g->ctr[3] & 0xFFu) + (id << 8);
+    s->pos = 4;
+    s->nuni = 0;
+}
+static double rand_pg(agplo_rng *g, int latent, double b, double c, uint32_t *nterms) {
     /* NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin
      * or throw its DomainError from a(n, 0), polyagamma.jl:175) */
-    if (!(b >= 0.0) || !(fabs(c) < INFINITY)) return NAN;
+    if (!(b >= 0.0) || !(fabs(c) < INFINITY) || !(b < 65535.0)) return NAN;
     if (b == 0.0) return 0.0;
-    if (b < 1.0) return rand_gamma_sum(g, c, b);
-    long tb = (long)floor(b);
+    const long tb = (long)floor(b);
+    const uint32_t base = 1u + ((uint32_t)latent << 16);
     double acc = 0.0;
-    for (long i = 0; i < tb; ++i) acc += sample_pg1(g, c, nterms);
+    agplo_rng s;
+    for (long j = 0; j < tb; ++j) {
+        rng_sub(g, base + (uint32_t)j, &s);
+        acc += sample_pg1(&s, c, nterms);
+        g->nuni += s.nuni;
+    }
     double res = b - (double)tb;
     if (res == 0.0) return acc;
-    return acc + rand_gamma_sum(g, c, res);
+    rng_sub(g, base + AGPLO_SUB_RESIDUAL, &s);
+    acc += rand_gamma_sum(&s, c, res);
+    g->nuni += s.nuni;
+    return acc;
 }
 
 /* upstream, unpinned: Distributions.jl 0.25 Poisson.  mu < 6: PoissonCountSampler (count unit-rate
@@ -414,7 +435,7 @@ AGPLO_API void agplo_rand_pg_many(double b, double c, int64_t n, uint64_t seed, 
         agplo_rng g;
         rng_init(&g, seed, (uint64_t)i, 0);
         uint32_t nt = 0;
-        out[i] = rand_pg(&g, b, c, &nt);
+        out[i] = rand_pg(&g, 0, b, c, &nt);
         if (nuni_out) nuni_out[i] = g.nuni;
         if (nterms_out) nterms_out[i] = nt;
     }
@@ -510,11 +531,11 @@ AGPLO_API int agplo_aux_sample(const agplo_lik *lik, int64_t n, const void *yv, 
         uint32_t nt = 0;
         switch (lik->kind) {
         case LIK_BERNOULLI_LOGISTIC: /* bernoulli.jl:13-15  PG(1,|f|) */
-            omega[i] = rand_pg(&g, 1.0, fabs(f[i]), &nt);
+            omega[i] = rand_pg(&g, 0, 1.0, fabs(f[i]), &nt);
             break;
         case LIK_NEGBINOMIAL: { /* negativebinomial.jl:20-22  PG(y+r,|f|) */
             const int32_t *y = (const int32_t *)yv;
-            omega[i] = rand_pg(&g, (double)y[i] + lik->p[0], fabs(f[i]), &nt);
+            omega[i] = rand_pg(&g, 0, (double)y[i] + lik->p[0], fabs(f[i]), &nt);
         } break;
         case LIK_STUDENTT: { /* studentt.jl:46-48  Gamma((nu+1)/2, scale 2/(nu/sigma^2+(y-f)^2)) */
             const double *y = (const double *)yv;
@@ -541,14 +562,14 @@ AGPLO_API int agplo_aux_sample(const agplo_lik *lik, int64_t n, const void *yv, 
             }
             for (int k = 0; k < L; ++k)
                 omega[i * L + k] =
-                    rand_pg(&g, (double)(nout[i * L + k] + (int64_t)y[i * L + k]), fabs(f[i * L + k]), &nt);
+                    rand_pg(&g, k, (double)(nout[i * L + k] + (int64_t)y[i * L + k]), fabs(f[i * L + k]), &nt);
         } break;
         case LIK_POISSON: { /* poisson.jl:26-28 ; PGPoisson ntrand polyagammapoisson.jl:23-27 */
             const int32_t *y = (const int32_t *)yv;
             double lam = lik->p[0] * logistic_(-f[i]);
             int64_t nn = rand_poisson(&g, lam);
             nout[i] = nn;
-            omega[i] = rand_pg(&g, (double)(nn + y[i]), fabs(f[i]), &nt);
+            omega[i] = rand_pg(&g, 0, (double)(nn + y[i]), fabs(f[i]), &nt);
         } break;
         case LIK_LAPLACE: { /* laplace.jl:40-42  IG(1/(2 beta |y-f|), 2 * (2 beta)^-2) */
             const double *y = (const double *)yv;
@@ -562,7 +583,7 @@ AGPLO_API int agplo_aux_sample(const agplo_lik *lik, int64_t n, const void *yv, 
             double lam = lik->p[0] * logistic_(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
             int64_t nn = rand_poisson(&g, lam);
             nout[i] = nn;
-            omega[i] = rand_pg(&g, 0.5 + (double)nn, fabs(gg), &nt);
+            omega[i] = rand_pg(&g, 0, 0.5 + (double)nn, fabs(gg), &nt);
         } break;
         default:
             bad |= 2;
@@ -1231,10 +1252,10 @@ AGPLO_API int agplo_gibbs_points(const agplo_lik *lik, int64_t N, int M, const f
         int64_t *nn = nout ? nout + i * Lo : NULL;
         switch (lik->kind) {
         case LIK_BERNOULLI_LOGISTIC:
-            om[0] = rand_pg(&g, 1.0, fabs(fi[0]), &nt);
+            om[0] = rand_pg(&g, 0, 1.0, fabs(fi[0]), &nt);
             break;
         case LIK_NEGBINOMIAL:
-            om[0] = rand_pg(&g, (double)((const int32_t *)yv)[i] + lik->p[0], fabs(fi[0]), &nt);
+            om[0] = rand_pg(&g, 0, (double)((const int32_t *)yv)[i] + lik->p[0], fabs(fi[0]), &nt);
             break;
         case LIK_STUDENTT: {
             double nu = lik->p[0], sg = lik->p[1], d = ((const double *)yv)[i] - fi[0];
@@ -1251,12 +1272,12 @@ AGPLO_API int agplo_gibbs_points(const agplo_lik *lik, int64_t N, int M, const f
             for (int k = 0; k < Lf; ++k)
                 nn[k] = rand_poisson(&g, exp(lik->logtheta[k]) * logistic_(fi[k]) / sumth * theta / (1.0 - p0));
             for (int k = 0; k < Lf; ++k)
-                om[k] = rand_pg(&g, (double)(nn[k] + (int64_t)y[i * Lf + k]), fabs(fi[k]), &nt);
+                om[k] = rand_pg(&g, k, (double)(nn[k] + (int64_t)y[i * Lf + k]), fabs(fi[k]), &nt);
         } break;
         case LIK_POISSON: {
             int64_t n1 = rand_poisson(&g, lik->p[0] * logistic_(-fi[0]));
             nn[0] = n1;
-            om[0] = rand_pg(&g, (double)(n1 + ((const int32_t *)yv)[i]), fabs(fi[0]), &nt);
+            om[0] = rand_pg(&g, 0, (double)(n1 + ((const int32_t *)yv)[i]), fabs(fi[0]), &nt);
         } break;
         case LIK_LAPLACE: {
             double beta = lik->p[0], lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
@@ -1266,7 +1287,7 @@ AGPLO_API int agplo_gibbs_points(const agplo_lik *lik, int64_t N, int M, const f
             double yy = ((const double *)yv)[i];
             int64_t n1 = rand_poisson(&g, lik->p[0] * logistic_(-fi[1]) * (fi[0] - yy) * (fi[0] - yy) / 2.0);
             nn[0] = n1;
-            om[0] = rand_pg(&g, 0.5 + (double)n1, fabs(fi[1]), &nt);
+            om[0] = rand_pg(&g, 0, 0.5 + (double)n1, fabs(fi[1]), &nt);
         } break;
         default:
             bad |= 2;
