@@ -661,7 +661,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor16_kernel(
 // Work item w = tile * L + l: a workgroup's run keeps a tile's L latents together (the B images stay L2-hot).
 // MF16 selects v_mfma_f32_16x16x32_f16 (see marginal_factor16_kernel) or v_mfma_f32_32x32x16_f16 fragments.
 // ------------------------------------------------------------------------------------------------
-template <bool MF16>
+template <bool MF16, int PF>
 __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int64_t nitems, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const float *__restrict__ resid, const float *__restrict__ mu0, const h8 *__restrict__ Wh,
@@ -673,6 +673,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
     float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
     float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
     float *mred = qred + 2 * 4 * NT2;                                  // [2][4 x 256]
+    unsigned char *touch_lds = reinterpret_cast<unsigned char *>(mred + 2 * 4 * NT2); // [16 waves][256 B] (PF > 0)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
@@ -732,6 +733,57 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
     AGPL_PM_SRC();
     AGPL_PM_ISSUE(0);
 
+    // L2 touch prefetch (PF > 0): the point images (B) of stage t + 1 + PF, pulled towards L2 by one 4-byte LDS-DMA per
+    // 128-byte line -- lanes 0-15 of every wave cover the 16 lines of the two pieces the wave itself will move PF stages
+    // later.  Why: one 64 KB stage in flight per CU against ~2 us of HBM latency is ~34 GB/s per CU = the ~8.7 TB/s the
+    // kernel's LDS-DMA runs at (profiles/r02_pmc_sq_c2.json: waves parked on s_waitcnt / barriers 47 % of their cycles,
+    // matrix pipe 58 % busy); with the lines already in L2 the same ring covers a ~4x shorter latency.  The touch is the
+    // wave's YOUNGEST vector-memory operation at every stage top, so the wait there is vmcnt(1), not vmcnt(0): it never
+    // holds back the real pieces, and is itself covered two stage tops later.
+    int pw = 0, prb = 0, pks = 0, pl2 = l0;
+    unsigned ptile2 = tile0;
+    const h8 *pb_src = b_src;
+#define AGPL_PM_TADV()                                                                                      \
+    do {                                                                                                    \
+        pks += KU;                                                                                          \
+        if (pks == 16 * (prb + 1)) {                                                                        \
+            pks = 0;                                                                                        \
+            if (++prb == nb2) {                                                                             \
+                prb = 0;                                                                                    \
+                if (++pl2 == L) {                                                                           \
+                    pl2 = 0;                                                                                \
+                    ++ptile2;                                                                               \
+                }                                                                                           \
+                ++pw;                                                                                       \
+                if (pw < nit) {                                                                             \
+                    const int64_t t128_ = 2 * (int64_t)ptile2 + (ia >> 1) < ntiles128                       \
+                                              ? 2 * (int64_t)ptile2 + (ia >> 1) : ntiles128 - 1;            \
+                    pb_src = b_img + t128_ * nks * 256 + qd * 64;                                           \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+#define AGPL_PM_TOUCH()                                                                                     \
+    do {                                                                                                    \
+        touched = false;                                                                                    \
+        if (PF > 0 && pw < nit) {                                                                           \
+            if (lane_v < 16u)                                                                               \
+                __builtin_amdgcn_global_load_lds(                                                           \
+                    reinterpret_cast<const unsigned *>(pb_src + (int64_t)(pks + (lane_v >> 3)) * 256 +     \
+                                                       (lane_v & 7u) * 8),                                  \
+                    (lds_void *)(touch_lds + wave * 256), 4, 0, 0);                                         \
+            touched = true;                                                                                 \
+            AGPL_PM_TADV();                                                                                 \
+        }                                                                                                   \
+    } while (0)
+    bool touched = false;
+    if (PF > 0) {
+#pragma unroll 1
+        for (int i = 0; i < PF + 1; ++i)
+            if (pw < nit) AGPL_PM_TADV(); // the touch pointer runs PF stages ahead of the issue pointer (now at stage 1)
+    }
+
     constexpr int NJ = MF16 ? 4 : 2;
     float qacc[NJ], macc[NJ];
 #pragma unroll
@@ -763,7 +815,9 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
     int pend = -1, pl = 0;               // item whose reduced rows are still to be written (behind the next barrier)
     unsigned ptile = 0;
     for (int t = 0; t < T; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
+        // stage t has landed once nothing but this wave's last touch (if any) is in flight
+        if (PF > 0 && touched) __builtin_amdgcn_s_waitcnt(0x0F71);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
         if (rb == 0 && ks == 0) {
             // first stage of an item: v of its latent into the item's parity buffer (first read 8+ stages on; the
@@ -812,6 +866,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
                 for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][0] = mfma32(ah[i], bh, acc16[MF16 ? i : 0][0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < T) AGPL_PM_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
+                AGPL_PM_TOUCH();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
@@ -829,8 +884,9 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][jj] = mfma32(al[i], bh, acc16[MF16 ? i : 0][jj]);
                 }
-            } else if (t + 1 < T) {
-                AGPL_PM_ISSUE(t + 1);
+            } else {
+                if (t + 1 < T) AGPL_PM_ISSUE(t + 1);
+                AGPL_PM_TOUCH();
             }
         } else {
             h8 ah0, ah1, bh0, bh1, bl0, bl1;
@@ -844,6 +900,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < T) AGPL_PM_ISSUE(t + 1);
+            AGPL_PM_TOUCH();
             __builtin_amdgcn_sched_barrier(0);
             if (act) {
 #pragma unroll
@@ -958,6 +1015,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
             }
         }
     }
+#undef AGPL_PM_TOUCH
+#undef AGPL_PM_TADV
 #undef AGPL_PM_ISSUE
 #undef AGPL_PM_SRC
     __syncthreads();
@@ -1415,28 +1474,29 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
         marginal_factor_rows512_kernel<<<gridp, 1024, lds5, ctx->stream>>>(
             N, M, L, nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi, (const h8 *)U_lo, v,
             mu_out, var_out);
-    } else if (cfg == 116 || cfg == 132) {
+    } else if (cfg == 116 || cfg == 132 || (cfg >= 117 && cfg <= 119)) {
         // persistent form: one resident workgroup per CU over a contiguous run of (tile, latent) items
-        const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2);
+        const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 16 * 256;
         int dev = 0, ncu = 256;
         AGPL_HIP(ctx, hipGetDevice(&dev));
         AGPL_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         const int64_t nitems = agpl_cdiv(N, NT2) * L;
         if (nitems > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
         const unsigned gridp = (unsigned)(nitems < ncu ? nitems : ncu);
-        if (cfg == 116) {
-            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_persist_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            marginal_factor_persist_kernel<true><<<gridp, 1024, lds2, ctx->stream>>>(
-                N, M, L, agpl_cdiv(N, NT), nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
-                (const h8 *)U_lo, v, mu_out, var_out);
-        } else {
-            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_persist_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            marginal_factor_persist_kernel<false><<<gridp, 1024, lds2, ctx->stream>>>(
-                N, M, L, agpl_cdiv(N, NT), nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
-                (const h8 *)U_lo, v, mu_out, var_out);
-        }
+#define AGPL_LAUNCH_PERSIST(MF_, PF_)                                                                                \
+    do {                                                                                                             \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_persist_kernel<MF_, PF_>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                   \
+        marginal_factor_persist_kernel<MF_, PF_><<<gridp, 1024, lds2, ctx->stream>>>(                                \
+            N, M, L, agpl_cdiv(N, NT), nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0,                  \
+            (const h8 *)U_hi, (const h8 *)U_lo, v, mu_out, var_out);                                                 \
+    } while (0)
+        if (cfg == 116) AGPL_LAUNCH_PERSIST(true, 0);
+        else if (cfg == 117) AGPL_LAUNCH_PERSIST(true, 2);
+        else if (cfg == 118) AGPL_LAUNCH_PERSIST(true, 3);
+        else if (cfg == 119) AGPL_LAUNCH_PERSIST(true, 5);
+        else AGPL_LAUNCH_PERSIST(false, 0);
+#undef AGPL_LAUNCH_PERSIST
     } else if (cfg == 16) {
         const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor16_kernel),

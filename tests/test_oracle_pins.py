@@ -496,3 +496,43 @@ print("ASAN_RUN_OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ASAN_RUN_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_conditioning_budget_of_an_unwhitened_on_the_fly_marginal_pass():
+    """SURVEY.md 8(f3) / VERDICT r1 item 9: generating K_ZX tiles in-kernel means the marginal pass has to run as
+    T = (U L^-1) K_ZX instead of T = U Phi with the stored whitened features Phi = L^-1 K_ZX.  This is its conditioning
+    budget on the bench's own kernel (SE, lengthscale 1.5 x inducing spacing, jitter 1e-8), with the device's operand
+    format emulated exactly (every float32 operand carried as hi + lo float16, the lo x lo product dropped): the
+    un-whitened product loses more than an order of magnitude of accuracy in sum_a T[a,n]^2 (the variance projection),
+    which puts it AT the 1e-5 natural-parameter bar with no margin where the whitened path clears it by ~10x.
+    That is why row (f3) is not built: the images it would save cost the path its tolerance."""
+    import scipy.linalg as sla
+
+    rng = np.random.default_rng(0)
+    M, n = 256, 1500
+    z = np.linspace(-10, 10, M)
+    ell = 1.5 * (z[1] - z[0])
+    Kzz = np.exp(-0.5 * ((z[:, None] - z[None, :]) / ell) ** 2) + 1e-8 * np.eye(M)
+    Linv = sla.solve_triangular(np.linalg.cholesky(Kzz), np.eye(M), lower=True)
+    x = rng.uniform(-10, 10, n)
+    K = np.exp(-0.5 * ((z[:, None] - x[None, :]) / ell) ** 2)
+    Phi = Linv @ K
+    G = (Phi * (rng.uniform(0.05, 0.25, n) * 5000)) @ Phi.T  # a posterior as sharp as N = 1e7 points make it
+    U = sla.solve_triangular(np.linalg.cholesky(np.eye(M) + G), np.eye(M), lower=True)
+
+    def split(a):
+        a = a.astype(np.float32).astype(np.float64)
+        hi = a.astype(np.float16).astype(np.float64)
+        return hi, (a - hi).astype(np.float16).astype(np.float64)
+
+    def prod3(A, B):
+        Ah, Al = split(A)
+        Bh, Bl = split(B)
+        return Ah @ Bh + Ah @ Bl + Al @ Bh
+
+    q_ref = ((U @ Phi) ** 2).sum(0)
+    err_w = np.abs((prod3(U, Phi) ** 2).sum(0) - q_ref).max() / q_ref.max()
+    err_u = np.abs((prod3(U @ Linv, K) ** 2).sum(0) - q_ref).max() / q_ref.max()
+    assert err_w < 5e-6            # the shipped (whitened) operand pair
+    assert err_u > 10 * err_w      # the un-whitened pair: measured 18-30x worse (|U L^-1| ~ 12 against |U| ~ 0.4)
+    assert err_u > 1e-5            # i.e. at / above the bar before any accumulation error is added
