@@ -678,10 +678,6 @@ size_t syrk_split_lds_bytes() { return 2 * kStageBytes; }
 // instance that is the row panel of a diagonal unit.  Same f32 accumulation length (one slab per unit and slice),
 // same fixed-order float64 reduction behind it: bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
-constexpr int kStripPlanes = 4;                        // 8 points each: a stage is 32 points
-constexpr int kSImgSlots = kStripPlanes * 148;         // 16-byte slots per image (hi or lo of one panel instance)
-constexpr int kSImgBytes = kSImgSlots * 16;            // 9472
-constexpr int kSStageBytes = 4 * 2 * kSImgBytes;       // 4 instances x (hi | lo) = 75776
 constexpr int kTypeWords = 16 + 16 * 8;                // plan words per workgroup type
 constexpr int kSuper = 4;                              // slices per super-slice (lcm of the replications 1, 2, 4)
 
@@ -690,8 +686,12 @@ constexpr int kSuper = 4;                              // slices per super-slice
 // stage st + 1, then they swap (two barriers per stage).  In lock step (PP = false) every wave converts at the same
 // time and the matrix pipe idles meanwhile: measured 8.47 ms against 8.11 ms for syrk_split_kernel at C2, whose four
 // independent workgroups per CU drift apart and overlap by themselves.
-template <bool PP>
-__global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
+// NW / PLANES: 16 waves with 32-point stages (4 planes of 8 points; one workgroup per CU) or 8 waves with 16-point stages
+// (2 planes; two workgroups per CU, <= 8 sub-tiles each: typically {off-diagonal tile + the diagonal tile of one of its
+// panels}, which folds the diagonal workgroups' separate panel reads away).  Wave w stages (instance w / PLANES, plane
+// w % PLANES); at most NW / PLANES = 4 instances either way.
+template <int NW, int PLANES, bool PP>
+__global__ __launch_bounds__(NW * 64, 4) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
                                                              const float *__restrict__ Phi,
                                                              const float *__restrict__ sg_all,
                                                              const float *__restrict__ bp_all,
@@ -699,6 +699,10 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
                                                              const int *__restrict__ plan, int ntypes, int nE,
                                                              int nsuper) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int kSPts = 8 * PLANES;                      // points per stage
+    constexpr int kSImgSlots = PLANES * 148;               // 16-byte slots per image (hi or lo of one panel instance)
+    constexpr int kSImgBytes = kSImgSlots * 16;
+    constexpr int kSStageBytes = 4 * 2 * kSImgBytes;       // 4 instances x (hi | lo)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsuper8 = (nsuper + 7) / 8;
@@ -717,13 +721,13 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
     const int nb = M / BS;
 
     // ---- this wave's staging job: instance q, plane h
-    const int q = wave >> 2, plane = wave & 3;
+    const int q = wave / PLANES, plane = wave % PLANES;
     const int sq = s0 + ty[6 + q];
     const bool stager = q < npan && sq < nsplit;
     const int64_t nbeg_q = (int64_t)sq * kChunk;
     int64_t nend_q = nbeg_q + kChunk;
     if (nend_q > N) nend_q = N;
-    const int nstage_q = stager ? (int)((nend_q - nbeg_q + 31) / 32) : 0;
+    const int nstage_q = stager ? (int)((nend_q - nbeg_q + kSPts - 1) / kSPts) : 0;
     const int plast_q = (int)(nend_q - 1 - nbeg_q);
     const bool gjob = stager && ty[10 + q] != 0;
     // the longest instance sets the loop length (instances differ only when one of them is the last, short slice)
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
         if (i < npan && si < nsplit) {
             int64_t b = (int64_t)si * kChunk, en = b + kChunk;
             if (en > N) en = N;
-            const int ns = (int)((en - b + 31) / 32);
+            const int ns = (int)((en - b + kSPts - 1) / kSPts);
             nstage = ns > nstage ? ns : nstage;
         }
     }
@@ -778,12 +782,12 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
             const bool in_ = (st_) < nstage_q;                                                     \
             /* rows past the slice end are clamped to its last point (their scale is 0) */        \
             _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
-                int r_ = stq_ * 32 + p0 + k_;                                                      \
+                int r_ = stq_ * kSPts + p0 + k_;                                                      \
                 r_ = r_ < plast_q ? r_ : plast_q;                                                  \
                 x[k_] = *reinterpret_cast<const float4 *>(sbase + (size_t)r_ * rowpitch + colofs4); \
             }                                                                                      \
-            sv = *reinterpret_cast<const float4 *>((in_ ? sgs + stq_ * 128 : zeros) + p0b);        \
-            if (gjob) bv = *reinterpret_cast<const float4 *>((in_ ? bps + stq_ * 128 : zeros) + p0b); \
+            sv = *reinterpret_cast<const float4 *>((in_ ? sgs + stq_ * (4 * kSPts) : zeros) + p0b);        \
+            if (gjob) bv = *reinterpret_cast<const float4 *>((in_ ? bps + stq_ * (4 * kSPts) : zeros) + p0b); \
         }                                                                                          \
     } while (0)
 #define AGPL_ST_STORE(buf_, gkeep_)                                                                \
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
     do {                                                                                           \
         if (active) {                                                                              \
             const h8v *I = reinterpret_cast<const h8v *>(smem_raw + (buf_) * kSStageBytes);        \
-            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                     \
+            _Pragma("unroll") for (int s2 = 0; s2 < PLANES / 2; ++s2) {                                     \
                 const int o = s2 * 2 * 148;                                                        \
                 const h8v ah0 = I[fa + o], ah1 = I[fa + o + 8], bh0 = I[fb + o], bh1 = I[fb + o + 8]; \
                 acc[0][0] = mfma16(ah0, bh0, acc[0][0]);                                           \
@@ -859,7 +863,7 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
         __builtin_amdgcn_s_barrier();                              \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
     } while (0)
-        const int second = wave >= 8 ? 1 : 0;
+        const int second = wave >= NW / 2 ? 1 : 0;
         if (second) AGPL_ST_LOAD(1 < nstage ? 1 : 0);
         AGPL_ST_BAR();
         if (second) {
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
                 }
     }
     // g: lanes (2 fq, 2 fq + 1) hold the two point halves of features 4 fq ..; the instance's 4 planes are waves 4 q ..
-    float *gw = reinterpret_cast<float *>(smem_raw); // [16 waves][128] (the stage images are dead: last barrier passed)
+    float *gw = reinterpret_cast<float *>(smem_raw); // [NW waves][128] (the stage images are dead: last barrier passed)
     if (gjob) {
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) gacc[e2] += __shfl_xor(gacc[e2], 1);
@@ -922,14 +926,16 @@ __global__ __launch_bounds__(1024, 1) void syrk_strip_kernel(int64_t N, int64_t 
     }
     __syncthreads();
     if (gjob && plane == 0) {
-        const float *g4 = gw + wave * 128; // planes = waves 4 q .. 4 q + 3 (this wave is 4 q)
-        for (int f = lane; f < BS; f += 64)
-            slabg[(((int64_t)l * nb + ty[2 + q]) * nsplit + sq) * BS + f] =
-                (g4[f] + g4[128 + f]) + (g4[256 + f] + g4[384 + f]);
+        const float *g4 = gw + wave * 128; // the instance's planes = waves PLANES q .. PLANES q + PLANES - 1 (this is the first)
+        for (int f = lane; f < BS; f += 64) {
+            float acc_g = g4[f] + g4[128 + f];
+            if (PLANES == 4) acc_g = acc_g + (g4[256 + f] + g4[384 + f]);
+            slabg[(((int64_t)l * nb + ty[2 + q]) * nsplit + sq) * BS + f] = acc_g;
+        }
     }
 }
 
-size_t syrk_strip_lds_bytes() { return 2 * kSStageBytes; }
+size_t syrk_strip_lds_bytes(int planes) { return (size_t)2 * 4 * 2 * planes * 148 * 16; }
 
 
 size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT + 128); }
@@ -1078,24 +1084,27 @@ static void strip_add_panel(std::vector<int> &ps, int p) {
     ps.push_back(p);
 }
 
-static std::vector<int> syrk_strip_plan(int nb, int *ntypes_out, int *nE_out) {
+static std::vector<int> syrk_strip_plan(int nb, int max_sub, int *ntypes_out, int *nE_out) {
+    const int max_pan = 4;
     std::vector<StripChunk> ch;
     for (int bi = nb - 1; bi >= 0; --bi) {
         int c = bi - 1;
         StripChunk first;
         first.units.push_back({bi, bi});
         strip_add_panel(first.panels, bi);
-        for (int k = 0; k < 3 && c >= 0; ++k, --c) {
+        while (c >= 0 && first.subtiles() + 4 <= max_sub && (int)first.panels.size() < max_pan) {
             first.units.push_back({bi, c});
             strip_add_panel(first.panels, c);
+            --c;
         }
         ch.push_back(first);
         while (c >= 0) {
             StripChunk nx;
             strip_add_panel(nx.panels, bi);
-            for (int k = 0; k < 3 && c >= 0; ++k, --c) {
+            while (c >= 0 && nx.subtiles() + 4 <= max_sub && (int)nx.panels.size() < max_pan) {
                 nx.units.push_back({bi, c});
                 strip_add_panel(nx.panels, c);
+                --c;
             }
             ch.push_back(nx);
         }
@@ -1105,16 +1114,16 @@ static std::vector<int> syrk_strip_plan(int nb, int *ntypes_out, int *nE_out) {
     for (;;) {
         int a = -1;
         for (int i = 0; i < (int)ch.size(); ++i)
-            if (!done[i] && ch[i].subtiles() < 12 && (a < 0 || ch[i].subtiles() < ch[a].subtiles())) a = i;
+            if (!done[i] && ch[i].subtiles() < max_sub - 3 && (a < 0 || ch[i].subtiles() < ch[a].subtiles())) a = i;
         if (a < 0) break;
         int best_b = -1, best_fill = 0;
         for (int b = 0; b < (int)ch.size(); ++b) {
             if (b == a) continue;
             const int fill = ch[a].subtiles() + ch[b].subtiles();
-            if (fill > 16 || fill <= best_fill) continue;
+            if (fill > max_sub || fill <= best_fill) continue;
             std::vector<int> un = ch[b].panels;
             for (int p : ch[a].panels) strip_add_panel(un, p);
-            if ((int)un.size() > 4) continue;
+            if ((int)un.size() > max_pan) continue;
             best_fill = fill;
             best_b = b;
         }
@@ -1133,7 +1142,7 @@ static std::vector<int> syrk_strip_plan(int nb, int *ntypes_out, int *nE_out) {
     for (auto &c : ch) {
         const int P = (int)c.panels.size(), S = c.subtiles();
         int r = 1;
-        while (2 * r * P <= 4 && 2 * r * S <= 16 && 2 * r <= kSuper) r *= 2;
+        while (2 * r * P <= max_pan && 2 * r * S <= max_sub && 2 * r <= kSuper) r *= 2;
         reps.push_back(r);
         std::vector<int> w(kTypeWords, 0);
         w[0] = r;
@@ -1192,7 +1201,11 @@ extern "C" int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap,
                                                                                 int32_t *ntypes, int32_t *nentries) {
     if (nb <= 0 || !out || !ntypes || !nentries) return -1;
     int nt = 0, ne = 0;
-    const std::vector<int> w = syrk_strip_plan(nb, &nt, &ne);
+    // nb's upper half-word selects the 8-sub-tile plan of the 8-wave form (nb | 8 << 16); default 16 sub-tiles
+    const int max_sub = (nb >> 16) == 8 ? 8 : 16;
+    nb &= 0xFFFF;
+    if (nb <= 0) return -1;
+    const std::vector<int> w = syrk_strip_plan(nb, max_sub, &nt, &ne);
     if ((int)w.size() > cap) return -(int32_t)w.size();
     for (size_t i = 0; i < w.size(); ++i) out[i] = w[i];
     *ntypes = nt;
@@ -1301,35 +1314,41 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
             syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
                 N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg);
         } else {
-            if (ctx->strip_nb != nb) {
+            // forms: strip / pp = 16 waves, 32-point stages, one workgroup per CU; strip8 / pp8 = 8 waves, 16-point stages, two
+            // per CU (<= 8 sub-tiles: off-diagonal tile + the diagonal tile of one of its panels)
+            const bool eight = !strcmp(form, "strip8") || !strcmp(form, "pp8");
+            const bool pp = !strcmp(form, "pp") || !strcmp(form, "pp8");
+            const int key = nb | ((eight ? 8 : 16) << 16);
+            if (ctx->strip_nb != key) {
                 int nt = 0, ne = 0;
-                const std::vector<int> w = syrk_strip_plan(nb, &nt, &ne);
+                const std::vector<int> w = syrk_strip_plan(nb, eight ? 8 : 16, &nt, &ne);
                 AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (ctx->strip_plan) AGPL_HIP(ctx, hipFree(ctx->strip_plan));
                 ctx->strip_plan = nullptr;
                 ctx->strip_nb = 0;
                 AGPL_HIP(ctx, hipMalloc((void **)&ctx->strip_plan, sizeof(int) * w.size()));
                 AGPL_HIP(ctx, hipMemcpy(ctx->strip_plan, w.data(), sizeof(int) * w.size(), hipMemcpyHostToDevice));
-                ctx->strip_nb = nb;
+                ctx->strip_nb = key;
                 ctx->strip_ntypes = nt;
                 ctx->strip_nE = ne;
             }
             const int nsuper = (ns + kSuper - 1) / kSuper;
             const int64_t nwg2 = (int64_t)L * ctx->strip_nE * ((nsuper + 7) / 8) * 8;
             if (nwg2 > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-            if (form && !strcmp(form, "strip")) { // lock-step form, kept for A/B runs
-                AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_strip_lds_bytes()));
-                syrk_strip_kernel<false><<<(unsigned)nwg2, 1024, syrk_strip_lds_bytes(), ctx->stream>>>(
-                    N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes,
-                    ctx->strip_nE, nsuper);
-            } else {
-                AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_strip_lds_bytes()));
-                syrk_strip_kernel<true><<<(unsigned)nwg2, 1024, syrk_strip_lds_bytes(), ctx->stream>>>(
-                    N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes,
-                    ctx->strip_nE, nsuper);
-            }
+#define AGPL_LAUNCH_STRIP(NW_, PL_, PP_)                                                                              \
+    do {                                                                                                              \
+        const size_t lds_ = syrk_strip_lds_bytes(PL_);                                                                \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<NW_, PL_, PP_>),          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                    \
+        syrk_strip_kernel<NW_, PL_, PP_><<<(unsigned)nwg2, NW_ * 64, lds_, ctx->stream>>>(                            \
+            N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes, ctx->strip_nE,    \
+            nsuper);                                                                                                  \
+    } while (0)
+            if (eight && pp) AGPL_LAUNCH_STRIP(8, 2, true);
+            else if (eight) AGPL_LAUNCH_STRIP(8, 2, false);
+            else if (pp) AGPL_LAUNCH_STRIP(16, 4, true);
+            else AGPL_LAUNCH_STRIP(16, 4, false);
+#undef AGPL_LAUNCH_STRIP
         }
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);

@@ -122,12 +122,13 @@ class SparseCAVI:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 marginal_precision: str = "f32", accumulate_precision: str = "f32"):
-        """``marginal_precision``: "f32" = float32-input MFMA marginal pass (default); "f16x2" = the split-float16
+                 marginal_precision: str = "auto", accumulate_precision: str = "f16x2"):
+        """``marginal_precision``: "auto" (default) = the shipped path, i.e. "f16x2-factor" when the feature count is a
+        multiple of 256, else "f16x2"; "f32" = float32-input MFMA marginal pass; "f16x2" = the split-float16
         pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM);
         "f16x2-factor" = the one-pass factor form of the same (agpl_marginals_factor_split: the update keeps
         U = chol(I + G)^-1 and v = U g instead of S and m; M % 256 == 0).
-        ``accumulate_precision``: "f32" or "f16x2" for G = Phi diag(gamma) Phi'."""
+        ``accumulate_precision``: "f16x2" (default, what bench.py measures) or "f32" for G = Phi diag(gamma) Phi'."""
         torch = _torch()
         self.ctx = ctx or default_context()
         self.lik = lik
@@ -140,8 +141,11 @@ class SparseCAVI:
         self.y = _prep_y(lik, y, torch.float32)
         self.mu0 = _prep(mu0, torch.float32, "mu0")
         self.group = group
+        if marginal_precision == "auto":
+            marginal_precision = "f16x2-factor" if self.M % 256 == 0 else "f16x2"
         if marginal_precision not in ("f32", "f16x2", "f16x2-factor"):
-            raise _ffi.ArgumentError(-1, "marginal_precision must be 'f32', 'f16x2' or 'f16x2-factor'")
+            raise _ffi.ArgumentError(-1, "marginal_precision must be 'auto', 'f32', 'f16x2' or 'f16x2-factor'")
+        self.marginal_precision = marginal_precision
         self.factor = marginal_precision == "f16x2-factor"
         if self.factor and self.M % 256:
             raise _ffi.ArgumentError(-1, f"the factor form needs a feature count that is a multiple of 256 (got {self.M})")
@@ -335,7 +339,7 @@ class SparseGibbs:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 accumulate_precision: str = "f32", point_offset: int = 0):
+                 accumulate_precision: str = "f16x2", point_offset: int = 0):
         torch = _torch()
         self.ctx = ctx or default_context()
         if accumulate_precision not in ("f32", "f16x2"):

@@ -58,7 +58,8 @@ SHIPPED = {"marginal_precision": "f16x2-factor", "accumulate_precision": "f16x2"
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("likname,N,M,kw", [("bernoulli", 30_001, 64, {}), ("bernoulli", 30_001, 200, SHIPPED),
+@pytest.mark.parametrize("likname,N,M,kw", [("bernoulli", 30_001, 64, {"marginal_precision": "f32", "accumulate_precision": "f32"}),
+                                            ("bernoulli", 30_001, 200, SHIPPED),
                                             # BASELINE config C3's likelihood and M, sharded: NegBin r = 15, M = 1024 (the
                                             # two-block factor route on every rank, identical on both)
                                             ("negbin", 20_000, 1024, SHIPPED)])

@@ -401,7 +401,7 @@ def test_cavi_natural_parameters_match_oracle(A, ctx, oracle, name, N, M):
         y = dev(yh) if name == "poisson" else dev(yh, torch.float32)
     else:
         x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, keep_points=True)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, keep_points=True, marginal_precision="f32", accumulate_precision="f32")  # the float32-MFMA kernels
     Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
     Mp, L = Phi_h.shape[1], olik.nlatent
     S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
@@ -443,7 +443,7 @@ def test_cavi_reference_example_lengthscale_whitened(A, ctx, oracle):
     Phi_h = np.zeros((N, 128), dtype=np.float32)
     Phi_h[:, :M] = K64 @ Linv.T
     kd_h = np.maximum(1.0 - (Phi_h.astype(np.float64) ** 2).sum(1), 0.0)
-    cavi = A.SparseCAVI(lik, dev(Phi_h), dev(kd_h, torch.float32), y, ctx=ctx)
+    cavi = A.SparseCAVI(lik, dev(Phi_h), dev(kd_h, torch.float32), y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
     S, m = np.eye(128)[None], np.zeros((1, 128))
     for _ in range(10):
         cavi.sweep()
@@ -617,7 +617,7 @@ def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
     lik, olik = A.BernoulliLikelihood(), O.bernoulli()
     N, M = 6000, 64
     x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
     Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
     Mp = Phi_h.shape[1]
     vals = []
@@ -1135,3 +1135,57 @@ def test_allreduce_nat_on_a_one_rank_rccl_communicator(A, ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ------------------------------------------------------------------------------------------ kernel variants (A/B forms)
+@pytest.mark.parametrize("stage", ["22", "16", "132", "512", "117"])
+def test_factor_marginal_kernel_variants_agree_with_the_shipped_one(A, ctx, stage, monkeypatch):
+    """The selectable forms of the factor-form marginal pass (AGPL_MARGINAL_STAGE is read per call) against the
+    shipped persistent 16x16x32 kernel on a ragged size with two latents: same q(f_n) to float32 round-off."""
+    import ctypes as C
+
+    rng = np.random.default_rng(3)
+    N, M, L = 3001, 512, 2
+    Phi = dev((rng.normal(size=(N, M)) * 0.05).astype(np.float32))
+    kd = dev(rng.uniform(0.1, 1.0, size=N).astype(np.float32))
+    lik = A.CategoricalLikelihood(np.zeros(L))
+    y = dev((rng.integers(0, L, size=N)[:, None] == np.arange(L)[None, :]).astype(np.uint8))
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)  # default = the shipped path
+    assert cavi.marginal_precision == "f16x2-factor"
+    try:
+        monkeypatch.delenv("AGPL_MARGINAL_STAGE", raising=False)
+        for _ in range(2):
+            cavi.sweep()
+        cavi.check()
+        mu0, var0 = (t.clone() for t in cavi.marginals())
+        monkeypatch.setenv("AGPL_MARGINAL_STAGE", stage)
+        mu1, var1 = cavi.marginals()
+        torch.cuda.synchronize()
+    finally:
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+    assert torch.isfinite(mu1).all() and torch.isfinite(var1).all()
+    assert relmax(host(mu1), host(mu0)) < 3e-6 and relmax(host(var1), host(var0)) < 3e-6
+
+
+@pytest.mark.parametrize("form", ["strip", "pp", "strip8", "pp8"])
+@pytest.mark.parametrize("N,M,L", [(70001, 512, 1), (9000, 1024, 1), (5000, 384, 2), (31, 128, 1)])
+def test_strip_accumulation_forms_are_bit_identical_on_G(A, ctx, split_accumulate, form, N, M, L, monkeypatch):
+    """syrk_strip_kernel (AGPL_SYRK is read per call) against the shipped tile kernel: the same
+    accumulation order per output element, so G must come out bit for bit the same; g (float32 partial sums in another order) to 2e-6."""
+    import ctypes as C
+
+    rng = np.random.default_rng(17 + M)
+    Phi = dev((rng.normal(size=(N, M)) * 0.3).astype(np.float32))
+    gam = dev(rng.uniform(0.01, 0.25, size=(L, N)).astype(np.float32))
+    bet = dev(rng.normal(size=(L, N)).astype(np.float32))
+    out = []
+    for f in ("tile", form):
+        monkeypatch.setenv("AGPL_SYRK", f)
+        G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+        g = torch.empty((L, M), dtype=torch.float64, device="cuda")
+        ctx.call("agpl_accumulate", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(Phi.data_ptr()),
+                 C.c_void_p(bet.data_ptr()), C.c_void_p(gam.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()))
+        torch.cuda.synchronize()
+        out.append((G, g))
+    assert torch.equal(out[0][0], out[1][0])
+    assert relmax(host(out[1][1]), host(out[0][1])) < 2e-6  # f32 partial sums of random-sign terms in another order

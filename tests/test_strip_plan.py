@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TYPE_WORDS, SUPER = 16 + 16 * 8, 4
 
 
-def plan(nb):
+def plan(nb, max_sub=16):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
 
@@ -26,7 +26,7 @@ def plan(nb):
     lib = C.CDLL(lib_path)
     buf = (C.c_int32 * 200000)()
     nt, ne = C.c_int32(), C.c_int32()
-    n = lib.agpl_debug_strip_plan(C.c_int32(nb), buf, C.c_int32(len(buf)), C.byref(nt), C.byref(ne))
+    n = lib.agpl_debug_strip_plan(C.c_int32(nb | ((8 << 16) if max_sub == 8 else 0)), buf, C.c_int32(len(buf)), C.byref(nt), C.byref(ne))
     assert n > 0
     w = np.frombuffer(buf, dtype=np.int32, count=n).copy()
     types = w[: nt.value * TYPE_WORDS].reshape(nt.value, TYPE_WORDS)
@@ -34,16 +34,17 @@ def plan(nb):
     return types, ents
 
 
+@pytest.mark.parametrize("max_sub", [16, 8])
 @pytest.mark.parametrize("nb", list(range(1, 11)) + [16])
-def test_strip_plan_covers_the_lower_triangle_exactly_once(nb):
-    types, ents = plan(nb)
+def test_strip_plan_covers_the_lower_triangle_exactly_once(nb, max_sub):
+    types, ents = plan(nb, max_sub)
     cover = {}   # (slice, unit, wr, wc) -> count
     gcount = {}  # (slice, panel) -> count
     stagings = 0
     for t, k0 in ents:
         ty = types[t]
         r, npan, nsub = ty[0], ty[1], ty[14]
-        assert 1 <= npan <= 4 and 1 <= nsub <= 16 and r in (1, 2, 4) and k0 % r == 0 and k0 + r <= SUPER
+        assert 1 <= npan <= 4 and 1 <= nsub <= max_sub and r in (1, 2, 4) and k0 % r == 0 and k0 + r <= SUPER
         pan, psl, gfl = ty[2:6], ty[6:10], ty[10:14]
         assert all(0 <= pan[i] < nb and 0 <= psl[i] < r for i in range(npan))
         assert len({(pan[i], psl[i]) for i in range(npan)}) == npan  # no instance staged twice
@@ -71,7 +72,7 @@ def test_strip_plan_covers_the_lower_triangle_exactly_once(nb):
     # what the form is for: fewer panel stagings per slice than one 128 x 128 tile per workgroup (nb diagonal tiles
     # stage one panel, nb (nb - 1) / 2 off-diagonal tiles two)
     if nb >= 4:
-        assert stagings / SUPER <= 0.7 * nb * nb
+        assert stagings / SUPER <= (0.7 if max_sub == 16 else 0.8) * nb * nb
 
 
 def test_strip_plan_m512_is_the_documented_decomposition():
@@ -79,3 +80,15 @@ def test_strip_plan_m512_is_the_documented_decomposition():
     assert len(types) == 3 and len(ents) == 4 + 4 + 2  # T0, T1 per slice; T2 per two slices
     by_panels = sorted((tuple(int(p) for p in t[2:2 + t[1]]), int(t[0]), int(t[14])) for t in types)
     assert by_panels == [((1, 0, 1, 0), 2, 14), ((2, 1, 0), 1, 14), ((3, 2, 1, 0), 1, 15)]
+
+
+def test_strip_plan_m512_eight_wave_form_folds_the_diagonal_tiles():
+    """The 8-wave form (<= 8 sub-tiles): every diagonal unit shares a workgroup with an off-diagonal unit of one of its
+    panels, so no workgroup stages a panel for a diagonal tile alone: 11 stagings per slice instead of 16."""
+    types, ents = plan(4, 8)
+    per_slice = sum(types[t][1] for t, _ in ents) / SUPER
+    assert per_slice == 11
+    for ty in types:
+        units = {int(ty[16 + 8 * s + 5]) for s in range(ty[14])}
+        diag = {u for u in units if u in (0, 2, 5, 9)}
+        assert not diag or len(units) > len(diag)  # a diagonal unit never sits alone
