@@ -439,13 +439,15 @@ template <bool DIAG>
 __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const float *__restrict__ sbase, int M,
                                                 int bi, int bj, int nstage, int plast,
                                                 const float *__restrict__ sgs, const float *__restrict__ bps,
-                                                f32x16 (&acc)[2][2], float (&gacc)[4]) {
+                                                f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
-    const bool active = !(DIAG && wr < wc);
+    // diag_full (AGPL_SYRK_DIAGFULL=1, experiment): the sub-tile above the diagonal of a diagonal tile is multiplied too, so
+    // that diagonal workgroups keep the pace of the off-diagonal ones that read the same panel (L2 sharing)
+    const bool active = !(DIAG && wr < wc) || diag_full;
     constexpr int PQ = DIAG ? 2 : 4; // points per thread
     const int panel = DIAG ? 0 : (wave >> 1);
     const int plane = wave & 1;
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
                                                             const float *__restrict__ Phi,
                                                             const float *__restrict__ sg_all,
                                                             const float *__restrict__ bp_all,
-                                                            float *__restrict__ slabG, float *__restrict__ slabg) {
+                                                            float *__restrict__ slabG, float *__restrict__ slabg,
+                                                            int diag_full) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nsplit8 = (nsplit + 7) / 8;
@@ -624,9 +627,9 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     float gacc[4] = {0.f, 0.f, 0.f, 0.f};
 
     if (diag)
-        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc);
+        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, diag_full != 0);
     else
-        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc);
+        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, false);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1311,8 +1314,9 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         const char *form = getenv("AGPL_SYRK");
         const bool tile_form = !form || !strcmp(form, "tile");
         if (tile_form) {
+            const char *df = getenv("AGPL_SYRK_DIAGFULL");
             syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
-                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg);
+                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0);
         } else {
             // forms: strip / pp = 16 waves, 32-point stages, one workgroup per CU; strip8 / pp8 = 8 waves, 16-point stages, two
             // per CU (<= 8 sub-tiles: off-diagonal tile + the diagonal tile of one of its panels)

@@ -1038,6 +1038,261 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// marginal_factor_queue_kernel: marginal_factor_persist_kernel<true> with the work cut one level finer and handed out
+// dynamically.  An item is ONE 256-row block of U against one (tile, latent); the items of a tile are queued back to
+// back, longest first, in eight queues (tiles t = q mod 8 in queue q; a workgroup serves queue blockIdx.x & 7, i.e.
+// under round-robin dispatch the queues line up with the XCDs -- for speed only, never correctness).  Resident
+// workgroups take the next item of their queue whenever they finish one, so the row blocks of a tile are picked up
+// within about a microsecond of each other by different CUs of one XCD and stream the tile's point images (B) through
+// the same L2 at the same time: the images reach the fabric once per tile instead of once per row block (round-1 / persistent
+// kernels: 1.56 x the image bytes at M = 512, 2.5 x at M = 1024).  The per-point sums of the row blocks go to two partial
+// arrays [row block][latent][N]; marginal_combine_kernel adds them to the residual in a fixed order (bitwise
+// reproducible: no atomics on the outputs).  The next-but-one item is fetched by ONE returning atomic per item, issued in
+// the first stage of an item and written to LDS in the second: its latency hides behind a whole stage.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
+    int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
+    const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
+    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int R = 2, KU = 2;
+    constexpr int kSlot = KU * 8 * 4096;
+    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
+    float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
+    float *mred = qred + 2 * 4 * NT2;                                  // [2][4 x 256]
+    int *qi = reinterpret_cast<int *>(mred + 2 * 4 * NT2);             // [4] queue indices of this workgroup's items
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
+    const unsigned lane_v = (unsigned)lane;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
+    const int qn = (int)(blockIdx.x & 7);
+    const int ntq = qn < ntiles2 ? (ntiles2 - qn + 7) / 8 : 0;
+    const int nitems = ntq * L * nb2;
+    unsigned *queue = queues + qn;
+
+    if (threadIdx.x == 0) qi[0] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+
+    const int ia = wave >> 2, qd = wave & 3;
+    const h8 *a_img = (ia & 1) ? Wl : Wh, *b_img = (ia & 1) ? Pl : Ph;
+    const int dma_off = ia * 4096 + qd * 1024;
+
+    // item k of this workgroup = queue index qi[k & 3]: (tile, latent, 256-row block), longest row block first
+#define AGPL_Q_DECODE(k_, valid_, tile_, l_, rb_)                                                           \
+    do {                                                                                                    \
+        const int j_ = __builtin_amdgcn_readfirstlane(qi[(k_) & 3]);                                        \
+        valid_ = j_ >= 0 && j_ < nitems;                                                                    \
+        const int jl_ = j_ / nb2;                                                                           \
+        rb_ = nb2 - 1 - (j_ - jl_ * nb2);                                                                   \
+        const int tq_ = jl_ / L;                                                                            \
+        l_ = jl_ - tq_ * L;                                                                                 \
+        tile_ = tq_ * 8 + qn;                                                                               \
+    } while (0)
+
+    int ik = 0, irb = 0, iks = 0, il = 0, itile = 0; // issue pointer
+    bool ivalid;
+    AGPL_Q_DECODE(0, ivalid, itile, il, irb);
+    if (!ivalid) return; // this queue is empty (uniform over the workgroup)
+    const h8 *a_src, *b_src;
+#define AGPL_Q_SRC()                                                                                        \
+    do {                                                                                                    \
+        const int64_t t128_ = 2 * (int64_t)itile + (ia >> 1) < ntiles128 ? 2 * (int64_t)itile + (ia >> 1)   \
+                                                                         : ntiles128 - 1;                   \
+        a_src = a_img + ((int64_t)il * nb + 2 * irb + (ia >> 1)) * nks * 256 + qd * 64;                     \
+        b_src = b_img + t128_ * nks * 256 + qd * 64;                                                        \
+    } while (0)
+    typedef __attribute__((address_space(3))) void lds_void;
+#define AGPL_Q_ISSUE(t_)                                                                                    \
+    do {                                                                                                    \
+        if (ivalid) {                                                                                       \
+            unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + dma_off;                                 \
+            _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                             \
+                __builtin_amdgcn_global_load_lds(a_src + (int64_t)(iks + u_) * 256 + lane_v,                \
+                                                 (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);            \
+                __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256 + lane_v,                \
+                                                 (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0); \
+            }                                                                                               \
+            iks += KU;                                                                                      \
+            if (iks == 16 * (irb + 1)) {                                                                    \
+                iks = 0;                                                                                    \
+                ++ik;                                                                                       \
+                AGPL_Q_DECODE(ik, ivalid, itile, il, irb);                                                  \
+                if (ivalid) AGPL_Q_SRC();                                                                   \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+    AGPL_Q_SRC();
+    AGPL_Q_ISSUE(0);
+
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f}, macc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ck = 0, rb = 0, ks = 0, cl = 0, ctile = 0; // consume pointer
+    bool cvalid;
+    AGPL_Q_DECODE(0, cvalid, ctile, cl, rb);
+    int pend = -1, pl = 0, prb = 0, ptile = 0;
+    unsigned fetched = 0u; // thread 0: the queue index fetched in the first stage of the item, stored in its second
+    bool fetch_pending = false;
+    for (int t = 0; cvalid; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
+        __builtin_amdgcn_s_barrier();
+        if (fetch_pending) {
+            if (threadIdx.x == 0) qi[(ck + 1) & 3] = (int)fetched;
+            fetch_pending = false;
+        }
+        if (ks == 0) {
+            // first stage of an item: v of its latent into the item's parity buffer
+            float *as = alpha_s + (ck & 1) * M;
+            for (int a = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); a < M;
+                 a += 1024)
+                as[a] = v_all[(int64_t)cl * M + a];
+        }
+        if (ks == 16 * (rb + 1) - 4 * KU) {
+            // four stages before the item ends: take the NEXT item of the queue -- as late as the pipeline allows (its
+            // index is stored next stage, visible the stage after, decoded by the issue pointer in the stage after that),
+            // so that the workgroups that take the row blocks of one tile start them within a stage or two of each other
+            if (threadIdx.x == 0) fetched = atomicAdd(queue, 1u);
+            fetch_pending = true;
+        }
+        if (pend >= 0) {
+            // the previous item's per-wave partial sums are in LDS (written before this barrier): rows out
+            const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if (tid_e < NT2) {
+                const int64_t n = (int64_t)ptile * NT2 + tid_e;
+                if (n < N) {
+                    const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
+                    const int64_t o = ((int64_t)prb * L + pl) * N + n;
+                    qpart[o] = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
+                    mpart[o] = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
+                }
+            }
+            pend = -1;
+        }
+        // U is lower triangular: this wave's rows 64 wr .. 64 wr + 63 of block rb are zero from slice 16 rb + 4 (wr + 1)
+        const bool act = ks < rb * 16 + 4 * (wr + 1);
+        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & 1) * kSlot);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int kg = ln >> 4;
+        const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
+        const int fa = fbase16 + (wr >> 1) * 512 + (wr & 1) * 64;
+        const int fb = fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
+        if (act) {
+            h8 ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ah[i] = st[fa + 16 * i];
+            h8 bh = st[fb], bl = st[256 + fb];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bh, acc[i][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            AGPL_Q_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j > 0) {
+                    bh = st[fb + 16 * j];
+                    bl = st[256 + fb + 16 * j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bh, acc[i][j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bl, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(al[i], bh, acc[i][j]);
+            }
+        } else {
+            AGPL_Q_ISSUE(t + 1);
+        }
+        ks += KU;
+        if (ks == 16 * (rb + 1)) {
+            // item finished: q_n = sum_a T[a,n]^2, m_n = sum_a v_a T[a,n] over this row block; lane rows a = 16 i + 4 kg + 0..3
+            const float *asrc = alpha_s + (ck & 1) * M + rb * NT2 + wr * 64 + 4 * kg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 16 * i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 &c = acc[i][j];
+                    qacc[j] += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+                    macc[j] += a0.x * c[0] + a0.y * c[1] + a0.z * c[2] + a0.w * c[3];
+                    c = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            float *qr = qred + (ck & 1) * 4 * NT2, *mr = mred + (ck & 1) * 4 * NT2;
+            const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qacc[j] += __shfl_xor(qacc[j], 16);
+                qacc[j] += __shfl_xor(qacc[j], 32);
+                macc[j] += __shfl_xor(macc[j], 16);
+                macc[j] += __shfl_xor(macc[j], 32);
+            }
+            if (lane_e < 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    qr[wr * NT2 + wc * 64 + 16 * j + lane_e] = qacc[j];
+                    mr[wr * NT2 + wc * 64 + 16 * j + lane_e] = macc[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qacc[j] = macc[j] = 0.f;
+            pend = ck;
+            pl = cl;
+            prb = rb;
+            ptile = ctile;
+            ks = 0;
+            ++ck;
+            AGPL_Q_DECODE(ck, cvalid, ctile, cl, rb);
+        }
+    }
+#undef AGPL_Q_ISSUE
+#undef AGPL_Q_SRC
+#undef AGPL_Q_DECODE
+    __syncthreads();
+    if (pend >= 0) {
+        const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (tid_e < NT2) {
+            const int64_t n = (int64_t)ptile * NT2 + tid_e;
+            if (n < N) {
+                const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
+                const int64_t o = ((int64_t)prb * L + pl) * N + n;
+                qpart[o] = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
+                mpart[o] = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
+            }
+        }
+    }
+}
+
+// var_n = resid_n + sum_rb qpart[rb][l][n], mu_n = mu0_n + sum_rb mpart[rb][l][n]  (row blocks in ascending order)
+__global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L, int nb2, const float *__restrict__ resid,
+                                                               const float *__restrict__ mu0,
+                                                               const float *__restrict__ qpart,
+                                                               const float *__restrict__ mpart,
+                                                               float *__restrict__ mu_out, float *__restrict__ var_out) {
+    const int64_t total = (int64_t)L * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i % N;
+        float q = 0.f, m = 0.f;
+        for (int rb = 0; rb < nb2; ++rb) {
+            q += qpart[(int64_t)rb * total + i];
+            m += mpart[(int64_t)rb * total + i];
+        }
+        if (mu0) m += mu0[i];
+        mu_out[i] = m;
+        var_out[i] = resid[n] + q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // marginal_factor_rows512_kernel: the factor-form pass with ALL accumulators of a 512-row pass resident, so that a
 // point's feature images are read from HBM once per 512 rows of U instead of once per 256 (M = 512: 1.0 x the image
 // bytes instead of 1.5 x; M = 1024: 1.5 x instead of 2.5 x -- the round-1 kernel moved 32 GB per launch at C2, 4.8 TB/s,
@@ -1444,11 +1699,13 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     // tuning knob: AGPL_MARGINAL_STAGE = <ring slots R><16-deep slices per stage KU>.  Measured at C2 on one box:
     // 41 9.73 ms, 31 9.84, 21 9.91, 22 9.33 (two slices per barrier, one 64 KB stage in flight) -> default 22
-    // AGPL_MARGINAL_STAGE (read per call: A/B runs in one process): 116 = persistent workgroups on 16x16x32 MFMA (default:
-    // 6.35 against 6.70 ms at C2, 1.98 against 2.65 ms at C4, same box), 132 = persistent on 32x32x16, 16 = one workgroup
-    // per tile on 16x16x32, 512 = all 512 rows resident (reads the images once, but 2.7x the stages per point: 8.7 ms),
-    // 22 / 41 / 31 / 21 = the round-1 kernel with <ring slots><slices per stage>
-    const int cfg = getenv("AGPL_MARGINAL_STAGE") ? atoi(getenv("AGPL_MARGINAL_STAGE")) : 116;
+    // AGPL_MARGINAL_STAGE (read per call: A/B runs in one process): 200 = resident workgroups on 16x16x32 MFMA serving
+    // per-XCD queues of (tile, latent, row block) items (default: 6.31-6.36 against 6.67-6.78 ms for the round-1 kernel at
+    // C2 on the same box, 1.92 against 2.63 ms at C4, and 20.6 GB fetched over the fabric instead of 31.9 GB), 116 = the same
+    // with a static run of whole tiles per workgroup, 132 = that on 32x32x16, 16 = one workgroup per tile on 16x16x32,
+    // 117-119 = 116 + L2 touch prefetch, 512 = all 512 rows resident (reads the images once, but 2.7x the stages per point:
+    // 8.7 ms), 22 / 41 / 31 / 21 = the round-1 kernel with <ring slots><slices per stage>
+    const int cfg = getenv("AGPL_MARGINAL_STAGE") ? atoi(getenv("AGPL_MARGINAL_STAGE")) : 200;
     dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
     int32_t rc = agpl_timing_begin(ctx, 0);
     if (rc) return rc;
@@ -1461,7 +1718,35 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
             N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,  \
             (const h8 *)U_lo, v, mu_out, var_out);                                                                   \
     } while (0)
-    if (cfg == 512 && M % 512 == 0) {
+    if (cfg == 200) {
+        // dynamic per-XCD queues of (tile, latent, row block) items: the row blocks of a tile share its images through L2
+        const int nb2 = M / NT2;
+        const int64_t ntiles2 = agpl_cdiv(N, NT2);
+        if (ntiles2 * L * nb2 > 0x3fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
+        const size_t part_bytes = sizeof(float) * (size_t)nb2 * L * N;
+        // the partial sums live at the base of the workspace (the slab region of the accumulation that follows them in a
+        // sweep; a caller that keeps mu / var in the workspace has reserved more than this already: no reallocation)
+        rc = agpl_ws_reserve(ctx, 2 * part_bytes + 256);
+        if (rc) return rc;
+        rc = agpl_ws2_reserve(ctx, 16384);
+        if (rc) return rc;
+        float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
+        unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192);
+        AGPL_HIP(ctx, hipMemsetAsync(queues, 0, 8 * sizeof(unsigned), ctx->stream));
+        const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
+        int dev = 0, ncu = 256;
+        AGPL_HIP(ctx, hipGetDevice(&dev));
+        AGPL_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_queue_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+        marginal_factor_queue_kernel<<<(unsigned)ncu, 1024, ldsq, ctx->stream>>>(
+            N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi,
+            (const h8 *)U_lo, v, qpart, mpart, queues);
+        AGPL_LAUNCH_CHECK(ctx);
+        int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
+        if (nbk > 8192) nbk = 8192;
+        marginal_combine_kernel<<<(unsigned)nbk, 256, 0, ctx->stream>>>(N, L, nb2, resid, mu0, qpart, mpart, mu_out, var_out);
+    } else if (cfg == 512 && M % 512 == 0) {
         const size_t lds5 = (size_t)3 * 10 * 4096 + sizeof(float) * (size_t)(2 * M + 32 * NT5);
         int dev = 0, ncu = 256;
         AGPL_HIP(ctx, hipGetDevice(&dev));

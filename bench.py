@@ -125,10 +125,10 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     ex_m = (1.0 + 64.0 / Mp) if (marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
     ex_s = (nbk + 0.5) / nbk
     executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
-    # kernel names as the library picks them (agpl_split.hip / agpl_mfma.hip defaults): the factor form runs persistent
-    # workgroups on 16x16x32 MFMA; the split accumulation is syrk_split_kernel unless AGPL_SYRK selects a strip form
+    # kernel names as the library picks them (agpl_split.hip / agpl_mfma.hip defaults): the factor form runs resident
+    # workgroups on 16x16x32 MFMA serving per-XCD item queues; the split accumulation is syrk_split_kernel unless AGPL_SYRK selects a strip form
     strip = os.environ.get("AGPL_SYRK") in ("strip", "pp")
-    names = (("marginal_factor_persist_kernel" if marginal == "f16x2-factor" else
+    names = (("marginal_factor_queue_kernel" if marginal == "f16x2-factor" else
               "marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
              ("syrk_strip_kernel" if strip else "syrk_split_kernel") if accumulate == "f16x2" else "syrk_kernel")
     mult = (3.0 if msplit else 1.0, 3.0 if accumulate == "f16x2" else 1.0)

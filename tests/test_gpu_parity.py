@@ -1138,10 +1138,10 @@ def test_allreduce_nat_on_a_one_rank_rccl_communicator(A, ctx):
 
 
 # ------------------------------------------------------------------------------------------ kernel variants (A/B forms)
-@pytest.mark.parametrize("stage", ["22", "16", "132", "512", "117"])
+@pytest.mark.parametrize("stage", ["22", "16", "132", "116", "512", "117"])
 def test_factor_marginal_kernel_variants_agree_with_the_shipped_one(A, ctx, stage, monkeypatch):
     """The selectable forms of the factor-form marginal pass (AGPL_MARGINAL_STAGE is read per call) against the
-    shipped persistent 16x16x32 kernel on a ragged size with two latents: same q(f_n) to float32 round-off."""
+    shipped queue-served 16x16x32 kernel on a ragged size with two latents: same q(f_n) to float32 round-off."""
     import ctypes as C
 
     rng = np.random.default_rng(3)

@@ -10,7 +10,7 @@ root, out = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-KEEP = ("marginal_factor_persist_kernel", "marginal_split256_kernel", "marginal_factor16_kernel", "syrk_strip_kernel",
+KEEP = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "marginal_factor16_kernel", "syrk_strip_kernel",
         "syrk_split_kernel", "factor_kernel", "reduce_slab_kernel", "aux_sample_kernel", "gibbs_project_kernel",
         "gibbs_sample_kernel")
 
