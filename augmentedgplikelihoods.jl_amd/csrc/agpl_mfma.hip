@@ -439,7 +439,8 @@ template <bool DIAG>
 __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const float *__restrict__ sbase, int M,
                                                 int bi, int bj, int nstage, int plast,
                                                 const float *__restrict__ sgs, const float *__restrict__ bps,
-                                                f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full) {
+                                                f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full,
+                                                unsigned *start_ctr, unsigned npartners) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,6 +542,18 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
 
     AGPL_SS_LOAD(0);
     AGPL_SS_STORE(0, 1.f);
+    if (start_ctr) {
+        // start hint: the workgroups of a slice are dispatched one per freed slot, ~8 us apart first to last, while an XCD's
+        // L2 holds ~4 us of its traffic; waiting here -- behind the first stage's loads and stores, in front of the barrier
+        // that follows them anyway; bounded at ~16 us: a hint, never a dependency (a workgroup whose partners do not show up
+        // simply goes on) -- until all of them have arrived lets them stream the slice's panels through L2 together:
+        // 1.21-1.26 x the algorithmic bytes fetched instead of 1.78 x
+        if (tid == 0) {
+            __hip_atomic_fetch_add(start_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int it = 0; it < 64 && __hip_atomic_load(start_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < npartners; ++it)
+                __builtin_amdgcn_s_sleep(8);
+        }
+    }
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
@@ -607,20 +620,6 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
     const int bj = p - bi * (bi + 1) / 2;
     const bool diag = (bi == bj);
-    if (start_ctr) {
-        // start hint: the workgroups of a slice are dispatched one per freed slot, ~8 us apart first to last, while an XCD's
-        // L2 holds ~4 us of its traffic; waiting here (bounded at ~16 us: a hint, never a dependency -- a workgroup whose
-        // partners do not show up simply goes on) until all npairs of them have arrived lets them stream the slice's panels
-        // through L2 together: 1.21 x the algorithmic bytes fetched instead of 1.78 x
-        if (tid == 0) {
-            unsigned *c = start_ctr + (size_t)l * nsplit + s;
-            __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int it = 0; it < 64 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)npairs; ++it)
-                __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-    }
-
     const int64_t nbeg = (int64_t)s * kChunk;
     int64_t nend = nbeg + kChunk;
     if (nend > N) nend = N;
@@ -640,9 +639,11 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     float gacc[4] = {0.f, 0.f, 0.f, 0.f};
 
     if (diag)
-        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, diag_full != 0);
+        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, diag_full != 0,
+                              start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs);
     else
-        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, false);
+        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, false,
+                               start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1328,13 +1329,14 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         const char *form = getenv("AGPL_SYRK");
         const bool tile_form = !form || !strcmp(form, "tile");
         if (tile_form) {
-            // start hint (AGPL_SYRK_SYNCSTART=0 / 1 forces it off / on): FETCH_SIZE at C2 24.7 GB instead of 36.5 GB for 8.41
-            // against 8.31 ms (profiles/r02_pmc_traffic_c2.json).  On by default up to 10 tile pairs per slice
-            // (M <= 512); beyond, the 36+ workgroups of a slice are dispatched over more than the wait bound and the hint costs
-            // more than it is worth (M = 1024: +4.5 %)
+            // start hint (AGPL_SYRK_SYNCSTART=0 / 1 forces it off / on): FETCH_SIZE at C2 24.4-25.8 GB instead of 36.5 GB for
+            // 1.2-2 % more time (8.41-8.44 against 8.28-8.31 ms; profiles/r02_pmc_traffic_c2.json).  On by default
+            // up to 10 tile pairs per slice (M <= 512) and from 1024 slices on: with 36+ workgroups per slice (M = 1024) they are
+            // dispatched over more than the wait bound (+4.5 %), and on a short launch (N / 8 per rank: 3 workgroup rounds) the
+            // waits are not amortised (+6 %)
             const char *df = getenv("AGPL_SYRK_DIAGFULL"), *ss = getenv("AGPL_SYRK_SYNCSTART");
             unsigned *start_ctr = nullptr;
-            if (ss ? ss[0] == '1' : npairs <= 10) {
+            if (ss ? ss[0] == '1' : (npairs <= 10 && ns >= 1024)) {
                 start_ctr = (unsigned *)((char *)slab_mem + lo.ctr);
                 AGPL_HIP(ctx, hipMemsetAsync(start_ctr, 0, sizeof(unsigned) * (size_t)L * ns, ctx->stream));
             }
