@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
                                                             const float *__restrict__ sg_all,
                                                             const float *__restrict__ bp_all,
                                                             float *__restrict__ slabG, float *__restrict__ slabg,
-                                                            int diag_full, unsigned *__restrict__ start_ctr) {
+                                                            int diag_full, unsigned *__restrict__ start_ctr, int prio_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nsplit8 = (nsplit + 7) / 8;
@@ -615,6 +615,29 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     const int s = (j / npairs) * 8 + xcd;
     const int p = j % npairs;
     if (s >= nsplit) return;
+    if (prio_mode) {
+        // static issue priorities that differ between groups of workgroups (AGPL_SYRK_PRIO; 2 = by block id / 256 is the
+        // default, 0 = off): the matrix pipe's 51 % duty is one wave's duty cycle -- the four waves on a SIMD (one per
+        // co-resident workgroup) interleave their MFMA blocks instruction by instruction, finish together and convert
+        // together.  Measured (profiles/r02_ab_syrk_priority.jsonl): mode 2 takes 1 % off at C2 and 4.5 % off at M = 1024
+        // (26.7 against 27.9-28.1 ms); priorities by the hardware's workgroup / wave slot (modes 4, 3), by slice (5), by tile
+        // pair (6) or hashed (1) change nothing
+        const unsigned h = prio_mode == 4   ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) // HW_ID.TG_ID
+                           : prio_mode == 3 ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4)  // HW_ID.WAVE_ID
+                           : prio_mode == 2 ? (blockIdx.x >> 8)
+                           : prio_mode == 5 ? (unsigned)(j / npairs)
+                           : prio_mode == 6 ? (unsigned)p
+                           : prio_mode == 7 ? 3u - ((blockIdx.x >> 8) & 3u)
+                           : prio_mode == 8 ? (blockIdx.x >> 7)
+                           : prio_mode == 9 ? (blockIdx.x >> 9)
+                                            : ((blockIdx.x * 2654435761u) >> 13);
+        switch (h & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
     const int nb = M / BS;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
@@ -1341,7 +1364,8 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
                 AGPL_HIP(ctx, hipMemsetAsync(start_ctr, 0, sizeof(unsigned) * (size_t)L * ns, ctx->stream));
             }
             syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
-                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr);
+                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr,
+                getenv("AGPL_SYRK_PRIO") ? atoi(getenv("AGPL_SYRK_PRIO")) : 2);
         } else {
             // forms: strip / pp = 16 waves, 32-point stages, one workgroup per CU; strip8 / pp8 = 8 waves, 16-point stages, two
             // per CU (<= 8 sub-tiles: off-diagonal tile + the diagonal tile of one of its panels)

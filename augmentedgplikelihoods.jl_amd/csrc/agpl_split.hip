@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
-    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues) {
+    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues, int prio_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int R = 2, KU = 2;
     constexpr int kSlot = KU * 8 * 4096;
@@ -1066,6 +1066,15 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
     const unsigned lane_v = (unsigned)lane;
     const int wr = wave >> 2, wc = wave & 3;
+    if (prio_mode) { // experiment (AGPL_MARGINAL_PRIO): static issue priority per wave row / column
+        const int h = prio_mode == 1 ? wr : prio_mode == 2 ? 3 - wr : wc;
+        switch (h & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
     const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
     const int qn = (int)(blockIdx.x & 7);
     const int ntq = qn < ntiles2 ? (ntiles2 - qn + 7) / 8 : 0;
@@ -1741,7 +1750,7 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
         marginal_factor_queue_kernel<<<(unsigned)ncu, 1024, ldsq, ctx->stream>>>(
             N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi,
-            (const h8 *)U_lo, v, qpart, mpart, queues);
+            (const h8 *)U_lo, v, qpart, mpart, queues, getenv("AGPL_MARGINAL_PRIO") ? atoi(getenv("AGPL_MARGINAL_PRIO")) : 0);
         AGPL_LAUNCH_CHECK(ctx);
         int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
         if (nbk > 8192) nbk = 8192;
