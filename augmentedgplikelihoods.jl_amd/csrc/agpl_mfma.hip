@@ -1352,14 +1352,13 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         const char *form = getenv("AGPL_SYRK");
         const bool tile_form = !form || !strcmp(form, "tile");
         if (tile_form) {
-            // start hint (AGPL_SYRK_SYNCSTART=0 / 1 forces it off / on): FETCH_SIZE at C2 24.4-25.8 GB instead of 36.5 GB for
-            // 1.2-2 % more time (8.41-8.44 against 8.28-8.31 ms; profiles/r02_pmc_traffic_c2.json).  On by default
-            // up to 10 tile pairs per slice (M <= 512) and from 1024 slices on: with 36+ workgroups per slice (M = 1024) they are
-            // dispatched over more than the wait bound (+4.5 %), and on a short launch (N / 8 per rank: 3 workgroup rounds) the
-            // waits are not amortised (+6 %)
+            // start hint (AGPL_SYRK_SYNCSTART=1; off by default): FETCH_SIZE at C2 24.4-25.8 GB instead of 36.5 GB, but 1.2-2 %
+            // more kernel time (8.41-8.44 against 8.28-8.31 ms same box; 16.22 against 15.90 ms per sweep in bench.py), +4.5 % at
+            // M = 1024 (36 workgroups per slice are dispatched over more than the wait bound) and +6 % on a short launch (N / 8
+            // per rank).  The traffic was not what the kernel waited for, so the faster setting ships.
             const char *df = getenv("AGPL_SYRK_DIAGFULL"), *ss = getenv("AGPL_SYRK_SYNCSTART");
             unsigned *start_ctr = nullptr;
-            if (ss ? ss[0] == '1' : (npairs <= 10 && ns >= 1024)) {
+            if (ss && ss[0] == '1') {
                 start_ctr = (unsigned *)((char *)slab_mem + lo.ctr);
                 AGPL_HIP(ctx, hipMemsetAsync(start_ctr, 0, sizeof(unsigned) * (size_t)L * ns, ctx->stream));
             }
