@@ -440,7 +440,7 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
                                                 int bi, int bj, int nstage, int plast,
                                                 const float *__restrict__ sgs, const float *__restrict__ bps,
                                                 f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full,
-                                                unsigned *start_ctr, unsigned npartners) {
+                                                unsigned *start_ctr, unsigned npartners, bool dbg_same) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -560,7 +560,10 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
         // unconditional (the last iteration re-loads its own stage): a conditional load would make x a phi of
         // loaded / not-loaded values and the copies would wait for the loads before the MFMAs
         const bool more = st + 1 < nstage;
-        AGPL_SS_LOAD(more ? st + 1 : st);
+        // dbg_same (AGPL_SYRK_PRIO bit 8): every stage re-reads stage 0 -- wrong sums, a timing experiment that takes the
+        // memory system out of the loop: 6.86 against 8.25 ms at C2 with four workgroups per CU, 7.22 against 8.98 ms with
+        // three (AGPL_SYRK_LDSPAD=15000) -- DESIGN 4.4d
+        AGPL_SS_LOAD(dbg_same ? 0 : (more ? st + 1 : st));
         __builtin_amdgcn_sched_barrier(0); // keep the loads above the MFMA block
         if (active) {
             const h8v *I = reinterpret_cast<const h8v *>(smem_raw + buf * kStageBytes);
@@ -615,21 +618,22 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     const int s = (j / npairs) * 8 + xcd;
     const int p = j % npairs;
     if (s >= nsplit) return;
-    if (prio_mode) {
+    const int pm = prio_mode & 255; // bit 8: same-stage timing experiment (syrk_split_body dbg_same)
+    if (pm) {
         // static issue priorities that differ between groups of workgroups (AGPL_SYRK_PRIO; 2 = by block id / 256 is the
         // default, 0 = off): the matrix pipe's 51 % duty is one wave's duty cycle -- the four waves on a SIMD (one per
         // co-resident workgroup) interleave their MFMA blocks instruction by instruction, finish together and convert
         // together.  Measured (profiles/r02_ab_syrk_priority.jsonl): mode 2 takes 1 % off at C2 and 4.5 % off at M = 1024
         // (26.7 against 27.9-28.1 ms); priorities by the hardware's workgroup / wave slot (modes 4, 3), by slice (5), by tile
         // pair (6) or hashed (1) change nothing
-        const unsigned h = prio_mode == 4   ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) // HW_ID.TG_ID
-                           : prio_mode == 3 ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4)  // HW_ID.WAVE_ID
-                           : prio_mode == 2 ? (blockIdx.x >> 8)
-                           : prio_mode == 5 ? (unsigned)(j / npairs)
-                           : prio_mode == 6 ? (unsigned)p
-                           : prio_mode == 7 ? 3u - ((blockIdx.x >> 8) & 3u)
-                           : prio_mode == 8 ? (blockIdx.x >> 7)
-                           : prio_mode == 9 ? (blockIdx.x >> 9)
+        const unsigned h = pm == 4   ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) // HW_ID.TG_ID
+                           : pm == 3 ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4)  // HW_ID.WAVE_ID
+                           : pm == 2 ? (blockIdx.x >> 8)
+                           : pm == 5 ? (unsigned)(j / npairs)
+                           : pm == 6 ? (unsigned)p
+                           : pm == 7 ? 3u - ((blockIdx.x >> 8) & 3u)
+                           : pm == 8 ? (blockIdx.x >> 7)
+                           : pm == 9 ? (blockIdx.x >> 9)
                                             : ((blockIdx.x * 2654435761u) >> 13);
         switch (h & 3u) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -663,10 +667,10 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
 
     if (diag)
         syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, diag_full != 0,
-                              start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs);
+                              start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs, (prio_mode & 256) != 0);
     else
         syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, false,
-                               start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs);
+                               start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs, (prio_mode & 256) != 0);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1362,7 +1366,9 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
                 start_ctr = (unsigned *)((char *)slab_mem + lo.ctr);
                 AGPL_HIP(ctx, hipMemsetAsync(start_ctr, 0, sizeof(unsigned) * (size_t)L * ns, ctx->stream));
             }
-            syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(
+            // AGPL_SYRK_LDSPAD: extra dynamic LDS per workgroup (occupancy experiments: 15000 -> three workgroups per CU)
+            const size_t ldspad = getenv("AGPL_SYRK_LDSPAD") ? (size_t)atoi(getenv("AGPL_SYRK_LDSPAD")) : 0;
+            syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes() + ldspad, ctx->stream>>>(
                 N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr,
                 getenv("AGPL_SYRK_PRIO") ? atoi(getenv("AGPL_SYRK_PRIO")) : 2);
         } else {
@@ -1431,6 +1437,79 @@ extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t 
     int32_t rc = agpl_ws_reserve(ctx, agpl_slab_bytes(N, M, L));
     if (rc) return rc;
     return agpl_accumulate_impl(ctx, N, M, L, Phi, beta, gamma, G_out, g_out, ctx->ws);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Measured float16 MFMA rate under sustained load (the ceiling the split contractions are priced against next to the
+// data-sheet peak): v_mfma_f32_32x32x16_f16 back to back, 12 per step into four 32 x 32 accumulators -- the instruction
+// mix of one 16-point stage of syrk_split_kernel's wave -- with (mode 1) or without (mode 0) the stage's eight 16-byte
+// fragment reads from LDS.  Launches are long (milliseconds) and repeated so that the clock the power management
+// settles on is the one measured.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void mfma_f16_probe_kernel(int iters, float *__restrict__ sink) {
+    __shared__ h8v frag[8][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int f = 0; f < 8; ++f) {
+        h8v v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (_Float16)((((lane * 7 + k * 13 + f * 29 + wave) & 63) - 31.5f) * 0.03125f);
+        frag[f][threadIdx.x] = v;
+    }
+    __syncthreads();
+    h8v ah0 = frag[0][threadIdx.x], ah1 = frag[1][threadIdx.x], al0 = frag[2][threadIdx.x], al1 = frag[3][threadIdx.x];
+    h8v bh0 = frag[4][threadIdx.x], bh1 = frag[5][threadIdx.x], bl0 = frag[6][threadIdx.x], bl1 = frag[7][threadIdx.x];
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 1) {
+            const int o = (threadIdx.x + i) & 255; // a changing address: the reads cannot be hoisted
+            ah0 = frag[0][o]; ah1 = frag[1][o]; bh0 = frag[4][o]; bh1 = frag[5][o];
+        }
+        c00 = mfma16(ah0, bh0, c00); c01 = mfma16(ah0, bh1, c01); c10 = mfma16(ah1, bh0, c10); c11 = mfma16(ah1, bh1, c11);
+        if (MODE == 1) { const int o = (threadIdx.x + i + 1) & 255; bl0 = frag[6][o]; bl1 = frag[7][o]; }
+        c00 = mfma16(ah0, bl0, c00); c01 = mfma16(ah0, bl1, c01); c10 = mfma16(ah1, bl0, c10); c11 = mfma16(ah1, bl1, c11);
+        if (MODE == 1) { const int o = (threadIdx.x + i + 2) & 255; al0 = frag[2][o]; al1 = frag[3][o]; }
+        c00 = mfma16(al0, bh0, c00); c01 = mfma16(al0, bh1, c01); c10 = mfma16(al1, bh0, c10); c11 = mfma16(al1, bh1, c11);
+        if (MODE == 0) { ah0 = -ah0; bl1 = -bl1; } // bounded sums, changing operands
+    }
+    const f32x16 s = c00 + c01 + c10 + c11;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s[k];
+    if (t == 1.2345e30f) sink[0] = t; // never true: keeps the chain alive
+}
+} // namespace
+
+extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
+                                       double *tflops_host, double *ms_host) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (iters <= 0 || !tflops_host || (mode != 0 && mode != 1) || workgroups_per_cu < 1 || workgroups_per_cu > 4)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    int32_t rc = agpl_ws2_reserve(ctx, 4096);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    AGPL_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    hipEvent_t e0, e1;
+    AGPL_HIP(ctx, hipEventCreate(&e0));
+    AGPL_HIP(ctx, hipEventCreate(&e1));
+    const int blocks = prop.multiProcessorCount * workgroups_per_cu, reps = 6;
+    for (int rep = 0; rep < 2 + reps; ++rep) { // two untimed launches settle the clocks, `reps` launches are one timed region
+        if (rep == 2) AGPL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        if (mode == 0) mfma_f16_probe_kernel<0><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
+        else mfma_f16_probe_kernel<1><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
+    }
+    AGPL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    AGPL_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    AGPL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    AGPL_LAUNCH_CHECK(ctx);
+    const double flop = (double)reps * blocks * 4.0 * (double)iters * 12.0 * (2.0 * 32 * 32 * 16);
+    *tflops_host = flop / ((double)ms * 1e-3) / 1e12;
+    if (ms_host) *ms_host = ms / reps;
+    return AGPL_OK;
 }
 
 extern "C" int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode) {

@@ -163,6 +163,26 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
             "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
 
 
+def sustained_f16(ctx, roofline):
+    """The float16 MFMA rate this device SUSTAINS (agpl_probe_mfma_f16: the accumulation kernel's own instruction mix, 12
+    MFMAs + 8 LDS fragment reads per step, nothing else, four waves per SIMD, ~40 ms of back-to-back launches): under
+    matrix load the clock settles well below the boost clock the 2.5 PFLOP/s data-sheet peak assumes, so this -- not
+    `peak` -- is what a perfect kernel of this shape could execute.  Added next to `peak`/`frac`, which stay the guide's."""
+    import ctypes as C
+    from agpl_amd import _ffi
+
+    tf, ms = C.c_double(0), C.c_double(0)
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f16(ctx.bind(), C.c_int32(5000), C.c_int32(1), C.c_int32(4),
+                                                          C.byref(tf), C.byref(ms)))
+    roofline["sustained_mfma_f16"] = {
+        "tflops": round(tf.value, 1), "frac_of_peak": round(tf.value / PEAK_F16_MFMA_TFLOPS, 3),
+        "probe": "agpl_probe_mfma_f16(mode 1: 12 v_mfma_f32_32x32x16_f16 + 8 ds_read_b128 per step, 4 waves/SIMD), "
+                 "6 launches of %.1f ms timed as one region" % ms.value}
+    for k in roofline["kernels"]:
+        if k.get("executed_mfma_tflops") and k["mfma_dtype"].startswith("f16"):
+            k["executed_frac_of_sustained"] = round(k["executed_mfma_tflops"] / tf.value, 4)
+
+
 def parity_slice(A, ctx, lik, likname, Phi, kd, y, marginal, accumulate, nsweeps=10, ns=20_000):
     """GPU vs oracle on a slice of the same workload: `nsweeps` full CAVI sweeps (10), natural parameters
     compared at the end (and after the first sweep)."""
@@ -386,6 +406,8 @@ def main():
     value = args.steps / dt
     roofline = roofline_of(kt, L, n_loc, M, Mp, args.marginal, args.accumulate, ms_per_step, world, N,
                            traffic_key={"lik": args.lik, "N": N, "M": M, "L": L})
+    if world == 1:
+        sustained_f16(ctx, roofline)
 
     out = {
         "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",

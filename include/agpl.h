@@ -246,6 +246,15 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *   ("FP64 peak is not in the local guide -- measure, don't assume").  Synchronous.              */
 AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host);
 
+/* agpl_probe_mfma_f16: SUSTAINED float16 MFMA rate of this device [TFLOP/s]: v_mfma_f32_32x32x16_f16 in the instruction
+ *   mix of one stage of the split accumulation's wave (12 per step into four 32 x 32 accumulators), six launches of
+ *   `iters` steps per wave timed as one region after two that settle the clocks, `workgroups_per_cu` (1..4) 4-wave
+ *   workgroups per CU.  mode 0: MFMA only; mode 1: with that stage's eight 16-byte LDS fragment reads.  The ceiling
+ *   bench.py reports next to the data-sheet peak (the clock under MFMA load is below the boost clock).  ms_host (may be
+ *   NULL): average launch duration.  Synchronous.                                                              */
+AGPL_API int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
+                                     double *tflops_host, double *ms_host);
+
 /* agpl_debug_strip_plan: the host-built decomposition the strip form of the split accumulation executes (AGPL_SYRK =
  *   strip | pp, agpl_mfma.hip syrk_strip_plan), for `nb` block rows of 128 features, as the device reads it: `ntypes`
  *   workgroup types of 144 words each, then `nentries` (type, first slice) pairs per super-slice of 4 slices.  Host

@@ -22,6 +22,7 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--m", type=int, default=512)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--forms", default="tile,strip")
+ap.add_argument("--envs", default="", help="';'-separated VAR=VALUE variants of the tile form to compare instead of forms")
 args = ap.parse_args()
 
 ctx = A.Context(0, seed=bench.SEED)
@@ -35,8 +36,12 @@ cavi.check()
 ref = None
 out = {"lik": args.lik, "N": args.n, "M": args.m, "L": A.nlatent(lik), "results": {}}
 for rnd in range(2):
-    for form in args.forms.split(","):
-        os.environ["AGPL_SYRK"] = form
+    for form in (args.envs.split(";") if args.envs else args.forms.split(",")):
+        if args.envs:
+            k, v = form.split("=")
+            os.environ[k] = v
+        else:
+            os.environ["AGPL_SYRK"] = form
         cavi.accumulate()
         torch.cuda.synchronize()
         _ffi.lib().agpl_timing_enable(ctx.bind(), 1)

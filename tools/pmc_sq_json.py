@@ -45,6 +45,16 @@ for k, d in acc.items():
         for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
             if n in c:
                 e["frac_" + n] = round(c[n] / c["SQ_WAVE_CYCLES"], 4)
+    # in-flight-count accumulators / instruction counts: mean latency in the counter's own tick (the ratio of the two
+    # is unit-free: how many LDS round trips one global load takes)
+    if c.get("SQ_INSTS_VMEM_RD") and "SQ_INST_LEVEL_VMEM" in c:
+        e["vmem_latency_ticks"] = round(c["SQ_INST_LEVEL_VMEM"] / c["SQ_INSTS_VMEM_RD"], 2)
+    if c.get("SQ_INSTS_LDS") and "SQ_INST_LEVEL_LDS" in c:
+        e["lds_latency_ticks"] = round(c["SQ_INST_LEVEL_LDS"] / c["SQ_INSTS_LDS"], 2)
+        if "vmem_latency_ticks" in e:
+            e["vmem_over_lds_latency"] = round(e["vmem_latency_ticks"] / e["lds_latency_ticks"], 1)
+    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+        e["lds_busy_frac_of_cu_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256), 3)
     res["kernels"][k] = e
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters"} for k, v in res["kernels"].items()}, indent=1))

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Sustained float16 MFMA rate of the device (agpl_probe_mfma_f16), one JSON line per (mode, workgroups per CU).
+Usage: python3 tools/probe_mfma.py [iters]"""
+import ctypes as C, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import agpl_amd as A
+from agpl_amd import _ffi
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+ctx = A.Context(seed=1)
+for mode in (0, 1):
+    for wpc in (1, 2, 4):
+        tf, ms = C.c_double(0), C.c_double(0)
+        _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f16(ctx.bind(), C.c_int32(iters // wpc), C.c_int32(mode),
+                                                              C.c_int32(wpc), C.byref(tf), C.byref(ms)))
+        print(json.dumps({"mode": ["mfma", "mfma+lds fragment reads"][mode], "workgroups_per_cu": wpc,
+                          "waves_per_simd": wpc, "tflops": round(tf.value, 1), "ms_per_launch": round(ms.value, 3),
+                          "frac_of_2500": round(tf.value / 2500, 3)}), flush=True)
