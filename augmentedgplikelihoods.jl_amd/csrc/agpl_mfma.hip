@@ -592,14 +592,6 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
     }
 #undef AGPL_SS_LOAD
 #undef AGPL_SS_STORE
-    if (DIAG) {
-        // lanes 4k..4k+3 hold the four point pairs of feature quad 16 (w >> 1) + k over this wave's plane
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gacc[e] += __shfl_xor(gacc[e], 1);
-            gacc[e] += __shfl_xor(gacc[e], 2);
-        }
-    }
 }
 
 __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
@@ -607,7 +599,10 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
                                                             const float *__restrict__ sg_all,
                                                             const float *__restrict__ bp_all,
                                                             float *__restrict__ slabG, float *__restrict__ slabg,
-                                                            int diag_full, unsigned *__restrict__ start_ctr, int prio_mode) {
+                                                            int diag_full, unsigned *__restrict__ start_ctr, int prio_mode,
+                                                            int ngrouped, int group) {
+    // nsplit counts work UNITS here: unit u < ngrouped covers `group` consecutive 4096-point slices (one f32 accumulation
+    // run of group x 4096 points, one slab), the units behind them one slice each -- see agpl_accumulate_impl
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nsplit8 = (nsplit + 7) / 8;
@@ -647,14 +642,8 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
     const int bj = p - bi * (bi + 1) / 2;
     const bool diag = (bi == bj);
-    const int64_t nbeg = (int64_t)s * kChunk;
-    int64_t nend = nbeg + kChunk;
-    if (nend > N) nend = N;
-    const int nstage = (int)((nend - nbeg + 15) / 16);
-    const int plast = (int)(nend - 1 - nbeg);
-    const float *sbase = Phi + nbeg * (int64_t)M;
-    const float *sgs = sg_all + (int64_t)l * Npad + nbeg;
-    const float *bps = bp_all + (int64_t)l * Npad + nbeg;
+    const int first = s < ngrouped ? s * group : ngrouped * group + (s - ngrouped);
+    const int count = s < ngrouped ? group : 1;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -665,12 +654,35 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
             for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
     float gacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (diag)
-        syrk_split_body<true>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, diag_full != 0,
-                              start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs, (prio_mode & 256) != 0);
-    else
-        syrk_split_body<false>(smem_raw, sbase, M, bi, bj, nstage, plast, sgs, bps, acc, gacc, false,
-                               start_ctr ? start_ctr + (size_t)l * nsplit + s : nullptr, (unsigned)npairs, (prio_mode & 256) != 0);
+    // the tile kind is decided once, outside the slice loop: one loop per body instance (a branch inside the loop makes the
+    // accumulators a merge of both bodies' and spills them)
+#define AGPL_SLICES(DIAG_, DF_)                                                                                          \
+    for (int q = 0; q < count; ++q) {                                                                                    \
+        const int64_t nbeg = (int64_t)(first + q) * kChunk;                                                              \
+        int64_t nend = nbeg + kChunk;                                                                                    \
+        if (nend > N) nend = N;                                                                                          \
+        const int nstage = (int)((nend - nbeg + 15) / 16);                                                               \
+        const int plast = (int)(nend - 1 - nbeg);                                                                        \
+        unsigned *hint = (start_ctr && q == 0) ? start_ctr + (size_t)l * nsplit + s : nullptr;                           \
+        /* (the body leaves through a barrier behind its last LDS reads: the next slice may restage at once) */          \
+        syrk_split_body<DIAG_>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast,                              \
+                               sg_all + (int64_t)l * Npad + nbeg, bp_all + (int64_t)l * Npad + nbeg, acc, gacc, DF_,     \
+                               hint, (unsigned)npairs, (prio_mode & 256) != 0);                                          \
+    }
+    if (diag) {
+        AGPL_SLICES(true, diag_full != 0)
+    } else {
+        AGPL_SLICES(false, false)
+    }
+#undef AGPL_SLICES
+    if (diag) {
+        // lanes 4k..4k+3 hold the four point pairs of feature quad 16 (w >> 1) + k over this wave's plane
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gacc[e] += __shfl_xor(gacc[e], 1);
+            gacc[e] += __shfl_xor(gacc[e], 2);
+        }
+    }
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1343,6 +1355,7 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
+    int nu = ns, ngu = ng; // slabs per tile / reduction groups actually written (the tile form of the split path may group slices)
     if (ctx->accumulate_split) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         float *sg = (float *)((char *)slab_mem + lo.sgam);
@@ -1368,9 +1381,25 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
             }
             // AGPL_SYRK_LDSPAD: extra dynamic LDS per workgroup (occupancy experiments: 15000 -> three workgroups per CU)
             const size_t ldspad = getenv("AGPL_SYRK_LDSPAD") ? (size_t)atoi(getenv("AGPL_SYRK_LDSPAD")) : 0;
-            syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes() + ldspad, ctx->stream>>>(
-                N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr,
-                getenv("AGPL_SYRK_PRIO") ? atoi(getenv("AGPL_SYRK_PRIO")) : 2);
+            // Slice grouping (AGPL_SYRK_GROUP = g > 1; off by default): a workgroup runs g consecutive slices through the same
+            // accumulators and writes ONE slab, all but the last AGPL_SYRK_TAIL slices (default: two rounds of the 1024
+            // resident workgroups) -- the f32 slabs (1.6 GB written here and read back by reduce_slab_kernel at C2) shrink to
+            // ~1/g.  Measured at C2 (profiles/r02_ab_syrk_group.jsonl): g = 4 saves 0.2 ms of reductions and costs 0.13 ms
+            // in this kernel (8.42 against 8.29 ms: the ten workgroups of a slice start together but the diagonal ones run
+            // ~15 % faster, so from the second slice of a group on they no longer share the panels in L2) -- 15.79 against
+            // 15.86 ms per sweep, inside the box-to-box noise, for a 4 x longer f32 accumulation run.  Not worth a default.
+            int group = 1;
+            int tail = (int)((2 * 1024 + (int64_t)L * npairs - 1) / ((int64_t)L * npairs));
+            if (getenv("AGPL_SYRK_GROUP")) group = atoi(getenv("AGPL_SYRK_GROUP"));
+            if (getenv("AGPL_SYRK_TAIL")) tail = atoi(getenv("AGPL_SYRK_TAIL"));
+            if (group < 1 || group > 64 || tail < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad AGPL_SYRK_GROUP / AGPL_SYRK_TAIL");
+            const int ngrouped = group > 1 && ns > tail ? (ns - tail) / group : 0;
+            nu = ngrouped + (ns - ngrouped * group);
+            ngu = (nu + kRedGroup - 1) / kRedGroup;
+            const int64_t nwg_u = (int64_t)L * npairs * ((nu + 7) / 8) * 8;
+            syrk_split_kernel<<<(unsigned)nwg_u, 256, syrk_split_lds_bytes() + ldspad, ctx->stream>>>(
+                N, Npad, M, npairs, nu, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr,
+                getenv("AGPL_SYRK_PRIO") ? atoi(getenv("AGPL_SYRK_PRIO")) : 2, ngrouped, group);
         } else {
             // forms: strip / pp = 16 waves, 32-point stages, one workgroup per CU; strip8 / pp8 = 8 waves, 16-point stages, two
             // per CU (<= 8 sub-tiles: off-diagonal tile + the diagonal tile of one of its panels)
@@ -1413,17 +1442,17 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 1);
     if (rc) return rc;
-    dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs));
-    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, slabG, partG);
+    dim3 r1(64, (unsigned)ngu, (unsigned)(L * npairs));
+    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(nu, ngu, slabG, partG);
     AGPL_LAUNCH_CHECK(ctx);
     dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out);
+    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ngu, partG, G_out);
     AGPL_LAUNCH_CHECK(ctx);
-    dim3 r2((unsigned)ng, (unsigned)(L * nb));
-    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(ns, ng, slabg, partg);
+    dim3 r2((unsigned)ngu, (unsigned)(L * nb));
+    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(nu, ngu, slabg, partg);
     AGPL_LAUNCH_CHECK(ctx);
     dim3 rg2((unsigned)agpl_cdiv(M, 128), (unsigned)L);
-    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ng, partg, g_out);
+    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ngu, partg, g_out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

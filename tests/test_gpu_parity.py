@@ -740,6 +740,40 @@ def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M,
     assert np.array_equal(host(G), G1)
 
 
+@pytest.mark.parametrize("N,M,L,group,tail", [(70001, 128, 2, 4, 3), (40000, 512, 1, 4, 0), (9000, 256, 1, 2, 1),
+                                              (4096 * 8 + 5, 128, 1, 8, 0), (300000, 128, 1, 4, 10)])
+def test_split_accumulate_with_grouped_slices(A, ctx, oracle, split_accumulate, monkeypatch, N, M, L, group, tail):
+    """Long launches run `group` slices through one set of accumulators and write one slab (agpl_accumulate_impl); the
+    grouping is forced here (AGPL_SYRK_GROUP / AGPL_SYRK_TAIL, read per call) at sizes the oracle finishes in seconds:
+    same bound against float64, symmetric, bitwise reproducible, and within f32 rounding of the ungrouped sums."""
+    import ctypes as C
+
+    rng = np.random.default_rng(N + 3 * M + group)
+    Phi = _features(rng, N, M)
+    gamma = rng.uniform(0.0, 0.25, size=(L, N)).astype(np.float32)
+    beta = rng.choice([-0.5, 0.5], size=(L, N)).astype(np.float32)
+    G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
+    args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
+            C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
+            C.c_void_p(g.data_ptr()))
+    monkeypatch.setenv("AGPL_SYRK_GROUP", "1")
+    ctx.call("agpl_accumulate", *args)
+    G0, g0 = host(G).copy(), host(g).copy()
+    monkeypatch.setenv("AGPL_SYRK_GROUP", str(group))
+    monkeypatch.setenv("AGPL_SYRK_TAIL", str(tail))
+    ctx.call("agpl_accumulate", *args)
+    G1, g1 = host(G).copy(), host(g).copy()
+    Gr, gr = oracle.accumulate(Phi, beta, gamma)
+    assert relmax(G1, Gr) < 5e-6 and relmax(g1, gr) < 5e-6
+    assert relmax(G1, G0) < 5e-6 and relmax(g1, g0) < 5e-6
+    assert not np.array_equal(G1, G0)  # the grouping really changed the accumulation runs
+    assert np.array_equal(G1, G1.transpose(0, 2, 1))
+    ctx.call("agpl_accumulate", *args)
+    assert np.array_equal(host(G), G1) and np.array_equal(host(g), g1)
+
+
 @pytest.mark.parametrize("N,M", [(1_000_003, 512), (2_500_000, 256)])
 def test_split_accumulate_with_every_cu_shared(A, ctx, split_accumulate, N, M):
     """Enough slices that four accumulation workgroups share every CU (the sizes above leave one per CU): a kernel
