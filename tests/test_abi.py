@@ -82,6 +82,10 @@ def test_no_gpu_means_loud_failure(built):
     from agpl_amd import _ffi
 
     assert _ffi.lib().agpl_ctx_create(ctypes.byref(h), 0, ctypes.c_uint64(0)) != 0  # no device: error code, no crash
+    tf = ctypes.c_double()
+    for probe in (lambda: _ffi.lib().agpl_probe_mfma_f64(None, 16, ctypes.byref(tf)),
+                  lambda: _ffi.lib().agpl_probe_mfma_f16(None, 16, 0, 1, ctypes.byref(tf), None)):
+        assert probe() == -1  # AGPL_ERR_INVALID_ARGUMENT on a null context, before anything touches a device
 
 
 def test_product_never_touches_the_oracle():

@@ -37,6 +37,12 @@ def test_bench_line_single_gpu_small_workload():
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=1e-4) and 0 < rf["frac"] < 1  # 4 decimals
+    # the measured ceiling next to the data-sheet peak: a sustained float16 MFMA rate below the peak and above half of it,
+    # and every split kernel's executed rate below that ceiling
+    sus = rf["sustained_mfma_f16"]
+    assert 0.5 * rf["peak"] < sus["tflops"] < rf["peak"] and "agpl_probe_mfma_f16" in sus["probe"]
+    for k in rf["kernels"]:
+        assert 0 < k["executed_frac_of_sustained"] < 1.0, k
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
     assert d["parity"]["pass"] and d["parity"]["max_rel_dG"] < 1e-5 and d["parity"]["max_rel_dg"] < 1e-5
