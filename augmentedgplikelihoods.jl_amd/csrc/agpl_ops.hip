@@ -219,8 +219,21 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
     }
 }
 
+// Waves per SIMD the sampler kernels are compiled for, by likelihood (register allocation only: the draws are bit-identical).
+// Unconstrained, the multi-draw kinds take 256 VGPRs + AGPR copies and run ONE wave per SIMD; measured with the bound
+// (profiles/r02_ab_sampler_occupancy.json): negative binomial r = 15 at 3 waves 10.7 against 11.9 ms per 4e6 points
+// (aux_sample_kernel) and 13.3 against 14.2 ms per Gibbs sweep; categorical K = 10 at 2 waves 2.78 against 3.35 ms per Gibbs
+// point pass.  Bernoulli loses with any bound (1.24 -> 1.34 -> 1.58 ms at 3 / 4 waves: spills cost more than occupancy buys).
+constexpr int sampler_wps(int kind) {
+    return kind == AGPL_LIK_NEGBINOMIAL ? 3
+           : (kind == AGPL_LIK_CATEGORICAL || kind == AGPL_LIK_CATEGORICAL_BIJ || kind == AGPL_LIK_POISSON ||
+              kind == AGPL_LIK_HETEROGAUSS)
+               ? 2
+               : 1;
+}
+
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void aux_sample_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+__global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
                                                             const double *__restrict__ f,
                                                             double *__restrict__ omega,
                                                             int64_t *__restrict__ nout, uint64_t seed,
@@ -1161,7 +1174,7 @@ __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, in
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void gibbs_sample_kernel(
+__global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
     agpl_lik_dev lik, int64_t N, const double *__restrict__ proj, const float *__restrict__ kdiag,
     const float *__restrict__ mu0, const void *yv, uint64_t seed, uint64_t i0, uint32_t sweep,
     float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
