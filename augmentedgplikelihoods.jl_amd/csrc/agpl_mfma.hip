@@ -427,6 +427,13 @@ constexpr int kStageBytes = 4 * kImgBytes;    // A hi | A lo | B hi | B lo
             : "v"(x1_), CS(s1_), "v"(H_));                                                                     \
     } while (0)
 
+// g = Phi beta rides the staging registers: one v_fmac_f32 per term, written out (volatile asm, in program order).  Left to
+// the compiler the same sums become v_pk_mul_f32 / v_pk_fma_f32 chains scheduled among the MFMAs, and in some shapes of the
+// surrounding code (an extra wave-uniform branch in the MFMA block; two staging register sets) g then differed from run to
+// run at the 1e-5 level on the hardware while G stayed bit-identical -- root cause not found (compiler hazard handling or
+// hardware); the explicit sequence is bitwise reproducible in every shape tried.
+#define AGPL_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
+
 // Staging geometry: a 16-lane group of a store must fill whole 16-byte slots (both 8-byte point halves) of
 // consecutive rows to touch every LDS bank once, so the point half is the lane's low bit.
 // DIAG = false: wave w -> (panel = w >> 1, plane = w & 1); lane -> (half = lane & 1, feature quad fq = lane >> 1);
@@ -440,7 +447,7 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
                                                 int bi, int bj, int nstage, int plast,
                                                 const float *__restrict__ sgs, const float *__restrict__ bps,
                                                 f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full,
-                                                unsigned *start_ctr, unsigned npartners, bool dbg_same) {
+                                                unsigned *start_ctr, unsigned npartners, int dbg) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,6 +456,10 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
     // diag_full (AGPL_SYRK_DIAGFULL=1, experiment): the sub-tile above the diagonal of a diagonal tile is multiplied too, so
     // that diagonal workgroups keep the pace of the off-diagonal ones that read the same panel (L2 sharing)
     const bool active = !(DIAG && wr < wc) || diag_full;
+    // the 32 x 32 block above the diagonal of a diagonal sub-tile (rows 0..31 x columns 32..63 of sub-tile (w, w) of a
+    // diagonal tile) is never read back: reduce_G_kernel mirrors element-wise from the lower triangle
+    const bool upper = !(DIAG && wr == wc) || diag_full || (dbg & 2); // dbg bit 1 (AGPL_SYRK_PRIO bit 10): A/B switch
+    const bool dbg_same = (dbg & 1) != 0;
     constexpr int PQ = DIAG ? 2 : 4; // points per thread
     const int panel = DIAG ? 0 : (wave >> 1);
     const int plane = wave & 1;
@@ -502,10 +513,10 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
         unsigned char *dst_ = smem_raw + (buf_) * kStageBytes + dst0;                              \
         if (DIAG) {                                                                                \
             const float ba_ = bv[0] * (gkeep_), bb2_ = bv[1] * (gkeep_);                           \
-            gacc[0] += ba_ * x[0].x + bb2_ * x[1].x;                                               \
-            gacc[1] += ba_ * x[0].y + bb2_ * x[1].y;                                               \
-            gacc[2] += ba_ * x[0].z + bb2_ * x[1].z;                                               \
-            gacc[3] += ba_ * x[0].w + bb2_ * x[1].w;                                               \
+            AGPL_GFMA(gacc[0], ba_, x[0].x); AGPL_GFMA(gacc[0], bb2_, x[1].x);                       \
+            AGPL_GFMA(gacc[1], ba_, x[0].y); AGPL_GFMA(gacc[1], bb2_, x[1].y);                       \
+            AGPL_GFMA(gacc[2], ba_, x[0].z); AGPL_GFMA(gacc[2], bb2_, x[1].z);                       \
+            AGPL_GFMA(gacc[3], ba_, x[0].w); AGPL_GFMA(gacc[3], bb2_, x[1].w);                       \
             unsigned h_, l_;                                                                       \
             AGPL_SPLIT2("v", x[0].x, sv[0], x[1].x, sv[1], h_, l_);                                \
             *reinterpret_cast<unsigned *>(dst_ + 0 * 36 * 16) = h_;                                \
@@ -569,17 +580,17 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
             const h8v *I = reinterpret_cast<const h8v *>(smem_raw + buf * kStageBytes);
             const h8v ah0 = I[fa], ah1 = I[fa + 8], bh0 = I[fb], bh1 = I[fb + 8];
             acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
+            if (upper) acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
             acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
             acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
             const h8v bl0 = I[kImgSlots + fb], bl1 = I[kImgSlots + fb + 8];
             acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
+            if (upper) acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
             acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
             acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
             const h8v al0 = I[kImgSlots + fa], al1 = I[kImgSlots + fa + 8];
             acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
+            if (upper) acc[0][1] = mfma16(al0, bh1, acc[0][1]);
             acc[1][0] = mfma16(al1, bh0, acc[1][0]);
             acc[1][1] = mfma16(al1, bh1, acc[1][1]);
         }
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
         /* (the body leaves through a barrier behind its last LDS reads: the next slice may restage at once) */          \
         syrk_split_body<DIAG_>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast,                              \
                                sg_all + (int64_t)l * Npad + nbeg, bp_all + (int64_t)l * Npad + nbeg, acc, gacc, DF_,     \
-                               hint, (unsigned)npairs, (prio_mode & 256) != 0);                                          \
+                               hint, (unsigned)npairs, ((prio_mode >> 8) & 1) | ((prio_mode >> 9) & 2));                                          \
     }
     if (diag) {
         AGPL_SLICES(true, diag_full != 0)
@@ -853,10 +864,14 @@ __global__ __launch_bounds__(NW * 64, 4) void syrk_strip_kernel(int64_t N, int64
             if (gjob) {                                                                            \
                 const float b0_ = bv.x * (gkeep_), b1_ = bv.y * (gkeep_), b2_ = bv.z * (gkeep_),   \
                             b3_ = bv.w * (gkeep_);                                                 \
-                gacc[0] += (b0_ * x[0].x + b1_ * x[1].x) + (b2_ * x[2].x + b3_ * x[3].x);          \
-                gacc[1] += (b0_ * x[0].y + b1_ * x[1].y) + (b2_ * x[2].y + b3_ * x[3].y);          \
-                gacc[2] += (b0_ * x[0].z + b1_ * x[1].z) + (b2_ * x[2].z + b3_ * x[3].z);          \
-                gacc[3] += (b0_ * x[0].w + b1_ * x[1].w) + (b2_ * x[2].w + b3_ * x[3].w);          \
+                AGPL_GFMA(gacc[0], b0_, x[0].x); AGPL_GFMA(gacc[0], b1_, x[1].x);                  \
+                AGPL_GFMA(gacc[0], b2_, x[2].x); AGPL_GFMA(gacc[0], b3_, x[3].x);                  \
+                AGPL_GFMA(gacc[1], b0_, x[0].y); AGPL_GFMA(gacc[1], b1_, x[1].y);                  \
+                AGPL_GFMA(gacc[1], b2_, x[2].y); AGPL_GFMA(gacc[1], b3_, x[3].y);                  \
+                AGPL_GFMA(gacc[2], b0_, x[0].z); AGPL_GFMA(gacc[2], b1_, x[1].z);                  \
+                AGPL_GFMA(gacc[2], b2_, x[2].z); AGPL_GFMA(gacc[2], b3_, x[3].z);                  \
+                AGPL_GFMA(gacc[3], b0_, x[0].w); AGPL_GFMA(gacc[3], b1_, x[1].w);                  \
+                AGPL_GFMA(gacc[3], b2_, x[2].w); AGPL_GFMA(gacc[3], b3_, x[3].w);                  \
             }                                                                                      \
             uint2 h_, l_;                                                                          \
             AGPL_SPLIT2("v", x[0].x, sv.x, x[1].x, sv.y, h_.x, l_.x);                              \

@@ -1066,8 +1066,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
     const unsigned lane_v = (unsigned)lane;
     const int wr = wave >> 2, wc = wave & 3;
-    if (prio_mode) { // experiment (AGPL_MARGINAL_PRIO): static issue priority per wave row / column
-        const int h = prio_mode == 1 ? wr : prio_mode == 2 ? 3 - wr : wc;
+    if (prio_mode & 15) { // experiment (AGPL_MARGINAL_PRIO): static issue priority per wave row / column
+        const int h = (prio_mode & 15) == 1 ? wr : (prio_mode & 15) == 2 ? 3 - wr : wc;
         switch (h & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1087,6 +1087,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int ia = wave >> 2, qd = wave & 3;
     const h8 *a_img = (ia & 1) ? Wl : Wh, *b_img = (ia & 1) ? Pl : Ph;
     const int dma_off = ia * 4096 + qd * 1024;
+    const int wra_ = 2 * (ia >> 1) + (qd & 1);          // the 64-row block of the item this wave stages (image layout: quarter qd = k half qd >> 1 of rows 64 (qd & 1) ..)
+    const bool skip_zero_rows = (prio_mode & 16) == 0; // AGPL_MARGINAL_PRIO bit 4 turns the skip off (A/B)
 
     // item k of this workgroup = queue index qi[k & 3]: (tile, latent, 256-row block), longest row block first
 #define AGPL_Q_DECODE(k_, valid_, tile_, l_, rb_)                                                           \
@@ -1118,8 +1120,11 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
         if (ivalid) {                                                                                       \
             unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + dma_off;                                 \
             _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                             \
-                __builtin_amdgcn_global_load_lds(a_src + (int64_t)(iks + u_) * 256 + lane_v,                \
-                                                 (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);            \
+                /* U is lower triangular: the 64 rows x 8 k this wave stages are the 64-row block wra_ of the item,  */  \
+                /* which is zero from slice 16 irb + 4 (wra_ + 1) on -- nobody reads it there (`act` below) */       \
+                if (!skip_zero_rows || iks + u_ < 16 * irb + 4 * (wra_ + 1))                                \
+                    __builtin_amdgcn_global_load_lds(a_src + (int64_t)(iks + u_) * 256 + lane_v,            \
+                                                     (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);        \
                 __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256 + lane_v,                \
                                                  (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0); \
             }                                                                                               \
@@ -1193,30 +1198,56 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
         const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
         const int fa = fbase16 + (wr >> 1) * 512 + (wr & 1) * 64;
         const int fb = fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
+        // the wave's LAST active stage covers k = its own rows 32..63 of the diagonal 64 x 64 block of U: rows 0..31 (i = 0, 1)
+        // are zero there -- their MFMAs would add exact zeros and are skipped (1 + 32 / M instead of 1 + 64 / M executed).
+        // One code path with wave-uniform branches around the i = 0, 1 groups (two copies of the loop body spill).
         if (act) {
+            const bool lo_rows = !(skip_zero_rows && ks + KU == rb * 16 + 4 * (wr + 1));
             h8 ah[4], al[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ah[i] = st[fa + 16 * i];
+            if (lo_rows) {
+                ah[0] = st[fa];
+                ah[1] = st[fa + 16];
+            }
+            ah[2] = st[fa + 32];
+            ah[3] = st[fa + 48];
             h8 bh = st[fb], bl = st[256 + fb];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bh, acc[i][0]);
+            if (lo_rows) {
+                acc[0][0] = mfma32(ah[0], bh, acc[0][0]);
+                acc[1][0] = mfma32(ah[1], bh, acc[1][0]);
+            }
+            acc[2][0] = mfma32(ah[2], bh, acc[2][0]);
+            acc[3][0] = mfma32(ah[3], bh, acc[3][0]);
             __builtin_amdgcn_sched_barrier(0);
             AGPL_Q_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
+            if (lo_rows) {
+                al[0] = st[256 + fa];
+                al[1] = st[256 + fa + 16];
+            }
+            al[2] = st[256 + fa + 32];
+            al[3] = st[256 + fa + 48];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j > 0) {
                     bh = st[fb + 16 * j];
                     bl = st[256 + fb + 16 * j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bh, acc[i][j]);
+                    if (lo_rows) {
+                        acc[0][j] = mfma32(ah[0], bh, acc[0][j]);
+                        acc[1][j] = mfma32(ah[1], bh, acc[1][j]);
+                    }
+                    acc[2][j] = mfma32(ah[2], bh, acc[2][j]);
+                    acc[3][j] = mfma32(ah[3], bh, acc[3][j]);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bl, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(al[i], bh, acc[i][j]);
+                if (lo_rows) {
+                    acc[0][j] = mfma32(ah[0], bl, acc[0][j]);
+                    acc[1][j] = mfma32(ah[1], bl, acc[1][j]);
+                    acc[0][j] = mfma32(al[0], bh, acc[0][j]);
+                    acc[1][j] = mfma32(al[1], bh, acc[1][j]);
+                }
+                acc[2][j] = mfma32(ah[2], bl, acc[2][j]);
+                acc[3][j] = mfma32(ah[3], bl, acc[3][j]);
+                acc[2][j] = mfma32(al[2], bh, acc[2][j]);
+                acc[3][j] = mfma32(al[3], bh, acc[3][j]);
             }
         } else {
             AGPL_Q_ISSUE(t + 1);

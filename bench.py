@@ -120,10 +120,12 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
     nbk = Mp // 128
     msplit = marginal in ("f16x2", "f16x2-factor")
-    # executed flops: factor-form marginal kernel -- a wave (64 rows) stops at its own diagonal -> (1 + 64 / M) M^2 per
-    # point; accumulation -- lower tile pairs only, the sub-tile above the diagonal of a diagonal tile idles
-    ex_m = (1.0 + 64.0 / Mp) if (marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
-    ex_s = (nbk + 0.5) / nbk
+    # executed flops: factor-form marginal kernel -- a wave (64 rows) stops at its own diagonal and skips the all-zero upper
+    # half of its last stage -> (1 + 32 / M) M^2 per point; accumulation -- lower tile pairs only, on a diagonal tile the
+    # sub-tile above the diagonal idles and (split tile kernel) the two diagonal sub-tiles skip their upper 32 x 32 block
+    ex_m = (1.0 + 32.0 / Mp) if (marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
+    tile_split = accumulate == "f16x2" and os.environ.get("AGPL_SYRK", "tile") == "tile"
+    ex_s = (nbk + (0.25 if tile_split else 0.5)) / nbk
     executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
     # kernel names as the library picks them (agpl_split.hip / agpl_mfma.hip defaults): the factor form runs resident
     # workgroups on 16x16x32 MFMA serving per-XCD item queues; the split accumulation is syrk_split_kernel unless AGPL_SYRK selects a strip form

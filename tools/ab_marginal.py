@@ -23,6 +23,7 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--m", type=int, default=512)
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--cfgs", default="22,16,132,116")
+ap.add_argument("--envs", default="", help="';'-separated VAR=VALUE variants of the shipped kernel (stage 200) to compare instead of --cfgs")
 args = ap.parse_args()
 
 ctx = A.Context(0, seed=bench.SEED)
@@ -36,8 +37,13 @@ cavi.check()
 ref = None
 out = {"lik": args.lik, "N": args.n, "M": args.m, "L": A.nlatent(lik), "results": {}}
 for rnd in range(2):  # two rounds: order effects / clock drift show up as a difference between them
-    for cfg in args.cfgs.split(","):
-        os.environ["AGPL_MARGINAL_STAGE"] = cfg
+    for cfg in (args.envs.split(";") if args.envs else args.cfgs.split(",")):
+        if args.envs:
+            os.environ["AGPL_MARGINAL_STAGE"] = "200"
+            k_, v_ = cfg.split("=")
+            os.environ[k_] = v_
+        else:
+            os.environ["AGPL_MARGINAL_STAGE"] = cfg
         mu, var = cavi.marginals()
         torch.cuda.synchronize()
         bench._ffi = None
