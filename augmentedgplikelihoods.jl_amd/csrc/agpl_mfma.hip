@@ -432,7 +432,33 @@ constexpr int kStageBytes = 4 * kImgBytes;    // A hi | A lo | B hi | B lo
 // surrounding code (an extra wave-uniform branch in the MFMA block; two staging register sets) g then differed from run to
 // run at the 1e-5 level on the hardware while G stayed bit-identical -- root cause not found (compiler hazard handling or
 // hardware); the explicit sequence is bitwise reproducible in every shape tried.
+#ifndef AGPL_G_VARIANT
+#define AGPL_G_VARIANT 0
+#endif
+#if AGPL_G_VARIANT == 0
 #define AGPL_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
+#define AGPL_GPRE()
+#else
+// investigation builds only (make GVAR=1|2|3): the compiler's own multiply-adds, optionally fenced
+#define AGPL_GFMA(acc_, b_, x_) (acc_) += (b_) * (x_)
+#if AGPL_G_VARIANT == 2
+#define AGPL_GPRE() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7")
+#elif AGPL_G_VARIANT == 3
+#define AGPL_GPRE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AGPL_GPRE()
+#endif
+#endif
+// variant 4: wait states between the products b * gkeep and their first use
+#if AGPL_G_VARIANT == 4
+#define AGPL_GMID(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
+#elif AGPL_G_VARIANT == 5
+#define AGPL_GMID(a_, b_) asm volatile("s_nop 0" : "+v"(a_), "+v"(b_))
+#elif AGPL_G_VARIANT == 6
+#define AGPL_GMID(a_, b_) asm volatile("" : "+v"(a_), "+v"(b_))
+#else
+#define AGPL_GMID(a_, b_)
+#endif
 
 // Staging geometry: a 16-lane group of a store must fill whole 16-byte slots (both 8-byte point halves) of
 // consecutive rows to touch every LDS bank once, so the point half is the lane's low bit.
@@ -512,7 +538,9 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
     do {                                                                                           \
         unsigned char *dst_ = smem_raw + (buf_) * kStageBytes + dst0;                              \
         if (DIAG) {                                                                                \
-            const float ba_ = bv[0] * (gkeep_), bb2_ = bv[1] * (gkeep_);                           \
+            AGPL_GPRE();                                                                           \
+            float ba_ = bv[0] * (gkeep_), bb2_ = bv[1] * (gkeep_);                                 \
+            AGPL_GMID(ba_, bb2_);                                                                  \
             AGPL_GFMA(gacc[0], ba_, x[0].x); AGPL_GFMA(gacc[0], bb2_, x[1].x);                       \
             AGPL_GFMA(gacc[1], ba_, x[0].y); AGPL_GFMA(gacc[1], bb2_, x[1].y);                       \
             AGPL_GFMA(gacc[2], ba_, x[0].z); AGPL_GFMA(gacc[2], bb2_, x[1].z);                       \
