@@ -430,8 +430,8 @@ constexpr int kStageBytes = 4 * kImgBytes;    // A hi | A lo | B hi | B lo
 // g = Phi beta rides the staging registers: one v_fmac_f32 per term, written out (volatile asm, in program order).  Left to
 // the compiler the same sums become v_pk_mul_f32 / v_pk_fma_f32 chains scheduled among the MFMAs, and in some shapes of the
 // surrounding code (an extra wave-uniform branch in the MFMA block; two staging register sets) g then differed from run to
-// run at the 1e-5 level on the hardware while G stayed bit-identical -- root cause not found (compiler hazard handling or
-// hardware); the explicit sequence is bitwise reproducible in every shape tried.
+// run at the 1e-4 level on the hardware while G stayed bit-identical -- root cause open (an isolated
+// replay of the instruction sequence computes correctly); the explicit sequence is bitwise reproducible in every shape tried.
 #ifndef AGPL_G_VARIANT
 #define AGPL_G_VARIANT 0
 #endif
