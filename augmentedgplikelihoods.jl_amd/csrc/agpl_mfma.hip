@@ -1378,15 +1378,21 @@ static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
     // padded 2^8 sqrt(gamma) | beta: N rounded up to a 32-point stage + one stage of zeros (syrk_strip_kernel reads it
     // for the stages a shorter slice of its workgroup no longer has)
     o.ctr = al(o.sgam + 2 * sizeof(float) * (size_t)((int64_t)L * (((N + 31) & ~(int64_t)31) + 32)));
-    o.total = al(o.ctr + sizeof(unsigned) * (size_t)L * o.ns); // arrival counters of the slices' workgroups (start hint)
+    o.total = al(o.ctr + sizeof(unsigned) * ((size_t)L * o.ns + 64)); // arrival counters of the slices' workgroups (start hint) / scale words
     return o;
 }
 
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) { return slab_layout(N, M, L).total; }
 
 // internal: accumulate with caller-provided slab storage (used by agpl_accumulate and agpl_cavi_pass)
-int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *beta,
-                             const float *gamma, double *G_out, double *g_out, void *slab_mem) {
+int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
+                               const float *gamma, const float *beta, float *sg, float *bp, unsigned *scal,
+                               float *slabG, float *slabg, int ns); // agpl_syrk.hip
+
+// acc_image != nullptr (and M % 256 == 0): the point-major split-float16 image of agpl_accumulate_image is the operand
+// (syrk_image_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
+int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image,
+                             const float *beta, const float *gamma, double *G_out, double *g_out, void *slab_mem) {
     const SlabLayout lo = slab_layout(N, M, L);
     const int ns = lo.ns, nb = lo.nb, npairs = (int)lo.npairs, ng = lo.ng;
     float *slabG = (float *)((char *)slab_mem + lo.slabG);
@@ -1399,7 +1405,16 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
     int nu = ns, ngu = ng; // slabs per tile / reduction groups actually written (the tile form of the split path may group slices)
-    if (ctx->accumulate_split) {
+    if (acc_image && M % 256 == 0) {
+        const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
+        float *sg = (float *)((char *)slab_mem + lo.sgam);
+        float *bp = sg + (int64_t)L * Npad;
+        rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, sg, bp,
+                                    (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns);
+        if (rc) return rc;
+    } else if (!Phi) {
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the accumulation needs the float32 features (no image, or M %% 256 != 0)");
+    } else if (ctx->accumulate_split) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         float *sg = (float *)((char *)slab_mem + lo.sgam);
         float *bp = sg + (int64_t)L * Npad;
@@ -1509,7 +1524,23 @@ extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t 
     if (!Phi || !beta || !gamma || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     int32_t rc = agpl_ws_reserve(ctx, agpl_slab_bytes(N, M, L));
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, beta, gamma, G_out, g_out, ctx->ws);
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, beta, gamma, G_out, g_out, ctx->ws);
+}
+
+extern "C" int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                                         const void *acc_image, const float *beta, const float *gamma, double *G_out,
+                                         double *g_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N <= 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
+    if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
+    if ((!Phi && !acc_image) || !beta || !gamma || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    int32_t rc = agpl_ws_reserve(ctx, agpl_slab_bytes(N, M, L));
+    if (rc) return rc;
+    const int keep = ctx->accumulate_split;
+    ctx->accumulate_split = 1;
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, beta, gamma, G_out, g_out, ctx->ws);
+    ctx->accumulate_split = keep;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

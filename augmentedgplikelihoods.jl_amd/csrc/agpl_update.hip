@@ -17,7 +17,7 @@
 // agpl_ops.hip / agpl_mfma.hip internals
 int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out);
-int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *beta,
+int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image, const float *beta,
                              const float *gamma, double *G_out, double *g_out, void *slab_mem);
 int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
                                          const float *kdiag, const float *mu0, const void *y, const double *v,
@@ -627,7 +627,7 @@ extern "C" int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
 }
 
 extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
@@ -660,7 +660,7 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
                                           n_out, nuni_out, bad, (double *)base);
     if (rc) return rc;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
     if (rc) return rc;
     if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
         int hbad = 0;
@@ -852,7 +852,7 @@ extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik,
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
 }
 
 extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
@@ -886,7 +886,7 @@ extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_des
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, bet, gam, G_out, g_out, base);
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
     if (rc) return rc;
     // everything of this pass is enqueued: now is the free moment to look at the outcome of the factorisation before it
     return agpl_pending_resolve(ctx);

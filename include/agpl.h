@@ -333,6 +333,29 @@ AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc 
                                              const void *U_lo, const float *v, double *G_out, double *g_out,
                                              float *c_out, float *gamma_out, float *beta_out);
 
+/* ---- split-float16 accumulation from a static point-major image (agpl_syrk.hip) --------------------------------
+ * G_l = Phi Diag(gamma_l) Phi', g_l = Phi beta_l (the accumulators of docs/src/index.md:154-163: S = (K_Z^-1 +
+ * kappa Diag(r) kappa')^-1, m = S (kappa t + ...), in the whitened basis; script.jl:35-36 in sparse form).  The reduction
+ * index of this product is the POINT, the strided index of the float32 features; the image stores, once per data set,
+ * hi = f16(s phi), lo = f16(s phi - hi) (s = 2^e chosen from max |Phi|: any finite feature range is representable, error
+ * <= 2^-22 |phi| down to 2^-17 max |Phi|) in 4 KB blocks [point slice of 16][feature block of 128][hi | lo] =
+ * [2 planes of 8 points][128 features][8 halves], whose 16-byte granule (one feature, 8 consecutive points) is one MFMA
+ * operand fragment.  The accumulation then reads ONLY the image: A = the image (HBM -> LDS by DMA), B = gamma_n x the
+ * image (rebuilt, scaled and re-split in registers), three float16 MFMA products per float32 product, float32
+ * accumulation over 4096-point slices, the fixed-order float64 slab reduction of agpl_accumulate.
+ *   agpl_accumulate_image_bytes : bytes of the image (256-byte header + blocks) for N points, M features (M % 128 == 0).
+ *   agpl_accumulate_image       : Phi (float32 [M,N] col-major) -> image.  AGPL_ERR_DOMAIN (with the offending point and
+ *                                 feature in agpl_last_error) if a feature is not finite.  Synchronises the stream once.
+ *   agpl_accumulate_split       : agpl_accumulate on the float16 matrix cores, whatever agpl_set_accumulate_precision says:
+ *                                 from the image when acc_image != NULL and M % 256 == 0 (Phi may then be NULL), else from
+ *                                 the float32 Phi (psi = sqrt(gamma) phi split while staging; |sqrt(gamma) phi| < 6e4).
+ *                                 gamma >= 0 (TestUtils.jl:88).                                                        */
+AGPL_API int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M);
+AGPL_API int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out);
+AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
+                                       const void *acc_image, const float *beta, const float *gamma, double *G_out,
+                                       double *g_out);
+
 /* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
  *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
  *   context's stream.  For hosts that own their communicator (the Julia / C++ callers of INTEGRATION.md); the
