@@ -1386,8 +1386,8 @@ size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) { return slab_layout(N, 
 
 // internal: accumulate with caller-provided slab storage (used by agpl_accumulate and agpl_cavi_pass)
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
-                               const float *gamma, const float *beta, float *sg, float *bp, unsigned *scal,
-                               float *slabG, float *slabg, int ns); // agpl_syrk.hip
+                               const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
+                               float *slabg, int ns); // agpl_syrk.hip
 
 // acc_image != nullptr (and M % 256 == 0): the point-major split-float16 image of agpl_accumulate_image is the operand
 // (syrk_image_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
@@ -1407,9 +1407,7 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     int nu = ns, ngu = ng; // slabs per tile / reduction groups actually written (the tile form of the split path may group slices)
     if (acc_image && M % 256 == 0) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
-        float *sg = (float *)((char *)slab_mem + lo.sgam);
-        float *bp = sg + (int64_t)L * Npad;
-        rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, sg, bp,
+        rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
                                     (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns);
         if (rc) return rc;
     } else if (!Phi) {

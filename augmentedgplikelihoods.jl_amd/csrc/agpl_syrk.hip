@@ -10,15 +10,15 @@
 //   8p .. 8p+7 of the slice; hl = 0: hi = f16(s_A phi), hl = 1: lo = f16(s_A phi - hi); s_A = 2^e_A chosen from max |Phi| so
 //   that hi and lo stay float16 normals over the widest range (header word scale_exp).
 //
-// syrk_image_kernel: one 1024-thread workgroup (16 waves, one per CU) owns a 256 x 256 tile of the lower triangle of G for
-// one slice of 4096 points (one f32 accumulation run, one slab set -- the slabs and the fixed-order float64 reduction
-// behind them are those of agpl_mfma.hip).  Per 32-point stage:
+// syrk_image8_kernel: one 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a 256 x 256 tile of the
+// lower triangle of G for one slice of 4096 points (one f32 accumulation run, one slab set -- the slabs and the fixed-order
+// float64 reduction behind them are those of agpl_mfma.hip).  Per 32-point stage:
 //   A = rows of panel I:  image blocks moved HBM -> LDS by the DMA path (global_load_lds_dwordx4), no VGPRs, no VALU;
-//   B = gamma_n * (rows of panel J):  every thread loads ONE granule (hi and lo: 2 x 16 B) of the same image into registers,
+//   B = gamma_n * (rows of panel J):  every thread loads TWO granules (hi and lo: 4 x 16 B) of the same image into registers,
 //       rebuilds x = hi + lo (exact in float32), forms y = (s_B gamma_n) x and splits it into hi / lo again
-//       (3 v_fma_mix per value, 24 per thread and stage) and stores the two 16-byte results into the B half of the next
-//       stage's LDS slot -- the granule is already the MFMA fragment, nothing is transposed;
-//   G_tile += A B'  as  hi hi' + hi lo' + lo hi'  with v_mfma_f32_16x16x32_f16 (48 per wave and stage, 64 x 64 per wave).
+//       (3 v_fma_mix per value) and stores the 16-byte results into the B half of the next stage's LDS slot -- the granule is
+//       already the MFMA fragment, nothing is transposed;
+//   G_tile += A B'  as  hi hi' + hi lo' + lo hi'  with v_mfma_f32_16x16x32_f16 (96 per wave and stage, 128 x 64 per wave).
 // Compared with syrk_split_kernel (agpl_mfma.hip: 128 x 128 tiles, both panels converted from float32 every stage by every
 // tile pair): a quarter of the conversions per flop, half the operand bytes per flop, no register staging of A.
 // g = Phi beta rides the B conversion of the diagonal tiles (x is the float32 feature there).
@@ -56,7 +56,7 @@ __device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
 }
 
 // hi / lo float16 pair of two products x s, packed (see agpl_mfma.hip AGPL_SPLIT2): one rounding of the exact fma per part
-#define AGPL_Q_SPLIT2(x0_, s0_, x1_, s1_, H_, L_)                                                              \
+#define AGPL_E_SPLIT2(x0_, s0_, x1_, s1_, H_, L_)                                                              \
     do {                                                                                                       \
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(H_) : "v"(x0_), "v"(s0_));                                  \
         asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(H_) : "v"(x1_), "v"(s1_));                                  \
@@ -65,14 +65,14 @@ __device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
             : "+v"(L_)                                                                                         \
             : "v"(x1_), "v"(s1_), "v"(H_));                                                                    \
     } while (0)
+// g += b x, one v_fmac_f32 per term in program order (agpl_mfma.hip AGPL_GFMA: no compiler-formed packed float32 forms)
+#define AGPL_E_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
 // x = hi + lo of the two halves of a packed pair (exact: hi and lo do not overlap and span <= 24 bits)
 #define AGPL_Q_JOIN2(H_, L_, x0_, x1_)                                                                         \
     do {                                                                                                       \
         asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x0_) : "v"(H_), "v"(L_));                 \
         asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1_) : "v"(H_), "v"(L_));  \
     } while (0)
-// g += b x, one v_fmac_f32 per term in program order (agpl_mfma.hip AGPL_GFMA: no compiler-formed packed float32 forms)
-#define AGPL_Q_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
 
 // ------------------------------------------------------------------------------------------------
 // image construction
@@ -151,51 +151,360 @@ __global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M,
     }
 }
 
-// per launch: padded gamma | beta (zeros beyond N) and max gamma (bits) -> scal[0]; scal[1] = 1 + index of a gamma that is
-// negative or not finite (0: none).  gamma >= 0 by construction (TestUtils.jl:88).
-__global__ __launch_bounds__(256) void acc_prep_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, float *__restrict__ sg,
-                                                       float *__restrict__ bp, unsigned *__restrict__ scal) {
+// The 8-wave kernel takes gamma and beta of a stage from ONE 256-byte record (gamma x 32 | beta x 32, zeros beyond N), which
+// one wave moves into LDS by DMA a stage ahead -- a scalar or vector load at the point of use would pay the HBM latency of a
+// cold, once-read array in every stage.  acc_prep8_kernel writes the records and max gamma, acc_scale_kernel then multiplies
+// gamma by s_B = 2^e_B (exact), so that the accumulation kernel applies no scale of its own.
+__global__ __launch_bounds__(256) void acc_prep8_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float *__restrict__ gb,
+                                                        unsigned *__restrict__ scal) {
     const int64_t total = (int64_t)L * Npad;
     unsigned m = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t l = i / Npad, n = i - l * Npad;
         const bool in = n < N;
         const float gv = in ? gamma[l * N + n] : 0.f;
-        const unsigned gb = __float_as_uint(gv), ab = gb & 0x7FFFFFFFu;
-        const bool bad = ab >= 0x7F800000u || ((gb >> 31) && ab != 0u); // inf, NaN or negative
+        const unsigned gbits = __float_as_uint(gv), ab = gbits & 0x7FFFFFFFu;
+        const bool bad = ab >= 0x7F800000u || ((gbits >> 31) && ab != 0u); // inf, NaN or negative
         if (bad) atomicMax(scal + 1, (unsigned)min((int64_t)0x7FFFFFFE, l * N + n) + 1u);
         m = max(m, bad ? 0u : ab);
-        sg[i] = gv;
-        bp[i] = in ? beta[l * N + n] : 0.f;
+        float *rec = gb + (l * (Npad / 32) + n / 32) * 64 + (n & 31);
+        rec[0] = gv;
+        rec[32] = in ? beta[l * N + n] : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(scal, m);
 }
 
-// ------------------------------------------------------------------------------------------------
-// the accumulation kernel
-// ------------------------------------------------------------------------------------------------
-// wave -> 64 x 64 sub-tile of a DIAGONAL 256 x 256 tile (only sub-tiles wr >= wc are needed): entry = wr | wc << 2 |
-// flags << 4, flags: 1 multiply, 2 store a slab part, 4 the sub-tile sits on the diagonal.  The ten needed sub-tiles are
-// dealt 2-2-3-3 over the four SIMDs (wave w runs on SIMD w & 3); waves 8, 9 only write the zeros of the two sub-tiles
-// (0,1), (2,3) that lie inside the diagonal 128 x 128 slabs above the diagonal (never read back, kept finite).
-__constant__ unsigned char kDiagWave[16] = {49, 51, 55, 59, 50, 54, 112, 122, 36, 46, 117, 127, 0, 0, 0, 0};
+__device__ __forceinline__ int acc_scale_exp(unsigned gmax) { // e_B: 2^e_B max(gamma) in [1/2, 1)
+    int eB = gmax ? 126 - (int)(gmax >> 23) : 0;
+    return eB < -60 ? -60 : (eB > 60 ? 60 : eB);
+}
 
-template <int CV, bool DSKIP>
-__global__ __launch_bounds__(1024, 1) void syrk_image_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit,
+__global__ __launch_bounds__(256) void acc_scale_kernel(int64_t nrec, float *__restrict__ gb, const unsigned *__restrict__ scal) {
+    const int eB = acc_scale_exp(scal[0]);
+    const float sB = __uint_as_float((unsigned)(127 + eB) << 23);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec * 32; i += (int64_t)gridDim.x * blockDim.x) {
+        float *p = gb + (i >> 5) * 64 + (i & 31);
+        const float v = *p * sB;
+        *p = v < 1.17549435e-38f ? 0.f : v; // (a product below the smallest normal is dropped)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// syrk_image8_kernel: the same tile, slots, images and slabs with EIGHT waves (512 threads, two per SIMD, up to 256
+// registers each): a wave owns 128 x 64 of the tile (8 x 4 accumulators), keeps the B fragments of its four column blocks
+// for the whole stage and streams the A fragments one 16-row block ahead of the twelve MFMAs that use them, so that a
+// wave alone keeps the matrix pipe fed (with sixteen 128-register waves the fragment reads of a group could not be issued
+// ahead of the previous group's MFMAs: a wave alone ran at ~40 cycles per MFMA instead of 16, and since a SIMD serves
+// its oldest wave first, the youngest finished each stage alone at that pace -- in-kernel stamps).
+// Staging per thread and stage: 4 DMA pieces of A, two granules of B (same row and plane in the stage's two slices).
+// Diagonal tiles: block (i, j) of sub-tile (wr, wc) is needed iff 8 wr + i >= 4 wc + j; the six sub-tiles that hold such
+// blocks are dealt over the SIMDs as 32 | 32 | 26 + 10 | 26 + 10 blocks (an off-diagonal tile: 64 per SIMD).
+// ------------------------------------------------------------------------------------------------
+#ifdef AGPL_QTRACE // diagnostic build (make QTRACE=1): per-wave cycle sums of the stage loop, tools/qtrace.py
+__device__ unsigned long long g_qtrace[64 * 16 * 8];
+constexpr bool kTrace = true;
+#else
+constexpr bool kTrace = false;
+#endif
+
+__constant__ unsigned char kDiagWave8[8] = {1 | 16, 1 | 4 | 16, 0 | 16, 1 | 8 | 16, 0, 0, 0 | 4 | 16, 1 | 12 | 16}; // wr | wc << 2 | active << 4
+
+template <bool DIAG>
+__device__ __forceinline__ void syrk_image8_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int l,
+                                                 int s, int I, int J, const unsigned char *__restrict__ image,
+                                                 const float *__restrict__ gb_all,
+                                                 const unsigned *__restrict__ scal, float *__restrict__ slabG,
+                                                 float *__restrict__ slabg) {
+    constexpr bool TRACE = kTrace;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..7
+    const int nb = M / BS;
+    int wr = wave >> 2, wc = wave & 3;
+    bool active = true;
+    if (DIAG) {
+        const unsigned e = kDiagWave8[wave];
+        wr = e & 1;
+        wc = (e >> 2) & 3;
+        active = (e >> 4) & 1;
+    }
+    const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
+    const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
+    const int eA = hdr->scale_exp;
+    const int eB = acc_scale_exp(scal[0]); // (gamma arrives scaled by 2^e_B: acc_scale_kernel)
+
+    const int64_t nbeg = (int64_t)s * kChunk;
+    int64_t nend = nbeg + kChunk;
+    if (nend > N) nend = N;
+    const int nstage = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
+    const int64_t ps0 = nbeg / 16;
+
+    // staging duty of a wave: 128-row block rbS = (wave >> 2) & 1 of BOTH panels, quarter qd = wave & 3 = (plane, 64-row half)
+    const int rbS = (wave >> 2) & 1, qd = wave & 3;
+    const int64_t slice_pitch = (int64_t)nb * 2 * 256; // h8 units between consecutive point slices
+    const h8 *a_src = blocks + ((ps0 * nb + 2 * I + rbS) * 2) * 256 + qd * 64 + lane; // + 256: lo; + slice_pitch: slice 1
+    const int a_dst = rbS * 2 * 4096 + qd * 1024;                                     // + 4096: lo; + kSliceBytes: slice 1
+    const h8 *b_src = blocks + ((ps0 * nb + 2 * J + rbS) * 2) * 256 + qd * 64 + lane;
+    const int b_dst = (4 + rbS * 2) * 4096 + qd * 1024 + lane * 16;
+    // gamma | beta records of the slice's stages; the 8 points of this wave's granules are 8 (qd >> 1) + 0..7 of each
+    // 16-point slice of a stage
+    const float *gb_src = gb_all + ((int64_t)l * (Npad / 32) + nbeg / 32) * 64 + lane;
+    float *gbuf = reinterpret_cast<float *>(smem_raw + 2 * kSlot); // [2 (stage parity)][64]
+    const int gofs = 8 * (qd >> 1);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gacc = 0.f;
+
+    u32x4 rh0, rl0, rh1, rl1; // the two raw granules in flight (slice 0, slice 1)
+
+#define AGPL_E_DMA(t_)                                                                                          \
+    do {                                                                                                        \
+        unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + a_dst;                                           \
+        const h8 *src_ = a_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
+        __builtin_amdgcn_global_load_lds(src_, (lds_void *)slot_, 16, 0, 0);                                    \
+        __builtin_amdgcn_global_load_lds(src_ + 256, (lds_void *)(slot_ + 4096), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds(src_ + slice_pitch, (lds_void *)(slot_ + kSliceBytes), 16, 0, 0);      \
+        __builtin_amdgcn_global_load_lds(src_ + slice_pitch + 256, (lds_void *)(slot_ + kSliceBytes + 4096), 16, 0, 0); \
+    } while (0)
+#define AGPL_E_DMA1(t_, k_) /* piece k_ = 0..3 of the four */                                                   \
+    do {                                                                                                        \
+        unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + a_dst + ((k_) & 1) * 4096 + ((k_) >> 1) * kSliceBytes; \
+        const h8 *src_ = a_src + (int64_t)(2 * (t_)) * slice_pitch + ((k_) & 1) * 256 + ((k_) >> 1) * slice_pitch; \
+        __builtin_amdgcn_global_load_lds(src_, (lds_void *)slot_, 16, 0, 0);                                    \
+    } while (0)
+#define AGPL_E_LOADB(t_)                                                                                        \
+    do {                                                                                                        \
+        const h8 *src_ = b_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
+        rh0 = *reinterpret_cast<const u32x4 *>(src_);                                                           \
+        rl0 = *reinterpret_cast<const u32x4 *>(src_ + 256);                                                     \
+        rh1 = *reinterpret_cast<const u32x4 *>(src_ + slice_pitch);                                             \
+        rl1 = *reinterpret_cast<const u32x4 *>(src_ + slice_pitch + 256);                                       \
+    } while (0)
+#define AGPL_E_DMAG(t_) /* wave 0: the gamma | beta record of stage t_ -> gbuf[t_ & 1] */                    \
+    do {                                                                                                        \
+        if (wave == 0)                                                                                          \
+            __builtin_amdgcn_global_load_lds(gb_src + (int64_t)(t_) * 64, (lds_void *)(gbuf + ((t_) & 1) * 64), 4, 0, 0); \
+    } while (0)
+#define AGPL_E_CVT(RH_, RL_, g0_, g1_, b0_, b1_)                                                                \
+    do {                                                                                                        \
+        float x0_, x1_;                                                                                         \
+        AGPL_Q_JOIN2(RH_, RL_, x0_, x1_);                                                                       \
+        if (DIAG) {                                                                                             \
+            AGPL_E_GFMA(gacc, b0_, x0_);                                                                        \
+            AGPL_E_GFMA(gacc, b1_, x1_);                                                                        \
+        }                                                                                                       \
+        AGPL_E_SPLIT2(x0_, g0_, x1_, g1_, RH_, RL_);                                                            \
+    } while (0)
+    // half a granule (4 points): its gamma (and beta on a diagonal tile) come out of the stage's record in LDS (one address
+    // for the whole wave: a broadcast read); keepf zeroes the beta of the clamped duplicate behind the last stage
+#define AGPL_E_CVT_HALF(c_, tt_, keepf_)                                                                        \
+    do {                                                                                                        \
+        const float *gq_ = gbuf + ((tt_) & 1) * 64 + gofs + 16 * ((c_) >> 1) + 4 * ((c_) & 1);                  \
+        const float4 g4_ = *reinterpret_cast<const float4 *>(gq_);                                              \
+        float4 b4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
+        if (DIAG) {                                                                                             \
+            b4_ = *reinterpret_cast<const float4 *>(gq_ + 32);                                                  \
+            b4_.x *= (keepf_); b4_.y *= (keepf_); b4_.z *= (keepf_); b4_.w *= (keepf_);                         \
+        }                                                                                                       \
+        if ((c_) == 0) { AGPL_E_CVT(rh0.x, rl0.x, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh0.y, rl0.y, g4_.z, g4_.w, b4_.z, b4_.w); } \
+        if ((c_) == 1) { AGPL_E_CVT(rh0.z, rl0.z, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh0.w, rl0.w, g4_.z, g4_.w, b4_.z, b4_.w); } \
+        if ((c_) == 2) { AGPL_E_CVT(rh1.x, rl1.x, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh1.y, rl1.y, g4_.z, g4_.w, b4_.z, b4_.w); } \
+        if ((c_) == 3) { AGPL_E_CVT(rh1.z, rl1.z, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh1.w, rl1.w, g4_.z, g4_.w, b4_.z, b4_.w); } \
+    } while (0)
+#define AGPL_E_STOREB(t_)                                                                                       \
+    do {                                                                                                        \
+        const unsigned d_ = lds_base + (unsigned)(((t_) & 1) * kSlot + b_dst);                                  \
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:4096\n\t"                             \
+                     "ds_write_b128 %0, %3 offset:32768\n\tds_write_b128 %0, %4 offset:36864" ::"v"(d_),        \
+                     "v"(rh0), "v"(rl0), "v"(rh1), "v"(rl1)                                                     \
+                     : "memory");                                                                               \
+    } while (0)
+
+    [[maybe_unused]] unsigned long long tr0 = 0, tr_wait = 0, tr_body = 0, tr_loop = 0, rt0 = 0, tr_h[4] = {0, 0, 0, 0};
+    if (TRACE) {
+        tr0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem_raw;
+    AGPL_E_DMAG(0);
+    AGPL_E_DMA(0);
+    AGPL_E_LOADB(0);
+    __builtin_amdgcn_s_waitcnt(0x0070); // the record of stage 0 is in LDS ...
+    __builtin_amdgcn_s_barrier();       // ... for every wave
+    if (nstage > 1) AGPL_E_DMAG(1);
+    AGPL_E_CVT_HALF(0, 0, 1.f);
+    AGPL_E_CVT_HALF(1, 0, 1.f);
+    AGPL_E_CVT_HALF(2, 0, 1.f);
+    AGPL_E_CVT_HALF(3, 0, 1.f);
+    AGPL_E_STOREB(0);
+    AGPL_E_LOADB(nstage > 1 ? 1 : 0);
+
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int kg = ln >> 4;
+    const int fbase = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
+    const int fa = fbase + wr * 512;
+    const int fb = fbase + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
+    const int jbase = DIAG ? 8 * wr - 4 * wc + 1 : 4; // blocks j < jbase + i of row block i are needed
+
+
+    if (TRACE) tr_loop = __builtin_amdgcn_s_memtime();
+    // hook i sits behind the MFMAs of row block i: the staging work of stage t + 1 in pieces
+#define AGPL_E_HOOK(i_)                                                                                         \
+    do {                                                                                                        \
+        if (TRACE && ((i_) == 0 || (i_) == 2 || (i_) == 4 || (i_) == 6)) {                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            tr_h[(i_) / 2] += __builtin_amdgcn_s_memtime() - tb;                                                \
+        }                                                                                                       \
+        if ((i_) == 0 && t + 2 < nstage) AGPL_E_DMAG(t + 2);                                                    \
+        if (more && (i_) < 4) AGPL_E_DMA1(t + 1, i_); /* one piece per hook: four at once queue behind each other */ \
+        if ((i_) >= 1 && (i_) <= 4) AGPL_E_CVT_HALF((i_) - 1, t + 1, keepf);                                    \
+        if ((i_) == 4) {                                                                                        \
+            AGPL_E_STOREB(t + 1);                                                                               \
+            AGPL_E_LOADB(tl);                                                                                   \
+        }                                                                                                       \
+    } while (0)
+    // the MFMA block with the set of needed blocks fixed at compile time: JB_ = 4 all of them, 1 / -3 the two kinds of
+    // sub-tile that straddle the diagonal (blocks j < JB_ + i of row block i), 100 = a wave with no sub-tile (staging only)
+#define AGPL_E_BLOCK(JB_)                                                                                       \
+    do {                                                                                                        \
+        h8 bh[4], bl[4];                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            bh[j] = st[fb + 16 * j];                                                                            \
+            bl[j] = st[256 + fb + 16 * j];                                                                      \
+        }                                                                                                       \
+        constexpr int i0_ = (JB_) >= 1 ? 0 : 1 - (JB_); /* first row block with a needed block */              \
+        h8 ah = st[fa + 16 * i0_], al = st[256 + fa + 16 * i0_];                                                \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                         \
+            if (i >= i0_) {                                                                                     \
+                const h8 ahc = ah, alc = al;                                                                    \
+                if (i < 7) { /* the next row block's fragments, ahead of this one's MFMAs */                    \
+                    ah = st[fa + 16 * (i + 1)];                                                                 \
+                    al = st[256 + fa + 16 * (i + 1)];                                                           \
+                }                                                                                               \
+                __builtin_amdgcn_s_setprio(1);                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < (JB_) + i) {                              \
+                    acc[i][j] = mfma32(ahc, bh[j], acc[i][j]);                                                  \
+                    acc[i][j] = mfma32(ahc, bl[j], acc[i][j]);                                                  \
+                    acc[i][j] = mfma32(alc, bh[j], acc[i][j]);                                                  \
+                }                                                                                               \
+                __builtin_amdgcn_s_setprio(0);                                                                  \
+            }                                                                                                   \
+            AGPL_E_HOOK(i);                                                                                     \
+        }                                                                                                       \
+    } while (0)
+    // one stage loop per kind of wave, chosen once: a branch inside the loop would make the accumulators a merge of the
+    // bodies' and spill them
+#define AGPL_E_LOOP(JB_)                                                                                        \
+    for (int t = 0; t < nstage; ++t) {                                                                          \
+        unsigned long long ta = 0, tb = 0;                                                                      \
+        if (TRACE) ta = __builtin_amdgcn_s_memtime();                                                           \
+        /* stage t's A pieces, the raw granules of stage t + 1 and the B' stores of stage t are done */        \
+        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */                                           \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        if (TRACE) tb = __builtin_amdgcn_s_memtime();                                                           \
+        const bool more = t + 1 < nstage;                                                                       \
+        const int tl = t + 2 < nstage ? t + 2 : nstage - 1; /* unconditional loads (clamped) */                \
+        const float keepf = more ? 1.f : 0.f;               /* behind the last stage the conversion is a duplicate */ \
+        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & 1) * kSlot);                                \
+        if ((JB_) == 100) {                                                                                     \
+            if (more) AGPL_E_DMA(t + 1);                                                                        \
+            if (t + 2 < nstage) AGPL_E_DMAG(t + 2);                                                             \
+            AGPL_E_CVT_HALF(0, t + 1, keepf);                                                                   \
+            AGPL_E_CVT_HALF(1, t + 1, keepf);                                                                   \
+            AGPL_E_CVT_HALF(2, t + 1, keepf);                                                                   \
+            AGPL_E_CVT_HALF(3, t + 1, keepf);                                                                   \
+            AGPL_E_STOREB(t + 1);                                                                               \
+            AGPL_E_LOADB(tl);                                                                                   \
+        } else {                                                                                                \
+            AGPL_E_BLOCK(JB_);                                                                                  \
+        }                                                                                                       \
+        if (TRACE) {                                                                                            \
+            const unsigned long long td = __builtin_amdgcn_s_memtime();                                         \
+            tr_wait += tb - ta;                                                                                 \
+            tr_body += td - tb;                                                                                 \
+        }                                                                                                       \
+    }
+    if (!DIAG || (active && jbase >= 4)) {
+        AGPL_E_LOOP(4)
+    } else if (!active) {
+        AGPL_E_LOOP(100)
+    } else if (jbase == 1) {
+        AGPL_E_LOOP(1)
+    } else {
+        AGPL_E_LOOP(-3)
+    }
+#undef AGPL_E_LOOP
+#undef AGPL_E_BLOCK
+#undef AGPL_E_HOOK
+#ifdef AGPL_QTRACE
+    if (blockIdx.x < 64 && lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memtime(), rte = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *o = g_qtrace + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = tr_h[0] | (tr_h[1] << 32); // (sums over <= 128 stages of < 2^24 cycles each: 32 bits are enough)
+        o[1] = te - tr_loop;
+        o[2] = tr_wait;
+        o[3] = tr_h[2] | (tr_h[3] << 32);
+        o[4] = tr_body;
+        o[5] = rte - rt0;
+        o[6] = (unsigned long long)nstage | ((unsigned long long)(DIAG ? 1 : 0) << 32) | ((unsigned long long)(active ? 1 : 0) << 33);
+        o[7] = te - tr0;
+    }
+#endif
+#undef AGPL_E_DMA
+#undef AGPL_E_LOADB
+#undef AGPL_E_DMAG
+#undef AGPL_E_DMA1
+#undef AGPL_E_CVT
+#undef AGPL_E_CVT_HALF
+#undef AGPL_E_STOREB
+
+    // ---- slabs: [l][128-pair][slice][128 x 128] float32; the accumulators carry (s_A phi)(s_B gamma s_A phi)'
+    const float unscale = __uint_as_float((unsigned)(127 - (2 * eA + eB)) << 23);
+    if (active) {
+        const int bi = 2 * I + wr, bj = 2 * J + (wc >> 1);
+        const int npairs = nb * (nb + 1) / 2;
+        const int p128 = bi * (bi + 1) / 2 + bj;
+        float *slab = slabG + (((int64_t)l * npairs + p128) * nsplit + s) * (int64_t)(BS * BS);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * kg + r;
+                    const int col = (wc & 1) * 64 + 16 * j + (ln & 15);
+                    slab[row * BS + col] = acc[i][j][r] * unscale;
+                }
+    }
+    if (DIAG) {
+        // the two plane waves of a (128-row block, half) hold partial sums of the same rows
+        float *gw = reinterpret_cast<float *>(smem_raw); // [2][256]; the stage slots are dead behind this barrier
+        __syncthreads();
+        gw[(qd >> 1) * 256 + rbS * 128 + (qd & 1) * 64 + lane] = gacc;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int r = threadIdx.x;
+            slabg[(((int64_t)l * nb + 2 * I + (r >> 7)) * nsplit + s) * BS + (r & 127)] =
+                (gw[r] + gw[256 + r]) * __uint_as_float((unsigned)(127 - eA) << 23);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void syrk_image8_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit,
                                                              const unsigned char *__restrict__ image,
-                                                             const float *__restrict__ sg_all,
-                                                             const float *__restrict__ bp_all,
+                                                             const float *__restrict__ gb_all,
                                                              const unsigned *__restrict__ scal,
                                                              float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    typedef __attribute__((address_space(3))) void lds_void;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
-
-    // ---- item decode: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch; speed only) walk whole slices
+    // item decode: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch; speed only) walk whole slices
     const int nsplit8 = (nsplit + 7) / 8;
     const int per_l = npairs2 * nsplit8 * 8;
     const int l = blockIdx.x / per_l;
@@ -204,7 +513,7 @@ __global__ __launch_bounds__(1024, 1) void syrk_image_kernel(int64_t N, int64_t 
     const int s = (jj / npairs2) * 8 + xcd;
     const int p2 = jj % npairs2;
     if (s >= nsplit) return;
-    const int nb = M / BS, nb2 = M / kPanel;
+    const int nb2 = M / kPanel;
     const int noff = nb2 * (nb2 - 1) / 2;
     int I, J;
     if (p2 < noff) { // off-diagonal tiles first (the long items of a slice)
@@ -214,231 +523,19 @@ __global__ __launch_bounds__(1024, 1) void syrk_image_kernel(int64_t N, int64_t 
     } else {
         I = J = p2 - noff;
     }
-    const bool diag = I == J;
-
-    int wr = wave >> 2, wc = wave & 3;
-    bool active = true, store = true, dsub = false;
-    if (diag) {
-        const unsigned e = kDiagWave[wave];
-        wr = e & 3;
-        wc = (e >> 2) & 3;
-        active = (e >> 4) & 1;
-        store = (e >> 5) & 1;
-        dsub = (e >> 6) & 1;
-    }
-
-    const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
-    const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
-    const int eA = hdr->scale_exp;
-    // s_B = 2^e_B with s_B max(gamma) in [1/2, 1): y = s_B gamma x stays in the range of x
-    const unsigned gmax = scal[0];
-    int eB = gmax ? 126 - (int)(gmax >> 23) : 0;
-    eB = eB < -60 ? -60 : (eB > 60 ? 60 : eB);
-    const float sB = __uint_as_float((unsigned)(127 + eB) << 23);
-
-    const int64_t nbeg = (int64_t)s * kChunk;
-    int64_t nend = nbeg + kChunk;
-    if (nend > N) nend = N;
-    const int nstage = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
-    const int64_t ps0 = nbeg / 16;
-
-    // A: wave -> (part ia = (128-row block, hl), quarter qd = (plane, 64-row half)); two DMA pieces per stage
-    const int ia = wave >> 2, qd = wave & 3;
-    const h8 *a_src = blocks + ((ps0 * nb + 2 * I + (ia >> 1)) * 2 + (ia & 1)) * 256 + qd * 64 + lane;
-    const int a_dst = ia * 4096 + qd * 1024;
-    const int64_t slice_pitch = (int64_t)nb * 2 * 256; // h8 units between consecutive point slices
-    // B: wave -> (slice ub of the stage, 128-row block rbB, quarter qd); one granule (hi + lo) per thread and stage
-    const int ub = wave >> 3, rbB = (wave >> 2) & 1;
-    const h8 *b_src = blocks + (((ps0 + ub) * nb + 2 * J + rbB) * 2) * 256 + qd * 64 + lane;
-    const int b_dst = ub * kSliceBytes + (4 + rbB * 2) * 4096 + qd * 1024 + lane * 16;
-    // the 8 points of this wave's granules: 16 ub + 8 (qd >> 1) + 0..7 of the stage
-    const float *sgp = sg_all + (int64_t)l * Npad + nbeg + 16 * ub + 8 * (qd >> 1);
-    const float *bpp = bp_all + (int64_t)l * Npad + nbeg + 16 * ub + 8 * (qd >> 1);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gacc = 0.f;
-
-    u32x4 rh, rl;         // raw granule in flight
-    float gr[8], br[8];   // its points' gamma and beta (wave-uniform: scalar registers)
-
-#define AGPL_Q_DMA(t_)                                                                                          \
-    do {                                                                                                        \
-        unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + a_dst;                                           \
-        const h8 *src_ = a_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
-        __builtin_amdgcn_global_load_lds(src_, (lds_void *)slot_, 16, 0, 0);                                    \
-        __builtin_amdgcn_global_load_lds(src_ + slice_pitch, (lds_void *)(slot_ + kSliceBytes), 16, 0, 0);      \
-    } while (0)
-#define AGPL_Q_LOADB(t_)                                                                                        \
-    do {                                                                                                        \
-        const h8 *src_ = b_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
-        rh = *reinterpret_cast<const u32x4 *>(src_);                                                            \
-        rl = *reinterpret_cast<const u32x4 *>(src_ + 256);                                                      \
-        const float *g_ = sgp + (t_) * kStagePts, *b_ = bpp + (t_) * kStagePts;                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                      \
-            gr[q_] = g_[q_];                                                                                    \
-            br[q_] = b_[q_];                                                                                    \
-        }                                                                                                       \
-    } while (0)
-    // one quarter (two points) of the conversion: x = hi + lo, g += beta x, y = (s_B gamma) x -> hi / lo
-#define AGPL_Q_CVT(k_, RH_, RL_, OH_, OL_, keep_)                                                               \
-    do {                                                                                                        \
-        float x0_, x1_;                                                                                         \
-        AGPL_Q_JOIN2(RH_, RL_, x0_, x1_);                                                                       \
-        const float b0_ = br[2 * (k_)] * (keep_), b1_ = br[2 * (k_) + 1] * (keep_);                             \
-        AGPL_Q_GFMA(gacc, b0_, x0_); /* (unconditional: a branch here would cut the MFMA block into pieces) */ \
-        AGPL_Q_GFMA(gacc, b1_, x1_);                                                                            \
-        const float s0_ = gr[2 * (k_)] * sB, s1_ = gr[2 * (k_) + 1] * sB;                                       \
-        AGPL_Q_SPLIT2(x0_, s0_, x1_, s1_, OH_, OL_);                                                            \
-    } while (0)
-#define AGPL_Q_CVT_ALL(keep_)                                                                                   \
-    do {                                                                                                        \
-        AGPL_Q_CVT(0, rh.x, rl.x, rh.x, rl.x, keep_);                                                           \
-        AGPL_Q_CVT(1, rh.y, rl.y, rh.y, rl.y, keep_);                                                           \
-        AGPL_Q_CVT(2, rh.z, rl.z, rh.z, rl.z, keep_);                                                           \
-        AGPL_Q_CVT(3, rh.w, rl.w, rh.w, rl.w, keep_);                                                           \
-    } while (0)
-#define AGPL_Q_STOREB(t_)                                                                                       \
-    do {                                                                                                        \
-        /* written out: a compiler-visible LDS store behind an LDS-DMA in flight (the A pieces of the same stage, */ \
-        /* a disjoint part of the slot) is given an s_waitcnt vmcnt(0) -- the whole memory latency, mid-stage    */ \
-        const unsigned d_ = lds_base + (unsigned)(((t_) & 1) * kSlot + b_dst);                                  \
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:4096" ::"v"(d_), "v"(rh), "v"(rl) : "memory"); \
-    } while (0)
-
-    const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem_raw;
-    // prologue: stage 0
-    AGPL_Q_DMA(0);
-    AGPL_Q_LOADB(0);
-    AGPL_Q_CVT_ALL(diag ? 1.f : 0.f);
-    AGPL_Q_STOREB(0);
-    AGPL_Q_LOADB(nstage > 1 ? 1 : 0);
-
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int kg = ln >> 4;
-    const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
-    const int fa = fbase16 + (wr >> 1) * 512 + (wr & 1) * 64;
-    const int fb = fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
-
-    for (int t = 0; t < nstage; ++t) {
-        // stage t's A pieces and the raw granule of stage t + 1 have landed; the B' stores of stage t are done
-        __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        const bool more = t + 1 < nstage;   // stage t + 1 exists (else the conversion below is a harmless duplicate)
-        const float keep = (more && diag) ? 1.f : 0.f; // g rides the diagonal tiles, once per stage
-        const int tl = t + 2 < nstage ? t + 2 : nstage - 1; // unconditional loads (clamped): no phi of loaded values
-        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & 1) * kSlot);
-        // hook h (0..7) sits behind the MFMAs of (row half h >> 2, column h & 3); CV places the staging work of stage t + 1:
-        //   0: everything in front of the MFMA block;  1: everything at hook 0;  2: DMA at hook 0, a quarter of the conversion at
-        //   hooks 1..4, store + next loads at hook 5
-#define AGPL_Q_HOOK(h_)                                                                                         \
-    do {                                                                                                        \
-        if (CV == 1 && (h_) == 0) {                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            if (more) AGPL_Q_DMA(t + 1);                                                                        \
-            AGPL_Q_CVT_ALL(keep);                                                                               \
-            AGPL_Q_STOREB(t + 1);                                                                               \
-            AGPL_Q_LOADB(tl);                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-        }                                                                                                       \
-        if (CV == 2 && (h_) <= 5) {                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            if ((h_) == 0 && more) AGPL_Q_DMA(t + 1);                                                           \
-            if ((h_) == 1) AGPL_Q_CVT(0, rh.x, rl.x, rh.x, rl.x, keep);                                         \
-            if ((h_) == 2) AGPL_Q_CVT(1, rh.y, rl.y, rh.y, rl.y, keep);                                         \
-            if ((h_) == 3) AGPL_Q_CVT(2, rh.z, rl.z, rh.z, rl.z, keep);                                         \
-            if ((h_) == 4) AGPL_Q_CVT(3, rh.w, rl.w, rh.w, rl.w, keep);                                         \
-            if ((h_) == 5) {                                                                                    \
-                AGPL_Q_STOREB(t + 1);                                                                           \
-                AGPL_Q_LOADB(tl);                                                                               \
-            }                                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-        }                                                                                                       \
-    } while (0)
-        if (CV == 0) {
-            if (more) AGPL_Q_DMA(t + 1);
-            AGPL_Q_CVT_ALL(keep);
-            AGPL_Q_STOREB(t + 1);
-            AGPL_Q_LOADB(tl);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (active) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const h8 ah0 = st[fa + 32 * hf], ah1 = st[fa + 32 * hf + 16];
-                const h8 al0 = st[256 + fa + 32 * hf], al1 = st[256 + fa + 32 * hf + 16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // a diagonal sub-tile needs the 16 x 16 blocks i >= j only
-                    const bool need0 = !DSKIP || !dsub || 2 * hf >= j, need1 = !DSKIP || !dsub || 2 * hf + 1 >= j;
-                    if (need1) {
-                        const h8 bh = st[fb + 16 * j], bl = st[256 + fb + 16 * j];
-                        if (need0) {
-                            acc[2 * hf][j] = mfma32(ah0, bh, acc[2 * hf][j]);
-                            acc[2 * hf][j] = mfma32(ah0, bl, acc[2 * hf][j]);
-                            acc[2 * hf][j] = mfma32(al0, bh, acc[2 * hf][j]);
-                        }
-                        acc[2 * hf + 1][j] = mfma32(ah1, bh, acc[2 * hf + 1][j]);
-                        acc[2 * hf + 1][j] = mfma32(ah1, bl, acc[2 * hf + 1][j]);
-                        acc[2 * hf + 1][j] = mfma32(al1, bh, acc[2 * hf + 1][j]);
-                    }
-                    AGPL_Q_HOOK(4 * hf + j);
-                }
-            }
-        } else if (CV != 0) {
-            if (more) AGPL_Q_DMA(t + 1);
-            AGPL_Q_CVT_ALL(keep);
-            AGPL_Q_STOREB(t + 1);
-            AGPL_Q_LOADB(tl);
-        }
-#undef AGPL_Q_HOOK
-    }
-#undef AGPL_Q_DMA
-#undef AGPL_Q_LOADB
-#undef AGPL_Q_CVT
-#undef AGPL_Q_CVT_ALL
-#undef AGPL_Q_STOREB
-
-    // ---- slabs (layout of agpl_mfma.hip: [l][128-pair][slice][128 x 128] float32, rescaled exactly)
-    const float unscale = __uint_as_float((unsigned)(127 - (eA + eB)) << 23);
-    if (store) {
-        const int bi = 2 * I + (wr >> 1), bj = 2 * J + (wc >> 1);
-        const int npairs = nb * (nb + 1) / 2;
-        const int p128 = bi * (bi + 1) / 2 + bj;
-        float *slab = slabG + (((int64_t)l * npairs + p128) * nsplit + s) * (int64_t)(BS * BS);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = (wr & 1) * 64 + 16 * i + 4 * kg + r;
-                    const int col = (wc & 1) * 64 + 16 * j + (ln & 15);
-                    slab[row * BS + col] = acc[i][j][r] * unscale;
-                }
-    }
-    if (diag) {
-        // the four (slice, plane) waves of a (128-row block, half) hold partial sums of the same rows
-        float *gw = reinterpret_cast<float *>(smem_raw); // [4][256]; the stage slots are dead behind this barrier
-        __syncthreads();
-        gw[(ub * 2 + (qd >> 1)) * 256 + rbB * 128 + (qd & 1) * 64 + lane] = gacc;
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            const int r = threadIdx.x;
-            const float gsum = (gw[r] + gw[256 + r]) + (gw[512 + r] + gw[768 + r]);
-            slabg[(((int64_t)l * nb + 2 * I + (r >> 7)) * nsplit + s) * BS + (r & 127)] =
-                gsum * __uint_as_float((unsigned)(127 - eA) << 23);
-        }
-    }
+    if (I == J) syrk_image8_body<true>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    else syrk_image8_body<false>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
 }
 
 } // namespace
 
-size_t agpl_syrk_image_lds_bytes() { return 2 * (size_t)kSlot; }
+#ifdef AGPL_QTRACE
+extern "C" __attribute__((visibility("default"))) int agpl_debug_qtrace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qtrace), sizeof(g_qtrace));
+}
+#endif
+
+size_t agpl_syrk_image_lds_bytes() { return 2 * (size_t)kSlot + 512; } // two stage slots + two gamma | beta records
 
 extern "C" int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M) {
     if (N <= 0 || M <= 0 || M % BS) return 0;
@@ -477,8 +574,8 @@ extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, co
     if (hmx) {
         const int ex = (int)(hmx >> 23) - 127; // max_abs in [2^ex, 2^(ex+1))   (a subnormal max reads ex = -127)
         eA = 13 - ex;
-        if (eA > 60) eA = 60;
-        if (eA < -60) eA = -60;
+        if (eA > 30) eA = 30; // 2 e_A + e_B stays an exponent of a normal float32 (e_B in [-60, 60])
+        if (eA < -30) eA = -30;
     }
     const float scale = ldexpf(1.f, eA);
     const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2;
@@ -488,38 +585,24 @@ extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, co
 }
 
 // internal (agpl_accumulate_impl): prep + accumulation kernel; slabs as agpl_mfma.hip lays them out.
-// sg / bp: [L][Npad] float32 scratch, Npad >= N rounded up to 32; scal: 2 words of scratch.
+// gb: 2 L Npad floats of scratch (the gamma | beta records), Npad = N rounded up to 32 (+ 32); scal: 2 words of scratch.
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
-                               const float *gamma, const float *beta, float *sg, float *bp, unsigned *scal,
-                               float *slabG, float *slabg, int ns) {
+                               const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
+                               float *slabg, int ns) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
     const int nb2 = M / kPanel;
     const int npairs2 = nb2 * (nb2 + 1) / 2;
     const int64_t nwg = (int64_t)L * npairs2 * ((ns + 7) / 8) * 8;
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     AGPL_HIP(ctx, hipMemsetAsync(scal, 0, 2 * sizeof(unsigned), ctx->stream));
-    acc_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, sg, bp, scal);
+    acc_prep8_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, gb, scal);
+    acc_scale_kernel<<<1024, 256, 0, ctx->stream>>>((int64_t)L * (Npad / 32), gb, scal);
     AGPL_LAUNCH_CHECK(ctx);
-    static const int cv = getenv("AGPL_SYRKQ_CV") ? atoi(getenv("AGPL_SYRKQ_CV")) : 1;
-    static const int dskip = getenv("AGPL_SYRKQ_DSKIP") ? atoi(getenv("AGPL_SYRKQ_DSKIP")) : 0;
     const size_t lds = agpl_syrk_image_lds_bytes();
-#define AGPL_LAUNCH_Q(CV_, DS_)                                                                                       \
-    do {                                                                                                              \
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_image_kernel<CV_, DS_>),               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        syrk_image_kernel<CV_, DS_><<<(unsigned)nwg, 1024, lds, ctx->stream>>>(                                       \
-            N, Npad, M, npairs2, ns, (const unsigned char *)image, sg, bp, scal, slabG, slabg);                      \
-    } while (0)
-    if (dskip) {
-        if (cv == 0) AGPL_LAUNCH_Q(0, true);
-        else if (cv == 2) AGPL_LAUNCH_Q(2, true);
-        else AGPL_LAUNCH_Q(1, true);
-    } else {
-        if (cv == 0) AGPL_LAUNCH_Q(0, false);
-        else if (cv == 2) AGPL_LAUNCH_Q(2, false);
-        else AGPL_LAUNCH_Q(1, false);
-    }
-#undef AGPL_LAUNCH_Q
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_image8_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    syrk_image8_kernel<<<(unsigned)nwg, 512, lds, ctx->stream>>>(N, Npad, M, npairs2, ns, (const unsigned char *)image, gb,
+                                                                 scal, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

@@ -630,7 +630,7 @@ extern "C" int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64
     return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
 }
 
-extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+static int32_t gibbs_pass_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi, const void *acc_image, bool force_split,
                                    const float *kdiag, const float *mu0, const void *y, const double *v,
                                    uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
                                    int64_t *n_out, uint32_t *nuni_out) {
@@ -660,7 +660,10 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
                                           n_out, nuni_out, bad, (double *)base);
     if (rc) return rc;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
+    const int keep_split = ctx->accumulate_split;
+    if (force_split) ctx->accumulate_split = 1;
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, bet, gam, G_out, g_out, base);
+    ctx->accumulate_split = keep_split;
     if (rc) return rc;
     if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
         int hbad = 0;
@@ -672,6 +675,22 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
                       "(negativemultinomial.jl:17-22)");
     }
     return AGPL_OK;
+}
+
+extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                   const float *kdiag, const float *mu0, const void *y, const double *v,
+                                   uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
+                                   int64_t *n_out, uint32_t *nuni_out) {
+    return gibbs_pass_impl(ctx, lik, N, M, Phi, nullptr, false, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
+                           n_out, nuni_out);
+}
+
+extern "C" int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                         const void *Phi_acc, const float *kdiag, const float *mu0, const void *y,
+                                         const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
+                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out) {
+    return gibbs_pass_impl(ctx, lik, N, M, Phi, Phi_acc, true, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
+                           n_out, nuni_out);
 }
 
 namespace {
@@ -852,7 +871,12 @@ extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik,
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
+    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
+    const int keep = ctx->accumulate_split;
+    ctx->accumulate_split = 1;
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
+    ctx->accumulate_split = keep;
+    return rc;
 }
 
 extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
@@ -860,18 +884,18 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
                                                const void *U_hi, const void *U_lo, const float *v, float *mu_out,
                                                float *var_out);
 
-extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                               const float *Phi, const void *Phi_hi, const void *Phi_lo,
-                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
-                                               const void *U_lo, const float *v, double *G_out, double *g_out,
-                                               float *c_out, float *gamma_out, float *beta_out) {
+// shared body: acc_image == nullptr -> the accumulation stages the float32 Phi (syrk_split_kernel)
+static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                     const void *Phi_hi, const void *Phi_lo, const void *acc_image, const float *resid,
+                                     const float *mu0, const void *y, const void *U_hi, const void *U_lo, const float *v,
+                                     double *G_out, double *g_out, float *c_out, float *gamma_out, float *beta_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     agpl_lik_dev ld;
     int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
     if (rc) return rc;
     const int L = ld.nlatent;
     if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
-    if (!Phi || !Phi_hi || !Phi_lo || !resid || !y || !U_hi || !U_lo || !v || !G_out || !g_out)
+    if ((!Phi && !acc_image) || !Phi_hi || !Phi_lo || !resid || !y || !U_hi || !U_lo || !v || !G_out || !g_out)
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
     const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
@@ -886,8 +910,33 @@ extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_des
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
+    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
+    const int keep = ctx->accumulate_split;
+    ctx->accumulate_split = 1;
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, bet, gam, G_out, g_out, base);
+    ctx->accumulate_split = keep;
     if (rc) return rc;
     // everything of this pass is enqueued: now is the free moment to look at the outcome of the factorisation before it
     return agpl_pending_resolve(ctx);
+}
+
+extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                               const float *Phi, const void *Phi_hi, const void *Phi_lo,
+                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
+                                               const void *U_lo, const float *v, double *G_out, double *g_out,
+                                               float *c_out, float *gamma_out, float *beta_out) {
+    if (ctx && !Phi) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    return cavi_pass_factor_impl(ctx, lik, N, M, Phi, Phi_hi, Phi_lo, nullptr, resid, mu0, y, U_hi, U_lo, v, G_out, g_out,
+                                 c_out, gamma_out, beta_out);
+}
+
+extern "C" int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                               const void *Phi_hi, const void *Phi_lo, const void *Phi_acc,
+                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
+                                               const void *U_lo, const float *v, double *G_out, double *g_out,
+                                               float *c_out, float *gamma_out, float *beta_out) {
+    if (ctx && !Phi_acc) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    if (ctx && M % 256) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 256", M);
+    return cavi_pass_factor_impl(ctx, lik, N, M, nullptr, Phi_hi, Phi_lo, Phi_acc, resid, mu0, y, U_hi, U_lo, v, G_out,
+                                 g_out, c_out, gamma_out, beta_out);
 }

@@ -164,6 +164,8 @@ class SparseCAVI:
                           _ptr(self.Phi_lo))
             self.W_hi = torch.empty(L * M * M, dtype=torch.float16, device=dev)
             self.W_lo = torch.empty(L * M * M, dtype=torch.float16, device=dev)
+        # the accumulation's own operand: the point-major split-float16 image (agpl_accumulate_image), M % 256 == 0
+        self.Phi_acc = accumulate_image(self.Phi, self.ctx) if (self.acc_split and M % 256 == 0) else None
         self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
         if self.factor:
@@ -212,6 +214,12 @@ class SparseCAVI:
         """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
         d = self.lik.desc()
         self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
+        if self.factor and self.Phi_acc is not None:
+            self.ctx.call("agpl_cavi_pass_factor_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
+                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.Phi_acc), _ptr(self.resid), _ptr(self.mu0),
+                          _ptr(self.y), _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g),
+                          _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
+            return
         if self.factor:
             self.ctx.call("agpl_cavi_pass_factor_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
                           _ptr(self.Phi), _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0),
@@ -305,6 +313,22 @@ class SparseCAVI:
         return mu, var
 
 
+def accumulate_image(Phi, ctx: Context | None = None):
+    """The accumulation's operand (agpl_accumulate_image): Phi float32 [N, Mp] -> the point-major split-float16 image
+    (uint8 tensor, 256-byte header + 4 KB blocks [point slice of 16][feature block of 128][hi | lo]).  Raises DomainError if
+    a feature is not finite."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    Phi = _prep(Phi, torch.float32, "Phi")
+    N, M = Phi.shape
+    nbytes = _ffi.lib().agpl_accumulate_image_bytes(C.c_int64(N), C.c_int32(M))
+    if nbytes <= 0:
+        raise _ffi.ArgumentError(-1, f"feature count {M} must be a multiple of {PAD} (zero-pad)")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=Phi.device)
+    ctx.call("agpl_accumulate_image", C.c_int64(N), C.c_int32(M), _ptr(Phi), _ptr(img))
+    return img
+
+
 def nystrom_residual(Phi, kxx, ctx: Context | None = None):
     """d_i = k_ii - |phi_i|^2 through agpl_marginals with W = I, alpha = 0."""
     torch = _torch()
@@ -358,6 +382,7 @@ class SparseGibbs:
         dev = self.Phi.device
         L, M = self.L, self.M
         f64 = torch.float64
+        self.Phi_acc = accumulate_image(self.Phi, self.ctx) if (self.acc_split and M % 256 == 0) else None
         self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.v = torch.empty((L, M), dtype=f64, device=dev)
         self.m = torch.empty((L, M), dtype=f64, device=dev)
@@ -387,12 +412,21 @@ class SparseGibbs:
         """Point pass of one sweep on the streams (seed, point_offset + i, sweep_index)."""
         d = self.lik.desc()
         self.sweep_index = self.ctx.next_sweep()
+        prev_offset = self.ctx.point_offset
         self.ctx.set_point_offset(self.point_offset)
-        self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
-        self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
-                      _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
-                      _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))
-        self.ctx.set_point_offset(0)
+        try:  # (a raising pass must not leave the context's point offset shifted for its other users)
+            if self.acc_split:
+                self.ctx.call("agpl_gibbs_pass_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
+                              _ptr(self.Phi_acc), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
+                              C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
+                              _ptr(self.n), C.c_void_p(0))
+            else:
+                self.ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+                self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
+                              _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
+                              _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))
+        finally:
+            self.ctx.set_point_offset(prev_offset)
 
     def exchange(self):
         exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))

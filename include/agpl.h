@@ -356,16 +356,34 @@ AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int3
                                        const void *acc_image, const float *beta, const float *gamma, double *G_out,
                                        double *g_out);
 
+/* The sweep entry points on the image (the shipped path: bench.py, SparseCAVI / SparseGibbs defaults):
+ *   agpl_cavi_pass_factor_image : agpl_cavi_pass_factor_split with the accumulation taken from Phi_acc (the image of
+ *                                 agpl_accumulate_image) -- the float32 features are not an argument; M % 256 == 0.
+ *   agpl_gibbs_pass_image       : agpl_gibbs_pass with the split-float16 accumulation, from Phi_acc when it is given
+ *                                 and M % 256 == 0 (Phi is still read by the projection phi_i' v).
+ * Every *_split / *_image entry point runs the split-float16 accumulation whatever agpl_set_accumulate_precision says.  */
+AGPL_API int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                             const void *Phi_hi, const void *Phi_lo, const void *Phi_acc,
+                                             const float *resid, const float *mu0, const void *y, const void *U_hi,
+                                             const void *U_lo, const float *v, double *G_out, double *g_out,
+                                             float *c_out, float *gamma_out, float *beta_out);
+AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
+                                       const float *Phi, const void *Phi_acc, const float *kdiag, const float *mu0,
+                                       const void *y, const double *v, uint32_t sweep, double *G_out, double *g_out,
+                                       double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
+
 /* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
  *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
  *   context's stream.  For hosts that own their communicator (the Julia / C++ callers of INTEGRATION.md); the
  *   Python host reaches the same RCCL through torch.distributed.  librccl is loaded at the first call.          */
 AGPL_API int32_t agpl_allreduce_nat(agpl_ctx *ctx, void *rccl_comm, double *buf, int64_t count);
 
-/* agpl_set_accumulate_precision: which kernel agpl_accumulate / agpl_cavi_pass(_split) / agpl_gibbs_pass use for
- *   G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default), 1 = split-float16 MFMA (psi = sqrt(gamma) phi is
- *   split into hi/lo float16 while staging; 3 float16 products per float32 product; needs gamma >= 0 and
- *   |sqrt(gamma) phi| < 6e4).  Same slabs, same fixed-order float64 reduction.                               */
+/* agpl_set_accumulate_precision: which kernel the float32-named entry points agpl_accumulate / agpl_cavi_pass /
+ *   agpl_gibbs_pass use for G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default: what their names promise),
+ *   1 = split-float16 MFMA (psi = sqrt(gamma) phi split into hi/lo float16 while staging; 3 float16 products per
+ *   float32 product; needs gamma >= 0 and |sqrt(gamma) phi| < 6e4).  Same slabs, same fixed-order float64 reduction.
+ *   The *_split / *_image entry points (agpl_accumulate_split, agpl_cavi_pass_split, agpl_cavi_pass_factor_split,
+ *   agpl_cavi_pass_factor_image, agpl_gibbs_pass_image) do not read this setting: they are the split path.      */
 AGPL_API int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode);
 
 /* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
