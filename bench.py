@@ -292,6 +292,30 @@ def c5_leg(A, args):
     return out
 
 
+def self_launch(ngpus):
+    """Run this script under torch.distributed.run with one rank per GPU as a child process; returns its exit code
+    (2: fewer than `ngpus` devices are visible).  The parent never initialises a GPU (device_count() does not)."""
+    import socket
+    import subprocess
+
+    single_dev = os.environ.get("AGPL_BENCH_SINGLE_DEVICE") == "1"  # test hook, see main()
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < (1 if single_dev else ngpus):
+        print(f"[bench] --gpus {ngpus} but only {have} device(s) are visible: refusing to measure fewer", file=sys.stderr,
+              flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +342,12 @@ def main():
     args = ap.parse_args()
     default_config = (args.n, args.m, args.lik) == (10_000_000, 512, "bernoulli")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL over
+        # xGMI) as a CHILD of this process -- before anything here has touched a GPU -- and relay rank 0's JSON line and
+        # the exit code.  A run that asks for N GPUs can therefore never silently measure one.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -334,6 +364,7 @@ def main():
     torch.cuda.set_device(local_rank)
     group = None
     watchdog = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
 
@@ -364,6 +395,7 @@ def main():
         if probe.item() != world:
             print(f"[bench rank {rank}] first all-reduce returned {probe.item()} != {world}", file=sys.stderr, flush=True)
             os._exit(4)
+        rccl_ranks = int(probe.item())  # what the communicator actually summed over (reported in the JSON line)
         watchdog.cancel()
 
     import agpl_amd as A
@@ -415,7 +447,8 @@ def main():
 
     out = {
         "metric": "CAVI sweeps/sec (N obs, M inducing) + max |Δnat-param| vs CPU ref",
-        "value": round(value, 4), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 4), "unit": "sweeps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if (args.marginal == "f32" and args.accumulate == "f32")
                  else "f32 via f16 hi/lo split operands (3 f16 MFMA products per f32 product, f32 accumulate, "

@@ -64,3 +64,29 @@ def test_bench_line_two_ranks_through_the_driver_launcher():
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun): the script starts its own ranks as a child process and the line says
+    n_gpus = 2 and rccl_ranks = 2 -- a run that asks for N GPUs never silently measures one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["AGPL_BENCH_SINGLE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--points", "300000", "--inducing", "256", "--steps",
+                        "3", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=550, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["value"] > 0
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AGPL_BENCH_SINGLE_DEVICE")}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
