@@ -31,8 +31,7 @@ struct agpl_ctx {
     int logtheta_n = 0;
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
     int accumulate_split = 0; // 0: f32-input MFMA accumulation, 1: split-float16 (agpl_set_accumulate_precision)
-    int *strip_plan = nullptr; // device copy of the syrk_strip_kernel decomposition for strip_nb block rows
-    int strip_nb = 0, strip_ntypes = 0, strip_nE = 0;
+    int ncu = 0;              // compute units of `device` (queried once, by the first queue-served launch)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

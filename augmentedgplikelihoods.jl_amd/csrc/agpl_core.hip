@@ -41,7 +41,6 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
-    if (ctx->strip_plan) (void)hipFree(ctx->strip_plan);
     if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
     if (ctx->pend_ev) (void)hipEventDestroy(ctx->pend_ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -431,34 +431,9 @@ constexpr int kStageBytes = 4 * kImgBytes;    // A hi | A lo | B hi | B lo
 // the compiler the same sums become v_pk_mul_f32 / v_pk_fma_f32 chains scheduled among the MFMAs, and in some shapes of the
 // surrounding code (an extra wave-uniform branch in the MFMA block; two staging register sets) g then differed from run to
 // run at the 1e-4 level on the hardware while G stayed bit-identical -- root cause open (an isolated
-// replay of the instruction sequence computes correctly); the explicit sequence is bitwise reproducible in every shape tried.
-#ifndef AGPL_G_VARIANT
-#define AGPL_G_VARIANT 0
-#endif
-#if AGPL_G_VARIANT == 0
+// replay of the instruction sequence computes correctly); the explicit sequence is bitwise reproducible in every shape tried
+// (tests/test_gpu_repeat.py soaks it).
 #define AGPL_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
-#define AGPL_GPRE()
-#else
-// investigation builds only (make GVAR=1|2|3): the compiler's own multiply-adds, optionally fenced
-#define AGPL_GFMA(acc_, b_, x_) (acc_) += (b_) * (x_)
-#if AGPL_G_VARIANT == 2
-#define AGPL_GPRE() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7")
-#elif AGPL_G_VARIANT == 3
-#define AGPL_GPRE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define AGPL_GPRE()
-#endif
-#endif
-// variant 4: wait states between the products b * gkeep and their first use
-#if AGPL_G_VARIANT == 4
-#define AGPL_GMID(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
-#elif AGPL_G_VARIANT == 5
-#define AGPL_GMID(a_, b_) asm volatile("s_nop 0" : "+v"(a_), "+v"(b_))
-#elif AGPL_G_VARIANT == 6
-#define AGPL_GMID(a_, b_) asm volatile("" : "+v"(a_), "+v"(b_))
-#else
-#define AGPL_GMID(a_, b_)
-#endif
 
 // Staging geometry: a 16-lane group of a store must fill whole 16-byte slots (both 8-byte point halves) of
 // consecutive rows to touch every LDS bank once, so the point half is the lane's low bit.
@@ -472,20 +447,16 @@ template <bool DIAG>
 __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const float *__restrict__ sbase, int M,
                                                 int bi, int bj, int nstage, int plast,
                                                 const float *__restrict__ sgs, const float *__restrict__ bps,
-                                                f32x16 (&acc)[2][2], float (&gacc)[4], bool diag_full,
-                                                unsigned *start_ctr, unsigned npartners, int dbg) {
+                                                f32x16 (&acc)[2][2], float (&gacc)[4]) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
-    // diag_full (AGPL_SYRK_DIAGFULL=1, experiment): the sub-tile above the diagonal of a diagonal tile is multiplied too, so
-    // that diagonal workgroups keep the pace of the off-diagonal ones that read the same panel (L2 sharing)
-    const bool active = !(DIAG && wr < wc) || diag_full;
+    const bool active = !(DIAG && wr < wc); // the sub-tile above the diagonal of a diagonal tile is not multiplied
     // the 32 x 32 block above the diagonal of a diagonal sub-tile (rows 0..31 x columns 32..63 of sub-tile (w, w) of a
     // diagonal tile) is never read back: reduce_G_kernel mirrors element-wise from the lower triangle
-    const bool upper = !(DIAG && wr == wc) || diag_full || (dbg & 2); // dbg bit 1 (AGPL_SYRK_PRIO bit 10): A/B switch
-    const bool dbg_same = (dbg & 1) != 0;
+    const bool upper = !(DIAG && wr == wc);
     constexpr int PQ = DIAG ? 2 : 4; // points per thread
     const int panel = DIAG ? 0 : (wave >> 1);
     const int plane = wave & 1;
@@ -538,9 +509,7 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
     do {                                                                                           \
         unsigned char *dst_ = smem_raw + (buf_) * kStageBytes + dst0;                              \
         if (DIAG) {                                                                                \
-            AGPL_GPRE();                                                                           \
             float ba_ = bv[0] * (gkeep_), bb2_ = bv[1] * (gkeep_);                                 \
-            AGPL_GMID(ba_, bb2_);                                                                  \
             AGPL_GFMA(gacc[0], ba_, x[0].x); AGPL_GFMA(gacc[0], bb2_, x[1].x);                       \
             AGPL_GFMA(gacc[1], ba_, x[0].y); AGPL_GFMA(gacc[1], bb2_, x[1].y);                       \
             AGPL_GFMA(gacc[2], ba_, x[0].z); AGPL_GFMA(gacc[2], bb2_, x[1].z);                       \
@@ -581,28 +550,13 @@ __device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const f
 
     AGPL_SS_LOAD(0);
     AGPL_SS_STORE(0, 1.f);
-    if (start_ctr) {
-        // start hint: the workgroups of a slice are dispatched one per freed slot, ~8 us apart first to last, while an XCD's
-        // L2 holds ~4 us of its traffic; waiting here -- behind the first stage's loads and stores, in front of the barrier
-        // that follows them anyway; bounded at ~16 us: a hint, never a dependency (a workgroup whose partners do not show up
-        // simply goes on) -- until all of them have arrived lets them stream the slice's panels through L2 together:
-        // 1.21-1.26 x the algorithmic bytes fetched instead of 1.78 x
-        if (tid == 0) {
-            __hip_atomic_fetch_add(start_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int it = 0; it < 64 && __hip_atomic_load(start_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < npartners; ++it)
-                __builtin_amdgcn_s_sleep(8);
-        }
-    }
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
         // unconditional (the last iteration re-loads its own stage): a conditional load would make x a phi of
         // loaded / not-loaded values and the copies would wait for the loads before the MFMAs
         const bool more = st + 1 < nstage;
-        // dbg_same (AGPL_SYRK_PRIO bit 8): every stage re-reads stage 0 -- wrong sums, a timing experiment that takes the
-        // memory system out of the loop: 6.86 against 8.25 ms at C2 with four workgroups per CU, 7.22 against 8.98 ms with
-        // three (AGPL_SYRK_LDSPAD=15000) -- DESIGN 4.4d
-        AGPL_SS_LOAD(dbg_same ? 0 : (more ? st + 1 : st));
+        AGPL_SS_LOAD(more ? st + 1 : st);
         __builtin_amdgcn_sched_barrier(0); // keep the loads above the MFMA block
         if (active) {
             const h8v *I = reinterpret_cast<const h8v *>(smem_raw + buf * kStageBytes);
@@ -637,11 +591,7 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
                                                             const float *__restrict__ Phi,
                                                             const float *__restrict__ sg_all,
                                                             const float *__restrict__ bp_all,
-                                                            float *__restrict__ slabG, float *__restrict__ slabg,
-                                                            int diag_full, unsigned *__restrict__ start_ctr, int prio_mode,
-                                                            int ngrouped, int group) {
-    // nsplit counts work UNITS here: unit u < ngrouped covers `group` consecutive 4096-point slices (one f32 accumulation
-    // run of group x 4096 points, one slab), the units behind them one slice each -- see agpl_accumulate_impl
+                                                            float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nsplit8 = (nsplit + 7) / 8;
@@ -652,37 +602,20 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
     const int s = (j / npairs) * 8 + xcd;
     const int p = j % npairs;
     if (s >= nsplit) return;
-    const int pm = prio_mode & 255; // bit 8: same-stage timing experiment (syrk_split_body dbg_same)
-    if (pm) {
-        // static issue priorities that differ between groups of workgroups (AGPL_SYRK_PRIO; 2 = by block id / 256 is the
-        // default, 0 = off): the matrix pipe's 51 % duty is one wave's duty cycle -- the four waves on a SIMD (one per
-        // co-resident workgroup) interleave their MFMA blocks instruction by instruction, finish together and convert
-        // together.  Measured (profiles/r02_ab_syrk_priority.jsonl): mode 2 takes 1 % off at C2 and 4.5 % off at M = 1024
-        // (26.7 against 27.9-28.1 ms); priorities by the hardware's workgroup / wave slot (modes 4, 3), by slice (5), by tile
-        // pair (6) or hashed (1) change nothing
-        const unsigned h = pm == 4   ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) // HW_ID.TG_ID
-                           : pm == 3 ? (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4)  // HW_ID.WAVE_ID
-                           : pm == 2 ? (blockIdx.x >> 8)
-                           : pm == 5 ? (unsigned)(j / npairs)
-                           : pm == 6 ? (unsigned)p
-                           : pm == 7 ? 3u - ((blockIdx.x >> 8) & 3u)
-                           : pm == 8 ? (blockIdx.x >> 7)
-                           : pm == 9 ? (blockIdx.x >> 9)
-                                            : ((blockIdx.x * 2654435761u) >> 13);
-        switch (h & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-        }
+    // static issue priorities that differ between groups of 256 consecutive workgroup ids: the four waves on a SIMD (one per
+    // co-resident workgroup) otherwise interleave their MFMA blocks instruction by instruction, finish together and convert
+    // together (round 2: -1 % at C2, -4.5 % at M = 1024; priorities by hardware slot, slice or tile pair change nothing)
+    switch ((blockIdx.x >> 8) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
     }
     const int nb = M / BS;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
     const int bj = p - bi * (bi + 1) / 2;
     const bool diag = (bi == bj);
-    const int first = s < ngrouped ? s * group : ngrouped * group + (s - ngrouped);
-    const int count = s < ngrouped ? group : 1;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -693,27 +626,19 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
             for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
     float gacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // the tile kind is decided once, outside the slice loop: one loop per body instance (a branch inside the loop makes the
-    // accumulators a merge of both bodies' and spills them)
-#define AGPL_SLICES(DIAG_, DF_)                                                                                          \
-    for (int q = 0; q < count; ++q) {                                                                                    \
-        const int64_t nbeg = (int64_t)(first + q) * kChunk;                                                              \
-        int64_t nend = nbeg + kChunk;                                                                                    \
-        if (nend > N) nend = N;                                                                                          \
-        const int nstage = (int)((nend - nbeg + 15) / 16);                                                               \
-        const int plast = (int)(nend - 1 - nbeg);                                                                        \
-        unsigned *hint = (start_ctr && q == 0) ? start_ctr + (size_t)l * nsplit + s : nullptr;                           \
-        /* (the body leaves through a barrier behind its last LDS reads: the next slice may restage at once) */          \
-        syrk_split_body<DIAG_>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast,                              \
-                               sg_all + (int64_t)l * Npad + nbeg, bp_all + (int64_t)l * Npad + nbeg, acc, gacc, DF_,     \
-                               hint, (unsigned)npairs, ((prio_mode >> 8) & 1) | ((prio_mode >> 9) & 2));                                          \
-    }
-    if (diag) {
-        AGPL_SLICES(true, diag_full != 0)
-    } else {
-        AGPL_SLICES(false, false)
-    }
-#undef AGPL_SLICES
+    // the tile kind is decided once: one call per body instance (a branch around the stage loop's body would make the
+    // accumulators a merge of both bodies' and spill them)
+    const int64_t nbeg = (int64_t)s * kChunk;
+    int64_t nend = nbeg + kChunk;
+    if (nend > N) nend = N;
+    const int nstage = (int)((nend - nbeg + 15) / 16);
+    const int plast = (int)(nend - 1 - nbeg);
+    if (diag)
+        syrk_split_body<true>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast, sg_all + (int64_t)l * Npad + nbeg,
+                              bp_all + (int64_t)l * Npad + nbeg, acc, gacc);
+    else
+        syrk_split_body<false>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast, sg_all + (int64_t)l * Npad + nbeg,
+                               bp_all + (int64_t)l * Npad + nbeg, acc, gacc);
     if (diag) {
         // lanes 4k..4k+3 hold the four point pairs of feature quad 16 (w >> 1) + k over this wave's plane
 #pragma unroll
@@ -752,289 +677,6 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
 
 size_t syrk_split_lds_bytes() { return 2 * kStageBytes; }
 
-// ------------------------------------------------------------------------------------------------
-// syrk_strip_kernel: the split-float16 accumulation with ONE 1024-thread workgroup (16 waves) per CU that owns up to
-// sixteen 64 x 64 sub-tiles of G drawn from at most FOUR staged 128-row panels, instead of four independent 4-wave
-// workgroups owning one 128 x 128 tile (two panels) each.  What that buys at M = 512 (lower triangle = 10 tiles):
-//   * panel stagings (global -> registers -> scale, split to hi / lo float16 -> LDS) per 4096-point slice: 9 instead of
-//     16 -- the L2 -> CU bytes AND the v_fma_mix conversions drop by 44 % (round 1 measured the next stage's loads at 26 %
-//     and conversion + LDS stores + barriers at 19 % of syrk_split_kernel);
-//   * a stage is 32 points: 24 MFMAs per wave between two barriers instead of 12;
-//   * workgroups that walk the same slices advance through the same stage indices at the same pace (every type has
-//     ~16 sub-tiles and 3-4 panels), so the re-reads of a panel by another workgroup type hit L2 more often.
-// The decomposition is a host-built plan (syrk_strip_plan): workgroup TYPES, each a list of <= 4 panel instances
-// (panel index, slice offset: a type that needs < 3 panels replicates itself over 2 or 4 slices) and <= 16 sub-tile
-// entries (A instance + 64-row half, B instance + half, output unit, position); per super-slice (4 slices) a list of
-// (type, first slice) entries.  M = 512:  T0 = {(3,0) (3,1) (3,2) (3,3)}  panels 3,0,1,2;  T1 = {(2,0) (2,1) (2,2) (0,0)}
-// panels 2,0,1;  T2 = {(1,0) (1,1)} x 2 slices: 5 workgroups per 2 slices, all of 14-15 active sub-tiles.
-// Staging, images, scaling and slabs are those of syrk_split_kernel (the [plane][slot][8 halves] image with
-// slot(r) = (r & 3) 36 + (r >> 2), here 4 planes of 8 points): wave w stages (instance w >> 2, plane w & 3) -- 16 values
-// per thread from 4 coalesced float4 loads, 8 ds_write_b64 -- and g = Phi beta rides the staging registers of the
-// instance that is the row panel of a diagonal unit.  Same f32 accumulation length (one slab per unit and slice),
-// same fixed-order float64 reduction behind it: bitwise reproducible.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTypeWords = 16 + 16 * 8;                // plan words per workgroup type
-constexpr int kSuper = 4;                              // slices per super-slice (lcm of the replications 1, 2, 4)
-
-// PP = true (shipped): the two halves of the workgroup (waves 0-7, 8-15: two waves of each on every SIMD) run half a
-// stage out of phase -- while one half multiplies stage st out of LDS, the other converts and stores its share of
-// stage st + 1, then they swap (two barriers per stage).  In lock step (PP = false) every wave converts at the same
-// time and the matrix pipe idles meanwhile: measured 8.47 ms against 8.11 ms for syrk_split_kernel at C2, whose four
-// independent workgroups per CU drift apart and overlap by themselves.
-// NW / PLANES: 16 waves with 32-point stages (4 planes of 8 points; one workgroup per CU) or 8 waves with 16-point stages
-// (2 planes; two workgroups per CU, <= 8 sub-tiles each: typically {off-diagonal tile + the diagonal tile of one of its
-// panels}, which folds the diagonal workgroups' separate panel reads away).  Wave w stages (instance w / PLANES, plane
-// w % PLANES); at most NW / PLANES = 4 instances either way.
-template <int NW, int PLANES, bool PP>
-__global__ __launch_bounds__(NW * 64, 4) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
-                                                             const float *__restrict__ Phi,
-                                                             const float *__restrict__ sg_all,
-                                                             const float *__restrict__ bp_all,
-                                                             float *__restrict__ slabG, float *__restrict__ slabg,
-                                                             const int *__restrict__ plan, int ntypes, int nE,
-                                                             int nsuper) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int kSPts = 8 * PLANES;                      // points per stage
-    constexpr int kSImgSlots = PLANES * 148;               // 16-byte slots per image (hi or lo of one panel instance)
-    constexpr int kSImgBytes = kSImgSlots * 16;
-    constexpr int kSStageBytes = 4 * 2 * kSImgBytes;       // 4 instances x (hi | lo)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nsuper8 = (nsuper + 7) / 8;
-    const int per_l = nE * nsuper8 * 8;
-    const int l = blockIdx.x / per_l;
-    const int rem = blockIdx.x - l * per_l;
-    const int xcd = rem & 7, jj_ = rem >> 3;
-    const int e = jj_ % nE;
-    const int sup = (jj_ / nE) * 8 + xcd;
-    if (sup >= nsuper) return;
-    const int *ent = plan + ntypes * kTypeWords + 2 * e;
-    const int *ty = plan + ent[0] * kTypeWords;
-    const int s0 = sup * kSuper + ent[1];
-    if (s0 >= nsplit) return;
-    const int npan = ty[1];
-    const int nb = M / BS;
-
-    // ---- this wave's staging job: instance q, plane h
-    const int q = wave / PLANES, plane = wave % PLANES;
-    const int sq = s0 + ty[6 + q];
-    const bool stager = q < npan && sq < nsplit;
-    const int64_t nbeg_q = (int64_t)sq * kChunk;
-    int64_t nend_q = nbeg_q + kChunk;
-    if (nend_q > N) nend_q = N;
-    const int nstage_q = stager ? (int)((nend_q - nbeg_q + kSPts - 1) / kSPts) : 0;
-    const int plast_q = (int)(nend_q - 1 - nbeg_q);
-    const bool gjob = stager && ty[10 + q] != 0;
-    // the longest instance sets the loop length (instances differ only when one of them is the last, short slice)
-    int nstage = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int si = s0 + ty[6 + i];
-        if (i < npan && si < nsplit) {
-            int64_t b = (int64_t)si * kChunk, en = b + kChunk;
-            if (en > N) en = N;
-            const int ns = (int)((en - b + kSPts - 1) / kSPts);
-            nstage = ns > nstage ? ns : nstage;
-        }
-    }
-
-    const int half = lane & 1, fq = lane >> 1;
-    const int p0 = 8 * plane + 4 * half; // first of this thread's 4 points within the stage
-    const unsigned colofs4 = (unsigned)(ty[2 + q] * BS + (fq << 2)) * 4u; // byte offset of the thread's 4 features in a row
-    const char *sbase = reinterpret_cast<const char *>(Phi + nbeg_q * (int64_t)M);
-    const unsigned rowpitch = (unsigned)M * 4u;
-    // wave-uniform bases + one per-lane byte offset (the thread's 4 points within a stage)
-    const char *sgs = reinterpret_cast<const char *>(sg_all + (int64_t)l * Npad + nbeg_q);
-    const char *bps = reinterpret_cast<const char *>(bp_all + (int64_t)l * Npad + nbeg_q);
-    const char *zeros = reinterpret_cast<const char *>(sg_all + (int64_t)l * Npad + (Npad - 32)); // 32 zeros past every slice
-    const unsigned p0b = (unsigned)p0 * 4u;
-    const unsigned dst0 = (unsigned)(q * 2 * kSImgBytes + plane * 148 * 16 + fq * 16 + (p0 & 7) * 2);
-
-    // ---- this wave's sub-tile
-    const int *sub = ty + 16 + 8 * wave;
-    const int qa = sub[1], ra = sub[2], qb = sub[3], rb_ = sub[4];
-    const bool active = wave < ty[14] && sub[0] != 0 && (s0 + ty[6 + qa]) < nsplit;
-    const int li = lane & 31, lk = lane >> 5;
-    const int fslot = lk * 148 + (li & 3) * 36 + (li >> 2);
-    const int fa = qa * 2 * kSImgSlots + fslot + ra * 16;
-    const int fb = qb * 2 * kSImgSlots + fslot + rb_ * 16;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float gacc[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 x[4];
-    float4 sv, bv;
-
-#define AGPL_ST_LOAD(st_)                                                                          \
-    do {                                                                                           \
-        if (stager) {                                                                              \
-            const int stq_ = (st_) < nstage_q ? (st_) : nstage_q - 1;                              \
-            const bool in_ = (st_) < nstage_q;                                                     \
-            /* rows past the slice end are clamped to its last point (their scale is 0) */        \
-            _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
-                int r_ = stq_ * kSPts + p0 + k_;                                                      \
-                r_ = r_ < plast_q ? r_ : plast_q;                                                  \
-                x[k_] = *reinterpret_cast<const float4 *>(sbase + (size_t)r_ * rowpitch + colofs4); \
-            }                                                                                      \
-            sv = *reinterpret_cast<const float4 *>((in_ ? sgs + stq_ * (4 * kSPts) : zeros) + p0b);        \
-            if (gjob) bv = *reinterpret_cast<const float4 *>((in_ ? bps + stq_ * (4 * kSPts) : zeros) + p0b); \
-        }                                                                                          \
-    } while (0)
-#define AGPL_ST_STORE(buf_, gkeep_)                                                                \
-    do {                                                                                           \
-        if (stager) {                                                                              \
-            unsigned char *dst_ = smem_raw + (buf_) * kSStageBytes + dst0;                         \
-            if (gjob) {                                                                            \
-                const float b0_ = bv.x * (gkeep_), b1_ = bv.y * (gkeep_), b2_ = bv.z * (gkeep_),   \
-                            b3_ = bv.w * (gkeep_);                                                 \
-                AGPL_GFMA(gacc[0], b0_, x[0].x); AGPL_GFMA(gacc[0], b1_, x[1].x);                  \
-                AGPL_GFMA(gacc[0], b2_, x[2].x); AGPL_GFMA(gacc[0], b3_, x[3].x);                  \
-                AGPL_GFMA(gacc[1], b0_, x[0].y); AGPL_GFMA(gacc[1], b1_, x[1].y);                  \
-                AGPL_GFMA(gacc[1], b2_, x[2].y); AGPL_GFMA(gacc[1], b3_, x[3].y);                  \
-                AGPL_GFMA(gacc[2], b0_, x[0].z); AGPL_GFMA(gacc[2], b1_, x[1].z);                  \
-                AGPL_GFMA(gacc[2], b2_, x[2].z); AGPL_GFMA(gacc[2], b3_, x[3].z);                  \
-                AGPL_GFMA(gacc[3], b0_, x[0].w); AGPL_GFMA(gacc[3], b1_, x[1].w);                  \
-                AGPL_GFMA(gacc[3], b2_, x[2].w); AGPL_GFMA(gacc[3], b3_, x[3].w);                  \
-            }                                                                                      \
-            uint2 h_, l_;                                                                          \
-            AGPL_SPLIT2("v", x[0].x, sv.x, x[1].x, sv.y, h_.x, l_.x);                              \
-            AGPL_SPLIT2("v", x[2].x, sv.z, x[3].x, sv.w, h_.y, l_.y);                              \
-            *reinterpret_cast<uint2 *>(dst_ + 0 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 0 * 36 * 16) = l_;                      \
-            AGPL_SPLIT2("v", x[0].y, sv.x, x[1].y, sv.y, h_.x, l_.x);                              \
-            AGPL_SPLIT2("v", x[2].y, sv.z, x[3].y, sv.w, h_.y, l_.y);                              \
-            *reinterpret_cast<uint2 *>(dst_ + 1 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 1 * 36 * 16) = l_;                      \
-            AGPL_SPLIT2("v", x[0].z, sv.x, x[1].z, sv.y, h_.x, l_.x);                              \
-            AGPL_SPLIT2("v", x[2].z, sv.z, x[3].z, sv.w, h_.y, l_.y);                              \
-            *reinterpret_cast<uint2 *>(dst_ + 2 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 2 * 36 * 16) = l_;                      \
-            AGPL_SPLIT2("v", x[0].w, sv.x, x[1].w, sv.y, h_.x, l_.x);                              \
-            AGPL_SPLIT2("v", x[2].w, sv.z, x[3].w, sv.w, h_.y, l_.y);                              \
-            *reinterpret_cast<uint2 *>(dst_ + 3 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kSImgBytes + 3 * 36 * 16) = l_;                      \
-        }                                                                                          \
-    } while (0)
-
-#define AGPL_ST_MFMA(buf_)                                                                         \
-    do {                                                                                           \
-        if (active) {                                                                              \
-            const h8v *I = reinterpret_cast<const h8v *>(smem_raw + (buf_) * kSStageBytes);        \
-            _Pragma("unroll") for (int s2 = 0; s2 < PLANES / 2; ++s2) {                                     \
-                const int o = s2 * 2 * 148;                                                        \
-                const h8v ah0 = I[fa + o], ah1 = I[fa + o + 8], bh0 = I[fb + o], bh1 = I[fb + o + 8]; \
-                acc[0][0] = mfma16(ah0, bh0, acc[0][0]);                                           \
-                acc[0][1] = mfma16(ah0, bh1, acc[0][1]);                                           \
-                acc[1][0] = mfma16(ah1, bh0, acc[1][0]);                                           \
-                acc[1][1] = mfma16(ah1, bh1, acc[1][1]);                                           \
-                const h8v bl0 = I[kSImgSlots + fb + o], bl1 = I[kSImgSlots + fb + o + 8];          \
-                acc[0][0] = mfma16(ah0, bl0, acc[0][0]);                                           \
-                acc[0][1] = mfma16(ah0, bl1, acc[0][1]);                                           \
-                acc[1][0] = mfma16(ah1, bl0, acc[1][0]);                                           \
-                acc[1][1] = mfma16(ah1, bl1, acc[1][1]);                                           \
-                const h8v al0 = I[kSImgSlots + fa + o], al1 = I[kSImgSlots + fa + o + 8];          \
-                acc[0][0] = mfma16(al0, bh0, acc[0][0]);                                           \
-                acc[0][1] = mfma16(al0, bh1, acc[0][1]);                                           \
-                acc[1][0] = mfma16(al1, bh0, acc[1][0]);                                           \
-                acc[1][1] = mfma16(al1, bh1, acc[1][1]);                                           \
-            }                                                                                      \
-        }                                                                                          \
-    } while (0)
-
-    AGPL_ST_LOAD(0);
-    AGPL_ST_STORE(0, 1.f);
-    if (PP) {
-        // Ping-pong without a role branch in the loop: BOTH halves run  C(st) | barrier | S(st + 1 + second) | barrier
-        // (C = loads of the stage stored next + multiply stage st, S = convert + store); the second half (waves 8-15)
-        // merely starts with one extra store step, so it is always half a stage behind:
-        //     first  half:          C0 | S1 | C1 | S2 | C2 | ...        (+ one closing barrier)
-        //     second half:     S1 | C0 | S2 | C1 | S3 | ...
-        // Stage k lives in buffer k & 1; S(k) of the second half rewrites the buffer both halves have finished reading
-        // one half-step earlier.  s_barrier counts arrivals, not program points, so the extra step pairs up correctly.
-#define AGPL_ST_BAR()                                              \
-    do {                                                           \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
-        __builtin_amdgcn_s_barrier();                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
-    } while (0)
-        const int second = wave >= NW / 2 ? 1 : 0;
-        if (second) AGPL_ST_LOAD(1 < nstage ? 1 : 0);
-        AGPL_ST_BAR();
-        if (second) {
-            AGPL_ST_STORE(1, 1 < nstage ? 1.f : 0.f);
-            AGPL_ST_BAR();
-        }
-        for (int st = 0; st < nstage; ++st) {
-            const int ld = st + 1 + second;
-            AGPL_ST_LOAD(ld < nstage ? ld : nstage - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            AGPL_ST_MFMA(st & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            AGPL_ST_BAR();
-            AGPL_ST_STORE(ld & 1, ld < nstage ? 1.f : 0.f);
-            AGPL_ST_BAR();
-        }
-        if (!second) AGPL_ST_BAR();
-#undef AGPL_ST_BAR
-    } else {
-        __syncthreads();
-        for (int st = 0; st < nstage; ++st) {
-            const int buf = st & 1;
-            const bool more = st + 1 < nstage;
-            AGPL_ST_LOAD(more ? st + 1 : st); // unconditional, as in syrk_split_body (a conditional load stalls the MFMAs)
-            __builtin_amdgcn_sched_barrier(0);
-            AGPL_ST_MFMA(buf);
-            __builtin_amdgcn_sched_barrier(0);
-            AGPL_ST_STORE(buf ^ 1, more ? 1.f : 0.f);
-            __syncthreads();
-        }
-    }
-#undef AGPL_ST_MFMA
-#undef AGPL_ST_LOAD
-#undef AGPL_ST_STORE
-
-    if (active) {
-        const int unit = sub[5], wr = sub[6], wc = sub[7];
-        const int ss = s0 + ty[6 + qa];
-        float *slab = slabG + (((int64_t)l * npairs + unit) * nsplit + ss) * (int64_t)(BS * BS);
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wr * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const int col = wc * 64 + j2 * 32 + li;
-                    slab[row * BS + col] = acc[ii][j2][r] * kPsiUnscale;
-                }
-    }
-    // g: lanes (2 fq, 2 fq + 1) hold the two point halves of features 4 fq ..; the instance's 4 planes are waves 4 q ..
-    float *gw = reinterpret_cast<float *>(smem_raw); // [NW waves][128] (the stage images are dead: last barrier passed)
-    if (gjob) {
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) gacc[e2] += __shfl_xor(gacc[e2], 1);
-        if (half == 0) {
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) gw[wave * 128 + 4 * fq + e2] = gacc[e2];
-        }
-    }
-    __syncthreads();
-    if (gjob && plane == 0) {
-        const float *g4 = gw + wave * 128; // the instance's planes = waves PLANES q .. PLANES q + PLANES - 1 (this is the first)
-        for (int f = lane; f < BS; f += 64) {
-            float acc_g = g4[f] + g4[128 + f];
-            if (PLANES == 4) acc_g = acc_g + (g4[256 + f] + g4[384 + f]);
-            slabg[(((int64_t)l * nb + ty[2 + q]) * nsplit + sq) * BS + f] = acc_g;
-        }
-    }
-}
-
-size_t syrk_strip_lds_bytes(int planes) { return (size_t)2 * 4 * 2 * planes * 148 * 16; }
 
 
 size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT + 128); }
@@ -1156,161 +798,9 @@ __global__ void reduce_g_kernel(int M, int ngroup, const double *__restrict__ pa
 
 inline int syrk_nsplit(int64_t N) { return (int)agpl_cdiv(N, kChunk); }
 
-// ------------------------------------------------------------------------------------------------
-// syrk_strip_plan: host-side decomposition of the lower triangle of G (nb x nb units of 128 x 128; a unit on the
-// diagonal needs 3 of its 4 sub-tiles of 64 x 64) into workgroup types of <= 16 sub-tiles over <= 4 panel instances.
-//   1. every block row bi is cut into chunks: {diagonal unit + up to 3 nearest off-diagonal units} (panels bi + 3),
-//      then runs of up to 3 off-diagonal units (panels bi + 3);
-//   2. small chunks are merged into the chunk that fills its 16 sub-tile slots best while the union of panels stays
-//      <= 4 (smallest chunk first; deterministic tie-break by index);
-//   3. a type with P <= 2 panels and <= 8 sub-tiles runs r = 2 (or 4) slices at once (r P <= 4, r sub-tiles <= 16).
-// Words per type: [0] r, [1] instances, [2..5] panel, [6..9] slice offset, [10..13] g flag, [14] sub-tiles, then 16 x
-// {active, A instance, A half, B instance, B half, unit, wr, wc}; then the per-super-slice entry list (type, slice).
-// ------------------------------------------------------------------------------------------------
-struct StripChunk {
-    std::vector<std::pair<int, int>> units; // (bi, bj), bj <= bi
-    std::vector<int> panels;
-    int subtiles() const {
-        int n = 0;
-        for (auto &u : units) n += u.first == u.second ? 3 : 4;
-        return n;
-    }
-};
-
-static void strip_add_panel(std::vector<int> &ps, int p) {
-    for (int x : ps)
-        if (x == p) return;
-    ps.push_back(p);
-}
-
-static std::vector<int> syrk_strip_plan(int nb, int max_sub, int *ntypes_out, int *nE_out) {
-    const int max_pan = 4;
-    std::vector<StripChunk> ch;
-    for (int bi = nb - 1; bi >= 0; --bi) {
-        int c = bi - 1;
-        StripChunk first;
-        first.units.push_back({bi, bi});
-        strip_add_panel(first.panels, bi);
-        while (c >= 0 && first.subtiles() + 4 <= max_sub && (int)first.panels.size() < max_pan) {
-            first.units.push_back({bi, c});
-            strip_add_panel(first.panels, c);
-            --c;
-        }
-        ch.push_back(first);
-        while (c >= 0) {
-            StripChunk nx;
-            strip_add_panel(nx.panels, bi);
-            while (c >= 0 && nx.subtiles() + 4 <= max_sub && (int)nx.panels.size() < max_pan) {
-                nx.units.push_back({bi, c});
-                strip_add_panel(nx.panels, c);
-                --c;
-            }
-            ch.push_back(nx);
-        }
-    }
-    // merge: smallest unfinished chunk into the partner that gives the fullest workgroup
-    std::vector<char> done(ch.size(), 0);
-    for (;;) {
-        int a = -1;
-        for (int i = 0; i < (int)ch.size(); ++i)
-            if (!done[i] && ch[i].subtiles() < max_sub - 3 && (a < 0 || ch[i].subtiles() < ch[a].subtiles())) a = i;
-        if (a < 0) break;
-        int best_b = -1, best_fill = 0;
-        for (int b = 0; b < (int)ch.size(); ++b) {
-            if (b == a) continue;
-            const int fill = ch[a].subtiles() + ch[b].subtiles();
-            if (fill > max_sub || fill <= best_fill) continue;
-            std::vector<int> un = ch[b].panels;
-            for (int p : ch[a].panels) strip_add_panel(un, p);
-            if ((int)un.size() > max_pan) continue;
-            best_fill = fill;
-            best_b = b;
-        }
-        if (best_b < 0) {
-            done[a] = 1; // no partner: it will run replicated over slices if it is small enough
-            continue;
-        }
-        for (auto &u : ch[a].units) ch[best_b].units.push_back(u);
-        for (int p : ch[a].panels) strip_add_panel(ch[best_b].panels, p);
-        done[best_b] = 0;
-        ch.erase(ch.begin() + a);
-        done.erase(done.begin() + a);
-    }
-    std::vector<int> words;
-    std::vector<int> reps;
-    for (auto &c : ch) {
-        const int P = (int)c.panels.size(), S = c.subtiles();
-        int r = 1;
-        while (2 * r * P <= max_pan && 2 * r * S <= max_sub && 2 * r <= kSuper) r *= 2;
-        reps.push_back(r);
-        std::vector<int> w(kTypeWords, 0);
-        w[0] = r;
-        w[1] = r * P;
-        for (int i = 0; i < r; ++i)
-            for (int k = 0; k < P; ++k) {
-                w[2 + i * P + k] = c.panels[k];
-                w[6 + i * P + k] = i;
-            }
-        int ns = 0;
-        for (int i = 0; i < r; ++i)
-            for (auto &u : c.units) {
-                int ia = -1, ib = -1;
-                for (int k = 0; k < P; ++k) {
-                    if (c.panels[k] == u.first) ia = i * P + k;
-                    if (c.panels[k] == u.second) ib = i * P + k;
-                }
-                const bool diag = u.first == u.second;
-                if (diag) w[10 + ia] = 1;
-                for (int wr = 0; wr < 2; ++wr)
-                    for (int wc = 0; wc < 2; ++wc) {
-                        if (diag && wr < wc) continue;
-                        int *sb = &w[16 + 8 * ns++];
-                        sb[0] = 1;
-                        sb[1] = ia;
-                        sb[2] = wr;
-                        sb[3] = ib;
-                        sb[4] = wc;
-                        sb[5] = u.first * (u.first + 1) / 2 + u.second;
-                        sb[6] = wr;
-                        sb[7] = wc;
-                    }
-            }
-        w[14] = ns;
-        words.insert(words.end(), w.begin(), w.end());
-    }
-    int nE = 0;
-    for (int t = 0; t < (int)ch.size(); ++t)
-        for (int k = 0; k < kSuper; k += reps[t]) {
-            words.push_back(t);
-            words.push_back(k);
-            ++nE;
-        }
-    *ntypes_out = (int)ch.size();
-    *nE_out = nE;
-    return words;
-}
-
-
 } // namespace
 
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
-
-// test hook (include/agpl.h): the strip plan for nb block rows, as the device reads it
-extern "C" int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap,
-                                                                                int32_t *ntypes, int32_t *nentries) {
-    if (nb <= 0 || !out || !ntypes || !nentries) return -1;
-    int nt = 0, ne = 0;
-    // nb's upper half-word selects the 8-sub-tile plan of the 8-wave form (nb | 8 << 16); default 16 sub-tiles
-    const int max_sub = (nb >> 16) == 8 ? 8 : 16;
-    nb &= 0xFFFF;
-    if (nb <= 0) return -1;
-    const std::vector<int> w = syrk_strip_plan(nb, max_sub, &nt, &ne);
-    if ((int)w.size() > cap) return -(int32_t)w.size();
-    for (size_t i = 0; i < w.size(); ++i) out[i] = w[i];
-    *ntypes = nt;
-    *nentries = ne;
-    return (int32_t)w.size();
-}
 
 extern "C" int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L) {
     if (N <= 0 || M <= 0 || M % BS || L <= 0) return 0;
@@ -1375,10 +865,10 @@ static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
     o.partG = al(o.slabg + sizeof(float) * (size_t)((int64_t)L * o.nb * o.ns * BS));
     o.partg = al(o.partG + sizeof(double) * (size_t)(L * o.npairs * o.ng * BS * BS));
     o.sgam = al(o.partg + sizeof(double) * (size_t)((int64_t)L * o.nb * o.ng * BS));
-    // padded 2^8 sqrt(gamma) | beta: N rounded up to a 32-point stage + one stage of zeros (syrk_strip_kernel reads it
-    // for the stages a shorter slice of its workgroup no longer has)
+    // padded 2^8 sqrt(gamma) | beta (split tile kernel) or the gamma | beta records (image kernel): N rounded up to a 32-point
+    // stage + one stage of zeros
     o.ctr = al(o.sgam + 2 * sizeof(float) * (size_t)((int64_t)L * (((N + 31) & ~(int64_t)31) + 32)));
-    o.total = al(o.ctr + sizeof(unsigned) * ((size_t)L * o.ns + 64)); // arrival counters of the slices' workgroups (start hint) / scale words
+    o.total = al(o.ctr + sizeof(unsigned) * 64); // scale / flag words of the image kernel
     return o;
 }
 
@@ -1404,7 +894,6 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
-    int nu = ns, ngu = ng; // slabs per tile / reduction groups actually written (the tile form of the split path may group slices)
     if (acc_image && M % 256 == 0) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
@@ -1417,99 +906,25 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         float *sg = (float *)((char *)slab_mem + lo.sgam);
         float *bp = sg + (int64_t)L * Npad;
         split_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, sg, bp);
-        // AGPL_SYRK = tile (default) | strip | pp.  Round-2 A/B on one box, ms per launch tile / strip / pp: C2 8.18 / 8.50 /
-        // 8.02; N/8 1.19 / 1.37 / 1.21; M = 1024 27.0 / 30.5 / 30.3; C4 2.60 / 3.02 / 2.55 -- and the PMC pass showed the
-        // strip forms FETCH MORE (40.8 GB against 36.7 GB at C2: their workgroup types do not stay in step, so a panel
-        // staged by two types is fetched twice; the tile kernel's ten workgroups per slice share L2 better).  A wash in
-        // time and worse in traffic: the tile kernel stays the default, the strip forms stay selectable.
-        const char *form = getenv("AGPL_SYRK");
-        const bool tile_form = !form || !strcmp(form, "tile");
-        if (tile_form) {
-            // start hint (AGPL_SYRK_SYNCSTART=1; off by default): FETCH_SIZE at C2 24.4-25.8 GB instead of 36.5 GB, but 1.2-2 %
-            // more kernel time (8.41-8.44 against 8.28-8.31 ms same box; 16.22 against 15.90 ms per sweep in bench.py), +4.5 % at
-            // M = 1024 (36 workgroups per slice are dispatched over more than the wait bound) and +6 % on a short launch (N / 8
-            // per rank).  The traffic was not what the kernel waited for, so the faster setting ships.
-            const char *df = getenv("AGPL_SYRK_DIAGFULL"), *ss = getenv("AGPL_SYRK_SYNCSTART");
-            unsigned *start_ctr = nullptr;
-            if (ss && ss[0] == '1') {
-                start_ctr = (unsigned *)((char *)slab_mem + lo.ctr);
-                AGPL_HIP(ctx, hipMemsetAsync(start_ctr, 0, sizeof(unsigned) * (size_t)L * ns, ctx->stream));
-            }
-            // AGPL_SYRK_LDSPAD: extra dynamic LDS per workgroup (occupancy experiments: 15000 -> three workgroups per CU)
-            const size_t ldspad = getenv("AGPL_SYRK_LDSPAD") ? (size_t)atoi(getenv("AGPL_SYRK_LDSPAD")) : 0;
-            // Slice grouping (AGPL_SYRK_GROUP = g > 1; off by default): a workgroup runs g consecutive slices through the same
-            // accumulators and writes ONE slab, all but the last AGPL_SYRK_TAIL slices (default: two rounds of the 1024
-            // resident workgroups) -- the f32 slabs (1.6 GB written here and read back by reduce_slab_kernel at C2) shrink to
-            // ~1/g.  Measured at C2 (profiles/r02_ab_syrk_group.jsonl): g = 4 saves 0.2 ms of reductions and costs 0.13 ms
-            // in this kernel (8.42 against 8.29 ms: the ten workgroups of a slice start together but the diagonal ones run
-            // ~15 % faster, so from the second slice of a group on they no longer share the panels in L2) -- 15.79 against
-            // 15.86 ms per sweep, inside the box-to-box noise, for a 4 x longer f32 accumulation run (relative error of G
-            // against float64: < 1e-6 at 4096-point runs, 6.5e-6 at 32768).  Not worth a default.
-            int group = 1;
-            int tail = (int)((2 * 1024 + (int64_t)L * npairs - 1) / ((int64_t)L * npairs));
-            if (getenv("AGPL_SYRK_GROUP")) group = atoi(getenv("AGPL_SYRK_GROUP"));
-            if (getenv("AGPL_SYRK_TAIL")) tail = atoi(getenv("AGPL_SYRK_TAIL"));
-            if (group < 1 || group > 64 || tail < 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad AGPL_SYRK_GROUP / AGPL_SYRK_TAIL");
-            const int ngrouped = group > 1 && ns > tail ? (ns - tail) / group : 0;
-            nu = ngrouped + (ns - ngrouped * group);
-            ngu = (nu + kRedGroup - 1) / kRedGroup;
-            const int64_t nwg_u = (int64_t)L * npairs * ((nu + 7) / 8) * 8;
-            syrk_split_kernel<<<(unsigned)nwg_u, 256, syrk_split_lds_bytes() + ldspad, ctx->stream>>>(
-                N, Npad, M, npairs, nu, Phi, sg, bp, slabG, slabg, df && df[0] == '1' ? 1 : 0, start_ctr,
-                getenv("AGPL_SYRK_PRIO") ? atoi(getenv("AGPL_SYRK_PRIO")) : 2, ngrouped, group);
-        } else {
-            // forms: strip / pp = 16 waves, 32-point stages, one workgroup per CU; strip8 / pp8 = 8 waves, 16-point stages, two
-            // per CU (<= 8 sub-tiles: off-diagonal tile + the diagonal tile of one of its panels)
-            const bool eight = !strcmp(form, "strip8") || !strcmp(form, "pp8");
-            const bool pp = !strcmp(form, "pp") || !strcmp(form, "pp8");
-            const int key = nb | ((eight ? 8 : 16) << 16);
-            if (ctx->strip_nb != key) {
-                int nt = 0, ne = 0;
-                const std::vector<int> w = syrk_strip_plan(nb, eight ? 8 : 16, &nt, &ne);
-                AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->strip_plan) AGPL_HIP(ctx, hipFree(ctx->strip_plan));
-                ctx->strip_plan = nullptr;
-                ctx->strip_nb = 0;
-                AGPL_HIP(ctx, hipMalloc((void **)&ctx->strip_plan, sizeof(int) * w.size()));
-                AGPL_HIP(ctx, hipMemcpy(ctx->strip_plan, w.data(), sizeof(int) * w.size(), hipMemcpyHostToDevice));
-                ctx->strip_nb = key;
-                ctx->strip_ntypes = nt;
-                ctx->strip_nE = ne;
-            }
-            const int nsuper = (ns + kSuper - 1) / kSuper;
-            const int64_t nwg2 = (int64_t)L * ctx->strip_nE * ((nsuper + 7) / 8) * 8;
-            if (nwg2 > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-#define AGPL_LAUNCH_STRIP(NW_, PL_, PP_)                                                                              \
-    do {                                                                                                              \
-        const size_t lds_ = syrk_strip_lds_bytes(PL_);                                                                \
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel<NW_, PL_, PP_>),          \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                    \
-        syrk_strip_kernel<NW_, PL_, PP_><<<(unsigned)nwg2, NW_ * 64, lds_, ctx->stream>>>(                            \
-            N, Npad, M, npairs, ns, Phi, sg, bp, slabG, slabg, ctx->strip_plan, ctx->strip_ntypes, ctx->strip_nE,    \
-            nsuper);                                                                                                  \
-    } while (0)
-            if (eight && pp) AGPL_LAUNCH_STRIP(8, 2, true);
-            else if (eight) AGPL_LAUNCH_STRIP(8, 2, false);
-            else if (pp) AGPL_LAUNCH_STRIP(16, 4, true);
-            else AGPL_LAUNCH_STRIP(16, 4, false);
-#undef AGPL_LAUNCH_STRIP
-        }
+        // the float32-staged split kernel: M % 256 != 0, or no image (agpl_accumulate with precision 1)
+        syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(N, Npad, M, npairs, ns, Phi, sg, bp,
+                                                                                       slabG, slabg);
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 1);
     if (rc) return rc;
-    dim3 r1(64, (unsigned)ngu, (unsigned)(L * npairs));
-    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(nu, ngu, slabG, partG);
+    dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs));
+    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, slabG, partG);
     AGPL_LAUNCH_CHECK(ctx);
     dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ngu, partG, G_out);
+    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out);
     AGPL_LAUNCH_CHECK(ctx);
-    dim3 r2((unsigned)ngu, (unsigned)(L * nb));
-    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(nu, ngu, slabg, partg);
+    dim3 r2((unsigned)ng, (unsigned)(L * nb));
+    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(ns, ng, slabg, partg);
     AGPL_LAUNCH_CHECK(ctx);
     dim3 rg2((unsigned)agpl_cdiv(M, 128), (unsigned)L);
-    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ngu, partg, g_out);
+    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ng, partg, g_out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

@@ -111,7 +111,10 @@ __device__ inline double pg_int_sum_wave(PgWaveScratch *scr, int lane, const Phi
 // rand(PolyaGamma(b, c)) for the lane's point, integer part dealt across the wave: the same value, uniforms consumed and
 // series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all 64 lanes.
 __device__ inline double pg_point_wave(PgWaveScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
-                                       double c, uint32_t &nterms) {
+                                       double c, uint32_t &nterms, int *bad) {
+    // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
+    // host as AGPL_ERR_UNSUPPORTED instead of a silent NaN
+    if (valid && b >= 65535.0) atomicOr(bad, 2);
     const bool ok = valid && (b >= 0.0) && (fabs(c) < __builtin_inf()) && (b < 65535.0);
     const int tb = ok ? (int)floor(b) : 0;
     const uint32_t base = 1u + ((uint32_t)latent << 16);
@@ -140,7 +143,7 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
     case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
         const int32_t *y = (const int32_t *)yv;
         const double b = valid ? (double)y[i] + lik.p[0] : 0.0, c = valid ? fabs(f[0]) : 0.0;
-        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt, bad);
         if (valid) om[0] = w;
     } break;
     case AGPL_LIK_STUDENTT: { // studentt.jl:46-48
@@ -175,7 +178,7 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
         }
         for (int k = 0; k < L; ++k) { // L is wave-uniform: every lane deals for every latent
             const double b = good ? (double)(nn[k] + (int64_t)y[i * L + k]) : 0.0, c = good ? fabs(f[k]) : 0.0;
-            const double w = pg_point_wave(scr, lane, good, g, k, b, c, nt);
+            const double w = pg_point_wave(scr, lane, good, g, k, b, c, nt, bad);
             if (good) om[k] = w;
         }
     } break;
@@ -189,7 +192,7 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
             b = (double)(n1 + y[i]);
             c = fabs(f[0]);
         }
-        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt, bad);
         if (valid) om[0] = w;
     } break;
     case AGPL_LIK_LAPLACE: { // laplace.jl:40-42
@@ -211,7 +214,7 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
             b = 0.5 + (double)n1;
             c = fabs(gg);
         }
-        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt);
+        const double w = pg_point_wave(scr, lane, valid, g, 0, b, c, nt, bad);
         if (valid) om[0] = w;
     } break;
     default:
@@ -780,6 +783,26 @@ int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// the sampler kernels' flag word: bit 0 = invalid NegativeMultinomial parameters, bit 1 = a PolyaGamma(b, c) draw with
+// b >= 65535 (outside the sub-stream id space).  Read (one stream synchronisation) for the likelihoods that can set it.
+int32_t agpl_sampler_outcome(agpl_ctx *ctx, int32_t kind, const int *bad) {
+    if (kind != AGPL_LIK_CATEGORICAL && kind != AGPL_LIK_CATEGORICAL_BIJ && kind != AGPL_LIK_NEGBINOMIAL &&
+        kind != AGPL_LIK_POISSON && kind != AGPL_LIK_HETEROGAUSS)
+        return AGPL_OK;
+    int hbad = 0;
+    AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hbad & 1)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
+                  "NegativeMultinomial: all p should be positive and their sum strictly smaller than 1 "
+                  "(negativemultinomial.jl:17-22)");
+    if (hbad & 2)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
+                  "PolyaGamma(b, c) with b >= 65535 (y + r, or y + n): this build numbers the PG(1, c) draws of a point "
+                  "with 16 bits; the outputs of that point are NaN");
+    return AGPL_OK;
+}
+
 extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                                    const double *f, double *omega_out, int64_t *n_out, uint32_t sweep,
                                    uint32_t *nuni_out, uint32_t *nterms_out) {
@@ -822,22 +845,16 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 3);
     if (rc) return rc;
-    if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
-        int hbad = 0;
-        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hbad)
-            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
-                      "NegativeMultinomial: all p should be positive and their sum strictly smaller than 1 "
-                      "(negativemultinomial.jl:17-22)");
-    }
-    return AGPL_OK;
+    return agpl_sampler_outcome(ctx, ld.kind, bad);
 }
 
 extern "C" int32_t agpl_rand_polyagamma(agpl_ctx *ctx, double b, double c, int64_t n, uint32_t sweep,
                                         double *out, uint32_t *nuni_out, uint32_t *nterms_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (n < 0 || !(b >= 0.0)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need n >= 0 and b >= 0");
+    if (b >= 65535.0)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "PolyaGamma(b, c) with b >= 65535: this build numbers the PG(1, c) draws of a "
+                                            "point with 16 bits (b = %g)", b);
     if (n == 0) return AGPL_OK;
     if (!out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null out");
     rand_pg_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(b, c, n, ctx->seed, sweep, out, nuni_out, nterms_out);

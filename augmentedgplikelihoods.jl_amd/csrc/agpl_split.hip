@@ -21,6 +21,7 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BS = 128;
 constexpr int KS = 16;  // reduction slice per stage
@@ -87,6 +88,11 @@ __global__ __launch_bounds__(256) void pack_w_split_kernel(int M, const double *
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_f16: the two 16-deep slices of a stage ARE the 32-deep reduction of one instruction (lane l reads row
+// l & 15 of k-group l >> 4 = slice l >> 5, plane (l >> 4) & 1 of the same 4 KB blocks; conflict-free ds_read_b128)
+__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // grid = (tiles of 128 points, L); 256 threads = 4 waves, each a 64 x 64 sub-tile (2 x 2 accumulators)
@@ -481,563 +487,6 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// marginal_factor16_kernel: the factor form of marginal_split256_kernel (same 256 x 256 tile, same images, same LDS-DMA
-// ring of two 64 KB stages of two 16-deep slices) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
-// A stage's two slices ARE the 32-deep reduction of one instruction: lane l reads row (l & 15) of k-group l >> 4
-// (= slice (l >> 5), plane (l >> 4) & 1 of the 4 KB blocks -- no image changes).  Per flop the 16 x 16 shape moves half
-// the accumulator registers through the matrix pipe; on a chip that holds its clock down under float16 MFMA load
-// (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15x the FLOP/s of the 32 x 32 loop at equal cycles per flop)
-// that is what pays.  Same fragment bytes per flop: a wave's 64 x 64 tile reads 16 fragments per 48 instructions.
-// ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-__global__ __launch_bounds__(1024, 1) void marginal_factor16_kernel(
-    int64_t N, int M, int64_t ntiles128, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
-    const float *__restrict__ resid, const float *__restrict__ mu0, const h8 *__restrict__ Wh,
-    const h8 *__restrict__ Wl, const float *__restrict__ v_all, float *__restrict__ mu_out,
-    float *__restrict__ var_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int R = 2, KU = 2;
-    constexpr int kSlot = KU * 8 * 4096;
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // M floats (v)
-    float *qred = alpha_s + M;                                         // 4 x 256
-    float *mred = qred + 4 * NT2;                                      // 4 x 256
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..15
-    const int wr = wave >> 2, wc = wave & 3;
-    const int l = blockIdx.y;
-    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
-    const int64_t tile2 = blockIdx.x;
-    const int64_t n0 = tile2 * NT2;
-
-    const int ia = wave >> 2, qd = wave & 3;
-    const int64_t t128 = 2 * tile2 + (ia >> 1) < ntiles128 ? 2 * tile2 + (ia >> 1) : ntiles128 - 1;
-    const h8 *a_src = ((ia & 1) ? Wl : Wh) + ((int64_t)l * nb + (ia >> 1)) * nks * 256 + qd * 64 + lane;
-    const h8 *b_src = ((ia & 1) ? Pl : Ph) + t128 * nks * 256 + qd * 64 + lane;
-    const int dma_off = ia * 4096 + qd * 1024;
-
-    const float *vv = v_all + (int64_t)l * M;
-    for (int a = tid; a < M; a += 1024) alpha_s[a] = vv[a];
-
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
-    float macc[4] = {0.f, 0.f, 0.f, 0.f};
-
-    const int T = 8 * nb2 * (nb2 + 1) / KU; // stages: 16 (rb + 1) slices per 256-row block rb
-    int irb = 0, iks = 0;                   // issue pointer
-    typedef __attribute__((address_space(3))) void lds_void;
-#define AGPL_DMA16_ISSUE(t_)                                                                                \
-    do {                                                                                                    \
-        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
-        _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                                 \
-            __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks + u_) * 256,          \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256,                             \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0);     \
-        }                                                                                                   \
-        iks += KU;                                                                                          \
-        if (iks == 16 * (irb + 1)) {                                                                        \
-            ++irb;                                                                                          \
-            iks = 0;                                                                                        \
-        }                                                                                                   \
-    } while (0)
-
-    if (0 < T) AGPL_DMA16_ISSUE(0);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment indices (16-byte units within a stage): k-group g = lane >> 4 -> slice g >> 1 (2048 units apart), plane
-    // g & 1 (128 units apart); row = sub-tile base + 16 i + (lane & 15)
-    const int kg = lane >> 4;
-    const int fbase = (kg >> 1) * 2048 + (kg & 1) * 128 + (lane & 15);
-    const int fa = fbase + (wr >> 1) * 512 + (wr & 1) * 64;        // A block (wr >> 1): hi, lo at +256
-    const int fb = fbase + 1024 + (wc >> 1) * 512 + (wc & 1) * 64; // B tile (wc >> 1)
-
-    int rb = 0, ks = 0; // consume pointer
-    for (int t = 0; t < T; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
-        __builtin_amdgcn_s_barrier();
-        // U is lower triangular: this wave's rows 64 wr .. 64 wr + 63 of block rb are zero from slice 16 rb + 4 (wr + 1)
-        const bool act = ks < rb * 16 + 4 * (wr + 1);
-        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
-        h8 ah[4], al[4];
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ah[i] = st[fa + 16 * i];
-            const h8 bh0 = st[fb], bl0 = st[256 + fb];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bh0, acc[i][0]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < T) AGPL_DMA16_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][0] = mfma32(ah[i], bl0, acc[i][0]);
-#pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const h8 bh = st[fb + 16 * j], bl = st[256 + fb + 16 * j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j - 1] = mfma32(al[i], j == 1 ? bh0 : st[fb + 16 * (j - 1)], acc[i][j - 1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bh, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(ah[i], bl, acc[i][j]);
-            }
-            {
-                const h8 bh3 = st[fb + 48];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][3] = mfma32(al[i], bh3, acc[i][3]);
-            }
-        } else {
-            if (t + 1 < T) AGPL_DMA16_ISSUE(t + 1);
-        }
-        ks += KU;
-        if (ks == 16 * (rb + 1)) {
-            // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n]; lane rows a = 16 i + 4 kg + 0..3
-            const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * kg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 16 * i);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t0 = acc[i][j][0], t1 = acc[i][j][1], t2 = acc[i][j][2], t3 = acc[i][j][3];
-                    qacc[j] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-                    macc[j] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            ++rb;
-            ks = 0;
-        }
-    }
-#undef AGPL_DMA16_ISSUE
-
-    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int tid_e = wave * 64 + lane_e;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        qacc[j] += __shfl_xor(qacc[j], 16);
-        qacc[j] += __shfl_xor(qacc[j], 32);
-        macc[j] += __shfl_xor(macc[j], 16);
-        macc[j] += __shfl_xor(macc[j], 32);
-    }
-    if (lane_e < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qred[wr * NT2 + wc * 64 + 16 * j + lane_e] = qacc[j];
-            mred[wr * NT2 + wc * 64 + 16 * j + lane_e] = macc[j];
-        }
-    }
-    __syncthreads();
-    if (tid_e < NT2) {
-        const int64_t n = n0 + tid_e;
-        if (n < N) {
-            float q = (qred[tid_e] + qred[NT2 + tid_e]) + (qred[2 * NT2 + tid_e] + qred[3 * NT2 + tid_e]);
-            float m = (mred[tid_e] + mred[NT2 + tid_e]) + (mred[2 * NT2 + tid_e] + mred[3 * NT2 + tid_e]);
-            if (mu0) m += mu0[(int64_t)l * N + n];
-            mu_out[(int64_t)l * N + n] = m;
-            var_out[(int64_t)l * N + n] = resid[n] + q;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// marginal_factor_persist_kernel<MF16>: the factor-form pass as ONE resident 1024-thread workgroup per CU that walks a
-// contiguous run of work items (256-point tile x latent), instead of one workgroup per tile.  The flat stage list of
-// marginal_split256_kernel simply continues across items, so the LDS-DMA ring never drains: the next tile's first stage
-// is in flight while the last stage of the current one is multiplied, the per-tile reduction (LDS) and output rows are
-// written behind the next stage's barrier, and no workgroup launch / teardown or ring fill sits between two tiles.
-// Measured reason (bench m1024 leg, round 2): the per-tile kernel ran at 49 % of the float16 peak at M = 512 (48
-// slices per workgroup) but 74 % at M = 1024 (160 slices) -- a fixed ~12-15 us per workgroup that this form removes.
-// Work item w = tile * L + l: a workgroup's run keeps a tile's L latents together (the B images stay L2-hot).
-// MF16 selects v_mfma_f32_16x16x32_f16 (see marginal_factor16_kernel) or v_mfma_f32_32x32x16_f16 fragments.
-// ------------------------------------------------------------------------------------------------
-template <bool MF16, int PF>
-__global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
-    int64_t N, int M, int L, int64_t ntiles128, int64_t nitems, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
-    const float *__restrict__ resid, const float *__restrict__ mu0, const h8 *__restrict__ Wh,
-    const h8 *__restrict__ Wl, const float *__restrict__ v_all, float *__restrict__ mu_out,
-    float *__restrict__ var_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int R = 2, KU = 2;
-    constexpr int kSlot = KU * 8 * 4096;
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
-    float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
-    float *mred = qred + 2 * 4 * NT2;                                  // [2][4 x 256]
-    unsigned char *touch_lds = reinterpret_cast<unsigned char *>(mred + 2 * 4 * NT2); // [16 waves][256 B] (PF > 0)
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
-    const unsigned lane_v = (unsigned)lane; // the per-lane part of every DMA source address (bases are wave-uniform)
-    const int wr = wave >> 2, wc = wave & 3;
-    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
-
-    // this workgroup's run of items: contiguous, sizes differ by at most one (nitems < 2^31: checked by the host)
-    const unsigned w0 = (unsigned)((uint64_t)blockIdx.x * (uint64_t)nitems / gridDim.x);
-    const unsigned w1 = (unsigned)((uint64_t)(blockIdx.x + 1) * (uint64_t)nitems / gridDim.x);
-    const int nit = (int)(w1 - w0);
-    if (nit <= 0) return;
-    const unsigned tile0 = w0 / (unsigned)L;
-    const int l0 = (int)(w0 - tile0 * (unsigned)L);
-
-    const int ia = wave >> 2, qd = wave & 3;
-    const h8 *a_img = (ia & 1) ? Wl : Wh, *b_img = (ia & 1) ? Pl : Ph;
-    const int dma_off = ia * 4096 + qd * 1024;
-    const int Tit = 8 * nb2 * (nb2 + 1) / KU; // stages per item
-    const int T = nit * Tit;
-
-    // issue pointer (item = (tile, latent), 256-row block, slice) and this wave's (uniform) source bases for that item
-    int iw = 0, irb = 0, iks = 0, il = l0;
-    unsigned itile = tile0;
-    const h8 *a_src, *b_src;
-#define AGPL_PM_SRC()                                                                                       \
-    do {                                                                                                    \
-        const int64_t t128_ = 2 * (int64_t)itile + (ia >> 1) < ntiles128 ? 2 * (int64_t)itile + (ia >> 1)   \
-                                                                         : ntiles128 - 1;                   \
-        a_src = a_img + ((int64_t)il * nb + (ia >> 1)) * nks * 256 + qd * 64;                               \
-        b_src = b_img + t128_ * nks * 256 + qd * 64;                                                        \
-    } while (0)
-    typedef __attribute__((address_space(3))) void lds_void;
-#define AGPL_PM_ISSUE(t_)                                                                                   \
-    do {                                                                                                    \
-        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
-        _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                                 \
-            __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks + u_) * 256 + lane_v, \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256 + lane_v,                    \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0);     \
-        }                                                                                                   \
-        iks += KU;                                                                                          \
-        if (iks == 16 * (irb + 1)) {                                                                        \
-            iks = 0;                                                                                        \
-            if (++irb == nb2) {                                                                             \
-                irb = 0;                                                                                    \
-                if (++il == L) {                                                                            \
-                    il = 0;                                                                                 \
-                    ++itile;                                                                                \
-                }                                                                                           \
-                if (++iw < nit) AGPL_PM_SRC();                                                              \
-            }                                                                                               \
-        }                                                                                                   \
-    } while (0)
-
-    AGPL_PM_SRC();
-    AGPL_PM_ISSUE(0);
-
-    // L2 touch prefetch (PF > 0): the point images (B) of stage t + 1 + PF, pulled towards L2 by one 4-byte LDS-DMA per
-    // 128-byte line -- lanes 0-15 of every wave cover the 16 lines of the two pieces the wave itself will move PF stages
-    // later.  Why: one 64 KB stage in flight per CU against ~2 us of HBM latency is ~34 GB/s per CU = the ~8.7 TB/s the
-    // kernel's LDS-DMA runs at (profiles/r02_pmc_sq_c2.json: waves parked on s_waitcnt / barriers 47 % of their cycles,
-    // matrix pipe 58 % busy); with the lines already in L2 the same ring covers a ~4x shorter latency.  The touch is the
-    // wave's YOUNGEST vector-memory operation at every stage top, so the wait there is vmcnt(1), not vmcnt(0): it never
-    // holds back the real pieces, and is itself covered two stage tops later.
-    int pw = 0, prb = 0, pks = 0, pl2 = l0;
-    unsigned ptile2 = tile0;
-    const h8 *pb_src = b_src;
-#define AGPL_PM_TADV()                                                                                      \
-    do {                                                                                                    \
-        pks += KU;                                                                                          \
-        if (pks == 16 * (prb + 1)) {                                                                        \
-            pks = 0;                                                                                        \
-            if (++prb == nb2) {                                                                             \
-                prb = 0;                                                                                    \
-                if (++pl2 == L) {                                                                           \
-                    pl2 = 0;                                                                                \
-                    ++ptile2;                                                                               \
-                }                                                                                           \
-                ++pw;                                                                                       \
-                if (pw < nit) {                                                                             \
-                    const int64_t t128_ = 2 * (int64_t)ptile2 + (ia >> 1) < ntiles128                       \
-                                              ? 2 * (int64_t)ptile2 + (ia >> 1) : ntiles128 - 1;            \
-                    pb_src = b_img + t128_ * nks * 256 + qd * 64;                                           \
-                }                                                                                           \
-            }                                                                                               \
-        }                                                                                                   \
-    } while (0)
-
-#define AGPL_PM_TOUCH()                                                                                     \
-    do {                                                                                                    \
-        touched = false;                                                                                    \
-        if (PF > 0 && pw < nit) {                                                                           \
-            if (lane_v < 16u)                                                                               \
-                __builtin_amdgcn_global_load_lds(                                                           \
-                    reinterpret_cast<const unsigned *>(pb_src + (int64_t)(pks + (lane_v >> 3)) * 256 +     \
-                                                       (lane_v & 7u) * 8),                                  \
-                    (lds_void *)(touch_lds + wave * 256), 4, 0, 0);                                         \
-            touched = true;                                                                                 \
-            AGPL_PM_TADV();                                                                                 \
-        }                                                                                                   \
-    } while (0)
-    bool touched = false;
-    if (PF > 0) {
-#pragma unroll 1
-        for (int i = 0; i < PF + 1; ++i)
-            if (pw < nit) AGPL_PM_TADV(); // the touch pointer runs PF stages ahead of the issue pointer (now at stage 1)
-    }
-
-    constexpr int NJ = MF16 ? 4 : 2;
-    float qacc[NJ], macc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) qacc[j] = macc[j] = 0.f;
-
-    // accumulators: MF16 -> 4 x 4 tiles of 16 x 16 (4 registers each), else 2 x 2 tiles of 32 x 32 (16 registers each)
-    f32x4 acc16[MF16 ? 4 : 1][MF16 ? 4 : 1];
-    f32x16 acc32[MF16 ? 1 : 2][MF16 ? 1 : 2];
-    if (MF16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[MF16 ? i : 0][MF16 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[MF16 ? 0 : i][MF16 ? 0 : j][r] = 0.f;
-    }
-
-    // fragment indices (16-byte units within a stage) are formed inside the loop from a lane index passed through an
-    // empty asm: kept live across the loop as invariants they (and everything derived from them) are what the
-    // 128-VGPR cap spills
-
-    int cw = 0, rb = 0, ks = 0, cl = l0; // consume pointer: item cw = (ctile, cl)
-    unsigned ctile = tile0;
-    int pend = -1, pl = 0;               // item whose reduced rows are still to be written (behind the next barrier)
-    unsigned ptile = 0;
-    for (int t = 0; t < T; ++t) {
-        // stage t has landed once nothing but this wave's last touch (if any) is in flight
-        if (PF > 0 && touched) __builtin_amdgcn_s_waitcnt(0x0F71);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
-        if (rb == 0 && ks == 0) {
-            // first stage of an item: v of its latent into the item's parity buffer (first read 8+ stages on; the
-            // previous item's readers use the other buffer)
-            const int ll = cl;
-            float *as = alpha_s + (cw & 1) * M;
-            for (int a = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); a < M;
-                 a += 1024)
-                as[a] = v_all[(int64_t)ll * M + a];
-        }
-        if (pend >= 0) {
-            // the previous item's per-wave partial sums are in LDS (written before this barrier): rows out
-            const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            if (tid_e < NT2) {
-                const int ll = pl;
-                const int64_t n = (int64_t)ptile * NT2 + tid_e;
-                if (n < N) {
-                    const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
-                    float q = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
-                    float m = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
-                    if (mu0) m += mu0[(int64_t)ll * N + n];
-                    mu_out[(int64_t)ll * N + n] = m;
-                    var_out[(int64_t)ll * N + n] = resid[n] + q;
-                }
-            }
-            pend = -1;
-        }
-        // U is lower triangular: this wave's rows 64 wr .. 64 wr + 63 of block rb are zero from slice 16 rb + 4 (wr + 1)
-        const bool act = ks < rb * 16 + 4 * (wr + 1);
-        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int kg = ln >> 4;
-        const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
-        const int li = ln & 31, lk = ln >> 5;
-        const int fa = MF16 ? fbase16 + (wr >> 1) * 512 + (wr & 1) * 64 : (wr >> 1) * 512 + lk * 128 + (wr & 1) * 64 + li;
-        const int fb = MF16 ? fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64
-                            : 1024 + (wc >> 1) * 512 + lk * 128 + (wc & 1) * 64 + li;
-        if (MF16) {
-            if (act) {
-                h8 ah[4], al[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ah[i] = st[fa + 16 * i];
-                h8 bh = st[fb], bl = st[256 + fb];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][0] = mfma32(ah[i], bh, acc16[MF16 ? i : 0][0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < T) AGPL_PM_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
-                AGPL_PM_TOUCH();
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) al[i] = st[256 + fa + 16 * i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jj = MF16 ? j : 0;
-                    if (j > 0) {
-                        bh = st[fb + 16 * j];
-                        bl = st[256 + fb + 16 * j];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][jj] = mfma32(ah[i], bh, acc16[MF16 ? i : 0][jj]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][jj] = mfma32(ah[i], bl, acc16[MF16 ? i : 0][jj]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc16[MF16 ? i : 0][jj] = mfma32(al[i], bh, acc16[MF16 ? i : 0][jj]);
-                }
-            } else {
-                if (t + 1 < T) AGPL_PM_ISSUE(t + 1);
-                AGPL_PM_TOUCH();
-            }
-        } else {
-            h8 ah0, ah1, bh0, bh1, bl0, bl1;
-            if (act) {
-                ah0 = st[fa]; ah1 = st[fa + 32]; bh0 = st[fb]; bh1 = st[fb + 32];
-                bl0 = st[256 + fb]; bl1 = st[256 + fb + 32];
-                acc32[0][0] = mfma16(ah0, bh0, acc32[0][0]);
-                acc32[0][MF16 ? 0 : 1] = mfma16(ah0, bh1, acc32[0][MF16 ? 0 : 1]);
-                acc32[MF16 ? 0 : 1][0] = mfma16(ah1, bh0, acc32[MF16 ? 0 : 1][0]);
-                acc32[MF16 ? 0 : 1][MF16 ? 0 : 1] = mfma16(ah1, bh1, acc32[MF16 ? 0 : 1][MF16 ? 0 : 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < T) AGPL_PM_ISSUE(t + 1);
-            AGPL_PM_TOUCH();
-            __builtin_amdgcn_sched_barrier(0);
-            if (act) {
-#pragma unroll
-                for (int u = 0; u < KU; ++u) {
-                    const h8 *su = st + u * 8 * 256;
-                    const h8 al0 = su[256 + fa], al1 = su[256 + fa + 32];
-                    constexpr int O = MF16 ? 0 : 1;
-                    acc32[0][0] = mfma16(ah0, bl0, acc32[0][0]);
-                    acc32[0][O] = mfma16(ah0, bl1, acc32[0][O]);
-                    acc32[O][0] = mfma16(ah1, bl0, acc32[O][0]);
-                    acc32[O][O] = mfma16(ah1, bl1, acc32[O][O]);
-                    acc32[0][0] = mfma16(al0, bh0, acc32[0][0]);
-                    acc32[0][O] = mfma16(al0, bh1, acc32[0][O]);
-                    acc32[O][0] = mfma16(al1, bh0, acc32[O][0]);
-                    acc32[O][O] = mfma16(al1, bh1, acc32[O][O]);
-                    if (u + 1 < KU) {
-                        const h8 *sn = su + 8 * 256;
-                        ah0 = sn[fa]; ah1 = sn[fa + 32]; bh0 = sn[fb]; bh1 = sn[fb + 32];
-                        bl0 = sn[256 + fb]; bl1 = sn[256 + fb + 32];
-                        acc32[0][0] = mfma16(ah0, bh0, acc32[0][0]);
-                        acc32[0][O] = mfma16(ah0, bh1, acc32[0][O]);
-                        acc32[O][0] = mfma16(ah1, bh0, acc32[O][0]);
-                        acc32[O][O] = mfma16(ah1, bh1, acc32[O][O]);
-                    }
-                }
-            }
-        }
-        ks += KU;
-        if (ks == 16 * (rb + 1)) {
-            // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n]
-            const float *as = alpha_s + (cw & 1) * M;
-            if (MF16) {
-                const float *asrc = as + rb * NT2 + wr * 64 + 4 * kg; // lane rows a = 16 i + 4 kg + 0..3
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 16 * i);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 &c = acc16[MF16 ? i : 0][MF16 ? j : 0];
-                        qacc[MF16 ? j : 0] += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
-                        macc[MF16 ? j : 0] += a0.x * c[0] + a0.y * c[1] + a0.z * c[2] + a0.w * c[3];
-                        c = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            } else {
-                const float *asrc = as + rb * NT2 + wr * 64 + 4 * lk; // lane rows a = .. + 8 g + 4 lk + 0..3
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g);
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            f32x16 &c = acc32[MF16 ? 0 : ii][MF16 ? 0 : jj];
-                            const float t0 = c[4 * g + 0], t1 = c[4 * g + 1], t2 = c[4 * g + 2], t3 = c[4 * g + 3];
-                            qacc[MF16 ? 0 : jj] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-                            macc[MF16 ? 0 : jj] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
-                        }
-                    }
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc32[MF16 ? 0 : ii][MF16 ? 0 : jj][r] = 0.f;
-            }
-            ks = 0;
-            if (++rb == nb2) {
-                // item finished: this wave's partial sums of its 64 points into the item's parity buffer
-                rb = 0;
-                float *qr = qred + (cw & 1) * 4 * NT2, *mr = mred + (cw & 1) * 4 * NT2;
-                const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-                if (MF16) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        qacc[j] += __shfl_xor(qacc[j], 16);
-                        qacc[j] += __shfl_xor(qacc[j], 32);
-                        macc[j] += __shfl_xor(macc[j], 16);
-                        macc[j] += __shfl_xor(macc[j], 32);
-                    }
-                    if (lane_e < 16) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            qr[wr * NT2 + wc * 64 + 16 * j + lane_e] = qacc[j];
-                            mr[wr * NT2 + wc * 64 + 16 * j + lane_e] = macc[j];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        qacc[j] += __shfl_xor(qacc[j], 32);
-                        macc[j] += __shfl_xor(macc[j], 32);
-                    }
-                    if (lane_e < 32) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            qr[wr * NT2 + wc * 64 + 32 * j + lane_e] = qacc[j];
-                            mr[wr * NT2 + wc * 64 + 32 * j + lane_e] = macc[j];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) qacc[j] = macc[j] = 0.f;
-                pend = cw;
-                pl = cl;
-                ptile = ctile;
-                ++cw;
-                if (++cl == L) {
-                    cl = 0;
-                    ++ctile;
-                }
-            }
-        }
-    }
-#undef AGPL_PM_TOUCH
-#undef AGPL_PM_TADV
-#undef AGPL_PM_ISSUE
-#undef AGPL_PM_SRC
-    __syncthreads();
-    if (pend >= 0) {
-        const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (tid_e < NT2) {
-            const int ll = pl;
-            const int64_t n = (int64_t)ptile * NT2 + tid_e;
-            if (n < N) {
-                const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
-                float q = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
-                float m = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
-                if (mu0) m += mu0[(int64_t)ll * N + n];
-                mu_out[(int64_t)ll * N + n] = m;
-                var_out[(int64_t)ll * N + n] = resid[n] + q;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // marginal_factor_queue_kernel: marginal_factor_persist_kernel<true> with the work cut one level finer and handed out
 // dynamically.  An item is ONE 256-row block of U against one (tile, latent); the items of a tile are queued back to
 // back, longest first, in eight queues (tiles t = q mod 8 in queue q; a workgroup serves queue blockIdx.x & 7, i.e.
@@ -1053,7 +502,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_persist_kernel(
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
-    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues, int prio_mode) {
+    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int R = 2, KU = 2;
     constexpr int kSlot = KU * 8 * 4096;
@@ -1066,17 +515,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
     const unsigned lane_v = (unsigned)lane;
     const int wr = wave >> 2, wc = wave & 3;
-    if (prio_mode & 15) { // experiment (AGPL_MARGINAL_PRIO): static issue priority per wave row / column
-        const int h = (prio_mode & 15) == 1 ? wr : (prio_mode & 15) == 2 ? 3 - wr : wc;
-        switch (h & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-        }
-    }
     const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
-    const int qn = (int)(blockIdx.x & 7);
+    const int qn = (int)(blockIdx.x & 7); // (the launch has >= 8 workgroups: every queue is served)
     const int ntq = qn < ntiles2 ? (ntiles2 - qn + 7) / 8 : 0;
     const int nitems = ntq * L * nb2;
     unsigned *queue = queues + qn;
@@ -1088,7 +528,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const h8 *a_img = (ia & 1) ? Wl : Wh, *b_img = (ia & 1) ? Pl : Ph;
     const int dma_off = ia * 4096 + qd * 1024;
     const int wra_ = 2 * (ia >> 1) + (qd & 1);          // the 64-row block of the item this wave stages (image layout: quarter qd = k half qd >> 1 of rows 64 (qd & 1) ..)
-    const bool skip_zero_rows = (prio_mode & 16) == 0; // AGPL_MARGINAL_PRIO bit 4 turns the skip off (A/B)
+    constexpr bool skip_zero_rows = true; // (-3.5 % at C2 with / without: profiles/r02_ab_marginal_zero_row_skip.jsonl)
 
     // item k of this workgroup = queue index qi[k & 3]: (tile, latent, 256-row block), longest row block first
 #define AGPL_Q_DECODE(k_, valid_, tile_, l_, rb_)                                                           \
@@ -1332,272 +772,6 @@ __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// marginal_factor_rows512_kernel: the factor-form pass with ALL accumulators of a 512-row pass resident, so that a
-// point's feature images are read from HBM once per 512 rows of U instead of once per 256 (M = 512: 1.0 x the image
-// bytes instead of 1.5 x; M = 1024: 1.5 x instead of 2.5 x -- the round-1 kernel moved 32 GB per launch at C2, 4.8 TB/s,
-// and ~100 GB at M = 1024, 5.7 TB/s: both at the fabric roof, not at the matrix pipe).
-//   work item   = (tile of 128 points, latent); one resident 1024-thread workgroup per CU walks a contiguous run of
-//                 items, the flat stage list and the LDS-DMA ring running on across item boundaries (as
-//                 marginal_factor_persist_kernel)
-//   pass rp     = rows 512 rp .. 512 rp + 511 of U against slices ks = 0 .. 32 (rp + 1) - 1 (16 deep each)
-//   wave (g, pg)= the two 32-row blocks g and g + 8 of the pass's sixteen (CYCLIC assignment) x points 64 pg .. + 63:
-//                 a 2 x 2 arrangement of 32 x 32 accumulators, as every other kernel here.  U is lower triangular: block f
-//                 is zero from slice 32 rp + 2 (f + 1) on, so a wave drops to one block, then none, slice by slice --
-//                 and because the blocks are dealt cyclically, every SIMD (row groups a, a + 2, a + 4, a + 6) sheds the
-//                 same share at every stage: the products executed are (1 + 32 / M) / 2 of the dense count.
-//   stage       = one 16-deep slice: B images of the tile (8 KB) + the non-zero 128-row image blocks of U (8 KB each,
-//                 4 .. 1 of them), moved global -> LDS by the DMA path into a ring of three 40 KB slots
-//                 [B hi | B lo | rows 384.. hi | lo | rows 256.. | rows 128.. | rows 0..]; two stages in flight.  Wave w
-//                 carries the quarter (w & 3) of image (w & 7) >> 2 of blocks {B, 2, 0} (w < 8) or {3, 1} (w >= 8): 1-3
-//                 pieces per stage, counted for the vmcnt wait.
-// ------------------------------------------------------------------------------------------------
-constexpr int NT5 = 128;
-
-__global__ __launch_bounds__(1024, 1) void marginal_factor_rows512_kernel(
-    int64_t N, int M, int L, int64_t nitems, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
-    const float *__restrict__ resid, const float *__restrict__ mu0, const h8 *__restrict__ Wh,
-    const h8 *__restrict__ Wl, const float *__restrict__ v_all, float *__restrict__ mu_out,
-    float *__restrict__ var_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int R = 3;
-    constexpr int kSlot = 10 * 4096;
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M]: v of the item, by item parity
-    float *qred = alpha_s + 2 * M;                                     // [2][8 row groups][128]
-    float *mred = qred + 2 * 8 * NT5;                                  // [2][8][128]
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
-    const unsigned lane_v = (unsigned)lane;
-    const int g = wave >> 1, pg = wave & 1;
-    const int nb = M / BS, nks = M / KS, nrp = M / 512;
-
-    const unsigned w0 = (unsigned)((uint64_t)blockIdx.x * (uint64_t)nitems / gridDim.x);
-    const unsigned w1 = (unsigned)((uint64_t)(blockIdx.x + 1) * (uint64_t)nitems / gridDim.x);
-    const int nit = (int)(w1 - w0);
-    if (nit <= 0) return;
-    const unsigned tile0 = w0 / (unsigned)L;
-    const int l0 = (int)(w0 - tile0 * (unsigned)L);
-
-    // this wave's DMA share: image (hi / lo) and quarter of every block it carries
-    const int dimg = (wave & 7) >> 2, dq = wave & 3;
-    const h8 *a_img = dimg ? Wl : Wh, *b_img = dimg ? Pl : Ph;
-    const int dma_off = dimg * 4096 + dq * 1024;
-    const int Tit = 16 * nrp * (nrp + 1); // stages per item: sum over passes of 32 (rp + 1)
-    const int T = nit * Tit;
-
-    int iw = 0, irp = 0, iks = 0, il = l0; // issue pointer
-    unsigned itile = tile0;
-    const h8 *a_src, *b_src; // wave-uniform bases of the item (and pass) being issued
-#define AGPL_R5_SRC()                                                                                        \
-    do {                                                                                                     \
-        a_src = a_img + ((int64_t)il * nb + 4 * irp) * nks * 256 + dq * 64;                                  \
-        b_src = b_img + (int64_t)itile * nks * 256 + dq * 64;                                                \
-    } while (0)
-    typedef __attribute__((address_space(3))) void lds_void;
-#define AGPL_R5_DMA(src_, off_) \
-    __builtin_amdgcn_global_load_lds((src_) + lane_v, (lds_void *)(slot_ + (off_)), 16, 0, 0)
-    // issues stage t_ (the one at the issue pointer), leaves the number of pieces this wave issued in cnt_
-#define AGPL_R5_ISSUE(t_, cnt_)                                                                              \
-    do {                                                                                                     \
-        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                      \
-        const int nba_ = iks < 32 * irp ? 4 : 4 - ((iks - 32 * irp) >> 3);                                   \
-        const h8 *as_ = a_src + (int64_t)iks * 256;                                                          \
-        const int64_t bp_ = (int64_t)nks * 256; /* one 128-row image block further */                        \
-        if (wave < 8) {                                                                                      \
-            AGPL_R5_DMA(b_src + (int64_t)iks * 256, 0);                                                      \
-            cnt_ = 1;                                                                                        \
-            if (nba_ >= 2) {                                                                                 \
-                AGPL_R5_DMA(as_ + 2 * bp_, 16384);                                                           \
-                cnt_ = 2;                                                                                    \
-            }                                                                                                \
-            if (nba_ >= 4) {                                                                                 \
-                AGPL_R5_DMA(as_, 32768);                                                                     \
-                cnt_ = 3;                                                                                    \
-            }                                                                                                \
-        } else {                                                                                             \
-            AGPL_R5_DMA(as_ + 3 * bp_, 8192);                                                                \
-            cnt_ = 1;                                                                                        \
-            if (nba_ >= 3) {                                                                                 \
-                AGPL_R5_DMA(as_ + bp_, 24576);                                                               \
-                cnt_ = 2;                                                                                    \
-            }                                                                                                \
-        }                                                                                                    \
-        if (++iks == 32 * (irp + 1)) {                                                                       \
-            iks = 0;                                                                                         \
-            if (++irp == nrp) {                                                                              \
-                irp = 0;                                                                                     \
-                if (++il == L) {                                                                             \
-                    il = 0;                                                                                  \
-                    ++itile;                                                                                 \
-                }                                                                                            \
-                ++iw;                                                                                        \
-            }                                                                                                \
-            if (iw < nit) AGPL_R5_SRC();                                                                     \
-        }                                                                                                    \
-    } while (0)
-
-    int c1 = 0; // pieces this wave has in flight for the stage after the one being consumed
-    AGPL_R5_SRC();
-    {
-        int c0;
-        AGPL_R5_ISSUE(0, c0);
-        (void)c0;
-        if (1 < T) AGPL_R5_ISSUE(1, c1);
-    }
-
-    float qacc[2] = {0.f, 0.f}, macc[2] = {0.f, 0.f};
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int cw = 0, rp = 0, ks = 0, cl = l0; // consume pointer: item cw = (ctile, cl)
-    unsigned ctile = tile0;
-    int pend = -1, pl = 0;
-    unsigned ptile = 0;
-    for (int t = 0; t < T; ++t) {
-        // stage t has landed once at most the pieces of stage t + 1 are outstanding
-        if (c1 == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-        else if (c1 == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
-        else if (c1 == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
-        else __builtin_amdgcn_s_waitcnt(0x0F73);
-        __builtin_amdgcn_s_barrier();
-        if (rp == 0 && ks == 0) {
-            float *as = alpha_s + (cw & 1) * M;
-            for (int a = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); a < M;
-                 a += 1024)
-                as[a] = v_all[(int64_t)cl * M + a];
-        }
-        if (pend >= 0) {
-            const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            if (tid_e < NT5) {
-                const int64_t n = (int64_t)ptile * NT5 + tid_e;
-                if (n < N) {
-                    const float *qr = qred + (pend & 1) * 8 * NT5 + tid_e, *mr = mred + (pend & 1) * 8 * NT5 + tid_e;
-                    float q = ((qr[0] + qr[NT5]) + (qr[2 * NT5] + qr[3 * NT5])) +
-                              ((qr[4 * NT5] + qr[5 * NT5]) + (qr[6 * NT5] + qr[7 * NT5]));
-                    float m = ((mr[0] + mr[NT5]) + (mr[2 * NT5] + mr[3 * NT5])) +
-                              ((mr[4 * NT5] + mr[5 * NT5]) + (mr[6 * NT5] + mr[7 * NT5]));
-                    if (mu0) m += mu0[(int64_t)pl * N + n];
-                    mu_out[(int64_t)pl * N + n] = m;
-                    var_out[(int64_t)pl * N + n] = resid[n] + q;
-                }
-            }
-            pend = -1;
-        }
-        // block f of the pass (rows 32 f ..) is zero from slice 32 rp + 2 (f + 1) on: f = g + 8 first, then f = g
-        const bool act2 = ks < 32 * rp + 2 * (g + 9), act1 = ks < 32 * rp + 2 * (g + 1);
-        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int li = ln & 31, lk = ln >> 5;
-        const int fb = lk * 128 + 64 * pg + li;                                   // B hi (lo at + 256), second frag + 32
-        const int fa2 = 512 + (3 - ((g + 8) >> 2)) * 512 + lk * 128 + (g & 3) * 32 + li; // block g + 8: hi (lo at + 256)
-        const int fa1 = 512 + (3 - (g >> 2)) * 512 + lk * 128 + (g & 3) * 32 + li;       // block g
-        int c2 = 0;
-        if (act2) {
-            const h8 bh0 = st[fb], bh1 = st[fb + 32], x2h = st[fa2];
-            const h8 bl0 = st[256 + fb], bl1 = st[256 + fb + 32], x2l = st[256 + fa2];
-            acc[1][0] = mfma16(x2h, bh0, acc[1][0]);
-            acc[1][1] = mfma16(x2h, bh1, acc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < T) AGPL_R5_ISSUE(t + 2, c2); // into the slot read in iteration t - 1
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1][0] = mfma16(x2h, bl0, acc[1][0]);
-            acc[1][1] = mfma16(x2h, bl1, acc[1][1]);
-            acc[1][0] = mfma16(x2l, bh0, acc[1][0]);
-            acc[1][1] = mfma16(x2l, bh1, acc[1][1]);
-            if (act1) {
-                const h8 x1h = st[fa1], x1l = st[256 + fa1];
-                acc[0][0] = mfma16(x1h, bh0, acc[0][0]);
-                acc[0][1] = mfma16(x1h, bh1, acc[0][1]);
-                acc[0][0] = mfma16(x1h, bl0, acc[0][0]);
-                acc[0][1] = mfma16(x1h, bl1, acc[0][1]);
-                acc[0][0] = mfma16(x1l, bh0, acc[0][0]);
-                acc[0][1] = mfma16(x1l, bh1, acc[0][1]);
-            }
-        } else if (t + 2 < T) {
-            AGPL_R5_ISSUE(t + 2, c2);
-        }
-        c1 = c2;
-        if (++ks == 32 * (rp + 1)) {
-            // pass finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n]; lane rows a = .. + 8 q + 4 lk + 0..3
-            const float *as = alpha_s + (cw & 1) * M + 512 * rp + 4 * lk;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float *asrc = as + 32 * (g + 8 * i);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 8 * q4);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float t0 = acc[i][j][4 * q4 + 0], t1 = acc[i][j][4 * q4 + 1];
-                        const float t2 = acc[i][j][4 * q4 + 2], t3 = acc[i][j][4 * q4 + 3];
-                        qacc[j] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-                        macc[j] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            ks = 0;
-            if (++rp == nrp) {
-                rp = 0;
-                float *qr = qred + (cw & 1) * 8 * NT5 + g * NT5 + 64 * pg, *mr = mred + (cw & 1) * 8 * NT5 + g * NT5 + 64 * pg;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    qacc[j] += __shfl_xor(qacc[j], 32);
-                    macc[j] += __shfl_xor(macc[j], 32);
-                }
-                if (lk == 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        qr[32 * j + li] = qacc[j];
-                        mr[32 * j + li] = macc[j];
-                    }
-                }
-                qacc[0] = qacc[1] = macc[0] = macc[1] = 0.f;
-                pend = cw;
-                pl = cl;
-                ptile = ctile;
-                ++cw;
-                if (++cl == L) {
-                    cl = 0;
-                    ++ctile;
-                }
-            }
-        }
-    }
-#undef AGPL_R5_ISSUE
-#undef AGPL_R5_DMA
-#undef AGPL_R5_SRC
-    __syncthreads();
-    if (pend >= 0) {
-        const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (tid_e < NT5) {
-            const int64_t n = (int64_t)ptile * NT5 + tid_e;
-            if (n < N) {
-                const float *qr = qred + (pend & 1) * 8 * NT5 + tid_e, *mr = mred + (pend & 1) * 8 * NT5 + tid_e;
-                float q = ((qr[0] + qr[NT5]) + (qr[2 * NT5] + qr[3 * NT5])) +
-                          ((qr[4 * NT5] + qr[5 * NT5]) + (qr[6 * NT5] + qr[7 * NT5]));
-                float m = ((mr[0] + mr[NT5]) + (mr[2 * NT5] + mr[3 * NT5])) +
-                          ((mr[4 * NT5] + mr[5 * NT5]) + (mr[6 * NT5] + mr[7 * NT5]));
-                if (mu0) m += mu0[(int64_t)pl * N + n];
-                mu_out[(int64_t)pl * N + n] = m;
-                var_out[(int64_t)pl * N + n] = resid[n] + q;
-            }
-        }
-    }
-}
-
 // U = R^-1 as rocSOLVER leaves it: column-major lower triangle of A, i.e. U[a][b] = A[b * M + a] for b <= a
 // (the other triangle of A still holds I + G and is never read) -> blocked hi / lo images of U
 __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
@@ -1685,8 +859,7 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
     dim3 grid((unsigned)agpl_cdiv(N, NT), (unsigned)L);
     int32_t rc = agpl_timing_begin(ctx, 0);
     if (rc) return rc;
-    static const int force128 = getenv("AGPL_MARGINAL_TILE") ? atoi(getenv("AGPL_MARGINAL_TILE")) == 128 : 0;
-    if (M % NT2 == 0 && !force128) {
+    if (M % NT2 == 0) {
         constexpr int R = 4;
         const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, false, 1>),
@@ -1737,103 +910,41 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
     if (N == 0) return AGPL_OK;
     if (!Phi_hi || !Phi_lo || !resid || !U_hi || !U_lo || !v || !mu_out || !var_out)
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    // tuning knob: AGPL_MARGINAL_STAGE = <ring slots R><16-deep slices per stage KU>.  Measured at C2 on one box:
-    // 41 9.73 ms, 31 9.84, 21 9.91, 22 9.33 (two slices per barrier, one 64 KB stage in flight) -> default 22
-    // AGPL_MARGINAL_STAGE (read per call: A/B runs in one process): 200 = resident workgroups on 16x16x32 MFMA serving
-    // per-XCD queues of (tile, latent, row block) items (default: 6.31-6.36 against 6.67-6.78 ms for the round-1 kernel at
-    // C2 on the same box, 1.92 against 2.63 ms at C4, and 20.6 GB fetched over the fabric instead of 31.9 GB), 116 = the same
-    // with a static run of whole tiles per workgroup, 132 = that on 32x32x16, 16 = one workgroup per tile on 16x16x32,
-    // 117-119 = 116 + L2 touch prefetch, 512 = all 512 rows resident (reads the images once, but 2.7x the stages per point:
-    // 8.7 ms), 22 / 41 / 31 / 21 = the round-1 kernel with <ring slots><slices per stage>
-    const int cfg = getenv("AGPL_MARGINAL_STAGE") ? atoi(getenv("AGPL_MARGINAL_STAGE")) : 200;
-    dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
+    // resident workgroups on 16x16x32 MFMA serving per-XCD queues of (tile, latent, row block) items: the row blocks of a tile
+    // share its images through L2 (round 2: 6.31-6.36 against 6.67-6.78 ms for the per-tile kernel at C2 on one box, 1.92
+    // against 2.63 ms at C4, 20.6 GB fetched over the fabric instead of 31.9 GB; the other forms measured then -- static
+    // persistent runs, 32x32x16, L2 touch prefetch, all 512 rows resident -- are in DESIGN 4.3c and no longer in the tree)
     int32_t rc = agpl_timing_begin(ctx, 0);
     if (rc) return rc;
-#define AGPL_LAUNCH_M256(R_, KU_)                                                                                    \
-    do {                                                                                                             \
-        const size_t lds2 = (size_t)(R_) * (KU_) * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);                 \
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R_, true, KU_>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                   \
-        marginal_split256_kernel<R_, true, KU_><<<grid2, 1024, lds2, ctx->stream>>>(                                 \
-            N, M, agpl_cdiv(N, NT), nullptr, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,  \
-            (const h8 *)U_lo, v, mu_out, var_out);                                                                   \
-    } while (0)
-    if (cfg == 200) {
-        // dynamic per-XCD queues of (tile, latent, row block) items: the row blocks of a tile share its images through L2
-        const int nb2 = M / NT2;
-        const int64_t ntiles2 = agpl_cdiv(N, NT2);
-        if (ntiles2 * L * nb2 > 0x3fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-        const size_t part_bytes = sizeof(float) * (size_t)nb2 * L * N;
-        // the partial sums live at the base of the workspace (the slab region of the accumulation that follows them in a
-        // sweep; a caller that keeps mu / var in the workspace has reserved more than this already: no reallocation)
-        rc = agpl_ws_reserve(ctx, 2 * part_bytes + 256);
-        if (rc) return rc;
-        rc = agpl_ws2_reserve(ctx, 16384);
-        if (rc) return rc;
-        float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
-        unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192);
-        AGPL_HIP(ctx, hipMemsetAsync(queues, 0, 8 * sizeof(unsigned), ctx->stream));
-        const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
-        int dev = 0, ncu = 256;
-        AGPL_HIP(ctx, hipGetDevice(&dev));
-        AGPL_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nb2 = M / NT2;
+    const int64_t ntiles2 = agpl_cdiv(N, NT2);
+    if (ntiles2 * L * nb2 > 0x3fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
+    const size_t part_bytes = sizeof(float) * (size_t)nb2 * L * N;
+    // the partial sums live at the base of the workspace (the slab region of the accumulation that follows them in a
+    // sweep; a caller that keeps mu / var in the workspace has reserved more than this already: no reallocation)
+    rc = agpl_ws_reserve(ctx, 2 * part_bytes + 256);
+    if (rc) return rc;
+    rc = agpl_ws2_reserve(ctx, 16384);
+    if (rc) return rc;
+    float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
+    unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192);
+    AGPL_HIP(ctx, hipMemsetAsync(queues, 0, 8 * sizeof(unsigned), ctx->stream));
+    const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
+    if (ctx->ncu <= 0) { // once per context
+        AGPL_HIP(ctx, hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_queue_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
-        marginal_factor_queue_kernel<<<(unsigned)ncu, 1024, ldsq, ctx->stream>>>(
-            N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi,
-            (const h8 *)U_lo, v, qpart, mpart, queues, getenv("AGPL_MARGINAL_PRIO") ? atoi(getenv("AGPL_MARGINAL_PRIO")) : 0);
-        AGPL_LAUNCH_CHECK(ctx);
-        int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
-        if (nbk > 8192) nbk = 8192;
-        marginal_combine_kernel<<<(unsigned)nbk, 256, 0, ctx->stream>>>(N, L, nb2, resid, mu0, qpart, mpart, mu_out, var_out);
-    } else if (cfg == 512 && M % 512 == 0) {
-        const size_t lds5 = (size_t)3 * 10 * 4096 + sizeof(float) * (size_t)(2 * M + 32 * NT5);
-        int dev = 0, ncu = 256;
-        AGPL_HIP(ctx, hipGetDevice(&dev));
-        AGPL_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        const int64_t nitems = agpl_cdiv(N, NT5) * L;
-        if (nitems > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-        const unsigned gridp = (unsigned)(nitems < ncu ? nitems : ncu);
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_rows512_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
-        marginal_factor_rows512_kernel<<<gridp, 1024, lds5, ctx->stream>>>(
-            N, M, L, nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi, (const h8 *)U_lo, v,
-            mu_out, var_out);
-    } else if (cfg == 116 || cfg == 132 || (cfg >= 117 && cfg <= 119)) {
-        // persistent form: one resident workgroup per CU over a contiguous run of (tile, latent) items
-        const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 16 * 256;
-        int dev = 0, ncu = 256;
-        AGPL_HIP(ctx, hipGetDevice(&dev));
-        AGPL_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        const int64_t nitems = agpl_cdiv(N, NT2) * L;
-        if (nitems > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-        const unsigned gridp = (unsigned)(nitems < ncu ? nitems : ncu);
-#define AGPL_LAUNCH_PERSIST(MF_, PF_)                                                                                \
-    do {                                                                                                             \
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_persist_kernel<MF_, PF_>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                   \
-        marginal_factor_persist_kernel<MF_, PF_><<<gridp, 1024, lds2, ctx->stream>>>(                                \
-            N, M, L, agpl_cdiv(N, NT), nitems, (const h8 *)Phi_hi, (const h8 *)Phi_lo, resid, mu0,                  \
-            (const h8 *)U_hi, (const h8 *)U_lo, v, mu_out, var_out);                                                 \
-    } while (0)
-        if (cfg == 116) AGPL_LAUNCH_PERSIST(true, 0);
-        else if (cfg == 117) AGPL_LAUNCH_PERSIST(true, 2);
-        else if (cfg == 118) AGPL_LAUNCH_PERSIST(true, 3);
-        else if (cfg == 119) AGPL_LAUNCH_PERSIST(true, 5);
-        else AGPL_LAUNCH_PERSIST(false, 0);
-#undef AGPL_LAUNCH_PERSIST
-    } else if (cfg == 16) {
-        const size_t lds2 = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor16_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        marginal_factor16_kernel<<<grid2, 1024, lds2, ctx->stream>>>(N, M, agpl_cdiv(N, NT), (const h8 *)Phi_hi,
-                                                                     (const h8 *)Phi_lo, resid, mu0, (const h8 *)U_hi,
-                                                                     (const h8 *)U_lo, v, mu_out, var_out);
-    } else if (cfg == 41) AGPL_LAUNCH_M256(4, 1);
-    else if (cfg == 31) AGPL_LAUNCH_M256(3, 1);
-    else if (cfg == 21) AGPL_LAUNCH_M256(2, 1);
-    else AGPL_LAUNCH_M256(2, 2);
-#undef AGPL_LAUNCH_M256
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    // one resident workgroup per CU, and never fewer than the eight queues (a masked / partitioned device would otherwise
+    // leave queues unserved and their tiles unwritten)
+    const int nwg = ctx->ncu < 8 ? 8 : ctx->ncu;
+    marginal_factor_queue_kernel<<<(unsigned)nwg, 1024, ldsq, ctx->stream>>>(
+        N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi, (const h8 *)U_lo,
+        v, qpart, mpart, queues);
+    AGPL_LAUNCH_CHECK(ctx);
+    int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
+    if (nbk > 8192) nbk = 8192;
+    marginal_combine_kernel<<<(unsigned)nbk, 256, 0, ctx->stream>>>(N, L, nb2, resid, mu0, qpart, mpart, mu_out, var_out);
     AGPL_LAUNCH_CHECK(ctx);
     return agpl_timing_end(ctx, 0);
 }

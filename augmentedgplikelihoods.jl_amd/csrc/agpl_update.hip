@@ -25,6 +25,7 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
                                          double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad,
                                          double *proj_work);
 int32_t agpl_launch_randn(agpl_ctx *ctx, int64_t n, uint32_t sweep, double *out);
+int32_t agpl_sampler_outcome(agpl_ctx *ctx, int32_t kind, const int *bad);
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
 
 namespace {
@@ -665,16 +666,7 @@ static int32_t gibbs_pass_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t 
     rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, bet, gam, G_out, g_out, base);
     ctx->accumulate_split = keep_split;
     if (rc) return rc;
-    if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_CATEGORICAL_BIJ) {
-        int hbad = 0;
-        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hbad)
-            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
-                      "NegativeMultinomial: all p should be positive and their sum strictly smaller than 1 "
-                      "(negativemultinomial.jl:17-22)");
-    }
-    return AGPL_OK;
+    return agpl_sampler_outcome(ctx, ld.kind, bad);
 }
 
 extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,

@@ -99,7 +99,10 @@ AGPL_API int32_t agpl_version(void);
  * The PG draw is polyagamma.jl:121-257 (Devroye alternating series, one lane per point, per-lane
  * Philox4x32-10 stream keyed (ctx seed, point index, sweep)).  f, omega_out are float64.
  * n_out: int64 counts ([L,N] categorical, [N] poisson / heterogauss) or NULL.
- * nuni_out / nterms_out: optional uint32[N] bookkeeping (uniforms consumed, summed series index).   */
+ * nuni_out / nterms_out: optional uint32[N] bookkeeping (uniforms consumed, summed series index).
+ * Limit: a point's PG(b, c) needs b = y + r (y + n) < 65535 -- its PG(1, c) draws are numbered with 16 bits of the Philox
+ *   counter; a larger b returns AGPL_ERR_UNSUPPORTED (that point's outputs are NaN), also from agpl_gibbs_pass* and
+ *   agpl_rand_polyagamma.  The reference draws any integer b (polyagamma.jl:129-134).                                  */
 AGPL_API int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                         const double *f, double *omega_out, int64_t *n_out, uint32_t sweep,
                         uint32_t *nuni_out, uint32_t *nterms_out);
@@ -254,13 +257,6 @@ AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflop
  *   NULL): average launch duration.  Synchronous.                                                              */
 AGPL_API int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
                                      double *tflops_host, double *ms_host);
-
-/* agpl_debug_strip_plan: the host-built decomposition the strip form of the split accumulation executes (AGPL_SYRK =
- *   strip | pp, agpl_mfma.hip syrk_strip_plan), for `nb` block rows of 128 features, as the device reads it: `ntypes`
- *   workgroup types of 144 words each, then `nentries` (type, first slice) pairs per super-slice of 4 slices.  Host
- *   only (no GPU needed; ctx-free): what tests/test_strip_plan.py checks.  Returns the number of words (or minus the
- *   number needed when `cap` is too small).                                                                         */
-AGPL_API int32_t agpl_debug_strip_plan(int32_t nb, int32_t *out, int32_t cap, int32_t *ntypes, int32_t *nentries);
 
 /* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
  * pair is recorded on the context's stream around every launch of the marginal (which = 0), the
