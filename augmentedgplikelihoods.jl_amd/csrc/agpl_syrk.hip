@@ -10,18 +10,16 @@
 //   8p .. 8p+7 of the slice; hl = 0: hi = f16(s_A phi), hl = 1: lo = f16(s_A phi - hi); s_A = 2^e_A chosen from max |Phi| so
 //   that hi and lo stay float16 normals over the widest range (header word scale_exp).
 //
-// syrk_image8_kernel: one 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a 256 x 256 tile of the
-// lower triangle of G for one slice of 4096 points (one f32 accumulation run, one slab set -- the slabs and the fixed-order
-// float64 reduction behind them are those of agpl_mfma.hip).  Per 32-point stage:
-//   A = rows of panel I:  image blocks moved HBM -> LDS by the DMA path (global_load_lds_dwordx4), no VGPRs, no VALU;
-//   B = gamma_n * (rows of panel J):  every thread loads TWO granules (hi and lo: 4 x 16 B) of the same image into registers,
-//       rebuilds x = hi + lo (exact in float32), forms y = (s_B gamma_n) x and splits it into hi / lo again
-//       (3 v_fma_mix per value) and stores the 16-byte results into the B half of the next stage's LDS slot -- the granule is
-//       already the MFMA fragment, nothing is transposed;
-//   G_tile += A B'  as  hi hi' + hi lo' + lo hi'  with v_mfma_f32_16x16x32_f16 (96 per wave and stage, 128 x 64 per wave).
+// syrk_strip_kernel (below): one 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a 256 x 256 tile of
+// the lower triangle of G for one slice of 4096 points (one f32 accumulation run, one slab set -- the slabs and the fixed-
+// order float64 reduction behind them are those of agpl_mfma.hip).  A = rows of panel I: image blocks moved HBM -> LDS by the
+// DMA path, no VGPRs, no VALU.  B = gamma_n * (rows of panel J): the granules of a wave's own 32 columns, loaded (or, on a
+// diagonal tile, read back from the A image in LDS) into registers, rebuilt (x = hi + lo, exact in float32), scaled
+// (y = (s_B gamma_n) x) and re-split there (3 v_fma_mix per value) -- the granule is already the MFMA fragment, nothing is
+// transposed and B never touches LDS.  G_tile += A B' as hi hi' + hi lo' + lo hi' with v_mfma_f32_16x16x32_f16.
 // Compared with syrk_split_kernel (agpl_mfma.hip: 128 x 128 tiles, both panels converted from float32 every stage by every
-// tile pair): a quarter of the conversions per flop, half the operand bytes per flop, no register staging of A.
-// g = Phi beta rides the B conversion of the diagonal tiles (x is the float32 feature there).
+// tile pair): a quarter of the conversions per flop, half the operand bytes per flop (a third on diagonal tiles), no register
+// staging of A.  g = Phi beta rides the B conversion of the diagonal tiles (x is the float32 feature there).
 #include <cstdlib>
 
 #include "agpl_common.h"
@@ -36,8 +34,6 @@ constexpr int BS = 128;       // feature rows per image block / per slab tile (t
 constexpr int kChunk = 4096;  // points per slice (must match agpl_mfma.hip)
 constexpr int kPanel = 256;   // feature rows per operand panel
 constexpr int kStagePts = 32; // points per stage (one MFMA K)
-constexpr int kSliceBytes = 8 * 4096;       // LDS bytes of one 16-point slice of a stage: A (rb, hl) x 4 | B (rb, hl) x 4
-constexpr int kSlot = 2 * kSliceBytes;      // one stage
 constexpr uint32_t kImageMagic = 0x41474951u; // "AGIQ"
 
 struct AccImageHeader { // 256 bytes in front of the blocks
@@ -151,11 +147,11 @@ __global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M,
     }
 }
 
-// The 8-wave kernel takes gamma and beta of a stage from ONE 256-byte record (gamma x 32 | beta x 32, zeros beyond N), which
+// The accumulation kernel takes gamma and beta of a stage from ONE 256-byte record (gamma x 32 | beta x 32, zeros beyond N), which
 // one wave moves into LDS by DMA a stage ahead -- a scalar or vector load at the point of use would pay the HBM latency of a
-// cold, once-read array in every stage.  acc_prep8_kernel writes the records and max gamma, acc_scale_kernel then multiplies
+// cold, once-read array in every stage.  acc_prep_kernel writes the records and max gamma, acc_scale_kernel then multiplies
 // gamma by s_B = 2^e_B (exact), so that the accumulation kernel applies no scale of its own.
-__global__ __launch_bounds__(256) void acc_prep8_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
+__global__ __launch_bounds__(256) void acc_prep_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ gb,
                                                         unsigned *__restrict__ scal) {
     const int64_t total = (int64_t)L * Npad;
@@ -192,17 +188,6 @@ __global__ __launch_bounds__(256) void acc_scale_kernel(int64_t nrec, float *__r
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// syrk_image8_kernel: the same tile, slots, images and slabs with EIGHT waves (512 threads, two per SIMD, up to 256
-// registers each): a wave owns 128 x 64 of the tile (8 x 4 accumulators), keeps the B fragments of its four column blocks
-// for the whole stage and streams the A fragments one 16-row block ahead of the twelve MFMAs that use them, so that a
-// wave alone keeps the matrix pipe fed (with sixteen 128-register waves the fragment reads of a group could not be issued
-// ahead of the previous group's MFMAs: a wave alone ran at ~40 cycles per MFMA instead of 16, and since a SIMD serves
-// its oldest wave first, the youngest finished each stage alone at that pace -- in-kernel stamps).
-// Staging per thread and stage: 4 DMA pieces of A, two granules of B (same row and plane in the stage's two slices).
-// Diagonal tiles: block (i, j) of sub-tile (wr, wc) is needed iff 8 wr + i >= 4 wc + j; the six sub-tiles that hold such
-// blocks are dealt over the SIMDs as 32 | 32 | 26 + 10 | 26 + 10 blocks (an off-diagonal tile: 64 per SIMD).
-// ------------------------------------------------------------------------------------------------
 #ifdef AGPL_QTRACE // diagnostic build (make QTRACE=1): per-wave cycle sums of the stage loop, tools/qtrace.py
 __device__ unsigned long long g_qtrace[64 * 16 * 8];
 constexpr bool kTrace = true;
@@ -210,27 +195,40 @@ constexpr bool kTrace = true;
 constexpr bool kTrace = false;
 #endif
 
-__constant__ unsigned char kDiagWave8[8] = {1 | 16, 1 | 4 | 16, 0 | 16, 1 | 8 | 16, 0, 0, 0 | 4 | 16, 1 | 12 | 16}; // wr | wc << 2 | active << 4
+// ------------------------------------------------------------------------------------------------
+// syrk_strip_kernel: the same tile, image and slabs with the B operand kept OUT of LDS.
+// A wave owns a column strip of the tile -- all 256 rows x 32 columns (16 x 2 accumulators of 16 x 16) -- so the B
+// fragments it multiplies are ITS OWN: lane l loads the granules (feature 16 cb + (l & 15) of the strip, points of k-group
+// l >> 4) of its two column blocks straight from the image into registers (the image granule IS the MFMA B fragment),
+// scales them by gamma and re-splits them there; nothing of B is stored to or read from LDS, no wave converts what another
+// one multiplies, and the B bytes are fetched once per CU.  LDS holds only A: a ring of four 32-point steps (32 KB each),
+// filled by DMA three steps ahead, plus each wave's private copies of the steps' gamma | beta records.
+// Per step and wave: 32 A-fragment reads (one 16-row block ahead of its six MFMAs), 96 MFMAs, 5 DMA pieces, 4 granule
+// loads, 48 v_fma_mix.  The granule loads are inline asm: beside an LDS-DMA in flight the compiler drains the whole queue
+// (vmcnt(0)) at the first use of an ordinary load; here the one wait of a step is `vmcnt(5)` = everything but this step's
+// DMA pieces.  Diagonal tiles: strip c needs row blocks i >= 2 c; the waves of a SIMD (w, w + 4) take the strips (s, 7 - s):
+// 34 blocks per SIMD against 64 of an off-diagonal tile.
+// ------------------------------------------------------------------------------------------------
+#ifndef AGPL_S_PRE
+#define AGPL_S_PRE 3 // row blocks of A-fragment lead (2, 3, 4 measured: 3.73 / 3.69 / 3.74 ms at N = 4e6, M = 512)
+#endif
+constexpr int kStepBytes = 32768;                  // A image of one 32-point step: [slice 2][(128-row block, hi | lo) 4][4096]
+constexpr int kRing = 4;                           // steps in the ring
+constexpr int kRecBytes = 256;                     // one gamma | beta record
+constexpr int kStripLds = kRing * kStepBytes + 8 * kRing * kRecBytes;
 
 template <bool DIAG>
-__device__ __forceinline__ void syrk_image8_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int l,
-                                                 int s, int I, int J, const unsigned char *__restrict__ image,
-                                                 const float *__restrict__ gb_all,
-                                                 const unsigned *__restrict__ scal, float *__restrict__ slabG,
-                                                 float *__restrict__ slabg) {
-    constexpr bool TRACE = kTrace;
+__device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int l,
+                                                int s, int I, int J, const unsigned char *__restrict__ image,
+                                                const float *__restrict__ gb_all, const unsigned *__restrict__ scal,
+                                                float *__restrict__ slabG, float *__restrict__ slabg) {
     typedef __attribute__((address_space(3))) void lds_void;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..7
     const int nb = M / BS;
-    int wr = wave >> 2, wc = wave & 3;
-    bool active = true;
-    if (DIAG) {
-        const unsigned e = kDiagWave8[wave];
-        wr = e & 1;
-        wc = (e >> 2) & 3;
-        active = (e >> 4) & 1;
-    }
+    // strip of this wave: on a diagonal tile the two waves of a SIMD (w, w + 4) take strips (s, 7 - s)
+    const int c = DIAG ? ((wave & 4) ? 7 - (wave & 3) : (wave & 3)) : wave;
+    const int i0 = DIAG ? 2 * c : 0; // first needed 16-row block
     const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
     const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
     const int eA = hdr->scale_exp;
@@ -239,272 +237,294 @@ __device__ __forceinline__ void syrk_image8_body(unsigned char *smem_raw, int64_
     const int64_t nbeg = (int64_t)s * kChunk;
     int64_t nend = nbeg + kChunk;
     if (nend > N) nend = N;
-    const int nstage = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
+    const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
     const int64_t ps0 = nbeg / 16;
-
-    // staging duty of a wave: 128-row block rbS = (wave >> 2) & 1 of BOTH panels, quarter qd = wave & 3 = (plane, 64-row half)
-    const int rbS = (wave >> 2) & 1, qd = wave & 3;
     const int64_t slice_pitch = (int64_t)nb * 2 * 256; // h8 units between consecutive point slices
-    const h8 *a_src = blocks + ((ps0 * nb + 2 * I + rbS) * 2) * 256 + qd * 64 + lane; // + 256: lo; + slice_pitch: slice 1
-    const int a_dst = rbS * 2 * 4096 + qd * 1024;                                     // + 4096: lo; + kSliceBytes: slice 1
-    const h8 *b_src = blocks + ((ps0 * nb + 2 * J + rbS) * 2) * 256 + qd * 64 + lane;
-    const int b_dst = (4 + rbS * 2) * 4096 + qd * 1024 + lane * 16;
-    // gamma | beta records of the slice's stages; the 8 points of this wave's granules are 8 (qd >> 1) + 0..7 of each
-    // 16-point slice of a stage
+
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int kg = ln >> 4, lr = ln & 15;
+    // A pieces of this wave: 128-row block rbS, quarter qd, both slices, hi and lo
+    const int rbS = (wave >> 2) & 1, qd = wave & 3;
+    const h8 *a_src = blocks + ((ps0 * nb + 2 * I + rbS) * 2) * 256 + qd * 64 + lane;
+    const int a_dst = rbS * 2 * 4096 + qd * 1024;
+    // B granules of this lane: strip rows 32 c + 16 cb + lr of panel J, k-group kg = (slice kg >> 1, plane kg & 1)
+    const int R0 = 32 * c + lr;
+    const h8 *b_src = blocks + (((ps0 + (kg >> 1)) * nb + 2 * J + (R0 >> 7)) * 2) * 256 + (kg & 1) * 128 + (R0 & 127);
+    // gamma | beta records: every wave keeps its own copy of a step's record (no wave waits for another's DMA)
     const float *gb_src = gb_all + ((int64_t)l * (Npad / 32) + nbeg / 32) * 64 + lane;
-    float *gbuf = reinterpret_cast<float *>(smem_raw + 2 * kSlot); // [2 (stage parity)][64]
-    const int gofs = 8 * (qd >> 1);
+    float *gbuf = reinterpret_cast<float *>(smem_raw + kRing * kStepBytes + wave * kRing * kRecBytes);
 
-    f32x4 acc[8][4];
+    f32x4 acc[16][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gacc = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gacc0 = 0.f, gacc1 = 0.f;
+    u32x4 rh0 = {0, 0, 0, 0}, rl0 = rh0, rh1 = rh0, rl1 = rh0; // raw granules of the two column blocks (hi, lo), then their converted form
+    h8 bh0, bl0, bh1, bl1;    // the B fragments in use
 
-    u32x4 rh0, rl0, rh1, rl1; // the two raw granules in flight (slice 0, slice 1)
-
-#define AGPL_E_DMA(t_)                                                                                          \
+#define AGPL_S_DMA(t_, k_) /* piece k_ = 0..3 of step t_: (slice k_ >> 1, hi / lo k_ & 1) */                    \
     do {                                                                                                        \
-        unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + a_dst;                                           \
-        const h8 *src_ = a_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
-        __builtin_amdgcn_global_load_lds(src_, (lds_void *)slot_, 16, 0, 0);                                    \
-        __builtin_amdgcn_global_load_lds(src_ + 256, (lds_void *)(slot_ + 4096), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds(src_ + slice_pitch, (lds_void *)(slot_ + kSliceBytes), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds(src_ + slice_pitch + 256, (lds_void *)(slot_ + kSliceBytes + 4096), 16, 0, 0); \
+        unsigned char *d_ = smem_raw + ((t_) & (kRing - 1)) * kStepBytes + ((k_) >> 1) * 16384 + a_dst + ((k_) & 1) * 4096; \
+        const h8 *src_ = a_src + (int64_t)(2 * (t_) + ((k_) >> 1)) * slice_pitch + ((k_) & 1) * 256;            \
+        __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);                                       \
     } while (0)
-#define AGPL_E_DMA1(t_, k_) /* piece k_ = 0..3 of the four */                                                   \
-    do {                                                                                                        \
-        unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + a_dst + ((k_) & 1) * 4096 + ((k_) >> 1) * kSliceBytes; \
-        const h8 *src_ = a_src + (int64_t)(2 * (t_)) * slice_pitch + ((k_) & 1) * 256 + ((k_) >> 1) * slice_pitch; \
-        __builtin_amdgcn_global_load_lds(src_, (lds_void *)slot_, 16, 0, 0);                                    \
-    } while (0)
-#define AGPL_E_LOADB(t_)                                                                                        \
+#define AGPL_S_DMAG(t_)                                                                                         \
+    __builtin_amdgcn_global_load_lds(gb_src + (int64_t)(t_) * 64, (lds_void *)(gbuf + ((t_) & (kRing - 1)) * 64), 4, 0, 0)
+    // The compiler does not see these loads in the memory queue (it believes their results are there at once): the waits
+    // are written out below, and the destinations are read-write operands of every statement that touches them and are never
+    // behind a condition -- a copy of an in-flight destination (the phi of a conditional load) would copy stale registers
+#define AGPL_S_LOADB(t_)                                                                                        \
     do {                                                                                                        \
         const h8 *src_ = b_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
-        rh0 = *reinterpret_cast<const u32x4 *>(src_);                                                           \
-        rl0 = *reinterpret_cast<const u32x4 *>(src_ + 256);                                                     \
-        rh1 = *reinterpret_cast<const u32x4 *>(src_ + slice_pitch);                                             \
-        rl1 = *reinterpret_cast<const u32x4 *>(src_ + slice_pitch + 256);                                       \
+        const h8 *srcl_ = src_ + 256; /* the lo block follows the hi block; column block 1 = 16 rows = 256 bytes on */ \
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"                   \
+                     "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256"  \
+                     : "+v"(rh0), "+v"(rl0), "+v"(rh1), "+v"(rl1)                                               \
+                     : "v"(src_), "v"(srcl_)                                                                    \
+                     : "memory");                                                                               \
     } while (0)
-#define AGPL_E_DMAG(t_) /* wave 0: the gamma | beta record of stage t_ -> gbuf[t_ & 1] */                    \
-    do {                                                                                                        \
-        if (wave == 0)                                                                                          \
-            __builtin_amdgcn_global_load_lds(gb_src + (int64_t)(t_) * 64, (lds_void *)(gbuf + ((t_) & 1) * 64), 4, 0, 0); \
-    } while (0)
-#define AGPL_E_CVT(RH_, RL_, g0_, g1_, b0_, b1_)                                                                \
+#define AGPL_S_CVT(RH_, RL_, g0_, g1_, b0_, b1_, GA_)                                                           \
     do {                                                                                                        \
         float x0_, x1_;                                                                                         \
         AGPL_Q_JOIN2(RH_, RL_, x0_, x1_);                                                                       \
         if (DIAG) {                                                                                             \
-            AGPL_E_GFMA(gacc, b0_, x0_);                                                                        \
-            AGPL_E_GFMA(gacc, b1_, x1_);                                                                        \
+            AGPL_E_GFMA(GA_, b0_, x0_);                                                                         \
+            AGPL_E_GFMA(GA_, b1_, x1_);                                                                         \
         }                                                                                                       \
         AGPL_E_SPLIT2(x0_, g0_, x1_, g1_, RH_, RL_);                                                            \
     } while (0)
-    // half a granule (4 points): its gamma (and beta on a diagonal tile) come out of the stage's record in LDS (one address
-    // for the whole wave: a broadcast read); keepf zeroes the beta of the clamped duplicate behind the last stage
-#define AGPL_E_CVT_HALF(c_, tt_, keepf_)                                                                        \
+    // a quarter of the conversion: points 4 q .. 4 q + 3 of the lane's k-group, both column blocks; tt_ = the step the raw
+    // granules belong to (its record gives gamma, and beta on a diagonal tile; keepf zeroes the beta of a duplicate)
+#define AGPL_S_CVTQ(q_, tt_, keepf_)                                                                            \
     do {                                                                                                        \
-        const float *gq_ = gbuf + ((tt_) & 1) * 64 + gofs + 16 * ((c_) >> 1) + 4 * ((c_) & 1);                  \
+        const float *gq_ = gbuf + ((tt_) & (kRing - 1)) * 64 + 8 * kg + 4 * ((q_) & 1);                         \
         const float4 g4_ = *reinterpret_cast<const float4 *>(gq_);                                              \
         float4 b4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
         if (DIAG) {                                                                                             \
             b4_ = *reinterpret_cast<const float4 *>(gq_ + 32);                                                  \
-            b4_.x *= (keepf_); b4_.y *= (keepf_); b4_.z *= (keepf_); b4_.w *= (keepf_);                         \
+            if (!(keepf_)) b4_ = float4{0.f, 0.f, 0.f, 0.f};                                                    \
         }                                                                                                       \
-        if ((c_) == 0) { AGPL_E_CVT(rh0.x, rl0.x, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh0.y, rl0.y, g4_.z, g4_.w, b4_.z, b4_.w); } \
-        if ((c_) == 1) { AGPL_E_CVT(rh0.z, rl0.z, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh0.w, rl0.w, g4_.z, g4_.w, b4_.z, b4_.w); } \
-        if ((c_) == 2) { AGPL_E_CVT(rh1.x, rl1.x, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh1.y, rl1.y, g4_.z, g4_.w, b4_.z, b4_.w); } \
-        if ((c_) == 3) { AGPL_E_CVT(rh1.z, rl1.z, g4_.x, g4_.y, b4_.x, b4_.y); AGPL_E_CVT(rh1.w, rl1.w, g4_.z, g4_.w, b4_.z, b4_.w); } \
-    } while (0)
-#define AGPL_E_STOREB(t_)                                                                                       \
-    do {                                                                                                        \
-        const unsigned d_ = lds_base + (unsigned)(((t_) & 1) * kSlot + b_dst);                                  \
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:4096\n\t"                             \
-                     "ds_write_b128 %0, %3 offset:32768\n\tds_write_b128 %0, %4 offset:36864" ::"v"(d_),        \
-                     "v"(rh0), "v"(rl0), "v"(rh1), "v"(rl1)                                                     \
-                     : "memory");                                                                               \
-    } while (0)
-
-    [[maybe_unused]] unsigned long long tr0 = 0, tr_wait = 0, tr_body = 0, tr_loop = 0, rt0 = 0, tr_h[4] = {0, 0, 0, 0};
-    if (TRACE) {
-        tr0 = __builtin_amdgcn_s_memtime();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-    const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem_raw;
-    AGPL_E_DMAG(0);
-    AGPL_E_DMA(0);
-    AGPL_E_LOADB(0);
-    __builtin_amdgcn_s_waitcnt(0x0070); // the record of stage 0 is in LDS ...
-    __builtin_amdgcn_s_barrier();       // ... for every wave
-    if (nstage > 1) AGPL_E_DMAG(1);
-    AGPL_E_CVT_HALF(0, 0, 1.f);
-    AGPL_E_CVT_HALF(1, 0, 1.f);
-    AGPL_E_CVT_HALF(2, 0, 1.f);
-    AGPL_E_CVT_HALF(3, 0, 1.f);
-    AGPL_E_STOREB(0);
-    AGPL_E_LOADB(nstage > 1 ? 1 : 0);
-
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int kg = ln >> 4;
-    const int fbase = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
-    const int fa = fbase + wr * 512;
-    const int fb = fbase + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
-    const int jbase = DIAG ? 8 * wr - 4 * wc + 1 : 4; // blocks j < jbase + i of row block i are needed
-
-
-    if (TRACE) tr_loop = __builtin_amdgcn_s_memtime();
-    // hook i sits behind the MFMAs of row block i: the staging work of stage t + 1 in pieces
-#define AGPL_E_HOOK(i_)                                                                                         \
-    do {                                                                                                        \
-        if (TRACE && ((i_) == 0 || (i_) == 2 || (i_) == 4 || (i_) == 6)) {                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            tr_h[(i_) / 2] += __builtin_amdgcn_s_memtime() - tb;                                                \
-        }                                                                                                       \
-        if ((i_) == 0 && t + 2 < nstage) AGPL_E_DMAG(t + 2);                                                    \
-        if (more && (i_) < 4) AGPL_E_DMA1(t + 1, i_); /* one piece per hook: four at once queue behind each other */ \
-        if ((i_) >= 1 && (i_) <= 4) AGPL_E_CVT_HALF((i_) - 1, t + 1, keepf);                                    \
-        if ((i_) == 4) {                                                                                        \
-            AGPL_E_STOREB(t + 1);                                                                               \
-            AGPL_E_LOADB(tl);                                                                                   \
-        }                                                                                                       \
-    } while (0)
-    // the MFMA block with the set of needed blocks fixed at compile time: JB_ = 4 all of them, 1 / -3 the two kinds of
-    // sub-tile that straddle the diagonal (blocks j < JB_ + i of row block i), 100 = a wave with no sub-tile (staging only)
-#define AGPL_E_BLOCK(JB_)                                                                                       \
-    do {                                                                                                        \
-        h8 bh[4], bl[4];                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            bh[j] = st[fb + 16 * j];                                                                            \
-            bl[j] = st[256 + fb + 16 * j];                                                                      \
-        }                                                                                                       \
-        constexpr int i0_ = (JB_) >= 1 ? 0 : 1 - (JB_); /* first row block with a needed block */              \
-        h8 ah = st[fa + 16 * i0_], al = st[256 + fa + 16 * i0_];                                                \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                         \
-            if (i >= i0_) {                                                                                     \
-                const h8 ahc = ah, alc = al;                                                                    \
-                if (i < 7) { /* the next row block's fragments, ahead of this one's MFMAs */                    \
-                    ah = st[fa + 16 * (i + 1)];                                                                 \
-                    al = st[256 + fa + 16 * (i + 1)];                                                           \
-                }                                                                                               \
-                __builtin_amdgcn_s_setprio(1);                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < (JB_) + i) {                              \
-                    acc[i][j] = mfma32(ahc, bh[j], acc[i][j]);                                                  \
-                    acc[i][j] = mfma32(ahc, bl[j], acc[i][j]);                                                  \
-                    acc[i][j] = mfma32(alc, bh[j], acc[i][j]);                                                  \
-                }                                                                                               \
-                __builtin_amdgcn_s_setprio(0);                                                                  \
-            }                                                                                                   \
-            AGPL_E_HOOK(i);                                                                                     \
-        }                                                                                                       \
-    } while (0)
-    // one stage loop per kind of wave, chosen once: a branch inside the loop would make the accumulators a merge of the
-    // bodies' and spill them
-#define AGPL_E_LOOP(JB_)                                                                                        \
-    for (int t = 0; t < nstage; ++t) {                                                                          \
-        unsigned long long ta = 0, tb = 0;                                                                      \
-        if (TRACE) ta = __builtin_amdgcn_s_memtime();                                                           \
-        /* stage t's A pieces, the raw granules of stage t + 1 and the B' stores of stage t are done */        \
-        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */                                           \
-        __builtin_amdgcn_s_barrier();                                                                           \
-        if (TRACE) tb = __builtin_amdgcn_s_memtime();                                                           \
-        const bool more = t + 1 < nstage;                                                                       \
-        const int tl = t + 2 < nstage ? t + 2 : nstage - 1; /* unconditional loads (clamped) */                \
-        const float keepf = more ? 1.f : 0.f;               /* behind the last stage the conversion is a duplicate */ \
-        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & 1) * kSlot);                                \
-        if ((JB_) == 100) {                                                                                     \
-            if (more) AGPL_E_DMA(t + 1);                                                                        \
-            if (t + 2 < nstage) AGPL_E_DMAG(t + 2);                                                             \
-            AGPL_E_CVT_HALF(0, t + 1, keepf);                                                                   \
-            AGPL_E_CVT_HALF(1, t + 1, keepf);                                                                   \
-            AGPL_E_CVT_HALF(2, t + 1, keepf);                                                                   \
-            AGPL_E_CVT_HALF(3, t + 1, keepf);                                                                   \
-            AGPL_E_STOREB(t + 1);                                                                               \
-            AGPL_E_LOADB(tl);                                                                                   \
+        if ((q_) == 0) {                                                                                        \
+            AGPL_S_CVT(rh0.x, rl0.x, g4_.x, g4_.y, b4_.x, b4_.y, gacc0);                                        \
+            AGPL_S_CVT(rh0.y, rl0.y, g4_.z, g4_.w, b4_.z, b4_.w, gacc0);                                        \
+            AGPL_S_CVT(rh1.x, rl1.x, g4_.x, g4_.y, b4_.x, b4_.y, gacc1);                                        \
+            AGPL_S_CVT(rh1.y, rl1.y, g4_.z, g4_.w, b4_.z, b4_.w, gacc1);                                        \
         } else {                                                                                                \
-            AGPL_E_BLOCK(JB_);                                                                                  \
+            AGPL_S_CVT(rh0.z, rl0.z, g4_.x, g4_.y, b4_.x, b4_.y, gacc0);                                        \
+            AGPL_S_CVT(rh0.w, rl0.w, g4_.z, g4_.w, b4_.z, b4_.w, gacc0);                                        \
+            AGPL_S_CVT(rh1.z, rl1.z, g4_.x, g4_.y, b4_.x, b4_.y, gacc1);                                        \
+            AGPL_S_CVT(rh1.w, rl1.w, g4_.z, g4_.w, b4_.z, b4_.w, gacc1);                                        \
         }                                                                                                       \
-        if (TRACE) {                                                                                            \
-            const unsigned long long td = __builtin_amdgcn_s_memtime();                                         \
-            tr_wait += tb - ta;                                                                                 \
-            tr_body += td - tb;                                                                                 \
+    } while (0)
+#define AGPL_S_TAKEB() /* the converted granules become the fragments of the next step */                      \
+    do {                                                                                                        \
+        bh0 = __builtin_bit_cast(h8, rh0);                                                                      \
+        bl0 = __builtin_bit_cast(h8, rl0);                                                                      \
+        bh1 = __builtin_bit_cast(h8, rh1);                                                                      \
+        bl1 = __builtin_bit_cast(h8, rl1);                                                                      \
+    } while (0)
+
+    // fragment slot of (row block i, part) inside a step: [slice kg >> 1][(rb = i >> 3, hl)][plane kg & 1][row]
+    const int fa = (kg >> 1) * 1024 + (kg & 1) * 128 + lr;
+#define AGPL_S_AOFF(i_) (fa + ((i_) >> 3) * 512 + ((i_) & 7) * 16)
+    // On a DIAGONAL tile the B panel is the A panel: the raw granules of the strip are row blocks 2 c, 2 c + 1 of the A
+    // image already in LDS -- read from there (step t_'s slot), not from memory: a diagonal tile moves 32 KB per step through
+    // the CU's vector-memory path instead of 64 (that path, ~15-20 bytes per clock and CU, is what bounds this kernel)
+#define AGPL_S_LDSB(t_)                                                                                         \
+    do {                                                                                                        \
+        const u32x4 *sn_ = reinterpret_cast<const u32x4 *>(smem_raw + ((t_) & (kRing - 1)) * kStepBytes);       \
+        rh0 = sn_[AGPL_S_AOFF(2 * c)];                                                                          \
+        rl0 = sn_[256 + AGPL_S_AOFF(2 * c)];                                                                    \
+        rh1 = sn_[AGPL_S_AOFF(2 * c + 1)];                                                                      \
+        rl1 = sn_[256 + AGPL_S_AOFF(2 * c + 1)];                                                                \
+    } while (0)
+
+    // ---- prologue: records and A of steps 0..2; B of step 0 converted; (off the diagonal) B of step 1 in flight
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nstep) {
+            AGPL_S_DMAG(t);
+            AGPL_S_DMA(t, 0);
+            AGPL_S_DMA(t, 1);
+            AGPL_S_DMA(t, 2);
+            AGPL_S_DMA(t, 3);
+        }
+    if (!DIAG) AGPL_S_LOADB(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (DIAG) {
+        __builtin_amdgcn_s_barrier(); // every wave's pieces of step 0 are in LDS
+        AGPL_S_LDSB(0);
+    }
+    AGPL_S_CVTQ(0, 0, true);
+    AGPL_S_CVTQ(1, 0, true);
+    AGPL_S_TAKEB();
+    if (!DIAG) AGPL_S_LOADB(nstep > 1 ? 1 : 0);
+
+    [[maybe_unused]] unsigned long long q0 = 0, q1 = 0, qw = 0, qa = 0, qb = 0, qr0 = 0;
+    if (kTrace) {
+        q0 = __builtin_amdgcn_s_memtime();
+        qr0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int t = 0; t < nstep; ++t) {
+        if (kTrace) qa = __builtin_amdgcn_s_memtime();
+        if (!DIAG) __builtin_amdgcn_s_barrier(); // every wave's pieces of step t have landed: each waited for them a step ago
+        if (kTrace && !DIAG) qw += __builtin_amdgcn_s_memtime() - qa;
+        const bool more = t + 1 < nstep; // (else the conversion below works on a duplicate: its beta reads as zero)
+        const int tl = t + 2 < nstep ? t + 2 : nstep - 1;
+        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & (kRing - 1)) * kStepBytes);
+        // hook h sits behind the MFMAs of row block h: the step's staging work in pieces
+        //   0..3  one DMA piece of step t + 3 each (hook 0: its record as well)
+        //   5     wait for everything but those five pieces: the raw granules of step t + 1 (off the diagonal), the A pieces
+        //         of step t + 2
+        //   6, 8  half of the conversion of step t + 1's granules each (a diagonal tile reads them from its A slot at 6)
+        //   10    they are set aside as the next fragments; off the diagonal the loads of step t + 2 go out
+#define AGPL_S_HOOK(h_)                                                                                         \
+    do {                                                                                                        \
+        if (!DIAG) {                                                                                            \
+            if ((h_) < 4 && t + 3 < nstep) {                                                                    \
+                if ((h_) == 0) AGPL_S_DMAG(t + 3);                                                              \
+                AGPL_S_DMA(t + 3, h_);                                                                          \
+            }                                                                                                   \
+            if ((h_) == 5) { /* (the last three steps issue no DMA pieces: everything outstanding is older) */ \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                if (t + 3 < nstep) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                             \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+            }                                                                                                   \
+            if ((h_) == 6) AGPL_S_CVTQ(0, t + 1, more);                                                         \
+            if ((h_) == 8) AGPL_S_CVTQ(1, t + 1, more);                                                         \
+        } else {                                                                                                \
+            /* a diagonal tile: ONE barrier per step, in its middle.  Before it a wave waits for its own pieces of */ \
+            /* step t + 1 (everything but the five of step t + 2); behind it A(t + 1) is in LDS for every wave -- for the */ \
+            /* next step's fragment reads and for this wave's raw B granules -- and every wave is through with step */ \
+            /* t - 1, whose slot takes the pieces of step t + 3: two full steps of flight for every piece */     \
+            if ((h_) == 7) {                                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                if (kTrace) qb = __builtin_amdgcn_s_memtime();                                                  \
+                if (t + 2 < nstep) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                             \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+                if (kTrace) q1 += __builtin_amdgcn_s_memtime() - qb;                                            \
+                if (kTrace) qb = __builtin_amdgcn_s_memtime();                                                  \
+                __builtin_amdgcn_s_barrier();                                                                   \
+                if (kTrace) qw += __builtin_amdgcn_s_memtime() - qb;                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                AGPL_S_LDSB(more ? t + 1 : t); /* (behind the last step: a duplicate, finite) */                \
+            }                                                                                                   \
+            if ((h_) >= 8 && (h_) < 12 && t + 3 < nstep) {                                                      \
+                if ((h_) == 8) AGPL_S_DMAG(t + 3);                                                              \
+                AGPL_S_DMA(t + 3, (h_) - 8);                                                                    \
+            }                                                                                                   \
+            if ((h_) == 9) AGPL_S_CVTQ(0, t + 1, more);                                                         \
+            if ((h_) == 11) AGPL_S_CVTQ(1, t + 1, more);                                                        \
         }                                                                                                       \
+    } while (0)
+        h8 nbh0, nbl0, nbh1, nbl1;
+        // A fragments kPre row blocks ahead of the six MFMAs that use them (a wave alone must cover the LDS latency: with
+        // one block of lead a wave ran at ~46 cycles per MFMA -- in-kernel stamps); the reads are unconditional, only the
+        // MFMAs of a diagonal tile's unneeded blocks (i < i0) are skipped
+        constexpr int kPre = AGPL_S_PRE;
+        h8 af[kPre + 1][2];
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            af[j][0] = st[AGPL_S_AOFF(j)];
+            af[j][1] = st[256 + AGPL_S_AOFF(j)];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i + kPre < 16) {
+                af[(i + kPre) % (kPre + 1)][0] = st[AGPL_S_AOFF(i + kPre)];
+                af[(i + kPre) % (kPre + 1)][1] = st[256 + AGPL_S_AOFF(i + kPre)];
+            }
+            if (!DIAG || i >= i0) {
+                const h8 ahc = af[i % (kPre + 1)][0], alc = af[i % (kPre + 1)][1];
+                acc[i][0] = mfma32(ahc, bh0, acc[i][0]);
+                acc[i][1] = mfma32(ahc, bh1, acc[i][1]);
+                acc[i][0] = mfma32(ahc, bl0, acc[i][0]);
+                acc[i][1] = mfma32(ahc, bl1, acc[i][1]);
+                acc[i][0] = mfma32(alc, bh0, acc[i][0]);
+                acc[i][1] = mfma32(alc, bh1, acc[i][1]);
+            }
+            AGPL_S_HOOK(i);
+            if (i == (DIAG ? 12 : 10)) { // the converted granules are kept aside until this step's MFMAs are through with the old ones
+                nbh0 = __builtin_bit_cast(h8, rh0);
+                nbl0 = __builtin_bit_cast(h8, rl0);
+                nbh1 = __builtin_bit_cast(h8, rh1);
+                nbl1 = __builtin_bit_cast(h8, rl1);
+                if (!DIAG) AGPL_S_LOADB(tl); // unconditional (clamped: the last steps re-load the last one)
+            }
+        }
+#undef AGPL_S_HOOK
+        bh0 = nbh0;
+        bl0 = nbl0;
+        bh1 = nbh1;
+        bl1 = nbl1;
     }
-    if (!DIAG || (active && jbase >= 4)) {
-        AGPL_E_LOOP(4)
-    } else if (!active) {
-        AGPL_E_LOOP(100)
-    } else if (jbase == 1) {
-        AGPL_E_LOOP(1)
-    } else {
-        AGPL_E_LOOP(-3)
-    }
-#undef AGPL_E_LOOP
-#undef AGPL_E_BLOCK
-#undef AGPL_E_HOOK
 #ifdef AGPL_QTRACE
     if (blockIdx.x < 64 && lane == 0) {
-        const unsigned long long te = __builtin_amdgcn_s_memtime(), rte = __builtin_amdgcn_s_memrealtime();
         unsigned long long *o = g_qtrace + ((size_t)blockIdx.x * 16 + wave) * 8;
-        o[0] = tr_h[0] | (tr_h[1] << 32); // (sums over <= 128 stages of < 2^24 cycles each: 32 bits are enough)
-        o[1] = te - tr_loop;
-        o[2] = tr_wait;
-        o[3] = tr_h[2] | (tr_h[3] << 32);
-        o[4] = tr_body;
-        o[5] = rte - rt0;
-        o[6] = (unsigned long long)nstage | ((unsigned long long)(DIAG ? 1 : 0) << 32) | ((unsigned long long)(active ? 1 : 0) << 33);
-        o[7] = te - tr0;
+        o[0] = q1;                                   // waiting for the memory queue
+        o[1] = __builtin_amdgcn_s_memtime() - q0;    // loop cycles
+        o[2] = qw;                                   // waiting at the barrier
+        o[5] = __builtin_amdgcn_s_memrealtime() - qr0;
+        o[6] = (unsigned long long)nstep | ((unsigned long long)(DIAG ? 1 : 0) << 32) | ((unsigned long long)c << 40);
+        o[7] = o[1];
     }
 #endif
-#undef AGPL_E_DMA
-#undef AGPL_E_LOADB
-#undef AGPL_E_DMAG
-#undef AGPL_E_DMA1
-#undef AGPL_E_CVT
-#undef AGPL_E_CVT_HALF
-#undef AGPL_E_STOREB
+    // the clamped loads of the last steps land in registers that must not look dead (and be reused) while they are in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(rh0), "v"(rl0), "v"(rh1), "v"(rl1));
+#undef AGPL_S_DMA
+#undef AGPL_S_DMAG
+#undef AGPL_S_LOADB
+#undef AGPL_S_CVT
+#undef AGPL_S_CVTQ
+#undef AGPL_S_TAKEB
+#undef AGPL_S_LDSB
+#undef AGPL_S_AOFF
 
     // ---- slabs: [l][128-pair][slice][128 x 128] float32; the accumulators carry (s_A phi)(s_B gamma s_A phi)'
     const float unscale = __uint_as_float((unsigned)(127 - (2 * eA + eB)) << 23);
-    if (active) {
-        const int bi = 2 * I + wr, bj = 2 * J + (wc >> 1);
-        const int npairs = nb * (nb + 1) / 2;
+    const int npairs = nb * (nb + 1) / 2;
+    const int bj = 2 * J + (c >> 2);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) { // the two 128-row blocks of the tile
+        const int bi = 2 * I + hb;
+        if (DIAG && bi < bj) continue; // the 128 x 128 block above the diagonal is never read back
         const int p128 = bi * (bi + 1) / 2 + bj;
         float *slab = slabG + (((int64_t)l * npairs + p128) * nsplit + s) * (int64_t)(BS * BS);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * kg + r;
-                    const int col = (wc & 1) * 64 + 16 * j + (ln & 15);
-                    slab[row * BS + col] = acc[i][j][r] * unscale;
+                    const int row = 16 * ii + 4 * kg + r;
+                    const int col = (c & 3) * 32 + 16 * cb + lr;
+                    slab[row * BS + col] = acc[8 * hb + ii][cb][r] * unscale;
                 }
     }
     if (DIAG) {
-        // the two plane waves of a (128-row block, half) hold partial sums of the same rows
-        float *gw = reinterpret_cast<float *>(smem_raw); // [2][256]; the stage slots are dead behind this barrier
-        __syncthreads();
-        gw[(qd >> 1) * 256 + rbS * 128 + (qd & 1) * 64 + lane] = gacc;
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            const int r = threadIdx.x;
-            slabg[(((int64_t)l * nb + 2 * I + (r >> 7)) * nsplit + s) * BS + (r & 127)] =
-                (gw[r] + gw[256 + r]) * __uint_as_float((unsigned)(127 - eA) << 23);
+        // g of the strip's 32 rows: the four k-groups of a row sit in lanes lr, lr + 16, lr + 32, lr + 48
+        gacc0 += __shfl_xor(gacc0, 16);
+        gacc0 += __shfl_xor(gacc0, 32);
+        gacc1 += __shfl_xor(gacc1, 16);
+        gacc1 += __shfl_xor(gacc1, 32);
+        const float g1s = __shfl(gacc1, (lane - 16) & 63); // (outside the branch: a shuffle reads live lanes only)
+        if (lane < 32) {
+            const int rr = 32 * c + lane; // row of the panel: column block lane >> 4, feature lane & 15
+            slabg[(((int64_t)l * nb + 2 * I + (rr >> 7)) * nsplit + s) * BS + (rr & 127)] =
+                (lane < 16 ? gacc0 : g1s) * __uint_as_float((unsigned)(127 - eA) << 23);
         }
     }
 }
 
-__global__ __launch_bounds__(512, 2) void syrk_image8_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit,
-                                                             const unsigned char *__restrict__ image,
-                                                             const float *__restrict__ gb_all,
-                                                             const unsigned *__restrict__ scal,
-                                                             float *__restrict__ slabG, float *__restrict__ slabg) {
+__global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit,
+                                                            const unsigned char *__restrict__ image,
+                                                            const float *__restrict__ gb_all,
+                                                            const unsigned *__restrict__ scal,
+                                                            float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // item decode: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch; speed only) walk whole slices
     const int nsplit8 = (nsplit + 7) / 8;
     const int per_l = npairs2 * nsplit8 * 8;
     const int l = blockIdx.x / per_l;
@@ -516,15 +536,15 @@ __global__ __launch_bounds__(512, 2) void syrk_image8_kernel(int64_t N, int64_t 
     const int nb2 = M / kPanel;
     const int noff = nb2 * (nb2 - 1) / 2;
     int I, J;
-    if (p2 < noff) { // off-diagonal tiles first (the long items of a slice)
+    if (p2 < noff) {
         I = 1;
         while ((I + 1) * I / 2 <= p2) ++I;
         J = p2 - I * (I - 1) / 2;
     } else {
         I = J = p2 - noff;
     }
-    if (I == J) syrk_image8_body<true>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
-    else syrk_image8_body<false>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    if (I == J) syrk_strip_body<true>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    else syrk_strip_body<false>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
 }
 
 } // namespace
@@ -535,7 +555,6 @@ extern "C" __attribute__((visibility("default"))) int agpl_debug_qtrace(unsigned
 }
 #endif
 
-size_t agpl_syrk_image_lds_bytes() { return 2 * (size_t)kSlot + 512; } // two stage slots + two gamma | beta records
 
 extern "C" int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M) {
     if (N <= 0 || M <= 0 || M % BS) return 0;
@@ -595,14 +614,13 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
     const int64_t nwg = (int64_t)L * npairs2 * ((ns + 7) / 8) * 8;
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     AGPL_HIP(ctx, hipMemsetAsync(scal, 0, 2 * sizeof(unsigned), ctx->stream));
-    acc_prep8_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, gb, scal);
+    acc_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, gb, scal);
     acc_scale_kernel<<<1024, 256, 0, ctx->stream>>>((int64_t)L * (Npad / 32), gb, scal);
     AGPL_LAUNCH_CHECK(ctx);
-    const size_t lds = agpl_syrk_image_lds_bytes();
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_image8_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    syrk_image8_kernel<<<(unsigned)nwg, 512, lds, ctx->stream>>>(N, Npad, M, npairs2, ns, (const unsigned char *)image, gb,
-                                                                 scal, slabG, slabg);
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
+    syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, (const unsigned char *)image, gb,
+                                                                     scal, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

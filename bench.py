@@ -124,15 +124,15 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     # half of its last stage -> (1 + 32 / M) M^2 per point; accumulation -- lower tile pairs only, on a diagonal tile the
     # sub-tile above the diagonal idles and (split tile kernel) the two diagonal sub-tiles skip their upper 32 x 32 block
     ex_m = (1.0 + 32.0 / Mp) if (marginal == "f16x2-factor" and Mp % 256 == 0) else (1.0 + 1.0 / nbk)
-    image_acc = accumulate == "f16x2" and Mp % 256 == 0  # syrk_image8_kernel (agpl_syrk.hip): 16 x 16 blocks on or below the diagonal
+    image_acc = accumulate == "f16x2" and Mp % 256 == 0  # syrk_strip_kernel (agpl_syrk.hip): 16 x 16 blocks on or below the diagonal
     ex_s = (1.0 + 16.0 / Mp) if image_acc else (nbk + (0.25 if accumulate == "f16x2" else 0.5)) / nbk
     executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
     # kernel names as the library picks them (agpl_split.hip / agpl_mfma.hip defaults): the factor form runs resident
     # workgroups on 16x16x32 MFMA serving per-XCD item queues; the split accumulation reads the point-major image
-    # (syrk_image8_kernel) when the padded M is a multiple of 256, else stages the float32 features (syrk_split_kernel)
+    # (syrk_strip_kernel) when the padded M is a multiple of 256, else stages the float32 features (syrk_split_kernel)
     names = (("marginal_factor_queue_kernel" if marginal == "f16x2-factor" else
               "marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
-             ("syrk_image8_kernel" if image_acc else "syrk_split_kernel")
+             ("syrk_strip_kernel" if image_acc else "syrk_split_kernel")
              if accumulate == "f16x2" else "syrk_kernel")
     mult = (3.0 if msplit else 1.0, 3.0 if accumulate == "f16x2" else 1.0)
     peaks = (PEAK_F16_MFMA_TFLOPS if msplit else PEAK_F32_MFMA_TFLOPS,

@@ -33,6 +33,8 @@ if args.envs and not args.child:
 import torch
 import agpl_amd as A
 from agpl_amd import _ffi
+if os.environ.get("AGPL_LIB_AB"):
+    _ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), os.environ["AGPL_LIB_AB"])
 
 N, M, L = args.n, args.m, args.l
 ctx = A.Context(0, seed=1)
@@ -79,5 +81,10 @@ if args.ref:
             Gr[l] += (P * gam[l, i0:i0 + step].double()[:, None]).t() @ P
             gr[l] += P.t() @ bet[l, i0:i0 + step].double()
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    if os.environ.get("AGPL_DUMP"):
+        E = (Gi[0] - Gr[0]).abs() / Gr[0].abs().max()
+        blk = E.reshape(M // 64, 64, M // 64, 64).amax(dim=(1, 3))
+        torch.set_printoptions(precision=1, linewidth=220, sci_mode=True)
+        print(blk.cpu(), file=sys.stderr)
     out.update(image_relG=rel(Gi, Gr), image_relg=rel(gi, gr), f32staged_relG=rel(Go, Gr), f32staged_relg=rel(go, gr))
 print(json.dumps(out), flush=True)
