@@ -155,19 +155,23 @@ int main(int argc, char **argv) {
     HIP(hipMalloc(&Phi_hi, (size_t)img));
     HIP(hipMalloc(&Phi_lo, (size_t)img));
     AGPL(agpl_split_features(ctx, N, M, Phi, Phi_hi, Phi_lo));
+    // the accumulation's own operand: the point-major split-float16 image (agpl_accumulate_image); the float32 features are
+    // not read by the sweep after this
+    void *Phi_acc = nullptr;
+    HIP(hipMalloc(&Phi_acc, (size_t)agpl_accumulate_image_bytes(N, M)));
+    AGPL(agpl_accumulate_image(ctx, N, M, Phi, Phi_acc));
     HIP(hipMalloc(&U_hi, sizeof(uint16_t) * (size_t)M * M));
     HIP(hipMalloc(&U_lo, sizeof(uint16_t) * (size_t)M * M));
     double *Gg = dalloc<double>((size_t)M * M + M, true); // one flat buffer: the exchange step is one collective
     double *G = Gg, *g = Gg + (size_t)M * M;
     double *A_work = dalloc<double>((size_t)M * M), *v = dalloc<double>((size_t)M, true);
     float *v32 = dalloc<float>((size_t)M, true);
-    AGPL(agpl_set_accumulate_precision(ctx, 1));
     // q(v) = N(0, I) (script.jl:41-42) carried as (U, v): the update of G = g = 0
     AGPL(agpl_gaussian_factor_async(ctx, M, 1, G, g, nullptr, A_work, v, v32, U_hi, U_lo, nullptr));
 
     auto sweep = [&]() {
         // marginals -> aux_posterior! -> expected potential / precision -> (G, g)   script.jl:32-34
-        AGPL(agpl_cavi_pass_factor_split(ctx, &lik, N, M, Phi, Phi_hi, Phi_lo, resid, nullptr, y, U_hi, U_lo, v32, G, g,
+        AGPL(agpl_cavi_pass_factor_image(ctx, &lik, N, M, Phi_hi, Phi_lo, Phi_acc, resid, nullptr, y, U_hi, U_lo, v32, G, g,
                                          nullptr, nullptr, nullptr));
         // S = (I + G)^-1, m = S g   script.jl:35-36
         AGPL(agpl_gaussian_factor_async(ctx, M, 1, G, g, nullptr, A_work, v, v32, U_hi, U_lo, nullptr));

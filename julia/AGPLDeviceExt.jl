@@ -268,6 +268,7 @@ mutable struct SparseSweep{Tlik}
     Φ::ROCMatrix{Float32}
     Φhi::ROCVector{Float16}
     Φlo::ROCVector{Float16}
+    Φacc::ROCVector{UInt8}      # point-major split-float16 image: the accumulation's operand (agpl_accumulate_image)
     d::ROCVector{Float32}
     y::ROCArray
     Gg::ROCVector{Float64}      # [G (L M M) | g (L M)]: ONE buffer, one all-reduce per sweep
@@ -288,8 +289,10 @@ function SparseSweep(lik, Φ::ROCMatrix{Float32}, d::ROCVector{Float32}, y::ROCA
     Φhi, Φlo = ROCVector{Float16}(undef, nh), ROCVector{Float16}(undef, nh)
     check(c.h, ccall((:agpl_split_features, libagpl), Int32,
         (Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), c.h, N, M, dptr(Φ), dptr(Φhi), dptr(Φlo)))
-    check(c.h, ccall((:agpl_set_accumulate_precision, libagpl), Int32, (Ptr{Cvoid}, Int32), c.h, 1))
-    s = SparseSweep(lik, Φ, Φhi, Φlo, d, y, AMDGPU.zeros(Float64, L * M * M + L * M),
+    Φacc = ROCVector{UInt8}(undef, ccall((:agpl_accumulate_image_bytes, libagpl), Int64, (Int64, Int32), N, M))
+    check(c.h, ccall((:agpl_accumulate_image, libagpl), Int32,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}), c.h, N, M, dptr(Φ), dptr(Φacc)))   # DomainError: a feature is not finite
+    s = SparseSweep(lik, Φ, Φhi, Φlo, Φacc, d, y, AMDGPU.zeros(Float64, L * M * M + L * M),
                     ROCArray{Float64}(undef, M, M, L), AMDGPU.zeros(Float64, M, L), AMDGPU.zeros(Float32, M, L),
                     ROCVector{Float16}(undef, L * M * M), ROCVector{Float16}(undef, L * M * M), comm)
     update!(s)                                    # G = 0, g = 0: S = I, m = 0 (script.jl:41-42)
@@ -317,10 +320,10 @@ function sweep!(s::SparseSweep)
     L = nlatent(s.lik)
     dsc, keep = desc(s.lik)
     G, g = Ptr{Cvoid}(UInt(pointer(s.Gg))), Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * L * M * M)
-    GC.@preserve keep check(c.h, ccall((:agpl_cavi_pass_factor_split, libagpl), Int32,
+    GC.@preserve keep check(c.h, ccall((:agpl_cavi_pass_factor_image, libagpl), Int32,
         (Ptr{Cvoid}, Ref{LikDesc}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
          Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-        c.h, dsc, N, M, dptr(s.Φ), dptr(s.Φhi), dptr(s.Φlo), dptr(s.d), C_NULL, dptr(s.y), dptr(s.Uhi), dptr(s.Ulo),
+        c.h, dsc, N, M, dptr(s.Φhi), dptr(s.Φlo), dptr(s.Φacc), dptr(s.d), C_NULL, dptr(s.y), dptr(s.Uhi), dptr(s.Ulo),
         dptr(s.v32), G, g, C_NULL, C_NULL, C_NULL))
     if s.comm != C_NULL                           # the one exchange step of the N-sharded sweep (SURVEY.md 8e)
         check(c.h, ccall((:agpl_allreduce_nat, libagpl), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),

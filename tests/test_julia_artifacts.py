@@ -84,7 +84,7 @@ def test_every_julia_ccall_matches_the_header():
     # the operator surface and the sweep must all be routed
     for need in ("agpl_aux_sample", "agpl_aux_posterior", "agpl_potential_precision",
                  "agpl_expected_potential_precision", "agpl_logtilt", "agpl_aug_loglik", "agpl_expected_logtilt",
-                 "agpl_aux_kldivergence", "agpl_cavi_pass_factor_split", "agpl_gaussian_factor_async",
+                 "agpl_aux_kldivergence", "agpl_cavi_pass_factor_image", "agpl_accumulate_image", "agpl_gaussian_factor_async",
                  "agpl_allreduce_nat", "agpl_gaussian_kl", "agpl_marginals_factor_split", "agpl_ctx_set_point_offset"):
         assert need in used, need
 
@@ -123,9 +123,9 @@ int main(void) {
     d.kind = AGPL_LIK_BERNOULLI_LOGISTIC; d.nlatent = 1; d.p[0] = d.p[1] = d.p[2] = d.p[3] = 0.0; d.logtheta = 0;
     int32_t (*sample)(agpl_ctx *, const agpl_lik_desc *, int64_t, const void *, const double *, double *, int64_t *,
                       uint32_t, uint32_t *, uint32_t *) = agpl_aux_sample;
-    int32_t (*pass)(agpl_ctx *, const agpl_lik_desc *, int64_t, int32_t, const float *, const void *, const void *,
+    int32_t (*pass)(agpl_ctx *, const agpl_lik_desc *, int64_t, int32_t, const void *, const void *, const void *,
                     const float *, const float *, const void *, const void *, const void *, const float *, double *,
-                    double *, float *, float *, float *) = agpl_cavi_pass_factor_split;
+                    double *, float *, float *, float *) = agpl_cavi_pass_factor_image;
     int32_t rc = agpl_aux_sample((agpl_ctx *)0, &d, 0, 0, 0, 0, 0, 0u, 0, 0); /* null context: argument error */
     printf("%d %d %d %d\n", (int)agpl_version(), (int)rc, sample != 0, pass != 0);
     return (agpl_version() == AGPL_VERSION && rc == AGPL_ERR_INVALID_ARGUMENT && (int)AGPL_F64 == 1) ? 0 : 1;
