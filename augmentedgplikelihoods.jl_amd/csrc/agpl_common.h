@@ -32,6 +32,7 @@ struct agpl_ctx {
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
     int accumulate_split = 0; // 0: f32-input MFMA accumulation, 1: split-float16 (agpl_set_accumulate_precision)
     int ncu = 0;              // compute units of `device` (queried once, by the first queue-served launch)
+    int strip_attr = 0;       // syrk_strip_kernel's dynamic-LDS attribute is set (once)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -40,7 +41,8 @@ struct agpl_ctx {
     bool pend = false;
     int pend_n = 0;          // info words (L, or 2 L for the two-block form)
     int pend_latents = 0;
-    int *pend_host = nullptr; // hipHostMalloc, 128 ints
+    int *pend_host = nullptr; // hipHostMalloc (mapped), 128 ints
+    int *pend_host_dev = nullptr; // the same memory as the device addresses it
     hipEvent_t pend_ev = nullptr;
     char err[512] = {0};
 };

@@ -91,7 +91,11 @@ int32_t agpl_ws_reserve(agpl_ctx *ctx, size_t bytes) {
     return AGPL_OK;
 }
 
+// Bytes 8192..16383 hold words that are ZERO between launches: the marginal kernel's item queues (8192, eight words) and the
+// factor kernel's hand-off flags (8448, 4 words per latent).  The kernels that use them leave them zero again (no memset per
+// sweep); a fresh allocation starts zeroed.
 int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes) {
+    if (bytes < 16384) bytes = 16384;
     if (bytes <= ctx->ws2_bytes) return AGPL_OK;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws2) AGPL_HIP(ctx, hipFree(ctx->ws2));
@@ -100,6 +104,7 @@ int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes) {
     if (hipMalloc(&ctx->ws2, bytes) != hipSuccess)
         AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the small workspace failed", bytes);
     ctx->ws2_bytes = bytes;
+    AGPL_HIP(ctx, hipMemsetAsync(ctx->ws2, 0, 16384, ctx->stream));
     return AGPL_OK;
 }
 

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     // rescue launch (NW = 1, queued behind every multi-workgroup launch): redo latent l alone iff the cooperative
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
-    if (NW == 1 && rescue && info[blockIdx.x] != -1) return;
+    if (NW == 1 && rescue) { // ... and leaves the hand-off flags of its latent zero for the next factorisation (no memset)
+        if (threadIdx.x < 4) sync_all[4 * blockIdx.x + threadIdx.x] = 0u;
+        if (info[blockIdx.x] != -1) return;
+    }
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *PX = sm;                 // [M][FP]: row c < ncx = X_k'[c] (column c of U), row g >= ncx = P of global row g
@@ -552,10 +555,10 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work) {
     const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
-    // AGPL_FACTOR_WGS = 1 | 2 | 3 | 5 | 4 | 8 workgroups per latent.  2, 3, 5 (default) = look-ahead (one spine workgroup
-    // + 1, 2, 4 tile workgroups); 4, 8 = the tiles of every step shared, hand-offs at step boundaries.  Measured at
-    // M = 512: see DESIGN.md 4.5.
-    static const int nw_env = getenv("AGPL_FACTOR_WGS") ? atoi(getenv("AGPL_FACTOR_WGS")) : 5;
+    // workgroups per latent: 5 = look-ahead, one spine workgroup + 4 tile workgroups (2, 3 = narrower look-ahead forms used when
+    // several latents share an XCD; the forms that shared the tiles of every step without look-ahead, 4 and 8, measured slower
+    // at M = 512 -- DESIGN.md 4.5 -- and are no longer instantiated)
+    constexpr int nw_env = 5;
     // the multi-workgroup forms spin on their partners: every working workgroup must be resident at once (one per CU,
     // the 150 KB of LDS see to that).  Latent l runs on XCD l % 8 (32 CUs each), so ceil(L / 8) latents share an XCD:
     // the widest look-ahead form that keeps their workgroups within 24 CUs is used, else one workgroup per latent
@@ -567,8 +570,9 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
         else if ((nw_env == 5 || nw_env == 3) && per_xcd * 2 <= 24) nw = 2;
     }
     double *PXg = (double *)coop_work;
-    unsigned *sync = coop_work ? (unsigned *)((char *)coop_work + sizeof(double) * (size_t)L * 2 * M * FB) : nullptr;
-    if (nw > 1) AGPL_HIP(ctx, hipMemsetAsync(sync, 0, sizeof(unsigned) * 4 * (size_t)L, ctx->stream));
+    // hand-off flags: fixed words of the small workspace that are zero between launches (agpl_ws2_reserve; the rescue launch
+    // behind every cooperative launch zeroes them again)
+    unsigned *sync = coop_work ? (unsigned *)((char *)ctx->ws2 + 8448) : nullptr;
 #define AGPL_LAUNCH_FACTOR(NW_, LA_, GRID_, RESCUE_)                                                                         \
     do {                                                                                                             \
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<NW_, LA_>),                 \
@@ -579,8 +583,6 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L), 0);
     else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L), 0);
     else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L), 0);
-    else if (nw == 4) AGPL_LAUNCH_FACTOR(4, false, dim3(32, (unsigned)L), 0);
-    else if (nw == 8) AGPL_LAUNCH_FACTOR(8, false, dim3(64, (unsigned)L), 0);
     else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 0);
     AGPL_LAUNCH_CHECK(ctx);
     // The multi-workgroup forms are plain launches that assume their partners co-resident (true when this process has

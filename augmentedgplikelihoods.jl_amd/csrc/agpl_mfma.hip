@@ -688,12 +688,33 @@ size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT +
 //   level 2: G[row][col] = sum over groups (in order) of the lower-triangle partial, mirrored.
 constexpr int kRedGroup = 64;
 
-__global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup, const float *__restrict__ slab,
-                                                          double *__restrict__ partial) {
+// blockIdx.z < npl: tile pl = l * npairs + p of G; beyond: 128-row block bl = l * nb + bi of g (one launch for both)
+__global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup, int npl, const float *__restrict__ slab,
+                                                          double *__restrict__ partial, const float *__restrict__ slabg,
+                                                          double *__restrict__ partialg) {
     __shared__ double sm[3][64][4];
     const int seg = blockIdx.x;  // 1 KB segment of the 128 x 128 tile (64 of them)
     const int grp = blockIdx.y;
     const int pl = blockIdx.z;   // l * npairs + p
+    if (pl >= npl) { // the g slabs: 128 floats per (row block, slice)
+        if (seg != 0 || threadIdx.x >= BS) return;
+        const int bl = pl - npl;
+        const float *base = slabg + ((int64_t)bl * nsplit) * BS + threadIdx.x;
+        const int s0 = grp * kRedGroup;
+        int s1 = s0 + kRedGroup;
+        if (s1 > nsplit) s1 = nsplit;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int s = s0;
+        for (; s + 4 <= s1; s += 4) {
+            a0 += (double)base[(int64_t)(s + 0) * BS];
+            a1 += (double)base[(int64_t)(s + 1) * BS];
+            a2 += (double)base[(int64_t)(s + 2) * BS];
+            a3 += (double)base[(int64_t)(s + 3) * BS];
+        }
+        for (; s < s1; ++s) a0 += (double)base[(int64_t)s * BS];
+        partialg[((int64_t)bl * ngroup + grp) * BS + threadIdx.x] = (a0 + a1) + (a2 + a3);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *base = slab + ((int64_t)pl * nsplit) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
     const int s0 = grp * kRedGroup;
@@ -743,14 +764,23 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup
     }
 }
 
+// blockIdx.y < M: row of G; == M: g (its group partials), so that the pair is one launch
 __global__ __launch_bounds__(128) void reduce_G_kernel(int M, int ngroup, const double *__restrict__ partial,
-                                                       double *__restrict__ G) {
+                                                       double *__restrict__ G, const double *__restrict__ partialg,
+                                                       double *__restrict__ g) {
     const int nb = M / BS;
     const int npairs = nb * (nb + 1) / 2;
     const int l = blockIdx.z;
     const int row = blockIdx.y;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= M) return;
+    if (row == M) {
+        const double *src = partialg + (((int64_t)l * nb + col / BS) * ngroup) * BS + (col % BS);
+        double acc = 0.0;
+        for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS];
+        g[(int64_t)l * M + col] = acc;
+        return;
+    }
     int r = row, c = col;
     if (r < c) { // mirror: always read the lower-triangle element (exact symmetry)
         int t = r;
@@ -766,35 +796,6 @@ __global__ __launch_bounds__(128) void reduce_G_kernel(int M, int ngroup, const 
 }
 
 // g: level 1 = one workgroup of 128 threads per (row block, group of slices); level 2 sums the groups
-__global__ __launch_bounds__(128) void reduce_gslab_kernel(int nsplit, int ngroup, const float *__restrict__ slabg,
-                                                           double *__restrict__ partial) {
-    const int grp = blockIdx.x, bl = blockIdx.y; // bl = l * nb + bi
-    const float *base = slabg + ((int64_t)bl * nsplit) * BS + threadIdx.x;
-    const int s0 = grp * kRedGroup;
-    int s1 = s0 + kRedGroup;
-    if (s1 > nsplit) s1 = nsplit;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int s = s0;
-    for (; s + 4 <= s1; s += 4) {
-        a0 += (double)base[(int64_t)(s + 0) * BS];
-        a1 += (double)base[(int64_t)(s + 1) * BS];
-        a2 += (double)base[(int64_t)(s + 2) * BS];
-        a3 += (double)base[(int64_t)(s + 3) * BS];
-    }
-    for (; s < s1; ++s) a0 += (double)base[(int64_t)s * BS];
-    partial[((int64_t)bl * ngroup + grp) * BS + threadIdx.x] = (a0 + a1) + (a2 + a3);
-}
-
-__global__ void reduce_g_kernel(int M, int ngroup, const double *__restrict__ partial, double *__restrict__ g) {
-    const int l = blockIdx.y;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= M) return;
-    const int nb = M / BS;
-    const double *src = partial + (((int64_t)l * nb + a / BS) * ngroup) * BS + (a % BS);
-    double acc = 0.0;
-    for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS];
-    g[(int64_t)l * M + a] = acc;
-}
 
 inline int syrk_nsplit(int64_t N) { return (int)agpl_cdiv(N, kChunk); }
 
@@ -877,12 +878,21 @@ size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) { return slab_layout(N, 
 // internal: accumulate with caller-provided slab storage (used by agpl_accumulate and agpl_cavi_pass)
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
-                               float *slabg, int ns); // agpl_syrk.hip
+                               float *slabg, int ns, bool records_ready); // agpl_syrk.hip
 
 // acc_image != nullptr (and M % 256 == 0): the point-major split-float16 image of agpl_accumulate_image is the operand
 // (syrk_image_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
+// internal (agpl_update.hip): where the gamma | beta records and the two scale words of the image path live in slab_mem
+void agpl_accumulate_records(int64_t N, int32_t M, int32_t L, void *slab_mem, float **gb, unsigned **scal) {
+    const SlabLayout lo = slab_layout(N, M, L);
+    *gb = (float *)((char *)slab_mem + lo.sgam);
+    *scal = (unsigned *)((char *)slab_mem + lo.ctr);
+}
+
+// records_ready: the caller's per-point kernel has filled agpl_accumulate_records already (image path; beta / gamma unread)
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image,
-                             const float *beta, const float *gamma, double *G_out, double *g_out, void *slab_mem) {
+                             const float *beta, const float *gamma, double *G_out, double *g_out, void *slab_mem,
+                             bool records_ready) {
     const SlabLayout lo = slab_layout(N, M, L);
     const int ns = lo.ns, nb = lo.nb, npairs = (int)lo.npairs, ng = lo.ng;
     float *slabG = (float *)((char *)slab_mem + lo.slabG);
@@ -897,7 +907,7 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     if (acc_image && M % 256 == 0) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
-                                    (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns);
+                                    (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, records_ready);
         if (rc) return rc;
     } else if (!Phi) {
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the accumulation needs the float32 features (no image, or M %% 256 != 0)");
@@ -914,17 +924,12 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 1);
     if (rc) return rc;
-    dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs));
-    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, slabG, partG);
+    // fixed-order float64 reduction of the slabs, G and g together: slices -> groups of kRedGroup, groups -> G, g
+    dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs + L * nb));
+    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, L * npairs, slabG, partG, slabg, partg);
     AGPL_LAUNCH_CHECK(ctx);
-    dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out);
-    AGPL_LAUNCH_CHECK(ctx);
-    dim3 r2((unsigned)ng, (unsigned)(L * nb));
-    reduce_gslab_kernel<<<r2, 128, 0, ctx->stream>>>(ns, ng, slabg, partg);
-    AGPL_LAUNCH_CHECK(ctx);
-    dim3 rg2((unsigned)agpl_cdiv(M, 128), (unsigned)L);
-    reduce_g_kernel<<<rg2, 128, 0, ctx->stream>>>(M, ng, partg, g_out);
+    dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M + 1, (unsigned)L);
+    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out, partg, g_out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }
@@ -937,7 +942,7 @@ extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t 
     if (!Phi || !beta || !gamma || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     int32_t rc = agpl_ws_reserve(ctx, agpl_slab_bytes(N, M, L));
     if (rc) return rc;
-    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, beta, gamma, G_out, g_out, ctx->ws);
+    return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, beta, gamma, G_out, g_out, ctx->ws, false);
 }
 
 extern "C" int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
@@ -951,7 +956,7 @@ extern "C" int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, in
     if (rc) return rc;
     const int keep = ctx->accumulate_split;
     ctx->accumulate_split = 1;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, beta, gamma, G_out, g_out, ctx->ws);
+    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, beta, gamma, G_out, g_out, ctx->ws, false);
     ctx->accumulate_split = keep;
     return rc;
 }

@@ -965,55 +965,57 @@ extern "C" int32_t agpl_aux_kldivergence(agpl_ctx *ctx, const agpl_lik_desc *lik
     return run_reduction(ctx, RED_KL, lik, n, A, out_host);
 }
 
-// fused elementwise step of agpl_cavi_pass (agpl_sweep.hip): aux_posterior! + expected potential/precision
-// from marginals stored latent-major [L][N] float32; writes gamma, beta [L][N] (and optional c [L,N]).
-__global__ __launch_bounds__(kBlock) void agpl_fused_elementwise_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
-                                                                        const float *__restrict__ mu,
-                                                                        const float *__restrict__ var,
-                                                                        float *__restrict__ gamma,
-                                                                        float *__restrict__ beta,
-                                                                        float *__restrict__ c_out) {
+// fused elementwise step of a sweep: aux_posterior! + expected potential / precision of point i from its marginals.
+// MG gives the marginal of latent k (m(k, i), v(k, i)); OUT takes (gamma, beta) of latent k.  One code path for both callers:
+// agpl_fused_elementwise_kernel (marginals in arrays, outputs in arrays) and agpl_fused_point_kernel (marginals summed on
+// the fly from the marginal kernel's row-block partials, outputs as the accumulation's gamma | beta records).
+template <class MG, class OUT>
+__device__ __forceinline__ void fused_point(const agpl_lik_dev &lik, int64_t n, int64_t i, const void *yv, const MG &mg,
+                                            OUT &out, float *__restrict__ c_out) {
     const int L = lik.nlatent;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    float og_[2], ob_[2]; // (single- and two-latent kinds; the categorical kinds put per k)
+#define out_g(k_) og_[k_]
+#define out_b(k_) ob_[k_]
+    {
         switch (lik.kind) {
         case AGPL_LIK_BERNOULLI_LOGISTIC: {
             const uint8_t *y = (const uint8_t *)yv;
-            float c = sqrtf(second_moment(mu[i], var[i]));
-            gamma[i] = pg_mean(1.0f, c);
-            beta[i] = y[i] ? 0.5f : -0.5f;
+            float c = sqrtf(second_moment(mg.m(0, i), mg.v(0, i)));
+            out_g(0) = pg_mean(1.0f, c);
+            out_b(0) = y[i] ? 0.5f : -0.5f;
             if (c_out) c_out[i] = c;
         } break;
         case AGPL_LIK_NEGBINOMIAL: {
             const int32_t *y = (const int32_t *)yv;
-            float c = sqrtf(second_moment(mu[i], var[i]));
+            float c = sqrtf(second_moment(mg.m(0, i), mg.v(0, i)));
             float r = (float)lik.p[0];
-            gamma[i] = pg_mean((float)y[i] + r, c);
-            beta[i] = ((float)y[i] - r) / 2.0f;
+            out_g(0) = pg_mean((float)y[i] + r, c);
+            out_b(0) = ((float)y[i] - r) / 2.0f;
             if (c_out) c_out[i] = c;
         } break;
         case AGPL_LIK_STUDENTT: {
             const float *y = (const float *)yv;
             float nu = (float)lik.p[0], sg = (float)lik.p[1];
-            float bi = (nu / (sg * sg) + second_moment_y(mu[i], var[i], y[i])) / 2.0f;
+            float bi = (nu / (sg * sg) + second_moment_y(mg.m(0, i), mg.v(0, i), y[i])) / 2.0f;
             float w = ((nu + 1.0f) / 2.0f) * (1.0f / bi);
-            gamma[i] = w;
-            beta[i] = w * y[i];
+            out_g(0) = w;
+            out_b(0) = w * y[i];
             if (c_out) c_out[i] = bi;
         } break;
         case AGPL_LIK_POISSON: {
             const int32_t *y = (const int32_t *)yv;
-            float c = sqrtf(second_moment(mu[i], var[i]));
-            float nbar = (float)lik.p[0] * approx_expected_logistic(-mu[i], c);
-            gamma[i] = pg_mean((float)y[i] + nbar, c);
-            beta[i] = ((float)y[i] - nbar) / 2.0f;
+            const float m0 = mg.m(0, i);
+            float c = sqrtf(second_moment(m0, mg.v(0, i)));
+            float nbar = (float)lik.p[0] * approx_expected_logistic(-m0, c);
+            out_g(0) = pg_mean((float)y[i] + nbar, c);
+            out_b(0) = ((float)y[i] - nbar) / 2.0f;
             if (c_out) c_out[i] = c;
         } break;
         case AGPL_LIK_LAPLACE: {
             const float *y = (const float *)yv;
-            float m = 1.0f / (2.0f * (float)lik.p[0] * sqrtf(second_moment_y(mu[i], var[i], y[i])));
-            gamma[i] = 2.0f * m;
-            beta[i] = 2.0f * m * y[i];
+            float m = 1.0f / (2.0f * (float)lik.p[0] * sqrtf(second_moment_y(mg.m(0, i), mg.v(0, i), y[i])));
+            out_g(0) = 2.0f * m;
+            out_b(0) = 2.0f * m * y[i];
             if (c_out) c_out[i] = m;
         } break;
         case AGPL_LIK_CATEGORICAL:
@@ -1022,41 +1024,169 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_elementwise_kernel(agpl_lik
             float den = lik.kind == AGPL_LIK_CATEGORICAL ? (float)L : (float)(lik.cat_const + (double)L);
             float sp = 0.0f;
             for (int k = 0; k < L; ++k) {
-                float m = mu[(int64_t)k * n + i];
-                float c = sqrtf(second_moment(m, var[(int64_t)k * n + i]));
+                float m = mg.m(k, i);
+                float c = sqrtf(second_moment(m, mg.v(k, i)));
                 sp += approx_expected_logistic(-m, c) / den;
             }
             float p0 = 1.0f - sp;
             for (int k = 0; k < L; ++k) {
-                float m = mu[(int64_t)k * n + i];
-                float c = sqrtf(second_moment(m, var[(int64_t)k * n + i]));
+                float m = mg.m(k, i);
+                float c = sqrtf(second_moment(m, mg.v(k, i)));
                 float p = approx_expected_logistic(-m, c) / den;
                 float nbar = 1.0f / p0 * p;
                 float yk = (float)y[i * L + k];
-                beta[(int64_t)k * n + i] = (yk - nbar) / 2.0f;
-                gamma[(int64_t)k * n + i] = pg_mean(yk + nbar, c);
+                const float bk_ = (yk - nbar) / 2.0f;
+                const float gk_ = pg_mean(yk + nbar, c);
+                out.put(k, i, gk_, bk_);
                 if (c_out) c_out[i * L + k] = c;
             }
         } break;
         case AGPL_LIK_HETEROGAUSS: {
             const float *y = (const float *)yv;
-            float psi = second_moment_y(mu[i], var[i], y[i]) / 2.0f;
-            float mg = mu[n + i];
-            float c = sqrtf(second_moment(mg, var[n + i]));
-            float ael = approx_expected_logistic(-mg, c);
+            float psi = second_moment_y(mg.m(0, i), mg.v(0, i), y[i]) / 2.0f;
+            float mgs = mg.m(1, i);
+            float c = sqrtf(second_moment(mgs, mg.v(1, i)));
+            float ael = approx_expected_logistic(-mgs, c);
             float lam = (float)lik.p[0];
             float nbar = lam * ael * psi;
             float lsg = lam * (1.0f - ael);
-            beta[i] = y[i] * lsg / 2.0f;
-            gamma[i] = lsg;
-            beta[n + i] = (0.5f - nbar) / 2.0f;
-            gamma[n + i] = pg_mean(0.5f + nbar, c);
+            out_b(0) = y[i] * lsg / 2.0f;
+            out_g(0) = lsg;
+            out_b(1) = (0.5f - nbar) / 2.0f;
+            out_g(1) = pg_mean(0.5f + nbar, c);
             if (c_out) c_out[i] = c;
         } break;
         default:
             break;
         }
     }
+#undef out_g
+#undef out_b
+    if (lik.kind != AGPL_LIK_CATEGORICAL && lik.kind != AGPL_LIK_CATEGORICAL_BIJ) {
+        out.put(0, i, og_[0], ob_[0]);
+        if (lik.kind == AGPL_LIK_HETEROGAUSS) out.put(1, i, og_[1], ob_[1]);
+    }
+}
+
+struct MargArrays { // marginals latent-major [L][N]
+    const float *mu, *var;
+    int64_t n;
+    __device__ __forceinline__ float m(int k, int64_t i) const { return mu[(int64_t)k * n + i]; }
+    __device__ __forceinline__ float v(int k, int64_t i) const { return var[(int64_t)k * n + i]; }
+};
+struct OutArrays {
+    float *gamma, *beta;
+    int64_t n;
+    __device__ __forceinline__ void put(int k, int64_t i, float g, float b) {
+        gamma[(int64_t)k * n + i] = g;
+        beta[(int64_t)k * n + i] = b;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void agpl_fused_elementwise_kernel(agpl_lik_dev lik, int64_t n, const void *yv,
+                                                                        const float *__restrict__ mu,
+                                                                        const float *__restrict__ var,
+                                                                        float *__restrict__ gamma,
+                                                                        float *__restrict__ beta,
+                                                                        float *__restrict__ c_out) {
+    const MargArrays mg{mu, var, n};
+    OutArrays out{gamma, beta, n};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        fused_point(lik, n, i, yv, mg, out, c_out);
+}
+
+// The sweep's ONE per-point kernel (image path): the marginal kernel's row-block partial sums -> q(f_i) -> aux_posterior! ->
+// expected potential / precision -> the accumulation's gamma | beta records (256 bytes per 32-point step: gamma x 32 |
+// beta x 32, zeros beyond N) and max gamma (one atomic per workgroup) -- what marginal_combine_kernel,
+// agpl_fused_elementwise_kernel and acc_prep_kernel did in three launches and three round trips through HBM.
+struct MargParts {
+    const float *resid, *mu0, *qpart, *mpart;
+    int64_t n;
+    int L, nb2;
+    __device__ __forceinline__ float m(int k, int64_t i) const {
+        float s = 0.f;
+        for (int rb = 0; rb < nb2; ++rb) s += mpart[((int64_t)rb * L + k) * n + i]; // (row blocks in ascending order)
+        return mu0 ? s + mu0[(int64_t)k * n + i] : s;
+    }
+    __device__ __forceinline__ float v(int k, int64_t i) const {
+        float q = 0.f;
+        for (int rb = 0; rb < nb2; ++rb) q += qpart[((int64_t)rb * L + k) * n + i];
+        return resid[i] + q;
+    }
+};
+struct OutRecords {
+    float *gamma, *beta; // optional [L][N] copies
+    float *gb;
+    int64_t n, nrec;     // nrec = records per latent
+    unsigned gmax, bad;
+    __device__ __forceinline__ void put(int k, int64_t i, float g, float b) {
+        if (gamma) gamma[(int64_t)k * n + i] = g;
+        if (beta) beta[(int64_t)k * n + i] = b;
+        float *rec = gb + ((int64_t)k * nrec + (i >> 5)) * 64 + (i & 31);
+        rec[0] = g;
+        rec[32] = b;
+        const unsigned gbits = __float_as_uint(g), ab = gbits & 0x7FFFFFFFu;
+        if (ab >= 0x7F800000u || ((gbits >> 31) && ab != 0u)) bad = max(bad, (unsigned)min((int64_t)0x7FFFFFFE, k * n + i) + 1u);
+        else gmax = max(gmax, ab);
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev lik, int64_t n, int64_t npad, int nb2,
+                                                                  const void *yv, const float *__restrict__ resid,
+                                                                  const float *__restrict__ mu0,
+                                                                  const float *__restrict__ qpart,
+                                                                  const float *__restrict__ mpart,
+                                                                  float *__restrict__ gamma, float *__restrict__ beta,
+                                                                  float *__restrict__ c_out, float *__restrict__ gb,
+                                                                  unsigned *__restrict__ scal,
+                                                                  unsigned *__restrict__ queues) {
+    __shared__ unsigned red[2][kBlock / 64];
+    const int L = lik.nlatent;
+    if (blockIdx.x == 0 && threadIdx.x < 8) queues[threadIdx.x] = 0u; // the marginal kernel's item queues, for its next launch
+    const MargParts mg{resid, mu0, qpart, mpart, n, L, nb2};
+    OutRecords out{gamma, beta, gb, n, npad / 32, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n) {
+            fused_point(lik, n, i, yv, mg, out, c_out);
+        } else { // the zero tail of the records
+            for (int k = 0; k < L; ++k) {
+                float *rec = gb + ((int64_t)k * out.nrec + (i >> 5)) * 64 + (i & 31);
+                rec[0] = 0.f;
+                rec[32] = 0.f;
+            }
+        }
+    }
+    unsigned m = out.gmax, b = out.bad;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m = max(m, (unsigned)__shfl_xor((int)m, o));
+        b = max(b, (unsigned)__shfl_xor((int)b, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = m;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            m = max(m, red[0][w]);
+            b = max(b, red[1][w]);
+        }
+        if (m) atomicMax(scal, m);
+        if (b) atomicMax(scal + 1, b);
+    }
+}
+
+// internal (agpl_update.hip): the per-point kernel of the image sweep; scal must be zero (the marginal kernel zeroes it)
+int32_t agpl_launch_fused_point(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, int64_t npad, int nb2, const void *y,
+                                const float *resid, const float *mu0, const float *qpart, const float *mpart,
+                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues) {
+    int64_t nblk = agpl_cdiv(npad, kBlock);
+    if (nblk > 1024) nblk = 1024; // (one atomic per workgroup on the max-gamma word)
+    agpl_fused_point_kernel<<<(unsigned)nblk, kBlock, 0, ctx->stream>>>(ld, n, npad, nb2, y, resid, mu0, qpart, mpart, gamma,
+                                                                       beta, c_out, gb, scal, queues);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
 }
 
 int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,

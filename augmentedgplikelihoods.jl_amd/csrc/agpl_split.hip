@@ -502,9 +502,10 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
-    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues) {
+    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues, unsigned *__restrict__ zero2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int R = 2, KU = 2;
+    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u; // (the caller's scale words: see the launch)
     constexpr int kSlot = KU * 8 * 4096;
     float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
     float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
@@ -757,7 +758,9 @@ __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L,
                                                                const float *__restrict__ mu0,
                                                                const float *__restrict__ qpart,
                                                                const float *__restrict__ mpart,
-                                                               float *__restrict__ mu_out, float *__restrict__ var_out) {
+                                                               float *__restrict__ mu_out, float *__restrict__ var_out,
+                                                               unsigned *__restrict__ queues) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) queues[threadIdx.x] = 0u; // the item queues, for the next marginal launch
     const int64_t total = (int64_t)L * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i % N;
@@ -774,10 +777,15 @@ __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L,
 
 // U = R^-1 as rocSOLVER leaves it: column-major lower triangle of A, i.e. U[a][b] = A[b * M + a] for b <= a
 // (the other triangle of A still holds I + G and is never read) -> blocked hi / lo images of U
+// info_host (may be null): pinned host memory the factorisation's info words are forwarded to -- the last kernel of an update
+// reports its outcome itself instead of a copy command behind it
 __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
-                                                                h8 *__restrict__ Wh, h8 *__restrict__ Wl) {
+                                                                h8 *__restrict__ Wh, h8 *__restrict__ Wl,
+                                                                const int *__restrict__ info, int *__restrict__ info_host,
+                                                                int ninfo) {
     const int nks = M / KS, nb = M / BS;
     const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
+    if (info_host && l == 0 && rb == 0 && ks == 0 && (int)threadIdx.x < ninfo) info_host[threadIdx.x] = info[threadIdx.x];
     const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
     const int a = rb * BS + row;
     const double *Al = A + (int64_t)l * M * M;
@@ -877,13 +885,19 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
     return agpl_timing_end(ctx, 0);
 }
 
-extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+// internal (agpl_update.hip): the same, forwarding ninfo <= 128 info words of the factorisation to pinned host memory
+int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
+                                    const int *info, int *info_host, int ninfo) {
+    if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo || ninfo > 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
-    pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo);
+    pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo, info, info_host, ninfo);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
+}
+
+extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    return agpl_pack_factor_split_info(ctx, M, L, A, U_hi, U_lo, nullptr, nullptr, 0);
 }
 
 extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
@@ -899,36 +913,30 @@ extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, co
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
-                                               const void *Phi_lo, const float *resid, const float *mu0,
-                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
-                                               float *var_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
-    if (M % NT2)
-        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "the factor form runs on 256-row blocks: M = %d must be a multiple of 256", M);
-    if (N == 0) return AGPL_OK;
-    if (!Phi_hi || !Phi_lo || !resid || !U_hi || !U_lo || !v || !mu_out || !var_out)
-        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+// internal: the MFMA part of the factor-form marginals -- per row block rb of U the partial sums
+// qpart[rb][l][n] = sum_{rows of rb} (U Phi_n)^2 and mpart[rb][l][n] = v . (U Phi_n) over those rows, at the base of the
+// workspace.  The caller's point kernel adds them up in ascending rb (marginal_combine_kernel, or agpl_fused_point_kernel
+// of a sweep) and zeroes the eight queue words again.  zero2 (may be null): two words this kernel zeroes for the caller
+// (the accumulation's scale words, which no kernel between the previous accumulation and this sweep's point kernel reads).
+int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
+                                    const void *U_hi, const void *U_lo, const float *v, unsigned *zero2, float **qpart_out,
+                                    float **mpart_out, unsigned **queues_out) {
     // resident workgroups on 16x16x32 MFMA serving per-XCD queues of (tile, latent, row block) items: the row blocks of a tile
     // share its images through L2 (round 2: 6.31-6.36 against 6.67-6.78 ms for the per-tile kernel at C2 on one box, 1.92
     // against 2.63 ms at C4, 20.6 GB fetched over the fabric instead of 31.9 GB; the other forms measured then -- static
     // persistent runs, 32x32x16, L2 touch prefetch, all 512 rows resident -- are in DESIGN 4.3c and no longer in the tree)
-    int32_t rc = agpl_timing_begin(ctx, 0);
-    if (rc) return rc;
     const int nb2 = M / NT2;
     const int64_t ntiles2 = agpl_cdiv(N, NT2);
     if (ntiles2 * L * nb2 > 0x3fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     const size_t part_bytes = sizeof(float) * (size_t)nb2 * L * N;
     // the partial sums live at the base of the workspace (the slab region of the accumulation that follows them in a
     // sweep; a caller that keeps mu / var in the workspace has reserved more than this already: no reallocation)
-    rc = agpl_ws_reserve(ctx, 2 * part_bytes + 256);
+    int32_t rc = agpl_ws_reserve(ctx, 2 * part_bytes + 256);
     if (rc) return rc;
     rc = agpl_ws2_reserve(ctx, 16384);
     if (rc) return rc;
     float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
-    unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192);
-    AGPL_HIP(ctx, hipMemsetAsync(queues, 0, 8 * sizeof(unsigned), ctx->stream));
+    unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192); // zero between launches (agpl_ws2_reserve)
     const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
     if (ctx->ncu <= 0) { // once per context
         AGPL_HIP(ctx, hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
@@ -940,11 +948,35 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
     const int nwg = ctx->ncu < 8 ? 8 : ctx->ncu;
     marginal_factor_queue_kernel<<<(unsigned)nwg, 1024, ldsq, ctx->stream>>>(
         N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi, (const h8 *)U_lo,
-        v, qpart, mpart, queues);
+        v, qpart, mpart, queues, zero2);
     AGPL_LAUNCH_CHECK(ctx);
+    *qpart_out = qpart;
+    *mpart_out = mpart;
+    *queues_out = queues;
+    return AGPL_OK;
+}
+
+extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
+                                               const void *Phi_lo, const float *resid, const float *mu0,
+                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
+                                               float *var_out) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
+    if (M % NT2)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "the factor form runs on 256-row blocks: M = %d must be a multiple of 256", M);
+    if (N == 0) return AGPL_OK;
+    if (!Phi_hi || !Phi_lo || !resid || !U_hi || !U_lo || !v || !mu_out || !var_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    int32_t rc = agpl_timing_begin(ctx, 0);
+    if (rc) return rc;
+    float *qpart, *mpart;
+    unsigned *queues;
+    rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, nullptr, &qpart, &mpart, &queues);
+    if (rc) return rc;
     int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
     if (nbk > 8192) nbk = 8192;
-    marginal_combine_kernel<<<(unsigned)nbk, 256, 0, ctx->stream>>>(N, L, nb2, resid, mu0, qpart, mpart, mu_out, var_out);
+    marginal_combine_kernel<<<(unsigned)nbk, 256, 0, ctx->stream>>>(N, L, M / NT2, resid, mu0, qpart, mpart, mu_out, var_out,
+                                                                    queues);
     AGPL_LAUNCH_CHECK(ctx);
     return agpl_timing_end(ctx, 0);
 }

@@ -148,44 +148,52 @@ __global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M,
 }
 
 // The accumulation kernel takes gamma and beta of a stage from ONE 256-byte record (gamma x 32 | beta x 32, zeros beyond N), which
-// one wave moves into LDS by DMA a stage ahead -- a scalar or vector load at the point of use would pay the HBM latency of a
-// cold, once-read array in every stage.  acc_prep_kernel writes the records and max gamma, acc_scale_kernel then multiplies
-// gamma by s_B = 2^e_B (exact), so that the accumulation kernel applies no scale of its own.
+// each wave moves into LDS by DMA three steps ahead -- a scalar or vector load at the point of use would pay the HBM latency
+// of a cold, once-read array in every step.  In a sweep the per-point kernel writes the records itself
+// (agpl_fused_point_kernel, agpl_ops.hip); acc_prep_kernel is the stand-alone form (agpl_accumulate_split, the Gibbs pass):
+// records + max gamma, one atomic per workgroup (8192 per-wave atomics on one word cost ~90 us, round 3).  The accumulation
+// kernel multiplies gamma by s_B = 2^e_B (exact) as it converts.
 __global__ __launch_bounds__(256) void acc_prep_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ gb,
                                                         unsigned *__restrict__ scal) {
+    __shared__ unsigned red[2][4];
     const int64_t total = (int64_t)L * Npad;
-    unsigned m = 0u;
+    unsigned m = 0u, bd = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t l = i / Npad, n = i - l * Npad;
         const bool in = n < N;
         const float gv = in ? gamma[l * N + n] : 0.f;
         const unsigned gbits = __float_as_uint(gv), ab = gbits & 0x7FFFFFFFu;
         const bool bad = ab >= 0x7F800000u || ((gbits >> 31) && ab != 0u); // inf, NaN or negative
-        if (bad) atomicMax(scal + 1, (unsigned)min((int64_t)0x7FFFFFFE, l * N + n) + 1u);
+        if (bad) bd = max(bd, (unsigned)min((int64_t)0x7FFFFFFE, l * N + n) + 1u);
         m = max(m, bad ? 0u : ab);
         float *rec = gb + (l * (Npad / 32) + n / 32) * 64 + (n & 31);
         rec[0] = gv;
         rec[32] = in ? beta[l * N + n] : 0.f;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(scal, m);
+    for (int o = 32; o > 0; o >>= 1) {
+        m = max(m, (unsigned)__shfl_xor((int)m, o));
+        bd = max(bd, (unsigned)__shfl_xor((int)bd, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = m;
+        red[1][threadIdx.x >> 6] = bd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            m = max(m, red[0][w]);
+            bd = max(bd, red[1][w]);
+        }
+        if (m) atomicMax(scal, m);
+        if (bd) atomicMax(scal + 1, bd);
+    }
 }
 
 __device__ __forceinline__ int acc_scale_exp(unsigned gmax) { // e_B: 2^e_B max(gamma) in [1/2, 1)
     int eB = gmax ? 126 - (int)(gmax >> 23) : 0;
     return eB < -60 ? -60 : (eB > 60 ? 60 : eB);
-}
-
-__global__ __launch_bounds__(256) void acc_scale_kernel(int64_t nrec, float *__restrict__ gb, const unsigned *__restrict__ scal) {
-    const int eB = acc_scale_exp(scal[0]);
-    const float sB = __uint_as_float((unsigned)(127 + eB) << 23);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec * 32; i += (int64_t)gridDim.x * blockDim.x) {
-        float *p = gb + (i >> 5) * 64 + (i & 31);
-        const float v = *p * sB;
-        *p = v < 1.17549435e-38f ? 0.f : v; // (a product below the smallest normal is dropped)
-    }
 }
 
 #ifdef AGPL_QTRACE // diagnostic build (make QTRACE=1): per-wave cycle sums of the stage loop, tools/qtrace.py
@@ -232,7 +240,8 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
     const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
     const int eA = hdr->scale_exp;
-    const int eB = acc_scale_exp(scal[0]); // (gamma arrives scaled by 2^e_B: acc_scale_kernel)
+    const int eB = acc_scale_exp(scal[0]);
+    const float sB = __uint_as_float((unsigned)(127 + eB) << 23); // gamma is scaled as it is used (exact)
 
     const int64_t nbeg = (int64_t)s * kChunk;
     int64_t nend = nbeg + kChunk;
@@ -298,7 +307,8 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
 #define AGPL_S_CVTQ(q_, tt_, keepf_)                                                                            \
     do {                                                                                                        \
         const float *gq_ = gbuf + ((tt_) & (kRing - 1)) * 64 + 8 * kg + 4 * ((q_) & 1);                         \
-        const float4 g4_ = *reinterpret_cast<const float4 *>(gq_);                                              \
+        float4 g4_ = *reinterpret_cast<const float4 *>(gq_);                                                    \
+        g4_.x *= sB, g4_.y *= sB, g4_.z *= sB, g4_.w *= sB;                                                     \
         float4 b4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
         if (DIAG) {                                                                                             \
             b4_ = *reinterpret_cast<const float4 *>(gq_ + 32);                                                  \
@@ -604,21 +614,28 @@ extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, co
 }
 
 // internal (agpl_accumulate_impl): prep + accumulation kernel; slabs as agpl_mfma.hip lays them out.
-// gb: 2 L Npad floats of scratch (the gamma | beta records), Npad = N rounded up to 32 (+ 32); scal: 2 words of scratch.
+// gb: 2 L Npad floats (the gamma | beta records), Npad = N rounded up to 32 (+ 32); scal: 2 words (max gamma bits, 1 + index
+// of a gamma that is negative or not finite).  records_ready: both are filled already; gamma / beta are not read.
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
-                               float *slabg, int ns) {
+                               float *slabg, int ns, bool records_ready) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
     const int nb2 = M / kPanel;
     const int npairs2 = nb2 * (nb2 + 1) / 2;
     const int64_t nwg = (int64_t)L * npairs2 * ((ns + 7) / 8) * 8;
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
-    AGPL_HIP(ctx, hipMemsetAsync(scal, 0, 2 * sizeof(unsigned), ctx->stream));
-    acc_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, gb, scal);
-    acc_scale_kernel<<<1024, 256, 0, ctx->stream>>>((int64_t)L * (Npad / 32), gb, scal);
-    AGPL_LAUNCH_CHECK(ctx);
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
+    if (!records_ready) { // (a sweep's per-point kernel has written the records and max gamma already)
+        AGPL_HIP(ctx, hipMemsetAsync(scal, 0, 2 * sizeof(unsigned), ctx->stream));
+        int64_t nblk = agpl_cdiv((int64_t)L * Npad, 256);
+        if (nblk > 1024) nblk = 1024;
+        acc_prep_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, gb, scal);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    if (!ctx->strip_attr) { // once per context
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_strip_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
+        ctx->strip_attr = 1;
+    }
     syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, (const unsigned char *)image, gb,
                                                                      scal, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);

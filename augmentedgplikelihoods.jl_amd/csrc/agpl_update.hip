@@ -15,10 +15,19 @@
 #include "agpl_common.h"
 
 // agpl_ops.hip / agpl_mfma.hip internals
+int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
+                                    const int *info, int *info_host, int ninfo); // agpl_split.hip
+int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
+                                    const void *U_hi, const void *U_lo, const float *v, unsigned *zero2, float **qpart_out,
+                                    float **mpart_out, unsigned **queues_out); // agpl_split.hip
+int32_t agpl_launch_fused_point(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, int64_t npad, int nb2, const void *y,
+                                const float *resid, const float *mu0, const float *qpart, const float *mpart,
+                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues); // agpl_ops.hip
+void agpl_accumulate_records(int64_t N, int32_t M, int32_t L, void *slab_mem, float **gb, unsigned **scal); // agpl_mfma.hip
 int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out);
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image, const float *beta,
-                             const float *gamma, double *G_out, double *g_out, void *slab_mem);
+                             const float *gamma, double *G_out, double *g_out, void *slab_mem, bool records_ready = false);
 int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
                                          const float *kdiag, const float *mu0, const void *y, const double *v,
                                          uint32_t sweep, float *gamma, float *beta, double *f_out,
@@ -199,9 +208,8 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     if (rc) return rc;
     const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
     const size_t info_off = 16384; // ws2 head is used by the reductions
-    static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
     const bool two = M > 512;
-    if ((M <= 512 || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64 && !use_lib) {
+    if ((M <= 512 || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64) {
         // one-launch factorisation (agpl_factor.hip; two block rows of it for 512 < M <= 1024): U = chol(I + G)^-1,
         // then S = U'U as one float64 GEMM -- 1.1 ms at M = 512 against 3.4 ms for the ~300 launches of potrf + potri
         const size_t own = two ? ((two_block_ws2_bytes(L) + 255) & ~(size_t)255) : info_off + 1024;
@@ -451,10 +459,20 @@ int32_t agpl_pending_resolve(agpl_ctx *ctx) {
 
 // the info words of a factorisation that was just enqueued: copied to pinned host memory behind it, checked by
 // agpl_pending_resolve
-static int32_t pending_arm(agpl_ctx *ctx, const int *info_dev, int n, int L) {
-    if (!ctx->pend_host) AGPL_HIP(ctx, hipHostMalloc((void **)&ctx->pend_host, sizeof(int) * 128, hipHostMallocDefault));
+static int32_t pending_prepare(agpl_ctx *ctx) {
+    if (!ctx->pend_host) {
+        AGPL_HIP(ctx, hipHostMalloc((void **)&ctx->pend_host, sizeof(int) * 128, hipHostMallocMapped));
+        AGPL_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->pend_host_dev, ctx->pend_host, 0));
+    }
     if (!ctx->pend_ev) AGPL_HIP(ctx, hipEventCreateWithFlags(&ctx->pend_ev, hipEventDisableTiming));
-    AGPL_HIP(ctx, hipMemcpyAsync(ctx->pend_host, info_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    return AGPL_OK;
+}
+// info_dev == nullptr: the last kernel enqueued has written the words to pend_host itself (agpl_pack_factor_split_info)
+static int32_t pending_arm(agpl_ctx *ctx, const int *info_dev, int n, int L) {
+    int32_t rc = pending_prepare(ctx);
+    if (rc) return rc;
+    if (info_dev)
+        AGPL_HIP(ctx, hipMemcpyAsync(ctx->pend_host, info_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
     AGPL_HIP(ctx, hipEventRecord(ctx->pend_ev, ctx->stream));
     ctx->pend = true;
     ctx->pend_n = n;
@@ -501,8 +519,7 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         const int32_t rp = agpl_pending_resolve(ctx); // the previous factorisation's outcome, before its slot is reused
         if (rp) return rp;
     }
-    static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
-    if (M <= 512 && M % 32 == 0 && !use_lib) {
+    if (M <= 512 && M % 32 == 0) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
         const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * M * 32 + 1024;
@@ -514,23 +531,27 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info, coop);
         if (rc) return rc;
         if (U_hi) {
-            rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
+            rc = pending_prepare(ctx);
+            if (rc) return rc;
+            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info, ctx->pend_host_dev, L);
             if (rc) return rc;
         }
-        rc = pending_arm(ctx, info, L, L);
+        rc = pending_arm(ctx, U_hi ? nullptr : info, L, L);
         if (rc) return rc;
         *armed = true;
         return AGPL_OK;
     }
-    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16 && !use_lib) {
+    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) {
         int *info2 = nullptr;
         int32_t rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, logdet_out, &info2);
         if (rc) return rc;
         if (U_hi) {
-            rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
+            rc = pending_prepare(ctx);
+            if (rc) return rc;
+            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info2, ctx->pend_host_dev, 2 * L);
             if (rc) return rc;
         }
-        rc = pending_arm(ctx, info2, 2 * L, L);
+        rc = pending_arm(ctx, U_hi ? nullptr : info2, 2 * L, L);
         if (rc) return rc;
         *armed = true;
         return AGPL_OK;
@@ -724,8 +745,7 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
-    static const int use_lib = getenv("AGPL_FACTOR") ? !strcmp(getenv("AGPL_FACTOR"), "rocsolver") : 0;
-    if (M <= 512 && M % 32 == 0 && L <= 64 && !use_lib) {
+    if (M <= 512 && M % 32 == 0 && L <= 64) {
         // I + G = C C', U = C^-1:  m = U'(U r),  v = m + C^-T z = U'(U r + z)   (one fused factor launch + one matvec)
         const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
@@ -756,7 +776,7 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
                           i, (int)hinfo[i] - 1);
         return AGPL_OK;
     }
-    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16 && !use_lib) {
+    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) {
         // the same with the two-block factorisation (agpl_gaussian_factor's 512 < M <= 1024 route)
         const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
@@ -894,6 +914,33 @@ static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, in
     rc = agpl_ws_reserve(ctx, slab + 4 * vec);
     if (rc) return rc;
     char *base = (char *)ctx->ws;
+    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
+    const int keep = ctx->accumulate_split;
+    if (acc_image && M % 256 == 0) {
+        // three launches up to the slabs: marginal partial sums (MFMA) -> ONE per-point kernel (q(f_i), aux_posterior!,
+        // expected potential / precision, written as the accumulation's gamma | beta records, and max gamma) -> accumulation.
+        // Neither mu / var nor (unless the caller asks for them) gamma / beta exist as arrays.
+        float *gb, *qpart, *mpart;
+        unsigned *scal, *queues;
+        agpl_accumulate_records(N, M, L, base, &gb, &scal);
+        rc = agpl_timing_begin(ctx, 0);
+        if (rc) return rc;
+        rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, scal, &qpart, &mpart, &queues);
+        if (rc) return rc;
+        rc = agpl_timing_end(ctx, 0);
+        if (rc) return rc;
+        if ((char *)gb < (char *)mpart + sizeof(float) * (size_t)(M / 256) * L * N)
+            AGPL_FAIL(ctx, AGPL_ERR_HIP, "workspace layout: the records overlap the marginal partial sums");
+        const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
+        rc = agpl_launch_fused_point(ctx, ld, N, Npad, M / 256, y, resid, mu0, qpart, mpart, gamma_out, beta_out, c_out, gb,
+                                     scal, queues);
+        if (rc) return rc;
+        ctx->accumulate_split = 1;
+        rc = agpl_accumulate_impl(ctx, N, M, L, nullptr, acc_image, nullptr, nullptr, G_out, g_out, base, true);
+        ctx->accumulate_split = keep;
+        if (rc) return rc;
+        return agpl_pending_resolve(ctx);
+    }
     float *mu = (float *)(base + slab);
     float *var = (float *)(base + slab + vec);
     float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
@@ -902,8 +949,6 @@ static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, in
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
-    const int keep = ctx->accumulate_split;
     ctx->accumulate_split = 1;
     rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, bet, gam, G_out, g_out, base);
     ctx->accumulate_split = keep;
