@@ -42,6 +42,7 @@ struct agpl_ctx {
     int pend_n = 0;          // info words (L, or 2 L for the two-block form)
     int pend_latents = 0;
     int *pend_host = nullptr; // hipHostMalloc (mapped), 128 ints
+    bool pend_gamma_word = false; // pend_host[127] carries the sweep's bad-gamma word
     int *pend_host_dev = nullptr; // the same memory as the device addresses it
     hipEvent_t pend_ev = nullptr;
     char err[512] = {0};

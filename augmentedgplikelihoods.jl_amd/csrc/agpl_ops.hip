@@ -1140,6 +1140,8 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
                                                                   float *__restrict__ c_out, float *__restrict__ gb,
                                                                   unsigned *__restrict__ scal,
                                                                   unsigned *__restrict__ queues) {
+    // queues[0..7]: the marginal kernel's item queues; queues[8]: 1 + index of a gamma that is negative or not finite, kept
+    // until the update's last kernel forwards it to the host (agpl_pending_resolve reports AGPL_ERR_DOMAIN)
     __shared__ unsigned red[2][kBlock / 64];
     const int L = lik.nlatent;
     if (blockIdx.x == 0 && threadIdx.x < 8) queues[threadIdx.x] = 0u; // the marginal kernel's item queues, for its next launch
@@ -1173,7 +1175,10 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
             b = max(b, red[1][w]);
         }
         if (m) atomicMax(scal, m);
-        if (b) atomicMax(scal + 1, b);
+        if (b) {
+            atomicMax(scal + 1, b);
+            atomicMax(queues + 8, b);
+        }
     }
 }
 

@@ -782,10 +782,16 @@ __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L,
 __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
                                                                 h8 *__restrict__ Wh, h8 *__restrict__ Wl,
                                                                 const int *__restrict__ info, int *__restrict__ info_host,
-                                                                int ninfo) {
+                                                                int ninfo, unsigned *__restrict__ bad_gamma) {
     const int nks = M / KS, nb = M / BS;
     const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
-    if (info_host && l == 0 && rb == 0 && ks == 0 && (int)threadIdx.x < ninfo) info_host[threadIdx.x] = info[threadIdx.x];
+    if (info_host && l == 0 && rb == 0 && ks == 0) {
+        if ((int)threadIdx.x < ninfo) info_host[threadIdx.x] = info[threadIdx.x];
+        if (threadIdx.x == 127) { // the sweep's "bad gamma" word (agpl_fused_point_kernel), reported with the outcome
+            info_host[127] = (int)*bad_gamma;
+            *bad_gamma = 0u;
+        }
+    }
     const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
     const int a = rb * BS + row;
     const double *Al = A + (int64_t)l * M * M;
@@ -829,11 +835,19 @@ extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
     return (int64_t)sizeof(_Float16) * ((N + NT - 1) / NT) * NT * M; // per image (hi and lo each)
 }
 
+int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float limit, const char *what,
+                                 unsigned *max_bits_out); // agpl_syrk.hip
+
 extern "C" int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *Phi_hi,
                                        void *Phi_lo) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (N <= 0 || M <= 0 || M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need N > 0 and M %% 128 == 0");
     if (!Phi || !Phi_hi || !Phi_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    // the marginal image is UNSCALED float16 hi / lo (its partner, the inverse factor U, has entries in [-1, 1]): a feature at or
+    // beyond the float16 range would become inf and every marginal behind it NaN -- refused here, with its position
+    unsigned max_bits = 0;
+    int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, 65504.0f, "the unscaled float16 marginal image", &max_bits);
+    if (rc) return rc;
     int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
     if (nblk > 65535 * 16) nblk = 65535 * 16;
     split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, (h8 *)Phi_hi, (h8 *)Phi_lo);
@@ -888,9 +902,10 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
 // internal (agpl_update.hip): the same, forwarding ninfo <= 128 info words of the factorisation to pinned host memory
 int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
                                     const int *info, int *info_host, int ninfo) {
-    if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo || ninfo > 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
+    if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo || ninfo > 127) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
-    pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo, info, info_host, ninfo);
+    pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo, info, info_host, ninfo,
+                                                            (unsigned *)((char *)ctx->ws2 + 8192) + 8);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

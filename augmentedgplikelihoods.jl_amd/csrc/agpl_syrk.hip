@@ -572,30 +572,47 @@ extern "C" int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M) {
     return (int64_t)sizeof(AccImageHeader) + nps * (M / BS) * 2 * 4096;
 }
 
+// internal: max |Phi| (bit pattern of a non-negative float) after checking every value finite and |x| < limit; otherwise
+// AGPL_ERR_DOMAIN naming the first offending (point, feature).  One stream synchronisation; features are static, so this
+// runs once per image, not per sweep.  `what` names the image in the message.
+int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float limit, const char *what,
+                                 unsigned *max_bits_out) {
+    int32_t rc = agpl_ws2_reserve(ctx, 4096);
+    if (rc) return rc;
+    unsigned *mx = (unsigned *)ctx->ws2 + 512; // words 512.. of the small scratch (the info flags live below)
+    AGPL_HIP(ctx, hipMemsetAsync(mx, 0, 16, ctx->stream));
+    const int64_t n = N * (int64_t)M, n4 = n / 4; // (M % 128 == 0: whole float4s)
+    absmax_kernel<<<4096, 256, 0, ctx->stream>>>(n4, reinterpret_cast<const float4 *>(Phi), mx);
+    AGPL_LAUNCH_CHECK(ctx);
+    unsigned hmx = 0, hlim;
+    memcpy(&hlim, &limit, 4);
+    AGPL_HIP(ctx, hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hmx >= 0x7F800000u || hmx >= hlim) {
+        unsigned long long *bad = (unsigned long long *)(mx + 2), hbad = ~0ull;
+        AGPL_HIP(ctx, hipMemsetAsync(bad, 0xFF, 8, ctx->stream));
+        find_bad_kernel<<<4096, 256, 0, ctx->stream>>>(n, Phi, limit, bad);
+        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const long long pt = (long long)(hbad / (unsigned long long)M), ft = (long long)(hbad % (unsigned long long)M);
+        if (hmx >= 0x7F800000u && !(limit < __builtin_inff()))
+            AGPL_FAIL(ctx, AGPL_ERR_DOMAIN, "feature value is not finite (point %lld, feature %lld)", pt, ft);
+        AGPL_FAIL(ctx, AGPL_ERR_DOMAIN,
+                  "feature value is not finite or its magnitude is not below %g, the range of %s (point %lld, feature %lld)",
+                  (double)limit, what, pt, ft);
+    }
+    *max_bits_out = hmx;
+    return AGPL_OK;
+}
+
 extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
     if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
     if (!Phi || !image_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    int32_t rc = agpl_ws2_reserve(ctx, 4096);
-    if (rc) return rc;
-    unsigned *mx = (unsigned *)ctx->ws2 + 512; // words 512.. of the small scratch (the info flags live below)
-    AGPL_HIP(ctx, hipMemsetAsync(mx, 0, 16, ctx->stream));
-    const int64_t n4 = N * (int64_t)M / 4;
-    absmax_kernel<<<4096, 256, 0, ctx->stream>>>(n4, reinterpret_cast<const float4 *>(Phi), mx);
-    AGPL_LAUNCH_CHECK(ctx);
     unsigned hmx = 0;
-    AGPL_HIP(ctx, hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (hmx >= 0x7F800000u) {
-        unsigned long long *bad = (unsigned long long *)(mx + 2), hbad = ~0ull;
-        AGPL_HIP(ctx, hipMemsetAsync(bad, 0xFF, 8, ctx->stream));
-        find_bad_kernel<<<4096, 256, 0, ctx->stream>>>(N * (int64_t)M, Phi, __builtin_inff(), bad);
-        AGPL_HIP(ctx, hipMemcpyAsync(&hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        AGPL_FAIL(ctx, AGPL_ERR_DOMAIN, "feature value is not finite (point %lld, feature %lld)",
-                  (long long)(hbad / (unsigned long long)M), (long long)(hbad % (unsigned long long)M));
-    }
+    int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, __builtin_inff(), "the accumulate image", &hmx);
+    if (rc) return rc;
     float max_abs;
     memcpy(&max_abs, &hmx, 4);
     // 2^e_A max|Phi| in [2^13, 2^14): hi stays finite, and lo = f16(x - hi) is a float16 normal for |x| down to 2^-17 max|Phi|

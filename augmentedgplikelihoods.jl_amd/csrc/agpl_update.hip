@@ -446,6 +446,15 @@ int32_t agpl_pending_resolve(agpl_ctx *ctx) {
     ctx->pend = false;
     AGPL_HIP(ctx, hipEventSynchronize(ctx->pend_ev));
     const int L = ctx->pend_latents;
+    if (ctx->pend_gamma_word) {
+        const unsigned bad = (unsigned)ctx->pend_host[127];
+        ctx->pend_host[127] = 0;
+        if (bad)
+            AGPL_FAIL(ctx, AGPL_ERR_DOMAIN,
+                      "the expected precision gamma of a sweep is negative or not finite (first at flat index %u of the "
+                      "[latent][point] array): observations or marginals outside the likelihood's domain",
+                      bad - 1u);
+    }
     for (int i = 0; i < ctx->pend_n; ++i) {
         const int info = ctx->pend_host[i];
         if (info < 0)
@@ -463,6 +472,7 @@ static int32_t pending_prepare(agpl_ctx *ctx) {
     if (!ctx->pend_host) {
         AGPL_HIP(ctx, hipHostMalloc((void **)&ctx->pend_host, sizeof(int) * 128, hipHostMallocMapped));
         AGPL_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->pend_host_dev, ctx->pend_host, 0));
+        memset(ctx->pend_host, 0, sizeof(int) * 128);
     }
     if (!ctx->pend_ev) AGPL_HIP(ctx, hipEventCreateWithFlags(&ctx->pend_ev, hipEventDisableTiming));
     return AGPL_OK;
@@ -471,6 +481,7 @@ static int32_t pending_prepare(agpl_ctx *ctx) {
 static int32_t pending_arm(agpl_ctx *ctx, const int *info_dev, int n, int L) {
     int32_t rc = pending_prepare(ctx);
     if (rc) return rc;
+    ctx->pend_gamma_word = info_dev == nullptr;
     if (info_dev)
         AGPL_HIP(ctx, hipMemcpyAsync(ctx->pend_host, info_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
     AGPL_HIP(ctx, hipEventRecord(ctx->pend_ev, ctx->stream));

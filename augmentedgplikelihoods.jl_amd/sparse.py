@@ -401,7 +401,27 @@ class SparseGibbs:
             self.omega = torch.empty((self.N, Lo), dtype=f64, device=dev)
             self.n = torch.zeros((self.N, Lo), dtype=torch.int64, device=dev)
         self.sweep_index = self.ctx.next_sweep()
+        self._check_ranks_agree()
         self.draw()  # G = 0, g = 0: v ~ N(0, I), the prior draw (script.jl:89 `f = randn(N)`)
+
+    def _check_ranks_agree(self):
+        """Every rank draws v itself: the ranks' Philox key (seed) and draw counter must be the same, or the ranks sample
+        different chains behind an all-reduce that still "works".  One tiny MIN / MAX exchange at construction."""
+        if self.group is None:
+            return
+        import torch.distributed as dist
+
+        torch = _torch()
+        dev = self.Phi.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        seed = int(self.ctx.seed) & 0xFFFFFFFFFFFFFFFF
+        mine = torch.tensor([seed & 0xFFFFFFFF, seed >> 32, int(self.sweep_index)], dtype=torch.int64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not bool((lo == hi).all()):
+            raise _ffi.ArgumentError(-1, "SparseGibbs(group=...): the ranks' Contexts differ in seed or draw counter "
+                                         f"(this rank: seed {seed}, sweep {self.sweep_index}); create every rank's "
+                                         "Context with the same seed and use them for the same sequence of draws")
 
     def draw(self):
         """v ~ N(m, S) on the streams (seed, l M + a, sweep_index | 2^31): identical on every rank."""

@@ -271,7 +271,9 @@ AGPL_API int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms
  * <= max(2^-22 |x|, 3e-8) per operand, |x| < 6e4).  Operands live in blocked images (4 KB blocks of
  * [2 planes][128 rows][8 halves], one per (row block, 16-wide k-slice)) that are both the HBM and the LDS layout.
  *   agpl_split_features_bytes: bytes of ONE image (hi or lo) for N points, M features.
- *   agpl_split_features: Phi (float32 [M,N] col-major) -> Phi_hi, Phi_lo images (once per data set).
+ *   agpl_split_features: Phi (float32 [M,N] col-major) -> Phi_hi, Phi_lo images (once per data set).  This image is
+ *                        UNSCALED: AGPL_ERR_DOMAIN (point and feature in agpl_last_error) if a feature is not finite
+ *                        or |x| >= 65504, the float16 range.  Synchronises the stream once.
  *   agpl_pack_w_split:   scale * W' (W symmetric float64 [L,M,M]) -> W_hi, W_lo images, L*M*M halves each
  *                        (each sweep, after agpl_gaussian_update: W = S, scale = -1).
  *   agpl_marginals_split / agpl_cavi_pass_split: drop-in twins of agpl_marginals / agpl_cavi_pass taking the
@@ -357,7 +359,12 @@ AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int3
  *                                 agpl_accumulate_image) -- the float32 features are not an argument; M % 256 == 0.
  *   agpl_gibbs_pass_image       : agpl_gibbs_pass with the split-float16 accumulation, from Phi_acc when it is given
  *                                 and M % 256 == 0 (Phi is still read by the projection phi_i' v).
- * Every *_split / *_image entry point runs the split-float16 accumulation whatever agpl_set_accumulate_precision says.  */
+ * Every *_split / *_image entry point runs the split-float16 accumulation whatever agpl_set_accumulate_precision says.
+ * agpl_cavi_pass_factor_image is three launches up to the slabs (marginal partial sums; ONE per-point kernel: q(f_i),
+ * aux_posterior!, expected potential / precision, written straight into the accumulation's gamma | beta records; the
+ * accumulation) -- gamma_out / beta_out / c_out may be NULL and are then never materialised.  A gamma that is negative or not
+ * finite (observations or marginals outside the likelihood's domain) is reported as AGPL_ERR_DOMAIN, with its flat index, by
+ * the call that reports the outcome of the update enqueued behind this pass (agpl_gaussian_factor_async's rules).          */
 AGPL_API int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
                                              const void *Phi_hi, const void *Phi_lo, const void *Phi_acc,
                                              const float *resid, const float *mu0, const void *y, const void *U_hi,

@@ -163,3 +163,48 @@ def test_two_rank_sharded_gibbs_sweep_is_the_single_process_sweep(oracle):
     assert not np.array_equal(res[0][5][:n1], res[1][5])
     assert np.allclose(res[0][6], G, rtol=1e-12, atol=1e-12)
     assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][8], res[1][8])
+
+
+def _agree_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import types
+
+    import torch
+    import torch.distributed as dist
+
+    import agpl_amd as A
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        for seed, sweep in ((7, 3), (7 + rank, 3), (2**40 + 5, 3 + rank)):
+            me = types.SimpleNamespace(group=dist.group.WORLD, Phi=torch.zeros(2, 2), ctx=types.SimpleNamespace(seed=seed),
+                                       sweep_index=sweep)
+            try:
+                A.SparseGibbs._check_ranks_agree(me)
+                out.append("ok")
+            except A.ArgumentError:
+                out.append("refused")
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sparse_gibbs_refuses_ranks_with_different_seed_or_draw_counter():
+    """Every rank draws v itself (no broadcast): SparseGibbs(group=...) checks at construction that all ranks hold the same
+    Philox key and draw counter (one MIN / MAX all-reduce of three words)."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 31400 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res[0] == res[1] == ["ok", "refused", "refused"]

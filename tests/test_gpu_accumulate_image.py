@@ -110,6 +110,42 @@ def test_image_rejects_non_finite_features_with_their_index(A, ctx):
         A.sparse.accumulate_image(Phi, ctx)
 
 
+def test_marginal_image_refuses_features_beyond_the_float16_range(A, ctx):
+    """The marginal image is unscaled float16 hi / lo: |x| >= 65504 (or a non-finite value) would turn into inf and every
+    marginal into NaN without a word -- agpl_split_features reports AGPL_ERR_DOMAIN with the position instead."""
+    N, M = 1000, 256
+    Phi = torch.zeros((N, M), dtype=torch.float32, device="cuda")
+    nh = A._ffi.lib().agpl_split_features_bytes(C.c_int64(N), C.c_int32(M)) // 2
+    hi, lo = (torch.empty(nh, dtype=torch.float16, device="cuda") for _ in range(2))
+    args = (C.c_int64(N), C.c_int32(M), _p(Phi), _p(hi), _p(lo))
+    Phi[5, 7] = 65000.0  # in range
+    ctx.call("agpl_split_features", *args)
+    for bad in (65504.0, -7.0e4, float("inf"), float("nan")):
+        Phi[411, 200] = bad
+        with pytest.raises(A.DomainError, match=r"point 411, feature 200"):
+            ctx.call("agpl_split_features", *args)
+    # ... while the accumulate image scales itself and takes the same magnitudes
+    Phi[411, 200] = -7.0e4
+    A.sparse.accumulate_image(Phi, ctx)
+
+
+def test_sweep_reports_a_non_finite_expected_precision(A, oracle):
+    """A NaN observation makes gamma NaN (StudentT: w_i from (y_i - f_i)^2): the per-point kernel flags it and the outcome of
+    the update behind it carries AGPL_ERR_DOMAIN with the flat index -- not a silent NaN posterior."""
+    import bench
+
+    ctx = A.Context(0, seed=3)
+    lik = A.StudentTLikelihood(3.0, 1.0)
+    y, Phi, kd = bench.build_workload(A, ctx, lik, 0, 5_000, 256)
+    y[1234] = float("nan")
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    assert cavi.Phi_acc is not None
+    with pytest.raises(A.DomainError, match=r"flat index 1234"):
+        for _ in range(3):
+            cavi.sweep()
+        cavi.check()
+
+
 def test_image_needs_a_padded_feature_count(A, ctx):
     with pytest.raises(A.ArgumentError):
         A.sparse.accumulate_image(torch.zeros((10, 100), dtype=torch.float32, device="cuda"), ctx)
