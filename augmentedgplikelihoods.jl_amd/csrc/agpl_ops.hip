@@ -21,43 +21,115 @@ inline int grid_for(int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// aux_sample!  src/generic.jl:5-12.  A wave owns 64 consecutive points; lane = point for everything drawn on the
-// point's main Philox stream (seed, i, sweep).  The PG(1, c) draws -- b_i = y_i + r of them for a negative-binomial
-// point, n_ik + y_ik per latent for the categorical / Poisson families (polyagamma.jl:129-134 draw_sum) -- live on
-// sub-streams (agpl_random.h) and are dealt across the lanes of the wave: an exclusive prefix sum of floor(b) over the
-// wave numbers the draws, lane l takes draws l, l + 64, ..., finds each one's owner by bisection, runs the Devroye
-// sampler (polyagamma.jl:225-257) with the owner's hoisted (z, K, r), and leaves the value in LDS where the owner adds
-// its own draws up left to right (the order of the sequential draw_sum loop: bit-identical sums).  With one lane per point the wave waited
-// for its largest b (NegBin r = 15: PG(1) draws at 0.66 of the Bernoulli rate, round-1 bench).
-// sample_point_wave is called by all 64 lanes (valid = the lane has a point); f / om / nn point at the lane's own
-// latent values (global memory for agpl_aux_sample, LDS scratch for the Gibbs pass).
+// aux_sample!  src/generic.jl:5-12.  A workgroup of four waves owns 256 consecutive points; lane = point for everything
+// drawn on the point's main Philox stream (seed, i, sweep).  The PG(1, c) draws -- one per Bernoulli point, b_i = y_i + r
+// for a negative-binomial point, n_ik + y_ik per latent for the categorical / Poisson families (polyagamma.jl:129-134
+// draw_sum) -- live on sub-streams (agpl_random.h) and are independent work items.  They are processed in three phases that
+// sort them by the branch the Devroye sampler (polyagamma.jl:225-257) takes, instead of every wave running both proposal
+// branches and both forms of a(n, x) one after the other with part of its lanes idle:
+//   A  each wave deals its points' draws over its lanes (exclusive prefix sum of floor(b) numbers them; lane l takes draws
+//      l, l + 64, ...; the owner is found by bisection), draws the first uniform and, if the proposal is the truncated
+//      exponential (x > t: a(n, x) in its exponential form), finishes the draw; otherwise the draw goes to the WORKGROUP's queue;
+//   B  the queue -- truncated inverse-Gaussian proposals (x <= t: a(n, x) in its logarithmic form) -- is served by as many
+//      whole waves as it fills: 108 of 256 Bernoulli draws on average = two waves, the other two wait at the barrier;
+//   C  the (rare: 8e-4) draws whose series rejected the proposal are redone by the sequential sampler sample_pg1.
+// A draw's value, uniforms consumed and series index do not depend on who runs it (its sub-stream is its own); the owner adds
+// its draws up left to right -- the order of the sequential draw_sum loop: bit-identical sums.  Round 2 dealt the draws per
+// wave but ran sample_pg1 whole in every lane: 7.9e9 Bernoulli PG(1) draws/s (profiles/r02_*), ~20 000 cycles per 64 draws.
+// sample_point_wave is called by ALL threads of the workgroup under uniform control flow (valid = the lane has a point);
+// f / om / nn point at the lane's own latent values (global memory for agpl_aux_sample, LDS scratch for the Gibbs pass).
 // ------------------------------------------------------------------------------------------------
-struct PgWaveScratch {
-    double draws[256]; // one chunk of dealt draws
-    double par[64][3]; // owner's (z, K, r)
-    int off[65];       // exclusive prefix sums of floor(b); off[64] = total
-    unsigned nuni[64], nterms[64];
+#ifdef AGPL_PG_TRACE // diagnostic build (make PGTRACE=1): per-phase cycle sums over all waves, tools/ab_sampler.py --trace
+__device__ unsigned long long g_pgtrace[8];
+#define PGT_DECL() long long pgt_ = clock64()
+#define PGT_MARK(k_)                                                                                              \
+    do {                                                                                                          \
+        const long long now_ = clock64();                                                                         \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&scr->trace[k_], (unsigned long long)(now_ - pgt_));               \
+        pgt_ = now_;                                                                                              \
+    } while (0)
+#else
+#define PGT_DECL()
+#define PGT_MARK(k_)
+#endif
+constexpr int kPgWaves = kBlock / 64;
+struct PgBlockScratch {
+    double draws[kPgWaves][256];        // the dealt draws of each wave's current chunk
+    double par[kPgWaves][64][4];        // owner's (z, K, bracket of r: pg_mass_bracket)
+    int off[kPgWaves][65];              // exclusive prefix sums of floor(b); off[.][64] = total
+    unsigned nuni[kPgWaves][64], nterms[kPgWaves][64];
+    unsigned long long index0[kPgWaves]; // point index (40 bits) of lane 0 of each wave
+    unsigned short queue[kPgWaves * 256]; // phase-B queue: (wave << 8) | slot
+    unsigned short queue2[kPgWaves * 256]; // phase-B queue of the mu <= t branch
+    unsigned short retry[kPgWaves * 256]; // phase-C queue
+    unsigned st[kPgWaves * 256];         // stream position of a parked proposal: (refills << 3) | words used
+    unsigned char owner[kPgWaves][256];  // owner lane of each dealt draw
+    int qn, q2n, qhead, rn, tmax;
+#ifdef AGPL_PG_TRACE
+    unsigned long long trace[8];
+#endif
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave execute in order: only the compiler must not move accesses across this point
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// a(n, x) polyagamma.jl:167-177 with the branch known: x > t ...
+__device__ __forceinline__ double pg_a_hi(int n, double x) {
+    const double k = (n + 0.5) * kPi;
+    return k * exp(-k * k * x / 2.0);
+}
+// ... and 0 < x <= t, with the term shared by all n: lx = -3/2 (log(pi / 2) + log(x))
+__device__ __forceinline__ double pg_a_lo(int n, double x, double lx) {
+    const double k = (n + 0.5) * kPi;
+    const double expnt = lx - 2.0 * (n + 0.5) * (n + 0.5) / x;
+    return k * exp(expnt);
+}
+// the alternating-series test of polyagamma.jl:243-256 for a proposal x; false = rejected.  HI: x > t.
+template <bool HI>
+__device__ __forceinline__ bool pg_series_accept(Philox &g, double x, uint32_t &nterms) {
+    const double lx = HI ? 0.0 : -3.0 / 2.0 * (log(kPi / 2.0) + log(x));
+    double s = HI ? pg_a_hi(0, x) : pg_a_lo(0, x, lx);
+    const double y = g.u01() * s;
+    int n = 0;
+    bool accepted = false;
+    for (;;) {
+        n += 1;
+        const double a = HI ? pg_a_hi(n, x) : pg_a_lo(n, x, lx);
+        if (n & 1) {
+            s -= a;
+            if (y <= s) { accepted = true; break; }
+        } else {
+            s += a;
+            if (y > s) break;
+        }
+    }
+    nterms += (uint32_t)n;
+    return accepted;
 }
 
-// sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: lane only helps)
-__device__ inline double pg_int_sum_wave(PgWaveScratch *scr, int lane, const Philox &g, uint32_t sub_base, int tb,
-                                         double c, uint32_t &nuni, uint32_t &nterms) {
+// sub-stream of draw `sub` of point `index`
+__device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, uint32_t sub) {
+    Philox s = g;
+    s.c0 = 0;
+    s.c2 = (uint32_t)index;
+    s.c3 = (uint32_t)(index >> 32) + (sub << 8);
+    s.pos = 4;
+    s.nuni = 0;
+    return s;
+}
+
+// sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: the lane only helps).
+// sub_base is uniform over the workgroup.
+__device__ inline double pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, uint32_t sub_base, int tb,
+                                          double c, uint32_t &nuni, uint32_t &nterms) {
+    PGT_DECL();
     if (tb > 0) {
-        Pg1Params p;
-        p.set(c);
-        scr->par[lane][0] = p.z;
-        scr->par[lane][1] = p.K;
-        scr->par[lane][2] = p.r;
+        double z, K, rlo, rhi;
+        pg_mass_bracket(c, z, K, rlo, rhi);
+        scr->par[wave][lane][0] = z;
+        scr->par[wave][lane][1] = K;
+        scr->par[wave][lane][2] = rlo;
+        scr->par[wave][lane][3] = rhi;
     }
-    scr->nuni[lane] = 0u;
-    scr->nterms[lane] = 0u;
+    scr->nuni[wave][lane] = 0u;
+    scr->nterms[wave][lane] = 0u;
     int incl = tb;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -66,80 +138,226 @@ __device__ inline double pg_int_sum_wave(PgWaveScratch *scr, int lane, const Phi
     }
     const int off = incl - tb;
     const int T = __shfl(incl, 63);
-    scr->off[lane] = off;
-    if (lane == 63) scr->off[64] = T;
-    wave_lds_sync();
-    const uint64_t my_index = (uint64_t)g.c2 | ((uint64_t)(g.c3 & 0xFFu) << 32); // lanes = consecutive points
+    scr->off[wave][lane] = off;
+    if (lane == 63) scr->off[wave][64] = T;
+    if (lane == 0) scr->index0[wave] = (uint64_t)g.c2 | ((uint64_t)(g.c3 & 0xFFu) << 32); // lanes = consecutive points
+    if (threadIdx.x == 0) scr->tmax = scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
+    PGT_MARK(0);
+    __syncthreads();
+    if (lane == 0 && T > 0) atomicMax(&scr->tmax, T);
+    __syncthreads();
+    const int tmax = scr->tmax;
     double acc = 0.0;
-    for (int cb = 0; cb < T; cb += 256) {
+    PGT_MARK(1);
+    for (int cb = 0; cb < tmax; cb += 256) {
+        // ---- phase A
         for (int r = 0; r < 4; ++r) {
             const int t = cb + 64 * r + lane;
+            bool to_b = false, to_b2 = false, to_c = false;
             if (t < T) {
                 int lo = 0, hi = 63; // owner = last lane whose first draw is <= t (lanes without draws share an offset
                 while (lo < hi) {    // with their successor and are skipped by "last")
                     const int mid = (lo + hi + 1) >> 1;
-                    if (scr->off[mid] <= t) lo = mid;
+                    if (scr->off[wave][mid] <= t) lo = mid;
                     else hi = mid - 1;
                 }
-                const uint64_t oi = my_index - (uint64_t)lane + (uint64_t)lo;
-                Philox s = g;
-                s.c0 = 0;
-                s.c2 = (uint32_t)oi;
-                s.c3 = (uint32_t)(oi >> 32) + ((sub_base + (uint32_t)(t - scr->off[lo])) << 8);
-                s.pos = 4;
-                s.nuni = 0;
-                Pg1Params p;
-                p.z = scr->par[lo][0];
-                p.K = scr->par[lo][1];
-                p.r = scr->par[lo][2];
-                uint32_t nt = 0;
-                scr->draws[t - cb] = sample_pg1(s, p, nt);
-                atomicAdd(&scr->nuni[lo], s.nuni);
-                atomicAdd(&scr->nterms[lo], nt);
+                scr->owner[wave][t - cb] = (unsigned char)lo;
+                Philox s = pg_substream(g, scr->index0[wave] + (uint64_t)lo, sub_base + (uint32_t)(t - scr->off[wave][lo]));
+                const double u = s.u01();
+                if (!(u < scr->par[wave][lo][2]) && !(u > scr->par[wave][lo][3])) // inside the bracket of r: decided exactly
+                    to_c = true;
+                else if (u < scr->par[wave][lo][2]) { // truncated exponential proposal, polyagamma.jl:239-240
+                    const double x = kPgT + s.exp1() / scr->par[wave][lo][1];
+                    uint32_t nt = 0;
+                    if (pg_series_accept<true>(s, x, nt)) {
+                        scr->draws[wave][t - cb] = x / 4.0;
+                        atomicAdd(&scr->nuni[wave][lo], s.nuni);
+                        atomicAdd(&scr->nterms[wave][lo], nt);
+                    } else
+                        to_c = true;
+                } else if (1.0 / scr->par[wave][lo][0] > kPgT) // (the test of rand_truncated_inverse_gaussian, polyagamma.jl:197)
+                    to_b = true;
+                else
+                    to_b2 = true;
+            }
+            const unsigned long long mb = __ballot(to_b), mc = __ballot(to_c), mb2 = __ballot(to_b2);
+            if (mb2) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scr->q2n, __popcll(mb2));
+                base = __shfl(base, 0);
+                if (to_b2) scr->queue2[base + __popcll(mb2 & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+            }
+            if (mb) { // (wave-uniform)
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scr->qn, __popcll(mb));
+                base = __shfl(base, 0);
+                if (to_b) scr->queue[base + __popcll(mb & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+            }
+            if (mc) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scr->rn, __popcll(mc));
+                base = __shfl(base, 0);
+                if (to_c) scr->retry[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
             }
         }
-        wave_lds_sync();
+        PGT_MARK(2);
+        __syncthreads();
+        PGT_MARK(3);
+        // ---- phase B: truncated inverse-Gaussian proposals, polyagamma.jl:241-242 (rand_truncated_inverse_gaussian :195-221)
+        // B1: the mu > t branch as a stream of TRIALS (E, E' -> test -> x, alpha -> test).  A wave running the two nested
+        // rejection loops waits for its unluckiest lane (measured: 4.9 inner iterations per pass against a mean of 1.6 per lane);
+        // here a lane whose proposal is accepted parks it (x in the draw's slot, the stream position beside it) and takes the next
+        // entry of the queue, so every iteration of the loop is a trial for (nearly) all 64 lanes of all four waves.
+        const int qn = scr->qn, q2n = scr->q2n;
+        {
+            int e = -1, w = 0, slot = 0;
+            double z = 0.0;
+            Philox s = g;
+            auto fetch = [&]() {
+                const int idx = atomicAdd(&scr->qhead, 1);
+                e = -1;
+                if (idx < qn) {
+                    e = scr->queue[idx];
+                    w = e >> 8, slot = e & 255;
+                    const int lo = scr->owner[w][slot];
+                    s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                    (void)s.u01(); // the branch uniform, drawn in phase A
+                    (void)s.u01(); // `while (alpha < rand())` with alpha = 0: always entered (u is in the open interval)
+                    z = scr->par[w][lo][0];
+                }
+            };
+            fetch();
+            while (__ballot(e >= 0)) {
+                if (e >= 0) {
+                    const double E = s.exp1();
+                    const double Ep = s.exp1();
+                    if (!(E * E > (2.0 * Ep / kPgT))) {
+                        const double d = 1.0 + E * kPgT;
+                        const double x = kPgT / (d * d);
+                        const double alpha = exp(-z * z * x / 2.0);
+                        if (!(alpha < s.u01())) {
+                            scr->draws[w][slot] = x;
+                            scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+                            fetch();
+                        }
+                    }
+                }
+            }
+        }
+        // the mu <= t branch (|c| >= 3.125: Michael-Schucany-Haas proposals until x <= t) is rare: whole passes of the loop as is
+        if (q2n) {
+            for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
+                const int e = scr->queue2[q];
+                const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                (void)s.u01();
+                scr->draws[w][slot] = rand_tig(s, scr->par[w][lo][0]);
+                scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+            }
+        }
+        PGT_MARK(4);
+        __syncthreads();
+        PGT_MARK(5);
+        // B2: the series test of the parked proposals (x <= t: a(n, x) in its logarithmic form), whole waves
+        for (int q = (int)threadIdx.x; q < ((qn + q2n + 63) & ~63); q += kBlock) {
+            bool to_c = false;
+            int e = 0;
+            if (q < qn + q2n) {
+                e = q < qn ? scr->queue[q] : scr->queue2[q - qn];
+                const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                const uint32_t st = scr->st[e], c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it
+                if (pos < 4u) {
+                    s.c0 = c0 - 1u;
+                    s.refill();
+                } else
+                    s.c0 = c0;
+                s.pos = (int)pos;
+                s.nuni = 2u * c0 - (4u - pos) / 2u; // (every uniform takes two of the four words of a block)
+                const double x = scr->draws[w][slot];
+                uint32_t nt = 0;
+                if (pg_series_accept<false>(s, x, nt)) {
+                    scr->draws[w][slot] = x / 4.0;
+                    atomicAdd(&scr->nuni[w][lo], s.nuni);
+                    atomicAdd(&scr->nterms[w][lo], nt);
+                } else
+                    to_c = true;
+            }
+            const unsigned long long mc = __ballot(to_c);
+            if (mc) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scr->rn, __popcll(mc));
+                base = __shfl(base, 0);
+                if (to_c) scr->retry[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)e;
+            }
+        }
+        PGT_MARK(4);
+        __syncthreads();
+        PGT_MARK(5);
+        // ---- phase C: the draws whose first proposal was rejected, from the start of their sub-stream
+        const int rn = scr->rn;
+        for (int q = (int)threadIdx.x; q < rn; q += kBlock) {
+            const int e = scr->retry[q];
+            const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+            Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+            Pg1Params p;
+            p.set(2.0 * scr->par[w][lo][0]); // (z = |c| / 2 exactly)
+            uint32_t nt = 0;
+            scr->draws[w][slot] = sample_pg1(s, p, nt);
+            atomicAdd(&scr->nuni[w][lo], s.nuni);
+            atomicAdd(&scr->nterms[w][lo], nt);
+        }
+        __syncthreads();
+        PGT_MARK(6);
+        if (threadIdx.x == 0) scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
         const int a0 = off > cb ? off : cb, a1 = (off + tb) < (cb + 256) ? (off + tb) : (cb + 256);
-        for (int t = a0; t < a1; ++t) acc += scr->draws[t - cb];
-        wave_lds_sync();
+        for (int t = a0; t < a1; ++t) acc += scr->draws[wave][t - cb];
+        __syncthreads();
+        PGT_MARK(1);
     }
-    nuni += scr->nuni[lane];
-    nterms += scr->nterms[lane];
+    nuni += scr->nuni[wave][lane];
+    nterms += scr->nterms[wave][lane];
     return acc;
 }
 
-// rand(PolyaGamma(b, c)) for the lane's point, integer part dealt across the wave: the same value, uniforms consumed and
-// series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all 64 lanes.
-__device__ inline double pg_point_wave(PgWaveScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
+// rand(PolyaGamma(b, c)) for the lane's point, integer part dealt across the workgroup: the same value, uniforms consumed and
+// series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all threads of the workgroup.  INT: b is
+// known to be an integer (Bernoulli: no Gamma-series code in the kernel).
+template <bool INT = false>
+__device__ inline double pg_point_wave(PgBlockScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
                                        double c, uint32_t &nterms, int *bad) {
+    const int wave = (int)(threadIdx.x >> 6);
     // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
     // host as AGPL_ERR_UNSUPPORTED instead of a silent NaN
     if (valid && b >= 65535.0) atomicOr(bad, 2);
     const bool ok = valid && (b >= 0.0) && (fabs(c) < __builtin_inf()) && (b < 65535.0);
     const int tb = ok ? (int)floor(b) : 0;
     const uint32_t base = 1u + ((uint32_t)latent << 16);
-    double acc = pg_int_sum_wave(scr, lane, g, base, tb, c, g.nuni, nterms);
+    double acc = pg_int_sum_block(scr, wave, lane, g, base, tb, c, g.nuni, nterms);
     if (!valid) return 0.0;
     if (!ok) return __builtin_nan("");
     if (b == 0.0) return 0.0;
-    const double res = b - (double)tb;
-    if (res != 0.0) {
-        Philox s = g.sub(base + kSubResidual);
-        acc += rand_gamma_sum(s, c, res);
-        g.nuni += s.nuni;
+    if (!INT) {
+        const double res = b - (double)tb;
+        if (res != 0.0) {
+            Philox s = g.sub(base + kSubResidual);
+            acc += rand_gamma_sum(s, c, res);
+            g.nuni += s.nuni;
+        }
     }
     return acc;
 }
 
 template <int KIND>
-__device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch *scr, int lane, bool valid, Philox &g,
+__device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgBlockScratch *scr, int lane, bool valid, Philox &g,
                                          int64_t i, const void *yv, const double *f, double *om, int64_t *nn,
                                          uint32_t &nt, int *bad) {
     const int L = lik.nlatent;
     switch (KIND) { // compile-time: each kernel instantiation carries one likelihood's sampler only
-    case AGPL_LIK_BERNOULLI_LOGISTIC: // bernoulli.jl:13-15: one draw per point, nothing to deal
-        if (valid) om[0] = rand_pg_int(g, 1, fabs(f[0]), nt);
-        break;
+    case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:13-15: one draw per point (= rand_pg_int(g, 1, |f|, .))
+        const double w = pg_point_wave<true>(scr, lane, valid, g, 0, 1.0, valid ? fabs(f[0]) : 0.0, nt, bad);
+        if (valid) om[0] = w;
+    } break;
     case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:20-22
         const int32_t *y = (const int32_t *)yv;
         const double b = valid ? (double)y[i] + lik.p[0] : 0.0, c = valid ? fabs(f[0]) : 0.0;
@@ -222,17 +440,13 @@ __device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgWaveScratch 
     }
 }
 
-// Waves per SIMD the sampler kernels are compiled for, by likelihood (register allocation only: the draws are bit-identical).
-// Unconstrained, the multi-draw kinds take 256 VGPRs + AGPR copies and run ONE wave per SIMD; measured with the bound
-// (profiles/r02_ab_sampler_occupancy.json): negative binomial r = 15 at 3 waves 10.7 against 11.9 ms per 4e6 points
-// (aux_sample_kernel) and 13.3 against 14.2 ms per Gibbs sweep; categorical K = 10 at 2 waves 2.78 against 3.35 ms per Gibbs
-// point pass.  Bernoulli loses with any bound (1.24 -> 1.34 -> 1.58 ms at 3 / 4 waves: spills cost more than occupancy buys).
+// Waves per SIMD the sampler kernels are compiled for (register allocation only: the draws are bit-identical).  The phased
+// sampler has workgroup barriers between its phases, which only other workgroups on the same SIMDs can fill: four waves per
+// SIMD (128 VGPRs, some spills) beat 1 / 2 / 3 on one box in round 3 -- Bernoulli 2.36 / 1.42 / 1.31 / 1.26 ms per 1e7 points,
+// negative binomial r = 15 16.9 / 10.4 / 8.9 / 8.5 ms per 4e6 points (profiles/r03_ab_sampler.txt).  The kinds without PG draws
+// have no barriers and keep their registers.
 constexpr int sampler_wps(int kind) {
-    return kind == AGPL_LIK_NEGBINOMIAL ? 3
-           : (kind == AGPL_LIK_CATEGORICAL || kind == AGPL_LIK_CATEGORICAL_BIJ || kind == AGPL_LIK_POISSON ||
-              kind == AGPL_LIK_HETEROGAUSS)
-               ? 2
-               : 1;
+    return (kind == AGPL_LIK_STUDENTT || kind == AGPL_LIK_LAPLACE) ? 1 : 4;
 }
 
 template <int KIND>
@@ -244,26 +458,210 @@ __global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(a
                                                             uint32_t *__restrict__ nuni_out,
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
-    __shared__ PgWaveScratch scratch[kBlock / 64];
+    __shared__ PgBlockScratch scratch;
+#ifdef AGPL_PG_TRACE
+    if (threadIdx.x < 8) scratch.trace[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
     const int Lf = lik.nlatent;
     const int Lo = lik.kind == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t nchunks = (n + 63) >> 6;
-    for (int64_t chunk = (int64_t)blockIdx.x * (kBlock / 64) + wave; chunk < nchunks;
-         chunk += (int64_t)gridDim.x * (kBlock / 64)) {
-        const int64_t i = (chunk << 6) + lane;
+    const int lane = threadIdx.x & 63;
+    const int64_t nblocks = (n + kBlock - 1) / kBlock; // (the trip count is uniform over the workgroup: the sampler has barriers)
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t i = blk * kBlock + threadIdx.x;
         const bool valid = i < n;
         Philox g;
         g.init(seed, i0 + (uint64_t)i, sweep);
         uint32_t nt = 0;
-        sample_point_wave<KIND>(lik, &scratch[wave], lane, valid, g, i, yv, f + i * Lf, omega + i * Lo,
+        sample_point_wave<KIND>(lik, &scratch, lane, valid, g, i, yv, f + i * Lf, omega + i * Lo,
                                 nout ? nout + i * Lo : nullptr, nt, bad);
         if (valid) {
             if (nuni_out) nuni_out[i] = g.nuni;
             if (nterms_out) nterms_out[i] = nt;
         }
     }
+#ifdef AGPL_PG_TRACE
+    __syncthreads();
+    if (threadIdx.x < 8) atomicAdd(&g_pgtrace[threadIdx.x], scratch.trace[threadIdx.x]);
+#endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// aux_sample! of the Bernoulli likelihood (bernoulli.jl:13-15): ONE PG(1, |f_i|) draw per point, so the draw is its own owner
+// and the dealing machinery above has nothing to deal -- but the trial queue wants to be long (a lane that finds the queue
+// empty idles until the unluckiest lane of its wave is done).  A workgroup therefore takes kPg1Pts points per thread through
+// the same phases: A (branch uniform; truncated-exponential proposals finished), B1 (trials of the truncated inverse-Gaussian
+// proposals with refill from the workgroup's queue), B2 (their series test), C (sequential redo of the 8e-4 rejected).  Same
+// sub-streams (draw 0 of latent 0 = id 1), same values, uniforms consumed and series indices as sample_point_wave's case.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPg1Pts = 8;                   // points per thread and workgroup iteration
+constexpr int kPg1Slots = kPg1Pts * kBlock;  // 2048 draws per iteration
+struct Pg1BlockScratch {
+    double x[kPg1Slots];                     // parked proposals
+    unsigned st[kPg1Slots];                  // their stream positions
+    unsigned short queue[kPg1Slots], queue2[kPg1Slots], retry[kPg1Slots];
+    int qn, q2n, qhead, rn;
+};
+
+__global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, const double *__restrict__ f,
+                                                                   double *__restrict__ omega, uint64_t seed, uint64_t i0,
+                                                                   uint32_t sweep, uint32_t *__restrict__ nuni_out,
+                                                                   uint32_t *__restrict__ nterms_out) {
+    __shared__ Pg1BlockScratch scr;
+    const int lane = threadIdx.x & 63;
+    const int64_t nblocks = (n + kPg1Slots - 1) / kPg1Slots;
+    if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = scr.rn = 0;
+    __syncthreads();
+    auto push = [&](bool flag, unsigned short *q, int *cnt, int slot) { // compacted append of the wave's flagged lanes
+        const unsigned long long m = __ballot(flag);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (flag) q[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)slot;
+        }
+    };
+    auto finish = [&](int64_t i, double w, const Philox &s, uint32_t nt) {
+        omega[i] = w;
+        if (nuni_out) nuni_out[i] = s.nuni;
+        if (nterms_out) nterms_out[i] = nt;
+    };
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t base = blk * kPg1Slots;
+        Philox g0; // key and sweep of every stream of this launch; point and sub-stream set by pg_substream
+        g0.init(seed, 0, sweep);
+        // ---- phase A
+        for (int p = 0; p < kPg1Pts; ++p) {
+            const int slot = p * kBlock + (int)threadIdx.x;
+            const int64_t i = base + slot;
+            bool to_b = false, to_b2 = false, to_c = false;
+            if (i < n) {
+                const double c = fabs(f[i]);
+                if (!(c < __builtin_inf())) { // NaN / Inf in, NaN out (rand_pg_int)
+                    omega[i] = __builtin_nan("");
+                    if (nuni_out) nuni_out[i] = 0u;
+                    if (nterms_out) nterms_out[i] = 0u;
+                } else {
+                    const double z = c / 2.0, K = kPi2_8 + z * z / 2.0; // (= Pg1Params::set, bit for bit)
+                    const double r = pg_mass_fit(z < 8.0 ? z : 0.0);
+                    Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+                    const double u = s.u01();
+                    if (!(z < 8.0) || (!(u < r - kPgMassSlack) && !(u > r + kPgMassSlack))) // no fit, or u inside the bracket of r:
+                        to_c = true;                                                        // the sequential sampler decides
+                    else if (u < r - kPgMassSlack) { // truncated exponential proposal, polyagamma.jl:239-240
+                        const double x = kPgT + s.exp1() / K;
+                        uint32_t nt = 0;
+                        if (pg_series_accept<true>(s, x, nt)) finish(i, x / 4.0, s, nt);
+                        else to_c = true;
+                    } else if (1.0 / z > kPgT)
+                        to_b = true;
+                    else
+                        to_b2 = true;
+                }
+            }
+            push(to_b, scr.queue, &scr.qn, slot);
+            push(to_b2, scr.queue2, &scr.q2n, slot);
+            push(to_c, scr.retry, &scr.rn, slot);
+        }
+        __syncthreads();
+        // ---- phase B1: trials with refill (see pg_int_sum_block)
+        const int qn = scr.qn, q2n = scr.q2n;
+        {
+            int e = -1;
+            double z = 0.0;
+            Philox s = g0;
+            auto fetch = [&]() {
+                const int idx = atomicAdd(&scr.qhead, 1);
+                e = -1;
+                if (idx < qn) {
+                    e = scr.queue[idx];
+                    const int64_t i = base + e;
+                    s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+                    (void)s.u01();
+                    (void)s.u01();
+                    z = fabs(f[i]) / 2.0; // (Pg1Params::set)
+                }
+            };
+            fetch();
+            while (__ballot(e >= 0)) {
+                if (e >= 0) {
+                    const double E = s.exp1();
+                    const double Ep = s.exp1();
+                    if (!(E * E > (2.0 * Ep / kPgT))) {
+                        const double d = 1.0 + E * kPgT;
+                        const double x = kPgT / (d * d);
+                        const double alpha = exp(-z * z * x / 2.0);
+                        if (!(alpha < s.u01())) {
+                            scr.x[e] = x;
+                            scr.st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+                            fetch();
+                        }
+                    }
+                }
+            }
+        }
+        if (q2n) {
+            for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
+                const int e = scr.queue2[q];
+                const int64_t i = base + e;
+                Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+                (void)s.u01();
+                scr.x[e] = rand_tig(s, fabs(f[i]) / 2.0);
+                scr.st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+            }
+        }
+        __syncthreads();
+        // ---- phase B2: series test of the parked proposals
+        for (int q = (int)threadIdx.x; q < ((qn + q2n + 63) & ~63); q += kBlock) {
+            bool to_c = false;
+            int e = 0;
+            if (q < qn + q2n) {
+                e = q < qn ? scr.queue[q] : scr.queue2[q - qn];
+                const int64_t i = base + e;
+                Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+                const uint32_t st = scr.st[e], c0 = st >> 3, pos = st & 7u;
+                if (pos < 4u) {
+                    s.c0 = c0 - 1u;
+                    s.refill();
+                } else
+                    s.c0 = c0;
+                s.pos = (int)pos;
+                s.nuni = 2u * c0 - (4u - pos) / 2u;
+                const double x = scr.x[e];
+                uint32_t nt = 0;
+                if (pg_series_accept<false>(s, x, nt)) finish(i, x / 4.0, s, nt);
+                else to_c = true;
+            }
+            push(to_c, scr.retry, &scr.rn, e);
+        }
+        __syncthreads();
+        // ---- phase C: rejected proposals, redone from the start of their sub-stream by the sequential sampler
+        const int rn = scr.rn;
+        for (int q = (int)threadIdx.x; q < rn; q += kBlock) {
+            const int64_t i = base + scr.retry[q];
+            Pg1Params prm;
+            prm.set(fabs(f[i]));
+            Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+            uint32_t nt = 0;
+            const double w = sample_pg1(s, prm, nt);
+            finish(i, w, s, nt);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = scr.rn = 0;
+        __syncthreads();
+    }
+}
+
+#ifdef AGPL_PG_TRACE
+extern "C" __attribute__((visibility("default"))) int32_t agpl_debug_pgtrace(unsigned long long *out_host, int32_t reset) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pgtrace), sizeof(unsigned long long) * 8) != hipSuccess) return -4;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pgtrace), z, sizeof(z)) != hipSuccess) return -4;
+    }
+    return 0;
+}
+#endif
 
 __global__ __launch_bounds__(kBlock) void rand_pg_kernel(double b, double c, int64_t n, uint64_t seed,
                                                          uint32_t sweep, double *__restrict__ out,
@@ -830,7 +1228,12 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
                                                                       nuni_out, nterms_out, bad);              \
         break;
     switch (ld.kind) {
-        AGPL_LAUNCH_AUX(AGPL_LIK_BERNOULLI_LOGISTIC)
+    case AGPL_LIK_BERNOULLI_LOGISTIC: { // one draw per point: the kernel with the long trial queue
+        int64_t nb = agpl_cdiv(n, kPg1Slots);
+        if (nb > 256 * 4 * 8) nb = 256 * 4 * 8;
+        aux_sample_pg1_kernel<<<(unsigned)nb, kBlock, 0, ctx->stream>>>(n, f, omega_out, ctx->seed, (uint64_t)ctx->point_offset,
+                                                                        sweep, nuni_out, nterms_out);
+    } break;
         AGPL_LAUNCH_AUX(AGPL_LIK_NEGBINOMIAL)
         AGPL_LAUNCH_AUX(AGPL_LIK_STUDENTT)
         AGPL_LAUNCH_AUX(AGPL_LIK_CATEGORICAL)
@@ -1207,7 +1610,7 @@ template <int KIND>
 __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int64_t N, int64_t base, int lane, int np,
                                                     int Lf, int Lo, const float *__restrict__ kdiag,
                                                     const float *__restrict__ mu0, const void *yv, uint64_t seed,
-                                                    uint64_t i0, uint32_t sweep, PgWaveScratch *scr, double *fS, double *omS,
+                                                    uint64_t i0, uint32_t sweep, PgBlockScratch *scr, double *fS, double *omS,
                                                     int64_t *nnS,
                                                     float *__restrict__ gamma, float *__restrict__ beta,
                                                     double *__restrict__ f_out, double *__restrict__ omega_out,
@@ -1298,10 +1701,10 @@ __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, in
     for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
     __syncthreads();
     const int q = lane & 15, grp = lane >> 4;
-    const int64_t nchunks = (N + 63) >> 6;
-    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
-        const int64_t base = chunk << 6;
-        const int np = (int)((N - base) < 64 ? (N - base) : 64);
+    const int64_t nblocks = (N + 255) >> 8; // (uniform trip count over the workgroup: the sampler has barriers)
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t base = (blk * 4 + wave) << 6;
+        const int np = (N - base) < 0 ? 0 : (int)((N - base) < 64 ? (N - base) : 64);
         for (int r = 0; r < 16; ++r) {
             int p = 4 * r + grp;
             const int pc = p < np ? p : np - 1; // clamp: keeps every lane in the shuffles
@@ -1332,20 +1735,20 @@ __global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
     float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,
     uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    __shared__ PgWaveScratch scratch[4];
+    __shared__ PgBlockScratch scratch;
     const int Lf = lik.nlatent;
     const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *fS = sh + (size_t)wave * 64 * (Lf + 2 * Lo);       // [64][Lf]
     double *omS = fS + 64 * Lf;                                 // [64][Lo]
     int64_t *nnS = reinterpret_cast<int64_t *>(omS + 64 * Lo);  // [64][Lo]
-    const int64_t nchunks = (N + 63) >> 6;
-    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
-        const int64_t base = chunk << 6;
-        const int np = (int)((N - base) < 64 ? (N - base) : 64);
+    const int64_t nblocks = (N + 255) >> 8; // (uniform trip count over the workgroup: the sampler has barriers)
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t base = (blk * 4 + wave) << 6;
+        const int np = (N - base) < 0 ? 0 : (int)((N - base) < 64 ? (N - base) : 64);
         if (lane < np)
             for (int l = 0; l < Lf; ++l) fS[lane * Lf + l] = proj[(base + lane) * Lf + l];
-        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, i0, sweep, &scratch[wave], fS, omS, nnS, gamma,
+        gibbs_sample_points<KIND>(lik, N, base, lane, np, Lf, Lo, kdiag, mu0, yv, seed, i0, sweep, &scratch, fS, omS, nnS, gamma,
                                   beta,
                                   f_out, omega_out, n_out, nuni_out, bad);
     }

@@ -5,7 +5,7 @@
 // point's stream (counter word 3 = (point index >> 32) in its low 8 bits, sub-stream id above: draw j of latent k has
 // id 1 + (k << 16) + j, the residual Gamma series id 1 + (k << 16) + 0xFFFF, id 0 is the main stream): the
 // b = y + r draws of a negative-binomial point are independent work items that the kernels deal across the lanes of
-// a wave (pg_int_sum_wave, agpl_ops.hip) and sum left to right in draw order -- the order of the sequential draw_sum loop (polyagamma.jl:129-134).  Uniform -> double
+// a workgroup, sorted by the sampler's branch (pg_int_sum_block, agpl_ops.hip), and sum left to right in draw order -- the order of the sequential draw_sum loop (polyagamma.jl:129-134).  Uniform -> double
 // conversion, randexp and randn are fixed transforms of the stream (52-bit open-interval uniform,
 // inversion, cosine Box-Muller) so that a float64 host evaluation of the same formulas consumes the
 // stream identically.
@@ -59,8 +59,9 @@ struct Philox {
         uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, q0 = k0, q1 = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
-            uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
-            uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+            // (64-bit products: one v_mad_u64_u32 gives the high and the low word; the 32-bit integer multiplies are quarter rate)
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
             uint32_t n0 = hi1 ^ x1 ^ q0;
             uint32_t n2 = hi0 ^ x3 ^ q1;
             x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
@@ -124,12 +125,53 @@ __device__ __forceinline__ double pg_mass_texpon(double z, double K) {
     const double t = kPgT;
     double b = sqrt(1.0 / t) * (t * z - 1.0);
     double a = -sqrt(1.0 / t) * (t * z + 1.0);
+    if (z < 8.0) {
+        // the same quantity without the round trip through logarithms: q / p = (4 / pi) K e^{K t} (e^{-z} Phi(b) + e^{z} Phi(a)),
+        // Phi(x) = erfc(-x / sqrt 2) / 2: all terms positive (no cancellation), every factor far inside the float64 range for
+        // z < 8 (K t < 22).  r is only ever compared with a uniform: the last-bit difference to the log-space form below is the
+        // same order as the difference between two libm's evaluating that form (round 3: identical draws over 1.6e8 PG(1)).
+        const double ez = exp(-z);
+        const double qdivp = (4.0 / kPi) * (K * exp(K * t)) * (ez * (0.5 * erfc(-b * kSqrtHalf)) + (0.5 * erfc(-a * kSqrtHalf)) / ez);
+        return 1.0 / (1.0 + qdivp);
+    }
     double x0 = log(K) + K * t;
     double xb = x0 - z + normlogcdf(b);
     double xa = x0 + z + normlogcdf(a);
     double qdivp = (4.0 / kPi) * (exp(xb) + exp(xa));
     return 1.0 / (1.0 + qdivp);
 }
+
+// A bracket of r(z) = mass_texpon(z, K(z)) for the branch test `r > u` of sample_pg1 (polyagamma.jl:238): Chebyshev fit on
+// z in [0, 8] (tools/fit_pg_mass.py: max |fit - exact| = 8.0e-11 against a 60-digit evaluation) widened by 1e-8 on both sides.
+// u below the bracket takes the truncated-exponential branch, u above it the inverse-Gaussian branch, and a draw whose u falls
+// INSIDE it (2e-8 of the draws) is handed to the sequential sampler with the exact formula (phase C of the kernels): the decisions
+// are those of the exact formula, at a twentieth of its ~900 instructions (two erfc, three exp, a division) per point.
+constexpr double kPgMassCheb[25] = {
+    0.17891350136487277, -0.29110615717444843, 0.14413720467193056,
+    -0.019096796213082485, -0.030408673533667163, 0.02413478068743331,
+    -0.005763120734068512, -0.0025295518306110215, 0.0022193291620839425,
+    -0.00036720422556672745, -0.0002554337564001494, 0.0001344480400196417,
+    2.6363411059142603e-06, -1.989863672582531e-05, 3.945796121778492e-06,
+    1.8751767350099586e-06, -8.57276875529128e-07, -9.114466427503223e-08,
+    1.221518168946105e-07, -8.29437512251279e-09, -1.3409793302941801e-08,
+    3.0516811956701023e-09, 1.0826812382200682e-09, -5.089763581593449e-10,
+    -3.546254472440936e-11,
+};
+constexpr double kPgMassSlack = 1e-8;
+__device__ __forceinline__ double pg_mass_fit(double z) { // z in [0, 8)
+    const double x = z * 0.25 - 1.0;
+    const double x2 = 2.0 * x;
+    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int j = 24; j > 0; --j) {
+        const double t = __builtin_fma(x2, b1, kPgMassCheb[j] - b2);
+        b2 = b1;
+        b1 = t;
+    }
+    return __builtin_fma(x, b1, kPgMassCheb[0] - b2);
+}
+// the bracket [rlo, rhi] of r for tilt c (rlo == rhi == the exact r where the fit does not apply)
+__device__ __forceinline__ void pg_mass_bracket(double c, double &z, double &K, double &rlo, double &rhi);
 
 // rand_truncated_inverse_gaussian(rng,z) polyagamma.jl:195-221
 __device__ inline double rand_tig(Philox &g, double z) {
@@ -176,6 +218,19 @@ struct Pg1Params {
     }
 };
 
+__device__ __forceinline__ void pg_mass_bracket(double c, double &z, double &K, double &rlo, double &rhi) {
+    z = fabs(c) / 2.0;
+    K = kPi2_8 + z * z / 2.0; // (= Pg1Params::set, bit for bit: z = 0 adds an exact zero)
+    if (z < 8.0) {
+        const double r = pg_mass_fit(z);
+        rlo = r - kPgMassSlack;
+        rhi = r + kPgMassSlack;
+    } else {
+        Pg1Params p;
+        p.set(c);
+        rlo = rhi = p.r;
+    }
+}
 // sample_pg1(rng,c) polyagamma.jl:237-257.  The alternating-series accept loop runs with the wave's
 // exec mask shrinking as lanes accept (the compiler's divergent-loop lowering is the wave ballot: the
 // loop back-edge is s_cbranch on exec != 0).
