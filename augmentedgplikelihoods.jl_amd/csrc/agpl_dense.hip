@@ -11,8 +11,9 @@
 //   B = I + D^1/2 K D^1/2 = C C'      (D = Diag(gamma); ONE float64 Cholesky per sweep: rocSOLVER potrf)
 //   f = f0 + K D^1/2 B^-1 (D^-1/2 beta - D^1/2 f0 - z2),   f0 = mu0 + L_K z1,  z1, z2 ~ N(0, I)
 // which is an exact draw from N(mu, Sigma) (Matheron's rule with pseudo-observations yhat = D^-1 beta of noise
-// variance D^-1).  The dense linear algebra is plain rocSOLVER / rocBLAS; the hand-written parts are the sampler
-// (agpl_ops.hip) and the fused elementwise steps below.
+// variance D^-1).  The N^3 / 3 of the Cholesky is the hand-written float64-MFMA trailing update below; the 2048-wide
+// diagonal blocks, the panel solves and the matrix-vector products are rocSOLVER / rocBLAS calls; the sampler (agpl_ops.hip)
+// and the fused elementwise steps are hand-written.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -80,16 +81,145 @@ __global__ void or_info_kernel(rocblas_int *info, int block_start) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && info[1] != 0 && info[0] == 0) info[0] = block_start + info[1];
 }
 
-// Lower Cholesky (column-major view, in place) of an N x N float64 matrix as a right-looking blocked factorisation on
-// rocBLAS level-3 calls: rocsolver_dpotrf on 2048-wide diagonal blocks, one dtrsm per panel and the trailing lower
-// block-triangle updated one block column at a time by dgemm.  rocSOLVER's own dpotrf runs this size at 16-30 TF/s
-// float64 on the MI355X; this arrangement measured 38 TF/s at N = 32768 (tools/scratch/blocked_chol.py), identical
-// to 5e-15.  info[0] = 0 or 1-based index of the first non-positive pivot, as potrf.
+// ------------------------------------------------------------------------------------------------
+// trailing_update_kernel: the N^3 of the factorisation, hand-written on the float64 matrix cores.
+//   A[r][c] -= sum_{q < w} A[r][k0 + q] A[c][k0 + q]   for e <= c <= r < N   (column-major, ld = N; e = k0 + w)
+// i.e. the symmetric rank-w update of the LOWER triangle of the trailing matrix by the panel P = A[e:, k0:e] that the
+// triangular solve has just produced -- only the lower triangle is computed (tiles with row block >= column block).
+// One workgroup = one 128 x 128 tile, four waves as 2 x 2 of 64 x 64 = 4 x 4 accumulators of v_mfma_f64_16x16x4_f64 (128
+// VGPRs).  Both operands are rows of P ([panel row][q], the row index contiguous in memory): 16 columns of P at a time go
+// through a double-buffered LDS tile [q][row] (row pitch 144 doubles: the four q-groups of a fragment read fall in distinct
+// bank halves), the next tile's global loads in flight during the 64 MFMAs of the current one.  An MFMA of this shape takes
+// 64 cycles for 2 x 8 bytes of operands per lane: the kernel is bound by the matrix pipe, not by LDS or HBM
+// (16 KB + 16 KB per 4096 MFMA-cycles and workgroup).  The product is formed transposed, D[c][r], so that the 16 lanes of a
+// result register run along the contiguous (row) index of A: 128-byte read-modify-writes.  The fixed summation order makes
+// the factor bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+typedef double d4t __attribute__((ext_vector_type(4)));
+constexpr int kTT = 128;      // tile edge
+constexpr int kTK = 16;       // panel columns per stage
+constexpr int kTPitch = 144;  // doubles per LDS row of a stage
+constexpr int kTStage = kTK * kTPitch; // doubles per operand and stage
+
+template <bool DIAG>
+__device__ __forceinline__ void trailing_tile(double *smem, int64_t N, double *__restrict__ A, int64_t k0, int w, int64_t r0,
+                                              int64_t c0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int li = lane & 15, lq = lane >> 4;
+    // staging role: rows (tid & 63) * 2, +1 of the tile; panel columns (tid >> 6) + 4 i
+    const int srow = (tid & 63) * 2, sq = tid >> 6;
+    int64_t gr = r0 + srow, gc = c0 + srow;
+    if (gr > N - 2) gr = N - 2; // (rows beyond N are never stored: any in-range address will do)
+    if (gc > N - 2) gc = N - 2;
+    const double *pr = A + gr + (k0 + sq) * N, *pc = A + gc + (k0 + sq) * N;
+    double *sR = smem, *sC = smem + 2 * kTStage; // [stage][q][row]
+    double2 vr0, vr1, vr2, vr3, vc0, vc1, vc2, vc3; // the next stage, in flight during the MFMAs of the current one
+#define AGPL_T_GLOAD(kt_)                                                                                       \
+    do {                                                                                                        \
+        const double *qr_ = pr + (int64_t)(kt_) * kTK * N, *qc_ = pc + (int64_t)(kt_) * kTK * N;                \
+        vr0 = *reinterpret_cast<const double2 *>(qr_);                                                          \
+        vr1 = *reinterpret_cast<const double2 *>(qr_ + 4 * N);                                                  \
+        vr2 = *reinterpret_cast<const double2 *>(qr_ + 8 * N);                                                  \
+        vr3 = *reinterpret_cast<const double2 *>(qr_ + 12 * N);                                                 \
+        if (!DIAG) {                                                                                            \
+            vc0 = *reinterpret_cast<const double2 *>(qc_);                                                      \
+            vc1 = *reinterpret_cast<const double2 *>(qc_ + 4 * N);                                              \
+            vc2 = *reinterpret_cast<const double2 *>(qc_ + 8 * N);                                              \
+            vc3 = *reinterpret_cast<const double2 *>(qc_ + 12 * N);                                             \
+        }                                                                                                       \
+    } while (0)
+#define AGPL_T_SWRITE(st_)                                                                                      \
+    do {                                                                                                        \
+        double *dr_ = sR + (st_) * kTStage + sq * kTPitch + srow, *dc_ = sC + (st_) * kTStage + sq * kTPitch + srow; \
+        *reinterpret_cast<double2 *>(dr_) = vr0;                                                                \
+        *reinterpret_cast<double2 *>(dr_ + 4 * kTPitch) = vr1;                                                  \
+        *reinterpret_cast<double2 *>(dr_ + 8 * kTPitch) = vr2;                                                  \
+        *reinterpret_cast<double2 *>(dr_ + 12 * kTPitch) = vr3;                                                 \
+        if (!DIAG) {                                                                                            \
+            *reinterpret_cast<double2 *>(dc_) = vc0;                                                            \
+            *reinterpret_cast<double2 *>(dc_ + 4 * kTPitch) = vc1;                                              \
+            *reinterpret_cast<double2 *>(dc_ + 8 * kTPitch) = vc2;                                              \
+            *reinterpret_cast<double2 *>(dc_ + 12 * kTPitch) = vc3;                                             \
+        }                                                                                                       \
+    } while (0)
+    d4t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = d4t{0.0, 0.0, 0.0, 0.0};
+    const int nkt = w / kTK;
+    AGPL_T_GLOAD(0);
+    AGPL_T_SWRITE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st = kt & 1;
+        AGPL_T_GLOAD(kt + 1 < nkt ? kt + 1 : kt); // (unconditional: the last iteration re-reads its own stage, unused)
+        const double *bR = sR + st * kTStage + lq * kTPitch + wr * 64 + li;           // B operand: rows of the row block
+        const double *bC = (DIAG ? sR : sC) + st * kTStage + lq * kTPitch + wc * 64 + li; // A operand: rows of the column block
+#pragma unroll
+        for (int ks = 0; ks < kTK / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = bC[ks * 4 * kTPitch + 16 * m];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = bR[ks * 4 * kTPitch + 16 * n];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        AGPL_T_SWRITE(st ^ 1);
+        __syncthreads();
+    }
+#undef AGPL_T_GLOAD
+#undef AGPL_T_SWRITE
+    // A[r][c] -= D[c][r]: register rr of lane l holds D[16 m + 4 rr + lq][16 n + li]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t c = c0 + wc * 64 + 16 * m + 4 * rr + lq;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int64_t r = r0 + wr * 64 + 16 * n + li;
+                if (r < N && c < N && (!DIAG || r >= c)) A[r + c * N] -= acc[m][n][rr];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int nt) {
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    // tile (I, J), J <= I, of the trailing matrix, row by row of the lower block triangle
+    const int64_t p = blockIdx.x;
+    int64_t I = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= p) ++I;
+    while (I * (I + 1) / 2 > p) --I;
+    const int64_t J = p - I * (I + 1) / 2;
+    const int64_t e = k0 + w;
+    if (I == J) trailing_tile<true>(tsm, N, A, k0, w, e + I * kTT, e + J * kTT);
+    else trailing_tile<false>(tsm, N, A, k0, w, e + I * kTT, e + J * kTT);
+}
+
+// Lower Cholesky (column-major view, in place) of an N x N float64 matrix as a right-looking blocked factorisation:
+// rocsolver_dpotrf on the 2048-wide diagonal blocks, one rocblas dtrsm per panel (together ~12 % of the flops at N = 65536),
+// and the trailing lower triangle -- the N^3 / 3 -- by trailing_update_kernel above (rounds 1-2: one rocblas dgemm per block
+// column, 54.7 TF/s at C5).  Round 3, N = 65536: the kernel runs at 63.4 TF/s = 0.96 of the probe's 65.9 TF/s
+// (profiles/r03_c5_kernel_stats.csv: 1404 ms of a 1741 ms step); what remains is the chain of small rocSOLVER / rocBLAS
+// kernels of the diagonal blocks and panel solves, serialised with the updates.
+// info[0] = 0 or 1-based index of the first non-positive pivot, as potrf.
+#ifndef AGPL_DENSE_NB
+#define AGPL_DENSE_NB 2048 // measured at C5 on one box (profiles/r03_c5_block_width.txt): 512 / 1024 / 2048 / 4096 -> 1876 / 1763 / 1741 / 1743 ms per step
+#endif
 int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
-    constexpr int64_t nb = 2048;
+    constexpr int64_t nb = AGPL_DENSE_NB;
+    static_assert(nb % kTK == 0, "panel width must be whole stages");
     AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), ctx->stream));
     AGPL_ROCBLAS(ctx, rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
-    const double one = 1.0, mone = -1.0;
+    const double one = 1.0;
+    const size_t lds = sizeof(double) * 4 * kTStage;
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trailing_update_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int64_t k = 0; k < N; k += nb) {
         const int64_t e = k + nb < N ? k + nb : N, w = e - k;
         double *Akk = A + k + k * N;
@@ -103,14 +233,10 @@ int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, roc
         AGPL_ROCBLAS(ctx, rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
                                         rocblas_diagonal_non_unit, (rocblas_int)m, (rocblas_int)w, &one, Akk,
                                         (rocblas_int)N, A21, (rocblas_int)N));
-        // trailing lower block-triangle: A[j:, j:je] -= A[j:, k:e] A[j:je, k:e]'
-        for (int64_t j = e; j < N; j += nb) {
-            const int64_t je = j + nb < N ? j + nb : N;
-            AGPL_ROCBLAS(ctx, rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose,
-                                            (rocblas_int)(N - j), (rocblas_int)(je - j), (rocblas_int)w, &mone,
-                                            A + j + k * N, (rocblas_int)N, A + j + k * N, (rocblas_int)N, &one,
-                                            A + j + j * N, (rocblas_int)N));
-        }
+        // trailing lower triangle: A[e:, e:] -= A21 A21'
+        const int64_t nt = (m + kTT - 1) / kTT;
+        trailing_update_kernel<<<(unsigned)(nt * (nt + 1) / 2), 256, lds, ctx->stream>>>(N, A, k, (int)w, (int)nt);
+        AGPL_LAUNCH_CHECK(ctx);
     }
     return AGPL_OK;
 }

@@ -15,7 +15,7 @@ At N = 1 the same JSON line also carries (each skippable by a --no-... flag):
            its own roofline and a 10-sweep parity slice;
   "gibbs"  the Gibbs half on the resident workload (point pass, PG sampler rates for Bernoulli AND NegBin r = 15);
   "parity" 10 sweeps on a 20 000-point slice against the oracle; "full_size_check"; "cpu_baseline";
-  "c5"     BASELINE configs[4]: StudentT full-rank Gibbs step at N = 65 536 (float64; library N^3).
+  "c5"     BASELINE configs[4]: StudentT full-rank Gibbs step at N = 65 536 (float64).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000000] [--m 512] [--lik bernoulli]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -247,9 +247,10 @@ def m1024_leg(A, ctx, args):
 
 def c5_leg(A, args):
     """BASELINE configs[4]: StudentTLikelihood Gibbs path, aug_sample (Gamma) + the full-rank N = 65 536 conditional
-    solve of examples/studentt/script.jl (gibbs_sample, :76-87 of the bernoulli example), float64.  The N^3 work is
-    rocSOLVER / rocBLAS calls in a blocked arrangement (labelled "library"); the rate is priced against
-    the float64 MFMA rate measured by the library's own probe kernel on this device."""
+    solve of examples/studentt/script.jl (gibbs_sample, :76-87 of the bernoulli example), float64.  The N^3 / 3 of the
+    Cholesky is the hand-written float64-MFMA trailing update of agpl_dense.hip (diagonal blocks and panel solves are
+    rocSOLVER / rocBLAS calls); the rate is priced against the float64 MFMA rate measured by the library's own
+    probe kernel on this device."""
     import torch
     from agpl_amd import _ffi
 
@@ -279,7 +280,8 @@ def c5_leg(A, args):
     tf = N ** 3 / 3 / dt / 1e12
     out = {"config": {"workload": f"StudentT(3.5, 2.0) full-rank Gibbs step, N={N}, SE kernel lengthscale 2.0, jitter 1e-6"},
            "value": round(1.0 / dt, 4), "unit": "sweeps/s", "ms_per_step": round(dt * 1e3, 1), "steps": steps, "dtype": "f64",
-           "n3_work": "library (rocSOLVER dpotrf on 2048-blocks + rocBLAS dtrsm/dgemm, blocked by agpl_dense.hip)",
+           "n3_work": "trailing update (the N^3/3): hand-written float64-MFMA lower-triangle kernel (agpl_dense.hip "
+                      "trailing_update_kernel); 2048-wide diagonal blocks and panel solves: rocSOLVER dpotrf / rocBLAS dtrsm",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s (N^3/3 per sweep, float64)",
                         "peak": round(peak.value, 1), "peak_source": "agpl_probe_mfma_f64: v_mfma_f64_16x16x4_f64 "
                         "back-to-back on every SIMD, measured on this device in this run",
