@@ -12,8 +12,8 @@ def means(root, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 KNOWN = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "syrk_strip_kernel", "syrk_split_kernel",
-         "reduce_slab_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_kernel", "split_prep_kernel",
-         "aux_sample_kernel")
+         "agpl_fused_point_kernel", "reduce_slab_kernel", "reduce_G_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_kernel",
+         "split_prep_kernel", "acc_prep_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel")
 
 
 def short(n):
@@ -29,7 +29,8 @@ for r in csv.DictReader(open(sys.argv[3])):
 N, M = 10_000_000, 512
 alg = {"marginal_split256_kernel": N * M * 4, "syrk_split_kernel": N * M * 4,
        "marginal_factor_persist_kernel": N * M * 4, "marginal_factor_queue_kernel": N * M * 4, "syrk_strip_kernel": N * M * 4, "gibbs_project_kernel": N * (M * 4 + 8),
-       "gibbs_sample_kernel": N * 24, "reduce_slab_kernel": None}
+       "gibbs_sample_kernel": N * 24, "reduce_slab_kernel": None, "agpl_fused_point_kernel": N * (2 * 2 * 4 + 4 + 1 + 8),
+       "aux_sample_pg1_kernel": N * 16}
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-cpu "
                "--no-parity at C2 (bernoulli N=1e7 M=512). FETCH_SIZE is reported in KiB and doubled per "
                "MI355X_MICROARCH.md 'HBM' (16 B/lane coalesced reads report 1/2; calibrated on reduce_slab_kernel: "
