@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B + correctness of the image accumulation (agpl_syrk.hip) against the float32-staged split kernel and a
-float64 reference: python tools/ab_syrk_image.py --n 4000000 --m 512 [--envs "AGPL_SYRKQ_CV=0;AGPL_SYRKQ_CV=1"]."""
+float64 reference: python tools/ab_syrk_image.py --n 4000000 --m 512 [--envs "AGPL_LIB_AB=libagpl.so;AGPL_LIB_AB=libagpl_variant.so"] (the library reads no environment variable: variants are builds)."""
 import argparse, ctypes as C, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
