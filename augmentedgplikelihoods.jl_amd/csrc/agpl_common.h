@@ -20,6 +20,8 @@ struct agpl_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     void *rocblas = nullptr; // rocblas_handle, created lazily by agpl_update.hip
+    hipStream_t aux_stream = nullptr; // high-priority side stream of the dense Cholesky's look-ahead (agpl_dense.hip), lazily created
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
     // scratch (lazily grown)
     void *ws = nullptr;
     size_t ws_bytes = 0;

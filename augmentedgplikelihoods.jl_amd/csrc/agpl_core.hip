@@ -43,6 +43,9 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
     if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
     if (ctx->pend_ev) (void)hipEventDestroy(ctx->pend_ev);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->aux_ev[i]) (void)hipEventDestroy(ctx->aux_ev[i]);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return AGPL_OK;

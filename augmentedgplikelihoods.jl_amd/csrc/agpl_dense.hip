@@ -11,9 +11,9 @@
 //   B = I + D^1/2 K D^1/2 = C C'      (D = Diag(gamma); ONE float64 Cholesky per sweep: rocSOLVER potrf)
 //   f = f0 + K D^1/2 B^-1 (D^-1/2 beta - D^1/2 f0 - z2),   f0 = mu0 + L_K z1,  z1, z2 ~ N(0, I)
 // which is an exact draw from N(mu, Sigma) (Matheron's rule with pseudo-observations yhat = D^-1 beta of noise
-// variance D^-1).  The N^3 / 3 of the Cholesky is the hand-written float64-MFMA trailing update below; the 2048-wide
-// diagonal blocks, the panel solves and the matrix-vector products are rocSOLVER / rocBLAS calls; the sampler (agpl_ops.hip)
-// and the fused elementwise steps are hand-written.
+// variance D^-1).  The Cholesky is hand-written: the N^3 / 3 as a float64-MFMA trailing update, the 2048-wide diagonal blocks
+// by own kernels overlapped with it on a side stream (look-ahead); the panel solves (dtrsm) and the matrix-vector products are
+// rocBLAS calls; the sampler (agpl_ops.hip) and the fused elementwise steps are hand-written.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -101,32 +101,37 @@ constexpr int kTK = 16;       // panel columns per stage
 constexpr int kTPitch = 144;  // doubles per LDS row of a stage
 constexpr int kTStage = kTK * kTPitch; // doubles per operand and stage
 
-template <bool DIAG>
-__device__ __forceinline__ void trailing_tile(double *smem, int64_t N, double *__restrict__ A, int64_t k0, int w, int64_t r0,
-                                              int64_t c0) {
+// The tile routine in its general form:  C[r][c] (-)= sum_{q < w} X[r][q] Y[c][q]  for the 128 x 128 tile at (r0, c0).
+// X[r][q] = Xp[r + q ldx], Y[c][q] = Yp[c + q ldy], C[r][c] = Cp[r + c ldc]; rows r < rmax and columns c < cmax exist (loads beyond
+// are clamped, stores guarded).  DIAG: X and Y are the same rows (one load) and only r >= c is stored.  ASSIGN: C = X Y' instead of
+// C -= X Y' (the in-block panel solve B <- B U': C may alias X because a tile reads all of its X rows before it writes).
+template <bool DIAG, bool ASSIGN>
+__device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int64_t ldx, const double *Yp, int64_t ldy,
+                                             double *Cp, int64_t ldc, int w, int64_t r0, int64_t c0, int64_t rmax,
+                                             int64_t cmax) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
     const int li = lane & 15, lq = lane >> 4;
     // staging role: rows (tid & 63) * 2, +1 of the tile; panel columns (tid >> 6) + 4 i
     const int srow = (tid & 63) * 2, sq = tid >> 6;
     int64_t gr = r0 + srow, gc = c0 + srow;
-    if (gr > N - 2) gr = N - 2; // (rows beyond N are never stored: any in-range address will do)
-    if (gc > N - 2) gc = N - 2;
-    const double *pr = A + gr + (k0 + sq) * N, *pc = A + gc + (k0 + sq) * N;
+    if (gr > rmax - 2) gr = rmax - 2; // (rows beyond the limit are never stored: any in-range address will do)
+    if (gc > cmax - 2) gc = cmax - 2;
+    const double *pr = Xp + gr + sq * ldx, *pc = Yp + gc + sq * ldy;
     double *sR = smem, *sC = smem + 2 * kTStage; // [stage][q][row]
     double2 vr0, vr1, vr2, vr3, vc0, vc1, vc2, vc3; // the next stage, in flight during the MFMAs of the current one
 #define AGPL_T_GLOAD(kt_)                                                                                       \
     do {                                                                                                        \
-        const double *qr_ = pr + (int64_t)(kt_) * kTK * N, *qc_ = pc + (int64_t)(kt_) * kTK * N;                \
+        const double *qr_ = pr + (int64_t)(kt_) * kTK * ldx, *qc_ = pc + (int64_t)(kt_) * kTK * ldy;            \
         vr0 = *reinterpret_cast<const double2 *>(qr_);                                                          \
-        vr1 = *reinterpret_cast<const double2 *>(qr_ + 4 * N);                                                  \
-        vr2 = *reinterpret_cast<const double2 *>(qr_ + 8 * N);                                                  \
-        vr3 = *reinterpret_cast<const double2 *>(qr_ + 12 * N);                                                 \
+        vr1 = *reinterpret_cast<const double2 *>(qr_ + 4 * ldx);                                                \
+        vr2 = *reinterpret_cast<const double2 *>(qr_ + 8 * ldx);                                                \
+        vr3 = *reinterpret_cast<const double2 *>(qr_ + 12 * ldx);                                               \
         if (!DIAG) {                                                                                            \
             vc0 = *reinterpret_cast<const double2 *>(qc_);                                                      \
-            vc1 = *reinterpret_cast<const double2 *>(qc_ + 4 * N);                                              \
-            vc2 = *reinterpret_cast<const double2 *>(qc_ + 8 * N);                                              \
-            vc3 = *reinterpret_cast<const double2 *>(qc_ + 12 * N);                                             \
+            vc1 = *reinterpret_cast<const double2 *>(qc_ + 4 * ldy);                                            \
+            vc2 = *reinterpret_cast<const double2 *>(qc_ + 8 * ldy);                                            \
+            vc3 = *reinterpret_cast<const double2 *>(qc_ + 12 * ldy);                                           \
         }                                                                                                       \
     } while (0)
 #define AGPL_T_SWRITE(st_)                                                                                      \
@@ -174,7 +179,7 @@ __device__ __forceinline__ void trailing_tile(double *smem, int64_t N, double *_
     }
 #undef AGPL_T_GLOAD
 #undef AGPL_T_SWRITE
-    // A[r][c] -= D[c][r]: register rr of lane l holds D[16 m + 4 rr + lq][16 n + li]
+    // C[r][c] (-)= D[c][r]: register rr of lane l holds D[16 m + 4 rr + lq][16 n + li]
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -183,61 +188,192 @@ __device__ __forceinline__ void trailing_tile(double *smem, int64_t N, double *_
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int64_t r = r0 + wr * 64 + 16 * n + li;
-                if (r < N && c < N && (!DIAG || r >= c)) A[r + c * N] -= acc[m][n][rr];
+                if (r < rmax && c < cmax && (!DIAG || r >= c)) {
+                    if (ASSIGN) Cp[r + c * ldc] = acc[m][n][rr];
+                    else Cp[r + c * ldc] -= acc[m][n][rr];
+                }
             }
         }
 }
 
-__global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int nt) {
+// grid (tile rows, tile columns): tile (I, j0 + blockIdx.y) of the lower triangle of A[e:lim, e:lim], e = k0 + w; the upper
+// block triangle exits
+__global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int j0,
+                                                                 int64_t lim) {
     extern __shared__ __attribute__((aligned(16))) double tsm[];
-    // tile (I, J), J <= I, of the trailing matrix, row by row of the lower block triangle
-    const int64_t p = blockIdx.x;
-    int64_t I = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= p) ++I;
-    while (I * (I + 1) / 2 > p) --I;
-    const int64_t J = p - I * (I + 1) / 2;
+    const int64_t I = blockIdx.x, J = (int64_t)j0 + blockIdx.y;
+    if (I < J) return;
     const int64_t e = k0 + w;
-    if (I == J) trailing_tile<true>(tsm, N, A, k0, w, e + I * kTT, e + J * kTT);
-    else trailing_tile<false>(tsm, N, A, k0, w, e + I * kTT, e + J * kTT);
+    const double *P = A + k0 * N; // the panel: P[r][q] = A[r][k0 + q]
+    if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
+    else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
 }
 
-// Lower Cholesky (column-major view, in place) of an N x N float64 matrix as a right-looking blocked factorisation:
-// rocsolver_dpotrf on the 2048-wide diagonal blocks, one rocblas dtrsm per panel (together ~12 % of the flops at N = 65536),
-// and the trailing lower triangle -- the N^3 / 3 -- by trailing_update_kernel above (rounds 1-2: one rocblas dgemm per block
-// column, 54.7 TF/s at C5).  Round 3, N = 65536: the kernel runs at 63.4 TF/s = 0.96 of the probe's 65.9 TF/s
-// (profiles/r03_c5_kernel_stats.csv: 1404 ms of a 1741 ms step); what remains is the chain of small rocSOLVER / rocBLAS
-// kernels of the diagonal blocks and panel solves, serialised with the updates.
+// ------------------------------------------------------------------------------------------------
+// The diagonal blocks, by our own kernels (round 3).  rocsolver_dpotrf may not run beside another kernel (its results then
+// differ from run to run: DESIGN 4.7), and the look-ahead wants exactly that.  A 2048-wide diagonal block is factored 64 columns
+// at a time: potrf64_kernel (one workgroup: Cholesky of the 64 x 64 block in LDS, and its inverse U = R^-1), the rows below it
+// within the block by B <- B U' (panel_solve_kernel, the tile routine in ASSIGN mode) and the rest of the block by the trailing
+// update above with w = 64.  About 100 us per step, 3 ms per block -- hidden behind the previous step's update.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPB = 64;
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), srclane);
+    return __hiloint2double(hi, lo);
+}
+// One WAVE, no barriers: lane r keeps row r of the block in registers; column step c reads the pivot and the multipliers of the
+// other rows by v_readlane (the loop is fully unrolled: register and lane indices are constants) -- 2016 readlane + FMA pairs, ~12 k
+// instructions.  A first version with 256 threads, the block in LDS and three barriers per column took 240 us beside the update
+// kernel (profiles/r03_c5_kernel_stats_lookahead_v1.csv).  Then U = R^-1, lane j owning column j: R is read back from LDS at
+// wave-uniform addresses (broadcast reads).
+__global__ __launch_bounds__(64) void potrf64_kernel(int64_t ld, double *__restrict__ D, double *__restrict__ Uout,
+                                                     rocblas_int *__restrict__ info, int first_row) {
+    __shared__ double rs[kPB][kPB + 1]; // rs[c][r] = R[r][c]
+    __shared__ double rinv[kPB];        // 1 / R[c][c]
+    __builtin_amdgcn_s_setprio(3); // this wave is the critical path of the side stream; the update's waves fill every SIMD around it
+    const int lane = threadIdx.x;
+    double a[kPB];
+#pragma unroll
+    for (int c = 0; c < kPB; ++c) a[c] = c <= lane ? D[lane + (int64_t)c * ld] : 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < kPB; ++c) {
+        const double p = readlane_f64(a[c], c);
+        if (!(p > 0.0) && bad == 0) bad = c + 1;
+        // 1 / sqrt(p) by v_rsq_f64 + two Newton steps (rounding-limited; the sqrt + divide sequences are ~150 dependent
+        // instructions per column on this single wave's critical path)
+        double r0 = __builtin_amdgcn_rsq(p);
+        r0 = r0 * (1.5 - 0.5 * p * r0 * r0);
+        r0 = r0 * (1.5 - 0.5 * p * r0 * r0);
+        if (lane == 0) rinv[c] = r0;
+        const double l = lane == c ? p * r0 : a[c] * r0; // R[lane][c] (rows above the diagonal carry zeros, then harmless leftovers)
+        a[c] = l;
+#pragma unroll
+        for (int j = c + 1; j < kPB; ++j) a[j] -= l * readlane_f64(l, j);
+    }
+#pragma unroll
+    for (int c = 0; c < kPB; ++c) {
+        const double v = c <= lane ? a[c] : 0.0;
+        rs[c][lane] = v;
+        if (c <= lane) D[lane + (int64_t)c * ld] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // U = R^-1, column `lane`: u_i = (delta_{i,lane} - sum_{k < i} R[i][k] u_k) / R[i][i]   (u_k = 0 for k < lane falls out)
+    double u[kPB];
+#pragma unroll
+    for (int i = 0; i < kPB; ++i) {
+        double acc = i == lane ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= rs[k][i] * u[k];
+        u[i] = acc * rinv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kPB; ++i) Uout[i + lane * kPB] = i >= lane ? u[i] : 0.0; // U[i][lane] at i + 64 lane
+    if (lane == 0 && bad && info[0] == 0) info[0] = first_row + bad;
+}
+
+// B <- B U' for the rows r0 .. rmax of the 64 columns at Bp (ld): one workgroup per 128 rows
+__global__ __launch_bounds__(256, 2) void panel_solve_kernel(int64_t ld, double *__restrict__ Bp, const double *__restrict__ U,
+                                                             int64_t r0, int64_t rmax) {
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    __builtin_amdgcn_s_setprio(3);
+    gemm_nt_tile<false, true>(tsm, Bp, ld, U, kPB, Bp, ld, kPB, r0 + (int64_t)blockIdx.x * kTT, 0, rmax, kPB);
+}
+
+// one diagonal block A[k : k + W, k : k + W] (W a multiple of 64) on `st`, by the three kernels above
+int32_t own_block_potrf(agpl_ctx *ctx, hipStream_t st, int64_t N, double *A, int64_t k, int64_t W, double *Ubuf,
+                        rocblas_int *info) {
+    const size_t lds = sizeof(double) * 4 * kTStage;
+    for (int64_t j = 0; j < W; j += kPB) {
+        const int64_t kj = k + j, rem = k + W - (kj + kPB);
+        potrf64_kernel<<<1, 64, 0, st>>>(N, A + kj + kj * N, Ubuf, info, (int)kj);
+        if (rem > 0) {
+            const unsigned nt = (unsigned)((rem + kTT - 1) / kTT);
+            panel_solve_kernel<<<nt, 256, lds, st>>>(N, A + kj * N, Ubuf, kj + kPB, k + W);
+            trailing_update_kernel<<<dim3(nt, nt), 256, lds, st>>>(N, A, kj, kPB, 0, k + W);
+        }
+    }
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+// Lower Cholesky (column-major view, in place) of an N x N float64 matrix as a right-looking blocked factorisation with
+// look-ahead on two streams.  Per 2048-wide step k: the diagonal block (own_block_potrf), the panel solve (one rocblas dtrsm)
+// and the update of the trailing lower triangle -- the N^3 / 3 -- by trailing_update_kernel (rounds 1-2: one rocblas dgemm per
+// block column, 54.7 TF/s at C5).  The update by panel k is launched in two parts: first the tile columns that form block column
+// k + 1, then the rest; as soon as the first part is done, block k + 1 is factored and panel k + 1 solved on a high-priority side
+// stream WHILE the rest of update k keeps the matrix pipes busy on the main stream (disjoint columns; events both ways).  Without
+// the look-ahead the chain of small kernels sat between the updates: 1741 ms per C5 step, 1404 of them in the update kernel.
+// A last block that is not a multiple of 64 wide goes to rocsolver_dpotrf (alone on the device by then).
 // info[0] = 0 or 1-based index of the first non-positive pivot, as potrf.
 #ifndef AGPL_DENSE_NB
-#define AGPL_DENSE_NB 2048 // measured at C5 on one box (profiles/r03_c5_block_width.txt): 512 / 1024 / 2048 / 4096 -> 1876 / 1763 / 1741 / 1743 ms per step
+#define AGPL_DENSE_NB 2048 // measured at C5 on one box without look-ahead (profiles/r03_c5_block_width.txt): 512 / 1024 / 2048 / 4096 -> 1876 / 1763 / 1741 / 1743 ms per step
 #endif
 int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
     constexpr int64_t nb = AGPL_DENSE_NB;
-    static_assert(nb % kTK == 0, "panel width must be whole stages");
-    AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), ctx->stream));
+    static_assert(nb % kTK == 0 && nb % kTT == 0 && nb % kPB == 0, "panel width must be whole stages, tiles and blocks");
+    hipStream_t S = ctx->stream;
+    if (!ctx->aux_stream) {
+        int least = 0, greatest = 0;
+        AGPL_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        AGPL_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, greatest));
+        for (int i = 0; i < 2; ++i) AGPL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
+    }
+    hipStream_t X = ctx->aux_stream;
+    hipEvent_t ev_col = ctx->aux_ev[0], ev_panel = ctx->aux_ev[1];
+    double *Ubuf = (double *)((char *)ctx->ws2 + 20480); // 64 x 64 doubles (callers reserve 64 KB of the small workspace)
+    AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), S));
     AGPL_ROCBLAS(ctx, rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
     const double one = 1.0;
     const size_t lds = sizeof(double) * 4 * kTStage;
     AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trailing_update_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_solve_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipStream_t cur = S; // the stream the diagonal block / panel of this step run on
     for (int64_t k = 0; k < N; k += nb) {
         const int64_t e = k + nb < N ? k + nb : N, w = e - k;
         double *Akk = A + k + k * N;
-        AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)w, Akk, (rocblas_int)N, info + 1));
-        or_info_kernel<<<1, 64, 0, ctx->stream>>>(info, (int)k);
-        AGPL_LAUNCH_CHECK(ctx);
+        if (w % kPB == 0) {
+            int32_t rc = own_block_potrf(ctx, cur, N, A, k, w, Ubuf, info);
+            if (rc) return rc;
+        } else { // (only the last block can be ragged)
+            AGPL_ROCBLAS(ctx, rocblas_set_stream(h, cur));
+            AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)w, Akk, (rocblas_int)N, info + 1));
+            or_info_kernel<<<1, 64, 0, cur>>>(info, (int)k);
+            AGPL_LAUNCH_CHECK(ctx);
+        }
+        if (e < N) {
+            const int64_t m = N - e;
+            double *A21 = A + e + k * N;
+            // A21 <- A21 L11^-T
+            AGPL_ROCBLAS(ctx, rocblas_set_stream(h, cur));
+            AGPL_ROCBLAS(ctx, rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
+                                            rocblas_diagonal_non_unit, (rocblas_int)m, (rocblas_int)w, &one, Akk,
+                                            (rocblas_int)N, A21, (rocblas_int)N));
+        }
+        if (cur == X) { // the main stream continues once this panel is there
+            AGPL_HIP(ctx, hipEventRecord(ev_panel, X));
+            AGPL_HIP(ctx, hipStreamWaitEvent(S, ev_panel, 0));
+        }
         if (e == N) break;
-        const int64_t m = N - e;
-        double *A21 = A + e + k * N;
-        // A21 <- A21 L11^-T
-        AGPL_ROCBLAS(ctx, rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
-                                        rocblas_diagonal_non_unit, (rocblas_int)m, (rocblas_int)w, &one, Akk,
-                                        (rocblas_int)N, A21, (rocblas_int)N));
-        // trailing lower triangle: A[e:, e:] -= A21 A21'
-        const int64_t nt = (m + kTT - 1) / kTT;
-        trailing_update_kernel<<<(unsigned)(nt * (nt + 1) / 2), 256, lds, ctx->stream>>>(N, A, k, (int)w, (int)nt);
+        // trailing lower triangle: A[e:, e:] -= A21 A21', block column k + 1 first
+        const int64_t m = N - e, nt = (m + kTT - 1) / kTT;
+        const int64_t ncol1 = nt < nb / kTT ? nt : nb / kTT;
+        trailing_update_kernel<<<dim3((unsigned)nt, (unsigned)ncol1), 256, lds, S>>>(N, A, k, (int)w, 0, N);
         AGPL_LAUNCH_CHECK(ctx);
+        AGPL_HIP(ctx, hipEventRecord(ev_col, S));
+        AGPL_HIP(ctx, hipStreamWaitEvent(X, ev_col, 0));
+        if (nt > ncol1) {
+            trailing_update_kernel<<<dim3((unsigned)nt, (unsigned)(nt - ncol1)), 256, lds, S>>>(N, A, k, (int)w, (int)ncol1, N);
+            AGPL_LAUNCH_CHECK(ctx);
+        }
+        cur = X;
     }
+    AGPL_ROCBLAS(ctx, rocblas_set_stream(h, S));
     return AGPL_OK;
 }
 
@@ -286,7 +422,7 @@ extern "C" int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A
         copy_kernel<<<4096, 256, 0, ctx->stream>>>(N * N, A, L_out);
         AGPL_LAUNCH_CHECK(ctx);
     }
-    rc = agpl_ws2_reserve(ctx, 32768);
+    rc = agpl_ws2_reserve(ctx, 65536);
     if (rc) return rc;
     rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + 16384);
     if (N >= 8192) {
@@ -340,7 +476,7 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     dim3 gb((unsigned)(agpl_cdiv(N, 512) < 64 ? agpl_cdiv(N, 512) : 64), (unsigned)N);
     build_b_kernel<<<gb, 256, 0, ctx->stream>>>(N, K, gamma, B_work);
     AGPL_LAUNCH_CHECK(ctx);
-    rc = agpl_ws2_reserve(ctx, 32768);
+    rc = agpl_ws2_reserve(ctx, 65536);
     if (rc) return rc;
     rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + 16384);
     if (N >= 8192) {
