@@ -136,6 +136,61 @@ def test_c4_categorical_k10_gibbs_counts_bit_exact(A, ctx, oracle):
 
 
 @pytest.mark.timeout(600)
+def test_c3_per_rank_full_size_properties(A, ctx):
+    """C3 at the size ONE rank of its 8-GPU configuration holds (NegBin r = 15, N = 1e7 / 8 = 1.25e6, M = 1024): sizes the
+    oracle cannot reach, so size-independent properties of the shipped path -- exact symmetry, bitwise reproducibility,
+    tr G = sum_n gamma_n |phi_n|^2 and g = Phi beta against float64 reductions, gamma = (y + r) tanh(c / 2) / (2 c) in
+    (0, (y + r) / 4], additivity over N (the sharding identity), a full sweep through the two-block M x M factor route, and
+    one Gibbs point pass with finite positive draws (negativebinomial.jl:20-49)."""
+    N, M, r = 1_250_000, 1024, 15.0
+    lik = A.NegativeBinomialLikelihood(r)
+    x, y, Phi, kd = setup_svgp(A, ctx, lik, N, M)
+
+    def make(sl=slice(None)):
+        return shipped(A, lik, Phi[sl], kd[sl], y[sl], ctx, keep_points=True)
+
+    try:
+        cavi = make()
+        assert cavi.Phi_acc is not None  # the image accumulation (M % 256 == 0)
+        mu, var = cavi.marginals()
+        assert mu.abs().max().item() == 0.0 and (var - 1.0).abs().max().item() < 4e-5
+        cavi.accumulate()
+        G1, g1 = cavi.G.clone(), cavi.g.clone()
+        assert torch.equal(G1, G1.transpose(1, 2))
+        gam, bet = cavi.gamma[0], cavi.beta[0]
+        assert torch.isfinite(gam).all() and (gam > 0).all() and bool((gam <= (y.float() + r) / 4 * (1 + 1e-6)).all())
+        assert torch.equal(bet, ((y.float() - r) / 2))
+        tr = 0.0
+        gref = torch.zeros(M, dtype=torch.float64, device="cuda")
+        for i0 in range(0, N, 250_000):
+            P = Phi[i0:i0 + 250_000].double()
+            tr += (gam[i0:i0 + 250_000].double() * (P * P).sum(1)).sum().item()
+            gref += P.T @ bet[i0:i0 + 250_000].double()
+        assert torch.diagonal(G1[0]).sum().item() == pytest.approx(tr, rel=2e-6)
+        assert relmax(host(g1[0]), host(gref)) < 2e-6
+        cavi.accumulate()
+        assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
+        for _ in range(3):  # the two-block factor route (M = 1024) inside whole sweeps
+            cavi.sweep()
+        cavi.check()
+        assert torch.isfinite(cavi.G).all() and torch.isfinite(cavi.v).all()
+        del cavi
+        h = N // 2
+        acc = None
+        for sl in (slice(0, h), slice(h, N)):
+            c = make(sl)
+            c.accumulate()
+            acc = (c.G.clone(), c.g.clone()) if acc is None else (acc[0] + c.G, acc[1] + c.g)
+            del c
+        assert relmax(host(acc[0]), host(G1)) < 2e-6 and relmax(host(acc[1]), host(g1)) < 2e-6
+        gib = A.SparseGibbs(lik, Phi, kd, y, ctx=A.Context(0, seed=SEED + 1), keep_points=True)
+        gib.sweep()
+        assert torch.isfinite(gib.omega).all() and (gib.omega > 0).all() and torch.isfinite(gib.v).all()
+        assert torch.equal(gib.G, gib.G.transpose(1, 2))
+    finally:
+        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+
+
 def test_c4_full_size_properties(A, ctx):
     """C4 at its configured size (K = 10, N = 1e6, M = 256): sizes the oracle cannot reach, so size-independent
     properties of one accumulation of the shipped path, per latent: exact symmetry, bitwise reproducibility,
