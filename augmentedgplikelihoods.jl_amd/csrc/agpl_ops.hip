@@ -116,8 +116,9 @@ __device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, 
 }
 
 // sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: the lane only helps).
-// sub_base is uniform over the workgroup.
-__device__ inline double pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, uint32_t sub_base, int tb,
+// sub_base is uniform over the workgroup.  __forceinline__ (and its callers): left to its heuristics the inliner turned this into a
+// real call in some builds -- the negative-binomial kernel then ran 18.0 instead of 8.6 ms per 4e6 points.
+__device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, uint32_t sub_base, int tb,
                                           double c, uint32_t &nuni, uint32_t &nterms) {
     PGT_DECL();
     if (tb > 0) {
@@ -324,7 +325,7 @@ __device__ inline double pg_int_sum_block(PgBlockScratch *scr, int wave, int lan
 // series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all threads of the workgroup.  INT: b is
 // known to be an integer (Bernoulli: no Gamma-series code in the kernel).
 template <bool INT = false>
-__device__ inline double pg_point_wave(PgBlockScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
+__device__ __forceinline__ double pg_point_wave(PgBlockScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
                                        double c, uint32_t &nterms, int *bad) {
     const int wave = (int)(threadIdx.x >> 6);
     // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
@@ -349,7 +350,7 @@ __device__ inline double pg_point_wave(PgBlockScratch *scr, int lane, bool valid
 }
 
 template <int KIND>
-__device__ inline void sample_point_wave(const agpl_lik_dev &lik, PgBlockScratch *scr, int lane, bool valid, Philox &g,
+__device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlockScratch *scr, int lane, bool valid, Philox &g,
                                          int64_t i, const void *yv, const double *f, double *om, int64_t *nn,
                                          uint32_t &nt, int *bad) {
     const int L = lik.nlatent;
@@ -503,10 +504,19 @@ struct Pg1BlockScratch {
     int qn, q2n, qhead, rn;
 };
 
+// GIBBS: the Bernoulli point pass of a sparse Gibbs sweep in the same kernel -- f_i = projection_i + sqrt(d_i) eps_i (+ mu0_i) on the
+// point's main stream (two uniforms) is formed in phase A and written over the projection (fbuf, read back by the later phases),
+// and a finished draw also leaves gamma_i = omega_i, beta_i = +-1/2 (auglik_precision / auglik_potential, bernoulli.jl:27-33).
+template <bool GIBBS>
 __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, const double *__restrict__ f,
                                                                    double *__restrict__ omega, uint64_t seed, uint64_t i0,
                                                                    uint32_t sweep, uint32_t *__restrict__ nuni_out,
-                                                                   uint32_t *__restrict__ nterms_out) {
+                                                                   uint32_t *__restrict__ nterms_out, double *fbuf,
+                                                                   const float *__restrict__ kdiag, const float *__restrict__ mu0,
+                                                                   const uint8_t *__restrict__ y, float *__restrict__ gamma,
+                                                                   float *__restrict__ beta, double *__restrict__ f_out) {
+    if (GIBBS) f = fbuf;
+    constexpr uint32_t kMain = GIBBS ? 2u : 0u; // uniforms the point's main stream has consumed (the normal of f)
     __shared__ Pg1BlockScratch scr;
     const int lane = threadIdx.x & 63;
     const int64_t nblocks = (n + kPg1Slots - 1) / kPg1Slots;
@@ -522,9 +532,13 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
         }
     };
     auto finish = [&](int64_t i, double w, const Philox &s, uint32_t nt) {
-        omega[i] = w;
-        if (nuni_out) nuni_out[i] = s.nuni;
+        if (!GIBBS || omega) omega[i] = w;
+        if (nuni_out) nuni_out[i] = kMain + s.nuni;
         if (nterms_out) nterms_out[i] = nt;
+        if (GIBBS) {
+            gamma[i] = (float)w;
+            beta[i] = y[i] ? 0.5f : -0.5f;
+        }
     };
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int64_t base = blk * kPg1Slots;
@@ -536,11 +550,21 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
             const int64_t i = base + slot;
             bool to_b = false, to_b2 = false, to_c = false;
             if (i < n) {
-                const double c = fabs(f[i]);
+                double fi;
+                if (GIBBS) { // (the point half of gibbs_sample_points for this likelihood)
+                    Philox g;
+                    g.init(seed, i0 + (uint64_t)i, sweep);
+                    const double kd = (double)kdiag[i];
+                    fi = fbuf[i] + sqrt(kd > 0.0 ? kd : 0.0) * g.normal();
+                    if (mu0) fi += (double)mu0[i];
+                    fbuf[i] = fi;
+                    if (f_out) f_out[i] = fi;
+                } else
+                    fi = f[i];
+                const double c = fabs(fi);
                 if (!(c < __builtin_inf())) { // NaN / Inf in, NaN out (rand_pg_int)
-                    omega[i] = __builtin_nan("");
-                    if (nuni_out) nuni_out[i] = 0u;
-                    if (nterms_out) nterms_out[i] = 0u;
+                    finish(i, __builtin_nan(""), g0, 0u);
+                    if (nuni_out) nuni_out[i] = kMain;
                 } else {
                     const double z = c / 2.0, K = kPi2_8 + z * z / 2.0; // (= Pg1Params::set, bit for bit)
                     const double r = pg_mass_fit(z < 8.0 ? z : 0.0);
@@ -1231,8 +1255,9 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     case AGPL_LIK_BERNOULLI_LOGISTIC: { // one draw per point: the kernel with the long trial queue
         int64_t nb = agpl_cdiv(n, kPg1Slots);
         if (nb > 256 * 4 * 8) nb = 256 * 4 * 8;
-        aux_sample_pg1_kernel<<<(unsigned)nb, kBlock, 0, ctx->stream>>>(n, f, omega_out, ctx->seed, (uint64_t)ctx->point_offset,
-                                                                        sweep, nuni_out, nterms_out);
+        aux_sample_pg1_kernel<false><<<(unsigned)nb, kBlock, 0, ctx->stream>>>(
+            n, f, omega_out, ctx->seed, (uint64_t)ctx->point_offset, sweep, nuni_out, nterms_out, nullptr, nullptr, nullptr, nullptr,
+            nullptr, nullptr, nullptr);
     } break;
         AGPL_LAUNCH_AUX(AGPL_LIK_NEGBINOMIAL)
         AGPL_LAUNCH_AUX(AGPL_LIK_STUDENTT)
@@ -1784,7 +1809,13 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
                                                                            bad);                                     \
         break;
         switch (ld.kind) {
-            AGPL_LAUNCH_GIBBS_S(AGPL_LIK_BERNOULLI_LOGISTIC)
+        case AGPL_LIK_BERNOULLI_LOGISTIC: { // one PG(1, |f_i|) draw per point: the kernel with the long trial queue (f over proj_work)
+            int64_t nb1 = agpl_cdiv(N, kPg1Slots);
+            if (nb1 > 256 * 4 * 8) nb1 = 256 * 4 * 8;
+            aux_sample_pg1_kernel<true><<<(unsigned)nb1, kBlock, 0, ctx->stream>>>(
+                N, nullptr, omega_out, ctx->seed, (uint64_t)ctx->point_offset, sweep, nuni_out, nullptr, proj_work, kdiag, mu0,
+                (const uint8_t *)y, gamma, beta, f_out);
+        } break;
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_NEGBINOMIAL)
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_STUDENTT)
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_CATEGORICAL)
