@@ -57,8 +57,15 @@ def run(image):
     call(); call()
     torch.cuda.synchronize()
     lib.agpl_timing_enable(ctx.bind(), 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.ExternalStream(ctx.stream_handle()) if hasattr(ctx, "stream_handle") else torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
     for _ in range(args.reps):
         call()
+    ctx.synchronize()
+    out["wall_ms_per_call_" + ("image" if image else "f32staged")] = round((time.perf_counter() - t0) * 1e3 / args.reps, 4)
     tot, cnt = C.c_double(), C.c_int64()
     lib.agpl_timing_read(ctx.bind(), C.c_int32(1), C.byref(tot), C.byref(cnt))
     lib.agpl_timing_enable(ctx.bind(), 0)
