@@ -50,6 +50,11 @@ struct agpl_ctx {
     char err[512] = {0};
 };
 
+// Points per accumulation slice (one workgroup's float32 accumulation run; one slab per slice and tile).  4096, and 8192 where the
+// feature matrix is a single 256-tile wide: there the slab write + reduction is a larger share of a slice (C4-shape accumulate
+// 2.92 against 3.27 ms on one box); at M >= 512 the longer slice measured slower (round 3).
+__host__ __device__ constexpr int agpl_chunk_points(int M) { return M <= 256 ? 8192 : 4096; }
+
 // reports (and clears) the deferred outcome of the last asynchronous factorisation; AGPL_OK when none is pending
 int32_t agpl_pending_resolve(agpl_ctx *ctx);
 

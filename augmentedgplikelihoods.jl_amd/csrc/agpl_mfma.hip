@@ -7,7 +7,7 @@
 //                           W' = upper-triangular with doubled off-diagonal, so only the block pairs
 //                           cb >= rb are visited: (nb+1)/(2 nb) of a full GEMM.
 //   syrk_kernel      (a12)  G = Phi Diag(gamma) Phi' on 128 x 128 output tiles of the lower triangle,
-//                           N split over workgroups in slices of 4096 points (one f32 accumulation run
+//                           N split over workgroups in slices of agpl_chunk_points(M) = 4096 points (8192 at M <= 256) (one f32 accumulation run
 //                           each), g = Phi beta on the diagonal tiles.
 //   reduce kernels          fixed-order float64 sum of the per-slice f32 slabs.
 //
@@ -31,7 +31,6 @@ constexpr int BS = 128;      // block of feature rows
 constexpr int KT = 16;       // k-slice per stage
 constexpr int NT = 128;      // points per marginal tile
 constexpr int KPITCH = KT + 1;
-constexpr int kChunk = 4096; // points per accumulation workgroup = length of one f32 accumulation run
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -226,8 +225,8 @@ size_t marginal_lds_bytes(int M) {
 // ------------------------------------------------------------------------------------------------
 // syrk kernel: 1-D grid of npairs * nsplit8 * L workgroups, remapped so that the workgroups that share an
 // XCD (blockIdx % 8) walk whole point-slices: all tile pairs of a slice read the same Phi panels through
-// one L2.  One workgroup = one 128 x 128 tile pair x one slice of kChunk points, accumulated in f32
-// (chains of <= 4096 terms) and written as an f32 slab; the slabs are summed in float64 by the reduce kernels.
+// one L2.  One workgroup = one 128 x 128 tile pair x one slice of agpl_chunk_points(M) points, accumulated in f32
+// (chains of <= 8192 terms) and written as an f32 slab; the slabs are summed in float64 by the reduce kernels.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npairs, int nsplit,
                                                       const float *__restrict__ Phi,
@@ -264,8 +263,8 @@ __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npai
     // frees its SIMD's matrix pipe for the other resident workgroups.
     const bool active = !(diag && wr < wc);
 
-    const int64_t nbeg = (int64_t)s * kChunk;
-    int64_t nend = nbeg + kChunk;
+    const int64_t nbeg = (int64_t)s * agpl_chunk_points(M);
+    int64_t nend = nbeg + agpl_chunk_points(M);
     if (nend > N) nend = N;
     const int nstage = (int)((nend - nbeg + KT - 1) / KT);
     const float *gam = gamma_all + (int64_t)l * N;
@@ -628,8 +627,8 @@ __global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t N
 
     // the tile kind is decided once: one call per body instance (a branch around the stage loop's body would make the
     // accumulators a merge of both bodies' and spill them)
-    const int64_t nbeg = (int64_t)s * kChunk;
-    int64_t nend = nbeg + kChunk;
+    const int64_t nbeg = (int64_t)s * agpl_chunk_points(M);
+    int64_t nend = nbeg + agpl_chunk_points(M);
     if (nend > N) nend = N;
     const int nstage = (int)((nend - nbeg + 15) / 16);
     const int plast = (int)(nend - 1 - nbeg);
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(128) void reduce_G_kernel(int M, int ngroup, const 
 
 // g: level 1 = one workgroup of 128 threads per (row block, group of slices); level 2 sums the groups
 
-inline int syrk_nsplit(int64_t N) { return (int)agpl_cdiv(N, kChunk); }
+inline int syrk_nsplit(int64_t N, int M) { return (int)agpl_cdiv(N, agpl_chunk_points(M)); }
 
 } // namespace
 
@@ -856,7 +855,7 @@ struct SlabLayout {
 };
 static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
     SlabLayout o;
-    o.ns = syrk_nsplit(N);
+    o.ns = syrk_nsplit(N, M);
     o.ng = (o.ns + kRedGroup - 1) / kRedGroup;
     o.nb = M / BS;
     o.npairs = (int64_t)o.nb * (o.nb + 1) / 2;

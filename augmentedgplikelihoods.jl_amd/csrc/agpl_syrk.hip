@@ -11,7 +11,7 @@
 //   that hi and lo stay float16 normals over the widest range (header word scale_exp).
 //
 // syrk_strip_kernel (below): one 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a 256 x 256 tile of
-// the lower triangle of G for one slice of 4096 points (one f32 accumulation run, one slab set -- the slabs and the fixed-
+// the lower triangle of G for one slice of agpl_chunk_points(M) = 4096 (8192 at M = 256) points (one f32 accumulation run, one slab set -- the slabs and the fixed-
 // order float64 reduction behind them are those of agpl_mfma.hip).  A = rows of panel I: image blocks moved HBM -> LDS by the
 // DMA path, no VGPRs, no VALU.  B = gamma_n * (rows of panel J): the granules of a wave's own 32 columns, loaded (or, on a
 // diagonal tile, read back from the A image in LDS) into registers, rebuilt (x = hi + lo, exact in float32), scaled
@@ -31,7 +31,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BS = 128;       // feature rows per image block / per slab tile (the slab layout of agpl_mfma.hip)
-constexpr int kChunk = 4096;  // points per slice (must match agpl_mfma.hip)
 constexpr int kPanel = 256;   // feature rows per operand panel
 constexpr int kStagePts = 32; // points per stage (one MFMA K)
 constexpr uint32_t kImageMagic = 0x41474951u; // "AGIQ"
@@ -243,8 +242,8 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     const int eB = acc_scale_exp(scal[0]);
     const float sB = __uint_as_float((unsigned)(127 + eB) << 23); // gamma is scaled as it is used (exact)
 
-    const int64_t nbeg = (int64_t)s * kChunk;
-    int64_t nend = nbeg + kChunk;
+    const int64_t nbeg = (int64_t)s * agpl_chunk_points(M);
+    int64_t nend = nbeg + agpl_chunk_points(M);
     if (nend > N) nend = N;
     const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
     const int64_t ps0 = nbeg / 16;
