@@ -506,6 +506,9 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int R = 2, KU = 2;
     if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u; // (the caller's scale words: see the launch)
+    // ... and the sweep's "bad gamma" word (queues[8]): the update behind the previous sweep has forwarded it by now, and an update
+    // route that does not forward it (M > 1024: library factorisation) must not leave a stale flag for a later problem
+    if (zero2 && blockIdx.x == 0 && threadIdx.x == 2) queues[8] = 0u;
     constexpr int kSlot = KU * 8 * 4096;
     float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
     float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
