@@ -84,9 +84,19 @@ __device__ __forceinline__ double pg_a_lo(int n, double x, double lx) {
 // the alternating-series test of polyagamma.jl:243-256 for a proposal x; false = rejected.  HI: x > t.
 template <bool HI>
 __device__ __forceinline__ bool pg_series_accept(Philox &g, double x, uint32_t &nterms) {
+    const double u = g.u01();
+    // The first test of the series (n = 1) is  u a_0 <= a_0 - a_1,  i.e.  u <= 1 - a_1 / a_0  with  a_1 / a_0 = 3 exp(-pi^2 x)
+    // (x > t) or 3 exp(-4 / x) (x <= t) -- at most 0.006: 99.5 % of the proposals are accepted here, and neither a_0 nor a_1 (one
+    // more exp; a log as well for x <= t) is needed to know it.  Decided through a bracket like the branch test: a u within 1e-9
+    // of the boundary (or beyond it) runs the series as the reference writes it, so the outcome and the series index are its.
+    const double rho = 3.0 * exp(HI ? -(kPi * kPi) * x : -4.0 / x);
+    if (u < 1.0 - rho - 1e-9) {
+        nterms += 1u;
+        return true;
+    }
     const double lx = HI ? 0.0 : -3.0 / 2.0 * (log(kPi / 2.0) + log(x));
     double s = HI ? pg_a_hi(0, x) : pg_a_lo(0, x, lx);
-    const double y = g.u01() * s;
+    const double y = u * s;
     int n = 0;
     bool accepted = false;
     for (;;) {
@@ -102,6 +112,16 @@ __device__ __forceinline__ bool pg_series_accept(Philox &g, double x, uint32_t &
     }
     nterms += (uint32_t)n;
     return accepted;
+}
+
+// The test `alpha < u` of rand_truncated_inverse_gaussian (polyagamma.jl:205-212), alpha = exp(-w), w = z^2 x / 2 >= 0, through the
+// bounds 1 - w <= exp(-w) <= 1 - w + w^2 / 2: the exponential is evaluated only when u falls between them (w^2 / 2 wide, widened by
+// 1e-12 against the rounding of the bounds) -- the outcome is the exact comparison's.
+__device__ __forceinline__ bool pg_alpha_below(double w, double u) {
+    const double lo = 1.0 - w;
+    if (u < lo - 1e-12) return false;                    // u < 1 - w <= alpha
+    if (u > lo + 0.5 * w * w + 1e-12) return true;       // u > 1 - w + w^2 / 2 >= alpha
+    return exp(-w) < u;
 }
 
 // sub-stream of draw `sub` of point `index`
@@ -235,8 +255,8 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
                     if (!(E * E > (2.0 * Ep / kPgT))) {
                         const double d = 1.0 + E * kPgT;
                         const double x = kPgT / (d * d);
-                        const double alpha = exp(-z * z * x / 2.0);
-                        if (!(alpha < s.u01())) {
+                        const double ua = s.u01();
+                        if (!pg_alpha_below(z * z * x / 2.0, ua)) { // `alpha < u` with alpha = exp(-z^2 x / 2) is false: accepted
                             scr->draws[w][slot] = x;
                             scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
                             fetch();
@@ -614,8 +634,8 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
                     if (!(E * E > (2.0 * Ep / kPgT))) {
                         const double d = 1.0 + E * kPgT;
                         const double x = kPgT / (d * d);
-                        const double alpha = exp(-z * z * x / 2.0);
-                        if (!(alpha < s.u01())) {
+                        const double ua = s.u01();
+                        if (!pg_alpha_below(z * z * x / 2.0, ua)) { // `alpha < u` with alpha = exp(-z^2 x / 2) is false: accepted
                             scr.x[e] = x;
                             scr.st[e] = (s.c0 << 3) | (uint32_t)s.pos;
                             fetch();
