@@ -481,7 +481,8 @@ def main():
         proj_ms = pms / max(pcnt, 1)
         out["gibbs"] = {
             "sweeps_per_s": round(1.0 / tg, 3), "ms_per_sweep": round(tg * 1e3, 3),
-            "point_pass": {"kernel": "gibbs_project_kernel + gibbs_sample_kernel", "avg_ms": round(proj_ms, 3), "bound": "hbm",
+            "point_pass": {"kernel": "gibbs_project_kernel + " + ("aux_sample_pg1_kernel<gibbs>" if args.lik == "bernoulli"
+                                                                  else "gibbs_sample_kernel"), "avg_ms": round(proj_ms, 3), "bound": "hbm",
                            "algorithmic_bytes": n_loc * (Mp * 4 + 16),
                            "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000}}
         del gib
@@ -505,7 +506,7 @@ def main():
                 pg1 = int(ys.to(torch.int64).sum().item()) + 15 * nd
             else:
                 pg1 = None
-            leg = {"kernel": "aux_sample_kernel", "likelihood": sname, "points": nd, "avg_ms": round(sms, 4),
+            leg = {"kernel": "aux_sample_pg1_kernel" if sname == "bernoulli" else "aux_sample_kernel", "likelihood": sname, "points": nd, "avg_ms": round(sms, 4),
                    "bound": "hbm (by contract)", "algorithmic_bytes_per_point": bytes_pt,
                    "points_per_s": round(nd / (sms * 1e-3), 0),
                    "achieved_GBps": round(nd * bytes_pt / (sms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
