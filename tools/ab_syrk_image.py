@@ -57,8 +57,6 @@ def run(image):
     call(); call()
     torch.cuda.synchronize()
     lib.agpl_timing_enable(ctx.bind(), 1)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st = torch.cuda.ExternalStream(ctx.stream_handle()) if hasattr(ctx, "stream_handle") else torch.cuda.current_stream()
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
