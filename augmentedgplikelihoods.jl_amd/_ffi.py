@@ -25,7 +25,7 @@ SYMBOLS = [
     "agpl_marginals_split", "agpl_cavi_pass_split", "agpl_set_accumulate_precision", "agpl_allreduce_nat", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_feature_residual", "agpl_gaussian_factor", "agpl_gaussian_factor_async",
     "agpl_pack_factor_split", "agpl_marginals_factor_split", "agpl_cavi_pass_factor_split", "agpl_probe_mfma_f64", "agpl_probe_mfma_f16",
     "agpl_accumulate_image_bytes", "agpl_accumulate_image", "agpl_accumulate_split", "agpl_cavi_pass_factor_image",
-    "agpl_gibbs_pass_image",
+    "agpl_gibbs_pass_image", "agpl_debug_force_factor_rescue",
 ]
 
 

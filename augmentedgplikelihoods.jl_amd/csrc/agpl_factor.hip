@@ -130,6 +130,10 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
                                                          int *__restrict__ info, double *__restrict__ PXg_all,
                                                          unsigned *__restrict__ sync_all, int rescue) {
     if (NW > 1 && (blockIdx.x & 7) != (blockIdx.y & 7)) return; // latent l works on XCD l % 8 (see the launch)
+    if (NW > 1 && rescue == 2) { // fault injection (agpl_debug_force_factor_rescue): behave as if a partner never arrived
+        if ((blockIdx.x >> 3) == 0 && threadIdx.x == 0) info[blockIdx.y] = -1;
+        return;
+    }
     // rescue launch (NW = 1, queued behind every multi-workgroup launch): redo latent l alone iff the cooperative
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
@@ -580,9 +584,10 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
         factor_kernel<NW_, LA_><<<GRID_, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,    \
                                                                    logdet_out, info_dev, PXg, sync, RESCUE_);        \
     } while (0)
-    if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L), 0);
-    else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L), 0);
-    else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L), 0);
+    const int coop_mode = ctx->debug_force_rescue ? 2 : 0;
+    if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L), coop_mode);
+    else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L), coop_mode);
+    else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L), coop_mode);
     else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 0);
     AGPL_LAUNCH_CHECK(ctx);
     // The multi-workgroup forms are plain launches that assume their partners co-resident (true when this process has
@@ -592,5 +597,14 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     if (nw > 1) AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 1);
 #undef AGPL_LAUNCH_FACTOR
     AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+// Test hook: make every cooperative factor launch of this context report "a partner never arrived" (info = -1) at once, so that
+// the rescue launch behind it -- the path taken when other work holds the CUs the cooperating workgroups need -- does the
+// factorisation.  The result must be the one the cooperative launch produces (tests/test_gpu_parity.py).
+extern "C" int32_t agpl_debug_force_factor_rescue(agpl_ctx *ctx, int32_t on) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    ctx->debug_force_rescue = on != 0;
     return AGPL_OK;
 }

@@ -249,6 +249,13 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *   ("FP64 peak is not in the local guide -- measure, don't assume").  Synchronous.              */
 AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host);
 
+/* agpl_debug_force_factor_rescue: test hook.  The one-launch M x M factorisation (agpl_gaussian_factor*, M <= 1024) runs as
+ *   cooperating workgroups that assume each other resident; should other work hold their CUs, the launch reports it and a
+ *   second launch queued behind it redoes the latent in one workgroup, without the host.  on != 0 makes every cooperative
+ *   launch of this context take that path at once, so that it can be tested (it is otherwise never exercised on an idle
+ *   device); the results are the cooperative launch's.  No reference counterpart (the reference calls LAPACK). */
+AGPL_API int32_t agpl_debug_force_factor_rescue(agpl_ctx *ctx, int32_t on);
+
 /* agpl_probe_mfma_f16: SUSTAINED float16 MFMA rate of this device [TFLOP/s]: v_mfma_f32_32x32x16_f16 in the instruction
  *   mix of one stage of the split accumulation's wave (12 per step into four 32 x 32 accumulators), six launches of
  *   `iters` steps per wave timed as one region after two that settle the clocks, `workgroups_per_cu` (1..4) 4-wave

@@ -953,6 +953,39 @@ def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
         assert host(ld)[l] == pytest.approx(np.linalg.slogdet(np.eye(M) + G[l])[1], rel=1e-12)
 
 
+@pytest.mark.parametrize("M,L", [(512, 1), (256, 3), (1024, 2)])
+def test_gaussian_factor_rescue_launch_reproduces_the_cooperative_result(A, M, L):
+    """The one-launch factorisation runs as cooperating workgroups that assume each other resident; when other work holds their
+    CUs the launch reports info = -1 and a second launch queued behind it redoes the latent in one workgroup.  On an idle device
+    that path never runs: agpl_debug_force_factor_rescue makes every cooperative launch take it.  U, v and log det
+    must be the cooperative launch's -- bitwise: both run the same elimination order -- and a sweep driven through it the same."""
+    import ctypes as C
+
+    rctx = A.Context(0, seed=3)
+    rng = np.random.default_rng(M + L)
+    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
+    G, g = dev(np.einsum("lik,ljk->lij", B, B) * 2.0), dev(rng.normal(size=(L, M)))
+    outs = []
+    for force in (0, 1):
+        rctx.call("agpl_debug_force_factor_rescue", C.c_int32(force))
+        Aw = torch.zeros((L, M, M), dtype=torch.float64, device="cuda")
+        v = torch.empty((L, M), dtype=torch.float64, device="cuda")
+        v32 = torch.empty((L, M), dtype=torch.float32, device="cuda")
+        Uh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+        Ul = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
+        ld = torch.empty(L, dtype=torch.float64, device="cuda")
+        rctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()),
+                  C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(v32.data_ptr()),
+                  C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(ld.data_ptr()))
+        outs.append((torch.triu(Aw).clone(), v.clone(), ld.clone(), Uh.clone(), Ul.clone()))
+    rctx.call("agpl_debug_force_factor_rescue", C.c_int32(0))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    for l in range(L):  # and it is the factor: U'U = (I + G)^-1
+        Ut = host(outs[1][0])[l]
+        assert relmax(Ut @ Ut.T, np.linalg.inv(np.eye(M) + host(G)[l])) < 1e-10
+
+
 @pytest.mark.parametrize("M,first_bad", [(256, 0), (1024, 0), (1024, 700)])
 def test_gaussian_factor_reports_indefinite_matrix(A, ctx, M, first_bad):
     import ctypes as C
