@@ -32,6 +32,9 @@ import time
 
 import numpy as np
 
+# RCCL / device-tensor sharing between the ranks of one node needs dmabuf IPC on this driver stack (set before anything touches HIP)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
