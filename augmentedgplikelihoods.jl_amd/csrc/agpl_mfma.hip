@@ -880,7 +880,7 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                float *slabg, int ns, bool records_ready); // agpl_syrk.hip
 
 // acc_image != nullptr (and M % 256 == 0): the point-major split-float16 image of agpl_accumulate_image is the operand
-// (syrk_image_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
+// (syrk_strip_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
 // internal (agpl_update.hip): where the gamma | beta records and the two scale words of the image path live in slab_mem
 void agpl_accumulate_records(int64_t N, int32_t M, int32_t L, void *slab_mem, float **gb, unsigned **scal) {
     const SlabLayout lo = slab_layout(N, M, L);
