@@ -97,6 +97,8 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
         cavi.sweep()
     barrier()
     _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    read_timing(ctx, 0)  # discard what earlier legs left in the kernel timers (the sampler legs call cavi.marginals() with the
+    read_timing(ctx, 1)  # timers on: two C2-size launches used to be averaged into the m1024 leg's marginal kernel: 16.8 for 20.1 ms)
     # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
     # used to land in one random sweep of the timed loop: collect now, keep the collector off while timing
     gc.collect()
