@@ -387,9 +387,15 @@ __device__ __forceinline__ double pg_point_wave(PgBlockScratch *scr, int lane, b
     return acc;
 }
 
-template <int KIND>
+template <typename NN>
+__device__ __forceinline__ NN count_cast(int64_t n) { // (saturating: a count beyond int32 is far beyond the PG(b) limit and is flagged there)
+    return sizeof(NN) == 4 && n > 0x7fffffffLL ? (NN)0x7fffffff : (NN)n;
+}
+// NN: the type the latent counts n are kept in (int64_t in the caller's n_out; int32_t in the Gibbs kernel's LDS scratch, which with
+// 64-bit counts pinned that kernel to one workgroup per CU at K = 10)
+template <int KIND, typename NN>
 __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlockScratch *scr, int lane, bool valid, Philox &g,
-                                         int64_t i, const void *yv, const double *f, double *om, int64_t *nn,
+                                         int64_t i, const void *yv, const double *f, double *om, NN *nn,
                                          uint32_t &nt, int *bad) {
     const int L = lik.nlatent;
     switch (KIND) { // compile-time: each kernel instantiation carries one likelihood's sampler only
@@ -429,7 +435,7 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
                 for (int k = 0; k < L; ++k) {
                     double pk = exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
                     double lam = pk * theta / (1.0 - p0);
-                    nn[k] = rand_poisson(g, lam);
+                    nn[k] = count_cast<NN>(rand_poisson(g, lam));
                 }
             }
         }
@@ -445,7 +451,7 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
         if (valid) {
             double lam = lik.p[0] * logistic(-f[0]);
             int64_t n1 = rand_poisson(g, lam);
-            nn[0] = n1;
+            nn[0] = count_cast<NN>(n1);
             b = (double)(n1 + y[i]);
             c = fabs(f[0]);
         }
@@ -467,7 +473,7 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
             double ff = f[0], gg = f[1];
             double lam = lik.p[0] * logistic(-gg) * (ff - y[i]) * (ff - y[i]) / 2.0;
             int64_t n1 = rand_poisson(g, lam);
-            nn[0] = n1;
+            nn[0] = count_cast<NN>(n1);
             b = 0.5 + (double)n1;
             c = fabs(gg);
         }
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(a
         Philox g;
         g.init(seed, i0 + (uint64_t)i, sweep);
         uint32_t nt = 0;
-        sample_point_wave<KIND>(lik, &scratch, lane, valid, g, i, yv, f + i * Lf, omega + i * Lo,
+        sample_point_wave<KIND, int64_t>(lik, &scratch, lane, valid, g, i, yv, f + i * Lf, omega + i * Lo,
                                 nout ? nout + i * Lo : nullptr, nt, bad);
         if (valid) {
             if (nuni_out) nuni_out[i] = g.nuni;
@@ -1674,7 +1680,7 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
                                                     int Lf, int Lo, const float *__restrict__ kdiag,
                                                     const float *__restrict__ mu0, const void *yv, uint64_t seed,
                                                     uint64_t i0, uint32_t sweep, PgBlockScratch *scr, double *fS, double *omS,
-                                                    int64_t *nnS,
+                                                    int32_t *nnS,
                                                     float *__restrict__ gamma, float *__restrict__ beta,
                                                     double *__restrict__ f_out, double *__restrict__ omega_out,
                                                     int64_t *__restrict__ n_out, uint32_t *__restrict__ nuni_out,
@@ -1694,7 +1700,7 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
             if (f_out) f_out[i * Lf + l] = f;
         }
     }
-    sample_point_wave<KIND>(lik, scr, lane, valid, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
+    sample_point_wave<KIND, int32_t>(lik, scr, lane, valid, g, i, yv, fS + lane * Lf, omS + lane * Lo, nnS + lane * Lo, nt, bad);
     if (valid) {
         if (nuni_out) nuni_out[i] = g.nuni;
         // auglik_potential / auglik_precision of the draw (same formulas as potential_precision_kernel)
@@ -1740,7 +1746,7 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
         if (omega_out)
             for (int k = 0; k < Lo; ++k) omega_out[i * Lo + k] = omS[lane * Lo + k];
         if (n_out)
-            for (int k = 0; k < Lo; ++k) n_out[i * Lo + k] = nnS[lane * Lo + k];
+            for (int k = 0; k < Lo; ++k) n_out[i * Lo + k] = (int64_t)nnS[lane * Lo + k];
     }
 }
 
@@ -1802,9 +1808,12 @@ __global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
     const int Lf = lik.nlatent;
     const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *fS = sh + (size_t)wave * 64 * (Lf + 2 * Lo);       // [64][Lf]
-    double *omS = fS + 64 * Lf;                                 // [64][Lo]
-    int64_t *nnS = reinterpret_cast<int64_t *>(omS + 64 * Lo);  // [64][Lo]
+    // per wave: f [64][Lf] and omega [64][Lo] in float64, the latent counts n [64][Lo] in int32 (a Poisson count that does not
+    // fit 31 bits would need a rate no float64 logistic produces): 12.8 KB per wave at K = 10 -- with 64-bit counts the kernel's
+    // 84 KB per workgroup pinned it to one workgroup per CU
+    double *fS = sh + (size_t)wave * (64 * (Lf + Lo) + 32 * Lo); // [64][Lf]
+    double *omS = fS + 64 * Lf;                                   // [64][Lo]
+    int32_t *nnS = reinterpret_cast<int32_t *>(omS + 64 * Lo);    // [64][Lo]
     const int64_t nblocks = (N + 255) >> 8; // (uniform trip count over the workgroup: the sampler has barriers)
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int64_t base = (blk * 4 + wave) << 6;
@@ -1832,7 +1841,7 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
     if (rc) return rc;
     if (!proj_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "Gibbs point pass: no projection scratch");
     {
-        const size_t lds_p = sizeof(double) * (size_t)Lf * M, lds_s = sizeof(double) * 4 * 64 * (size_t)(Lf + 2 * Lo);
+        const size_t lds_p = sizeof(double) * (size_t)Lf * M, lds_s = sizeof(double) * 4 * (size_t)(64 * (Lf + Lo) + 32 * Lo);
         int64_t nbp = agpl_cdiv(agpl_cdiv(N, 64), 4);
         if (nbp > 256 * 16) nbp = 256 * 16;
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_kernel),
