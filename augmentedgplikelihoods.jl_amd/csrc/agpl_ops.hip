@@ -64,11 +64,19 @@ struct PgBlockScratch {
     unsigned short retry[kPgWaves * 256]; // phase-C queue
     unsigned st[kPgWaves * 256];         // stream position of a parked proposal: (refills << 3) | words used
     unsigned char owner[kPgWaves][256];  // owner lane of each dealt draw
+    double etheta[64];                   // categorical kinds: exp(log theta_k), filled once per kernel (pg_scratch_init)
     int qn, q2n, qhead, rn, tmax;
 #ifdef AGPL_PG_TRACE
     unsigned long long trace[8];
 #endif
 };
+
+// once per kernel, by the whole workgroup
+__device__ __forceinline__ void pg_scratch_init(PgBlockScratch *scr, const agpl_lik_dev &lik) {
+    if ((lik.kind == AGPL_LIK_CATEGORICAL || lik.kind == AGPL_LIK_CATEGORICAL_BIJ) && (int)threadIdx.x < lik.nlatent)
+        scr->etheta[threadIdx.x] = exp(lik.logtheta[threadIdx.x]);
+    __syncthreads();
+}
 
 // a(n, x) polyagamma.jl:167-177 with the branch known: x > t ...
 __device__ __forceinline__ double pg_a_hi(int n, double x) {
@@ -424,8 +432,14 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
         const uint8_t *y = (const uint8_t *)yv;
         bool good = valid;
         if (valid) {
+            // p_k = theta_k logistic(f_k) / sum(theta): formed once, kept in the point's omega slots until the draws replace them
+            // (the same values the reference forms twice); theta_k = exp(log theta_k) comes from the workgroup's table
             double sp = 0.0;
-            for (int k = 0; k < L; ++k) sp += exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+            for (int k = 0; k < L; ++k) {
+                const double pk = scr->etheta[k] * logistic(f[k]) / lik.sum_theta;
+                om[k] = pk;
+                sp += pk;
+            }
             double p0 = 1.0 - sp;
             if (!(sp < 1.0)) { // ArgumentError negativemultinomial.jl:17-22
                 atomicOr(bad, 1);
@@ -433,7 +447,7 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
             } else {
                 double theta = (1.0 / p0 - 1.0) * rand_gamma(g, 1.0);
                 for (int k = 0; k < L; ++k) {
-                    double pk = exp(lik.logtheta[k]) * logistic(f[k]) / lik.sum_theta;
+                    const double pk = om[k];
                     double lam = pk * theta / (1.0 - p0);
                     nn[k] = count_cast<NN>(rand_poisson(g, lam));
                 }
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(a
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
     __shared__ PgBlockScratch scratch;
+    pg_scratch_init(&scratch, lik);
 #ifdef AGPL_PG_TRACE
     if (threadIdx.x < 8) scratch.trace[threadIdx.x] = 0ull;
     __syncthreads();
@@ -1805,6 +1820,7 @@ __global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
     uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     __shared__ PgBlockScratch scratch;
+    pg_scratch_init(&scratch, lik);
     const int Lf = lik.nlatent;
     const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
