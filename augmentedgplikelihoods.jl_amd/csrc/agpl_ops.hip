@@ -53,10 +53,13 @@ __device__ unsigned long long g_pgtrace[8];
 #define PGT_MARK(k_)
 #endif
 constexpr int kPgWaves = kBlock / 64;
+constexpr int kPgMaxLat = 4;                 // latents dealt together by one engine call (owner o = 64 j + lane fits the owner byte)
+constexpr int kPgMaxOwners = 64 * kPgMaxLat;
 struct PgBlockScratch {
     double draws[kPgWaves][256];        // the dealt draws of each wave's current chunk
-    double par[kPgWaves][64][4];        // owner's (z, K, bracket of r: pg_mass_bracket)
-    int off[kPgWaves][65];              // exclusive prefix sums of floor(b); off[.][64] = total
+    double par[kPgWaves][256];          // owners' parameters: one latent per call -- (z, K, bracket of r) of lane l at [4 l ..];
+                                        // NB > 1 latents per call -- z of owner o = 64 j + lane at [o] (the rest per draw)
+    int off[kPgWaves][kPgMaxOwners + 1]; // exclusive prefix sums of floor(b) over the owners; off[.][owners] = total
     unsigned nuni[kPgWaves][64], nterms[kPgWaves][64];
     unsigned long long index0[kPgWaves]; // point index (40 bits) of lane 0 of each wave
     unsigned short queue[kPgWaves * 256]; // phase-B queue: (wave << 8) | slot
@@ -165,29 +168,42 @@ __device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, 
 // sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: the lane only helps).
 // sub_base is uniform over the workgroup.  __forceinline__ (and its callers): left to its heuristics the inliner turned this into a
 // real call in some builds -- the negative-binomial kernel then ran 18.0 instead of 8.6 ms per 4e6 points.
-__device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, uint32_t sub_base, int tb,
-                                          double c, uint32_t &nuni, uint32_t &nterms) {
+template <int NB>
+__device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, int latent0,
+                                                 const int (&tb)[NB], const double (&c)[NB], double (&acc)[NB], uint32_t &nuni,
+                                                 uint32_t &nterms) {
+    static_assert(NB >= 1 && NB <= kPgMaxLat, "latents per engine call");
+    constexpr int kOwners = 64 * NB;
     PGT_DECL();
-    if (tb > 0) {
-        double z, K, rlo, rhi;
-        pg_mass_bracket(c, z, K, rlo, rhi);
-        scr->par[wave][lane][0] = z;
-        scr->par[wave][lane][1] = K;
-        scr->par[wave][lane][2] = rlo;
-        scr->par[wave][lane][3] = rhi;
-    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (tb[j] > 0) {
+            if (NB == 1) {
+                double z, K, rlo, rhi;
+                pg_mass_bracket(c[0], z, K, rlo, rhi);
+                scr->par[wave][4 * lane + 0] = z;
+                scr->par[wave][4 * lane + 1] = K;
+                scr->par[wave][4 * lane + 2] = rlo;
+                scr->par[wave][4 * lane + 3] = rhi;
+            } else
+                scr->par[wave][64 * j + lane] = fabs(c[j]) / 2.0;
+        }
     scr->nuni[wave][lane] = 0u;
     scr->nterms[wave][lane] = 0u;
-    int incl = tb;
+    int off[NB], T = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
+    for (int j = 0; j < NB; ++j) { // owners in the order (latent, lane)
+        int incl = tb[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        off[j] = T + incl - tb[j];
+        T += __shfl(incl, 63);
+        scr->off[wave][64 * j + lane] = off[j];
     }
-    const int off = incl - tb;
-    const int T = __shfl(incl, 63);
-    scr->off[wave][lane] = off;
-    if (lane == 63) scr->off[wave][64] = T;
+    if (lane == 63) scr->off[wave][kOwners] = T;
     if (lane == 0) scr->index0[wave] = (uint64_t)g.c2 | ((uint64_t)(g.c3 & 0xFFu) << 32); // lanes = consecutive points
     if (threadIdx.x == 0) scr->tmax = scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
     PGT_MARK(0);
@@ -195,35 +211,48 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
     if (lane == 0 && T > 0) atomicMax(&scr->tmax, T);
     __syncthreads();
     const int tmax = scr->tmax;
-    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = 0.0;
     PGT_MARK(1);
+    // the parameters of owner o_ of wave w_ (z always; K, the bracket of r: stored for NB == 1, formed per draw otherwise)
+#define PG_OWNER_Z(w_, o_) (NB == 1 ? scr->par[w_][4 * (o_)] : scr->par[w_][o_])
+#define PG_OWNER_SUB(o_) (1u + ((uint32_t)(latent0 + ((o_) >> 6)) << 16))
     for (int cb = 0; cb < tmax; cb += 256) {
         // ---- phase A
         for (int r = 0; r < 4; ++r) {
             const int t = cb + 64 * r + lane;
             bool to_b = false, to_b2 = false, to_c = false;
             if (t < T) {
-                int lo = 0, hi = 63; // owner = last lane whose first draw is <= t (lanes without draws share an offset
-                while (lo < hi) {    // with their successor and are skipped by "last")
+                int lo = 0, hi = kOwners - 1; // owner = last one whose first draw is <= t (owners without draws share an offset
+                while (lo < hi) {             // with their successor and are skipped by "last")
                     const int mid = (lo + hi + 1) >> 1;
                     if (scr->off[wave][mid] <= t) lo = mid;
                     else hi = mid - 1;
                 }
                 scr->owner[wave][t - cb] = (unsigned char)lo;
-                Philox s = pg_substream(g, scr->index0[wave] + (uint64_t)lo, sub_base + (uint32_t)(t - scr->off[wave][lo]));
+                Philox s = pg_substream(g, scr->index0[wave] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(t - scr->off[wave][lo]));
                 const double u = s.u01();
-                if (!(u < scr->par[wave][lo][2]) && !(u > scr->par[wave][lo][3])) // inside the bracket of r: decided exactly
+                const double z = PG_OWNER_Z(wave, lo);
+                double K, rlo, rhi;
+                if (NB == 1) {
+                    K = scr->par[wave][4 * lo + 1], rlo = scr->par[wave][4 * lo + 2], rhi = scr->par[wave][4 * lo + 3];
+                } else { // (no fit for z >= 8: an empty bracket around u sends the draw to the sequential sampler)
+                    K = kPi2_8 + z * z / 2.0;
+                    const double rf = pg_mass_fit(z < 8.0 ? z : 0.0);
+                    rlo = z < 8.0 ? rf - kPgMassSlack : u, rhi = z < 8.0 ? rf + kPgMassSlack : u;
+                }
+                if (!(u < rlo) && !(u > rhi)) // inside the bracket of r: decided exactly
                     to_c = true;
-                else if (u < scr->par[wave][lo][2]) { // truncated exponential proposal, polyagamma.jl:239-240
-                    const double x = kPgT + s.exp1() / scr->par[wave][lo][1];
+                else if (u < rlo) { // truncated exponential proposal, polyagamma.jl:239-240
+                    const double x = kPgT + s.exp1() / K;
                     uint32_t nt = 0;
                     if (pg_series_accept<true>(s, x, nt)) {
                         scr->draws[wave][t - cb] = x / 4.0;
-                        atomicAdd(&scr->nuni[wave][lo], s.nuni);
-                        atomicAdd(&scr->nterms[wave][lo], nt);
+                        atomicAdd(&scr->nuni[wave][lo & 63], s.nuni);
+                        atomicAdd(&scr->nterms[wave][lo & 63], nt);
                     } else
                         to_c = true;
-                } else if (1.0 / scr->par[wave][lo][0] > kPgT) // (the test of rand_truncated_inverse_gaussian, polyagamma.jl:197)
+                } else if (1.0 / z > kPgT) // (the test of rand_truncated_inverse_gaussian, polyagamma.jl:197)
                     to_b = true;
                 else
                     to_b2 = true;
@@ -268,10 +297,10 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
                     e = scr->queue[idx];
                     w = e >> 8, slot = e & 255;
                     const int lo = scr->owner[w][slot];
-                    s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                    s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
                     (void)s.u01(); // the branch uniform, drawn in phase A
                     (void)s.u01(); // `while (alpha < rand())` with alpha = 0: always entered (u is in the open interval)
-                    z = scr->par[w][lo][0];
+                    z = PG_OWNER_Z(w, lo);
                 }
             };
             fetch();
@@ -296,9 +325,9 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
             for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
                 const int e = scr->queue2[q];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
                 (void)s.u01();
-                scr->draws[w][slot] = rand_tig(s, scr->par[w][lo][0]);
+                scr->draws[w][slot] = rand_tig(s, PG_OWNER_Z(w, lo));
                 scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
             }
         }
@@ -312,7 +341,7 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
             if (q < qn + q2n) {
                 e = q < qn ? scr->queue[q] : scr->queue2[q - qn];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
                 const uint32_t st = scr->st[e], c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it
                 if (pos < 4u) {
                     s.c0 = c0 - 1u;
@@ -325,8 +354,8 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
                 uint32_t nt = 0;
                 if (pg_series_accept<false>(s, x, nt)) {
                     scr->draws[w][slot] = x / 4.0;
-                    atomicAdd(&scr->nuni[w][lo], s.nuni);
-                    atomicAdd(&scr->nterms[w][lo], nt);
+                    atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
+                    atomicAdd(&scr->nterms[w][lo & 63], nt);
                 } else
                     to_c = true;
             }
@@ -346,53 +375,76 @@ __device__ __forceinline__ double pg_int_sum_block(PgBlockScratch *scr, int wave
         for (int q = (int)threadIdx.x; q < rn; q += kBlock) {
             const int e = scr->retry[q];
             const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-            Philox s = pg_substream(g, scr->index0[w] + (uint64_t)lo, sub_base + (uint32_t)(cb + slot - scr->off[w][lo]));
+            Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
             Pg1Params p;
-            p.set(2.0 * scr->par[w][lo][0]); // (z = |c| / 2 exactly)
+            p.set(2.0 * PG_OWNER_Z(w, lo)); // (z = |c| / 2 exactly)
             uint32_t nt = 0;
             scr->draws[w][slot] = sample_pg1(s, p, nt);
-            atomicAdd(&scr->nuni[w][lo], s.nuni);
-            atomicAdd(&scr->nterms[w][lo], nt);
+            atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
+            atomicAdd(&scr->nterms[w][lo & 63], nt);
         }
         __syncthreads();
         PGT_MARK(6);
         if (threadIdx.x == 0) scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
-        const int a0 = off > cb ? off : cb, a1 = (off + tb) < (cb + 256) ? (off + tb) : (cb + 256);
-        for (int t = a0; t < a1; ++t) acc += scr->draws[wave][t - cb];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int a0 = off[j] > cb ? off[j] : cb, a1 = (off[j] + tb[j]) < (cb + 256) ? (off[j] + tb[j]) : (cb + 256);
+            for (int t = a0; t < a1; ++t) acc[j] += scr->draws[wave][t - cb];
+        }
         __syncthreads();
         PGT_MARK(1);
     }
     nuni += scr->nuni[wave][lane];
     nterms += scr->nterms[wave][lane];
-    return acc;
+#undef PG_OWNER_Z
+#undef PG_OWNER_SUB
 }
 
-// rand(PolyaGamma(b, c)) for the lane's point, integer part dealt across the workgroup: the same value, uniforms consumed and
-// series indices as agpl::rand_pg(g, latent, b, c, .) run by one lane.  Called by all threads of the workgroup.  INT: b is
-// known to be an integer (Bernoulli: no Gamma-series code in the kernel).
+// rand(PolyaGamma(b_j, c_j)) for latents latent0 .. latent0 + nk - 1 of the lane's point (nk <= NB), integer parts dealt across
+// the workgroup in ONE pass of the phases: the same values, uniforms consumed and series indices as agpl::rand_pg(g, latent, b, c, .)
+// run by one lane, latent after latent.  Called by all threads of the workgroup.  INT: every b is known to be an integer (no
+// Gamma-series code in the kernel).  The categorical likelihood's K latents go through in groups of kPgMaxLat: per call the
+// engine costs six workgroup barriers whatever it has to draw, and a latent of that likelihood brings ~13 draws per wave.
+template <int NB, bool INT = false>
+__device__ __forceinline__ void pg_points_wave(PgBlockScratch *scr, int lane, bool valid, Philox &g, int latent0, int nk,
+                                               const double (&b)[NB], const double (&c)[NB], double (&w)[NB], uint32_t &nterms,
+                                               int *bad) {
+    const int wave = (int)(threadIdx.x >> 6);
+    int tb[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const bool on = valid && j < nk;
+        // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
+        // host as AGPL_ERR_UNSUPPORTED instead of a silent NaN
+        if (on && b[j] >= 65535.0) atomicOr(bad, 2);
+        ok[j] = on && (b[j] >= 0.0) && (fabs(c[j]) < __builtin_inf()) && (b[j] < 65535.0);
+        tb[j] = ok[j] ? (int)floor(b[j]) : 0;
+    }
+    pg_int_sum_block<NB>(scr, wave, lane, g, latent0, tb, c, w, g.nuni, nterms);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (!(valid && j < nk)) w[j] = 0.0;
+        else if (!ok[j]) w[j] = __builtin_nan("");
+        else if (b[j] == 0.0) w[j] = 0.0;
+        else if (!INT) {
+            const double res = b[j] - (double)tb[j];
+            if (res != 0.0) {
+                Philox s = g.sub(1u + ((uint32_t)(latent0 + j) << 16) + kSubResidual);
+                w[j] += rand_gamma_sum(s, c[j], res);
+                g.nuni += s.nuni;
+            }
+        }
+    }
+}
+// one latent
 template <bool INT = false>
 __device__ __forceinline__ double pg_point_wave(PgBlockScratch *scr, int lane, bool valid, Philox &g, int latent, double b,
                                        double c, uint32_t &nterms, int *bad) {
-    const int wave = (int)(threadIdx.x >> 6);
-    // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
-    // host as AGPL_ERR_UNSUPPORTED instead of a silent NaN
-    if (valid && b >= 65535.0) atomicOr(bad, 2);
-    const bool ok = valid && (b >= 0.0) && (fabs(c) < __builtin_inf()) && (b < 65535.0);
-    const int tb = ok ? (int)floor(b) : 0;
-    const uint32_t base = 1u + ((uint32_t)latent << 16);
-    double acc = pg_int_sum_block(scr, wave, lane, g, base, tb, c, g.nuni, nterms);
-    if (!valid) return 0.0;
-    if (!ok) return __builtin_nan("");
-    if (b == 0.0) return 0.0;
-    if (!INT) {
-        const double res = b - (double)tb;
-        if (res != 0.0) {
-            Philox s = g.sub(base + kSubResidual);
-            acc += rand_gamma_sum(s, c, res);
-            g.nuni += s.nuni;
-        }
-    }
-    return acc;
+    const double bb[1] = {b}, cc[1] = {c};
+    double w[1];
+    pg_points_wave<1, INT>(scr, lane, valid, g, latent, 1, bb, cc, w, nterms, bad);
+    return w[0];
 }
 
 template <typename NN>
@@ -453,10 +505,19 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
                 }
             }
         }
-        for (int k = 0; k < L; ++k) { // L is wave-uniform: every lane deals for every latent
-            const double b = good ? (double)(nn[k] + (int64_t)y[i * L + k]) : 0.0, c = good ? fabs(f[k]) : 0.0;
-            const double w = pg_point_wave(scr, lane, good, g, k, b, c, nt, bad);
-            if (good) om[k] = w;
+        for (int k0 = 0; k0 < L; k0 += kPgMaxLat) { // L is uniform over the workgroup: every lane deals for every group of latents
+            const int nk = L - k0 < kPgMaxLat ? L - k0 : kPgMaxLat;
+            double b[kPgMaxLat], c[kPgMaxLat], w[kPgMaxLat];
+#pragma unroll
+            for (int j = 0; j < kPgMaxLat; ++j) {
+                const bool on = good && j < nk;
+                b[j] = on ? (double)(nn[k0 + j] + (int64_t)y[i * L + k0 + j]) : 0.0;
+                c[j] = on ? fabs(f[k0 + j]) : 0.0;
+            }
+            pg_points_wave<kPgMaxLat, true>(scr, lane, good, g, k0, nk, b, c, w, nt, bad); // (counts + one-hot labels: integers)
+#pragma unroll
+            for (int j = 0; j < kPgMaxLat; ++j)
+                if (good && j < nk) om[k0 + j] = w[j];
         }
     } break;
     case AGPL_LIK_POISSON: { // poisson.jl:26-28, polyagammapoisson.jl:23-27
