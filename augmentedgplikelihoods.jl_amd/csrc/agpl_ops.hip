@@ -1838,6 +1838,10 @@ __device__ __forceinline__ void gibbs_sample_points(const agpl_lik_dev &lik, int
 // Fused into one kernel (the first form) the sampler's ~255 VGPRs held the streaming half at one wave per SIMD:
 // 6.2 ms at C2 against 4.9 ms for the pair.
 // ------------------------------------------------------------------------------------------------
+// NV > 0: M = 64 NV and the lane's NV float4 of a row are loaded ONCE and kept in registers for all latents (the generic form,
+// NV = 0, re-reads the row per latent: with K = 10 latents that was 10 x the loads of a pass that is otherwise free); the
+// summation order per latent is the same, so the projections are bit for bit those of the generic form.
+template <int NV>
 __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, int Lf, const float *__restrict__ Phi,
                                                             const double *__restrict__ v, double *__restrict__ proj) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1846,24 +1850,72 @@ __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, in
     for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
     __syncthreads();
     const int q = lane & 15, grp = lane >> 4;
-    const int64_t nblocks = (N + 255) >> 8; // (uniform trip count over the workgroup: the sampler has barriers)
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int64_t base = (blk * 4 + wave) << 6;
-        const int np = (N - base) < 0 ? 0 : (int)((N - base) < 64 ? (N - base) : 64);
+    const int64_t nchunks = (N + 63) >> 6; // (a wave per 64-point chunk; no barrier in the loop: waves run out independently)
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+        const int64_t base = chunk << 6;
+        const int np = (int)((N - base) < 64 ? (N - base) : 64); // >= 1
         for (int r = 0; r < 16; ++r) {
             int p = 4 * r + grp;
             const int pc = p < np ? p : np - 1; // clamp: keeps every lane in the shuffles
             const float *row = Phi + (base + pc) * (int64_t)M;
-            for (int l = 0; l < Lf; ++l) {
+            double xd[NV > 0 ? 4 * NV : 1]; // (converted once, not per latent)
+            if (NV > 0) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const float4 x = *reinterpret_cast<const float4 *>(row + (q << 2) + 64 * i);
+                    xd[4 * i] = (double)x.x, xd[4 * i + 1] = (double)x.y, xd[4 * i + 2] = (double)x.z, xd[4 * i + 3] = (double)x.w;
+                }
+            }
+            int l = 0;
+            if (NV > 0) { // four latents at a time: their accumulation chains are independent and overlap (each sum in its own order)
+                for (; l + 4 <= Lf; l += 4) {
+                    const double *v0 = v_s + (size_t)l * M, *v1 = v0 + M, *v2 = v1 + M, *v3 = v2 + M;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int a = (q << 2) + 64 * i;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a0 += xd[4 * i + e] * v0[a + e];
+                            a1 += xd[4 * i + e] * v1[a + e];
+                            a2 += xd[4 * i + e] * v2[a + e];
+                            a3 += xd[4 * i + e] * v3[a + e];
+                        }
+                    }
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) {
+                        a0 += __shfl_xor(a0, off);
+                        a1 += __shfl_xor(a1, off);
+                        a2 += __shfl_xor(a2, off);
+                        a3 += __shfl_xor(a3, off);
+                    }
+                    if (q == 0 && p < np) {
+                        double *dst = proj + (base + p) * Lf + l;
+                        dst[0] = a0, dst[1] = a1, dst[2] = a2, dst[3] = a3;
+                    }
+                }
+            }
+            for (; l < Lf; ++l) {
                 const double *vl = v_s + (size_t)l * M;
                 double acc = 0.0;
+                if (NV > 0) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int a = (q << 2) + 64 * i;
+                        acc += xd[4 * i] * vl[a];
+                        acc += xd[4 * i + 1] * vl[a + 1];
+                        acc += xd[4 * i + 2] * vl[a + 2];
+                        acc += xd[4 * i + 3] * vl[a + 3];
+                    }
+                } else {
 #pragma unroll 8
-                for (int a = q << 2; a < M; a += 64) {
-                    const float4 x = *reinterpret_cast<const float4 *>(row + a);
-                    acc += (double)x.x * vl[a];
-                    acc += (double)x.y * vl[a + 1];
-                    acc += (double)x.z * vl[a + 2];
-                    acc += (double)x.w * vl[a + 3];
+                    for (int a = q << 2; a < M; a += 64) {
+                        const float4 x = *reinterpret_cast<const float4 *>(row + a);
+                        acc += (double)x.x * vl[a];
+                        acc += (double)x.y * vl[a + 1];
+                        acc += (double)x.z * vl[a + 2];
+                        acc += (double)x.w * vl[a + 3];
+                    }
                 }
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -1921,9 +1973,17 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
         const size_t lds_p = sizeof(double) * (size_t)Lf * M, lds_s = sizeof(double) * 4 * (size_t)(64 * (Lf + Lo) + 32 * Lo);
         int64_t nbp = agpl_cdiv(agpl_cdiv(N, 64), 4);
         if (nbp > 256 * 16) nbp = 256 * 16;
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-        gibbs_project_kernel<<<(unsigned)nbp, 256, lds_p, ctx->stream>>>(N, M, Lf, Phi, v, proj_work);
+#define AGPL_LAUNCH_PROJECT(NV_)                                                                                    \
+    do {                                                                                                            \
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_kernel<NV_>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));                 \
+        gibbs_project_kernel<NV_><<<(unsigned)nbp, 256, lds_p, ctx->stream>>>(N, M, Lf, Phi, v, proj_work);         \
+    } while (0)
+        if (Lf > 1 && M == 256) AGPL_LAUNCH_PROJECT(4); // several latents: the row stays in registers (M = 64 NV)
+        else if (Lf > 1 && M == 512) AGPL_LAUNCH_PROJECT(8);
+        else if (Lf > 1 && M == 1024) AGPL_LAUNCH_PROJECT(16);
+        else AGPL_LAUNCH_PROJECT(0);
+#undef AGPL_LAUNCH_PROJECT
         AGPL_LAUNCH_CHECK(ctx);
 #define AGPL_LAUNCH_GIBBS_S(K)                                                                                        \
     case K:                                                                                                           \
