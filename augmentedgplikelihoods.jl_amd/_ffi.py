@@ -26,6 +26,8 @@ SYMBOLS = [
     "agpl_pack_factor_split", "agpl_marginals_factor_split", "agpl_cavi_pass_factor_split", "agpl_probe_mfma_f64", "agpl_probe_mfma_f16",
     "agpl_accumulate_image_bytes", "agpl_accumulate_image", "agpl_accumulate_split", "agpl_cavi_pass_factor_image",
     "agpl_gibbs_pass_image", "agpl_debug_force_factor_rescue",
+    "agpl_plan_bytes", "agpl_plan_create", "agpl_plan_destroy", "agpl_plan_info", "agpl_plan_factor", "agpl_plan_state", "agpl_cavi_pass_plan",
+    "agpl_plan_update", "agpl_marginals_plan", "agpl_gibbs_pass_plan",
 ]
 
 
@@ -86,6 +88,7 @@ def lib() -> C.CDLL:
         _lib.agpl_workspace_bytes.restype = C.c_int64
         _lib.agpl_split_features_bytes.restype = C.c_int64
         _lib.agpl_accumulate_image_bytes.restype = C.c_int64
+        _lib.agpl_plan_bytes.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # raises AttributeError if the library does not export the ABI
     return _lib

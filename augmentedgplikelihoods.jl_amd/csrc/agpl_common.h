@@ -34,7 +34,9 @@ struct agpl_ctx {
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
     int accumulate_split = 0; // 0: f32-input MFMA accumulation, 1: split-float16 (agpl_set_accumulate_precision)
     int ncu = 0;              // compute units of `device` (queried once, by the first queue-served launch)
-    int strip_attr = 0;       // syrk_strip_kernel's dynamic-LDS attribute is set (once)
+    int strip_attr = 0;       // the accumulation kernels' dynamic-LDS attributes are set (once)
+    int queue_attr = 0;       // marginal_factor_queue_kernel's dynamic-LDS attribute is set (once)
+    double *elbo_part = nullptr;  // per-workgroup partial sums of the ELBO terms that ride the per-point kernel (1024 doubles)
     bool debug_force_rescue = false; // agpl_debug_force_factor_rescue (test hook)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample

@@ -40,6 +40,7 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->elbo_part) (void)hipFree(ctx->elbo_part);
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
     if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
     if (ctx->pend_ev) (void)hipEventDestroy(ctx->pend_ev);
@@ -171,6 +172,9 @@ int32_t agpl_timing_begin(agpl_ctx *ctx, int which) {
         AGPL_HIP(ctx, hipEventCreate(&pr.second));
     }
     AGPL_HIP(ctx, hipEventRecord(pr.first, ctx->stream));
+    // the stop event is recorded here as well (agpl_timing_end records it again, the later record counts): a caller that
+    // fails between begin and end leaves a well-formed pair of ~0 ms instead of an event that was never recorded
+    AGPL_HIP(ctx, hipEventRecord(pr.second, ctx->stream));
     ctx->ev[which].push_back(pr);
     return AGPL_OK;
 }

@@ -115,7 +115,11 @@ __device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int
     // staging role: rows (tid & 63) * 2, +1 of the tile; panel columns (tid >> 6) + 4 i
     const int srow = (tid & 63) * 2, sq = tid >> 6;
     int64_t gr = r0 + srow, gc = c0 + srow;
-    if (gr > rmax - 2) gr = rmax - 2; // (rows beyond the limit are never stored: any in-range address will do)
+    // A thread stages the row pair (gr, gr + 1).  Pairs beyond the limit are never stored: any in-range address will do.  The pair
+    // that STRADDLES the limit (gr == rmax - 1: an odd number of rows is left) is read as (rmax - 2, rmax - 1) and its second
+    // value moved into the first slot, so that the LDS slot of row rmax - 1 holds row rmax - 1
+    const bool tailr = gr == rmax - 1, tailc = gc == cmax - 1;
+    if (gr > rmax - 2) gr = rmax - 2;
     if (gc > cmax - 2) gc = cmax - 2;
     const double *pr = Xp + gr + sq * ldx, *pc = Yp + gc + sq * ldy;
     double *sR = smem, *sC = smem + 2 * kTStage; // [stage][q][row]
@@ -132,7 +136,9 @@ __device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int
             vc1 = *reinterpret_cast<const double2 *>(qc_ + 4 * ldy);                                            \
             vc2 = *reinterpret_cast<const double2 *>(qc_ + 8 * ldy);                                            \
             vc3 = *reinterpret_cast<const double2 *>(qc_ + 12 * ldy);                                           \
+            if (tailc) vc0.x = vc0.y, vc1.x = vc1.y, vc2.x = vc2.y, vc3.x = vc3.y;                              \
         }                                                                                                       \
+        if (tailr) vr0.x = vr0.y, vr1.x = vr1.y, vr2.x = vr2.y, vr3.x = vr3.y;                                  \
     } while (0)
 #define AGPL_T_SWRITE(st_)                                                                                      \
     do {                                                                                                        \
@@ -312,7 +318,7 @@ int32_t own_block_potrf(agpl_ctx *ctx, hipStream_t st, int64_t N, double *A, int
 #ifndef AGPL_DENSE_NB
 #define AGPL_DENSE_NB 2048 // measured at C5 on one box without look-ahead (profiles/r03_c5_block_width.txt): 512 / 1024 / 2048 / 4096 -> 1876 / 1763 / 1741 / 1743 ms per step
 #endif
-int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
+int32_t blocked_potrf_steps(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
     constexpr int64_t nb = AGPL_DENSE_NB;
     static_assert(nb % kTK == 0 && nb % kTT == 0 && nb % kPB == 0, "panel width must be whole stages, tiles and blocks");
     hipStream_t S = ctx->stream;
@@ -375,6 +381,18 @@ int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, roc
     }
     AGPL_ROCBLAS(ctx, rocblas_set_stream(h, S));
     return AGPL_OK;
+}
+// On an error in the middle of the steps the library handle may be bound to the side stream and the side stream may still be
+// working: put both back (the handle on the main stream, the main stream behind whatever the side stream was given) before
+// the error is reported, so that the context stays usable.
+int32_t blocked_potrf(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *A, rocblas_int *info) {
+    const int32_t rc = blocked_potrf_steps(ctx, h, N, A, info);
+    if (rc != AGPL_OK) {
+        (void)rocblas_set_stream(h, ctx->stream);
+        if (ctx->aux_stream && ctx->aux_ev[1] && hipEventRecord(ctx->aux_ev[1], ctx->aux_stream) == hipSuccess)
+            (void)hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0);
+    }
+    return rc;
 }
 
 } // namespace

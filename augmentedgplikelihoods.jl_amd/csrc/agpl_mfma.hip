@@ -892,6 +892,7 @@ void agpl_accumulate_records(int64_t N, int32_t M, int32_t L, void *slab_mem, fl
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image,
                              const float *beta, const float *gamma, double *G_out, double *g_out, void *slab_mem,
                              bool records_ready) {
+    const bool use_image = acc_image && M % 256 == 0;
     const SlabLayout lo = slab_layout(N, M, L);
     const int ns = lo.ns, nb = lo.nb, npairs = (int)lo.npairs, ng = lo.ng;
     float *slabG = (float *)((char *)slab_mem + lo.slabG);
@@ -901,15 +902,15 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     const size_t lds = syrk_lds_bytes();
     const int64_t nwg = (int64_t)L * npairs * ((ns + 7) / 8) * 8;
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
+    if (!use_image && !Phi)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the accumulation needs the float32 features (no image, or M %% 256 != 0)");
     int32_t rc = agpl_timing_begin(ctx, 1);
     if (rc) return rc;
-    if (acc_image && M % 256 == 0) {
+    int32_t launch_rc = AGPL_OK; // reported behind agpl_timing_end: a failed launch must not leave an open event pair
+    if (use_image) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
-        rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
-                                    (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, records_ready);
-        if (rc) return rc;
-    } else if (!Phi) {
-        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the accumulation needs the float32 features (no image, or M %% 256 != 0)");
+        launch_rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
+                                           (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, records_ready);
     } else if (ctx->accumulate_split) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         float *sg = (float *)((char *)slab_mem + lo.sgam);
@@ -920,8 +921,9 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
                                                                                        slabG, slabg);
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
-    AGPL_LAUNCH_CHECK(ctx);
     rc = agpl_timing_end(ctx, 1);
+    if (launch_rc) return launch_rc;
+    AGPL_LAUNCH_CHECK(ctx);
     if (rc) return rc;
     // fixed-order float64 reduction of the slabs, G and g together: slices -> groups of kRedGroup, groups -> G, g
     dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs + L * nb));

@@ -12,6 +12,7 @@ using namespace agpl;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kRedParts = 1016; // reduction partials: doubles 8..1023 of the small scratch (bytes 64..8191)
 
 inline int grid_for(int64_t n) {
     int64_t b = agpl_cdiv(n, kBlock);
@@ -1103,6 +1104,120 @@ struct RedArgs {
     const double *var; // var
 };
 
+// One point's expected_logtilt (bernoulli.jl:59-65, negativebinomial.jl:59-65, studentt.jl:80-83, categorical.jl:172-180,
+// poisson.jl:76-85, laplace.jl:83-88) and aux_kldivergence (generic.jl:56-62) term from accessors -- y(k), q1(k), q2(k), mu(k),
+// var(k), all double, k = latent -- shared by the reduction kernels (accessors over arrays) and by the sweep's per-point kernel
+// (accessors over the marginals it has just formed): the same expressions, hence the same float64 results.
+template <class Y, class Q1, class Q2, class MU, class VAR>
+__device__ __forceinline__ double expected_logtilt_point(const agpl_lik_dev &lik, Y y, Q1 q1, Q2 q2, MU mu, VAR var) {
+    const int L = lik.nlatent;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:59-65
+        double s = y(0) != 0.0 ? 1.0 : -1.0;
+        double th = pg_mean(1.0, q1(0));
+        return -kLogTwo + (s * mu(0) - (mu(0) * mu(0) + var(0)) * th) / 2.0;
+    }
+    case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:59-65
+        double r = lik.p[0], yy = y(0);
+        double th = pg_mean(yy + r, q1(0));
+        return negbin_logconst(yy, r) - (yy + r) * kLogTwo + (mu(0) * (yy - r) - (mu(0) * mu(0) + var(0)) * th) / 2.0;
+    }
+    case AGPL_LIK_STUDENTT: { // studentt.jl:80-83
+        double th = ((lik.p[0] + 1.0) / 2.0) / q1(0);
+        double d = mu(0) - y(0);
+        return -0.5 * kLog2Pi + 0.5 * log(th) - 0.5 * d * d * th - var(0) * th / 2.0;
+    }
+    case AGPL_LIK_CATEGORICAL:
+    case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:172-180
+        double sp = 0.0;
+        for (int k = 0; k < L; ++k) sp += q2(k);
+        double p0 = 1.0 - sp, s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < L; ++k) {
+            double yk = y(k), nbar = q2(k) / p0;
+            double w = pg_mean(yk + nbar, q1(k));
+            double m = mu(k), v = var(k);
+            s1 += yk + nbar;
+            s2 += ((yk - nbar) * m - (m * m + v) * w) / 2.0;
+        }
+        return -s1 * kLogTwo + s2;
+    }
+    case AGPL_LIK_POISSON: { // poisson.jl:76-85
+        double yy = y(0), nbar = q2(0);
+        double w = pg_mean(yy + nbar, q1(0));
+        return -(yy + nbar) * kLogTwo + ((yy - nbar) * mu(0) - (mu(0) * mu(0) + var(0)) * w) / 2.0 + yy * log(lik.p[0]) -
+               lgamma(yy + 1.0);
+    }
+    case AGPL_LIK_LAPLACE: { // laplace.jl:83-88
+        double yy = y(0);
+        return lgamma(0.5) - 0.5 * log(kPi) - log(2.0 * lik.p[0]) - ((mu(0) - yy) * (mu(0) - yy) + var(0)) * q1(0);
+    }
+    default:
+        return __builtin_nan("");
+    }
+}
+template <class Y, class Q1, class Q2>
+__device__ __forceinline__ double aux_kl_point(const agpl_lik_dev &lik, Y y, Q1 q1, Q2 q2) {
+    const int L = lik.nlatent;
+    switch (lik.kind) {
+    case AGPL_LIK_BERNOULLI_LOGISTIC:
+        return pg_kl(1.0, q1(0));
+    case AGPL_LIK_NEGBINOMIAL:
+        return pg_kl(y(0) + lik.p[0], q1(0));
+    case AGPL_LIK_STUDENTT: { // KL(Gamma(alpha, 1/beta_i) || Gamma(nu/2, 2 sigma^2/nu)) studentt.jl:85-91
+        double nu = lik.p[0], sg = lik.p[1];
+        double ap = (nu + 1.0) / 2.0, thp = 1.0 / q1(0);
+        double aq = nu / 2.0, thq = sg * sg / (nu / 2.0);
+        return (ap - aq) * digamma_(ap) - lgamma(ap) + lgamma(aq) + aq * (log(thq) - log(thp)) + ap * (thp - thq) / thq;
+    }
+    case AGPL_LIK_POISSON: { // polyagammapoisson.jl:47-51
+        double lq = q2(0), lp = lik.p[0];
+        double klp = lq > 0 ? lq * (log(lq) - log(lp)) - lq + lp : lp;
+        return pg_kl(y(0) + lq, q1(0)) + klp;
+    }
+    case AGPL_LIK_LAPLACE: { // laplace.jl:96-104
+        double lam = 1.0 / ((2.0 * lik.p[0]) * (2.0 * lik.p[0]));
+        return log(2.0 * lam) / 2.0 - log(2.0 * kPi) / 2.0 - log(lam) / 2.0 + lgamma(0.5) + lam / q1(0);
+    }
+    case AGPL_LIK_CATEGORICAL_BIJ: { // polyagammanegativemultinomial.jl:56-65, negativemultinomial.jl:72-82
+        double sp = 0.0;
+        for (int k = 0; k < L; ++k) sp += q2(k);
+        double p0 = 1.0 - sp;
+        double pp = 1.0 / lik.sum_theta;
+        double p0p = 1.0 - L * pp;
+        double s = 0.0, acc = 0.0;
+        for (int k = 0; k < L; ++k) {
+            double nbar = q2(k) / p0;
+            acc += pg_kl(y(k) + nbar, q1(k));
+            s += q2(k) * (log(q2(k)) - log(pp));
+        }
+        return acc + log(p0) - log(p0p) + s / p0;
+    }
+    default:
+        return __builtin_nan("");
+    }
+}
+// y of (point i, latent k) as a double, by the likelihood's observation type (REAL: the element type of real-valued y)
+template <typename REAL>
+struct YAcc {
+    const void *y;
+    int64_t i;
+    int kind, L;
+    __device__ __forceinline__ double operator()(int k) const {
+        switch (kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC:
+            return (double)((const uint8_t *)y)[i];
+        case AGPL_LIK_NEGBINOMIAL:
+        case AGPL_LIK_POISSON:
+            return (double)((const int32_t *)y)[i];
+        case AGPL_LIK_CATEGORICAL:
+        case AGPL_LIK_CATEGORICAL_BIJ:
+            return (double)((const uint8_t *)y)[i * L + k];
+        default:
+            return (double)((const REAL *)y)[i];
+        }
+    }
+};
+
 __device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A);
 
 // logdensity_def(aux_prior(lik, y), Omega) per point -- the second half of aug_loglik (generic.jl:48-50).
@@ -1169,96 +1284,15 @@ __device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const R
             return nanv;
         }
     }
-    if (mode == RED_EXPECTED_LOGTILT) {
-        const double *q1 = A.a1, *q2 = A.a2, *mu = A.f, *var = A.var;
-        switch (lik.kind) {
-        case AGPL_LIK_BERNOULLI_LOGISTIC: { // bernoulli.jl:59-65
-            double s = ((const uint8_t *)A.y)[i] ? 1.0 : -1.0;
-            double th = pg_mean(1.0, q1[i]);
-            return -kLogTwo + (s * mu[i] - (mu[i] * mu[i] + var[i]) * th) / 2.0;
-        }
-        case AGPL_LIK_NEGBINOMIAL: { // negativebinomial.jl:59-65
-            double r = lik.p[0], yy = (double)((const int32_t *)A.y)[i];
-            double th = pg_mean(yy + r, q1[i]);
-            return negbin_logconst(yy, r) - (yy + r) * kLogTwo +
-                   (mu[i] * (yy - r) - (mu[i] * mu[i] + var[i]) * th) / 2.0;
-        }
-        case AGPL_LIK_STUDENTT: { // studentt.jl:80-83
-            double th = ((lik.p[0] + 1.0) / 2.0) / q1[i];
-            double d = mu[i] - ((const double *)A.y)[i];
-            return -0.5 * kLog2Pi + 0.5 * log(th) - 0.5 * d * d * th - var[i] * th / 2.0;
-        }
-        case AGPL_LIK_CATEGORICAL:
-        case AGPL_LIK_CATEGORICAL_BIJ: { // categorical.jl:172-180
-            const uint8_t *y = (const uint8_t *)A.y;
-            double sp = 0.0;
-            for (int k = 0; k < L; ++k) sp += q2[i * L + k];
-            double p0 = 1.0 - sp, s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < L; ++k) {
-                double yk = (double)y[i * L + k], nbar = q2[i * L + k] / p0;
-                double w = pg_mean(yk + nbar, q1[i * L + k]);
-                double m = mu[i * L + k], v = var[i * L + k];
-                s1 += yk + nbar;
-                s2 += ((yk - nbar) * m - (m * m + v) * w) / 2.0;
-            }
-            return -s1 * kLogTwo + s2;
-        }
-        case AGPL_LIK_POISSON: { // poisson.jl:76-85
-            double yy = (double)((const int32_t *)A.y)[i], nbar = q2[i];
-            double w = pg_mean(yy + nbar, q1[i]);
-            return -(yy + nbar) * kLogTwo + ((yy - nbar) * mu[i] - (mu[i] * mu[i] + var[i]) * w) / 2.0 +
-                   yy * log(lik.p[0]) - lgamma(yy + 1.0);
-        }
-        case AGPL_LIK_LAPLACE: { // laplace.jl:83-88
-            double yy = ((const double *)A.y)[i];
-            return lgamma(0.5) - 0.5 * log(kPi) - log(2.0 * lik.p[0]) -
-                   ((mu[i] - yy) * (mu[i] - yy) + var[i]) * q1[i];
-        }
-        default:
-            return nanv;
-        }
-    }
-    // RED_KL: aux_kldivergence generic.jl:56-62
     const double *q1 = A.a1, *q2 = A.a2;
-    switch (lik.kind) {
-    case AGPL_LIK_BERNOULLI_LOGISTIC:
-        return pg_kl(1.0, q1[i]);
-    case AGPL_LIK_NEGBINOMIAL:
-        return pg_kl((double)((const int32_t *)A.y)[i] + lik.p[0], q1[i]);
-    case AGPL_LIK_STUDENTT: { // KL(Gamma(alpha, 1/beta_i) || Gamma(nu/2, 2 sigma^2/nu)) studentt.jl:85-91
-        double nu = lik.p[0], sg = lik.p[1];
-        double ap = (nu + 1.0) / 2.0, thp = 1.0 / q1[i];
-        double aq = nu / 2.0, thq = sg * sg / (nu / 2.0);
-        return (ap - aq) * digamma_(ap) - lgamma(ap) + lgamma(aq) + aq * (log(thq) - log(thp)) +
-               ap * (thp - thq) / thq;
+    const YAcc<double> y{A.y, i, lik.kind, L};
+    auto q1a = [&](int k) { return q1[i * L + k]; };
+    auto q2a = [&](int k) { return q2[i * L + k]; };
+    if (mode == RED_EXPECTED_LOGTILT) {
+        const double *mu = A.f, *var = A.var;
+        return expected_logtilt_point(lik, y, q1a, q2a, [&](int k) { return mu[i * L + k]; }, [&](int k) { return var[i * L + k]; });
     }
-    case AGPL_LIK_POISSON: { // polyagammapoisson.jl:47-51
-        double lq = q2[i], lp = lik.p[0];
-        double klp = lq > 0 ? lq * (log(lq) - log(lp)) - lq + lp : lp;
-        return pg_kl((double)((const int32_t *)A.y)[i] + lq, q1[i]) + klp;
-    }
-    case AGPL_LIK_LAPLACE: { // laplace.jl:96-104
-        double lam = 1.0 / ((2.0 * lik.p[0]) * (2.0 * lik.p[0]));
-        return log(2.0 * lam) / 2.0 - log(2.0 * kPi) / 2.0 - log(lam) / 2.0 + lgamma(0.5) + lam / q1[i];
-    }
-    case AGPL_LIK_CATEGORICAL_BIJ: { // polyagammanegativemultinomial.jl:56-65, negativemultinomial.jl:72-82
-        const uint8_t *y = (const uint8_t *)A.y;
-        double sp = 0.0;
-        for (int k = 0; k < L; ++k) sp += q2[i * L + k];
-        double p0 = 1.0 - sp;
-        double pp = 1.0 / lik.sum_theta;
-        double p0p = 1.0 - L * pp;
-        double s = 0.0, acc = 0.0;
-        for (int k = 0; k < L; ++k) {
-            double nbar = q2[i * L + k] / p0;
-            acc += pg_kl((double)y[i * L + k] + nbar, q1[i * L + k]);
-            s += q2[i * L + k] * (log(q2[i * L + k]) - log(pp));
-        }
-        return acc + log(p0) - log(p0p) + s / p0;
-    }
-    default:
-        return nanv;
-    }
+    return aux_kl_point(lik, y, q1a, q2a); // RED_KL: aux_kldivergence generic.jl:56-62
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_terms_kernel(int mode, agpl_lik_dev lik, int64_t n, RedArgs A,
@@ -1306,9 +1340,11 @@ int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t
         *out_host = 0.0;
         return AGPL_OK;
     }
+    // partials live in bytes 64..8191 of the small scratch: bytes 8192..16383 belong to the marginal item queues and the
+    // factor hand-off flags, which must read zero between launches (agpl_split.hip, agpl_factor.hip)
     int nb = grid_for(n);
-    if (nb > 1024) nb = 1024;
-    rc = agpl_ws2_reserve(ctx, sizeof(double) * (1024 + 8));
+    if (nb > kRedParts) nb = kRedParts;
+    rc = agpl_ws2_reserve(ctx, 16384);
     if (rc) return rc;
     double *partial = (double *)ctx->ws2;
     reduce_terms_kernel<<<nb, kBlock, 0, ctx->stream>>>(mode, ld, n, A, partial + 8);
@@ -1616,6 +1652,36 @@ __device__ __forceinline__ void fused_point(const agpl_lik_dev &lik, int64_t n, 
     }
 }
 
+// expected_logtilt_i - aux_kldivergence_i (the per-point part of aug_elbo, examples/bernoulli/script.jl:65-70) for q(f_i) = the
+// marginal `mg` gives and qOmega_i = aux_posterior(lik, y_i, q(f_i)), evaluated in float64 FROM the float32 marginals -- the value
+// the float64 operator kernels (aux_posterior_kernel<double>, reduce_terms_kernel) give for the same marginals.  NaN for the
+// likelihoods whose terms the reference does not define (non-bijective categorical KL, heteroscedastic).
+template <class MG>
+__device__ __forceinline__ double elbo_point(const agpl_lik_dev &lik, int64_t i, const void *yv, const MG &mg) {
+    const int L = lik.nlatent;
+    const YAcc<float> y{yv, i, lik.kind, L};
+    auto mu = [&](int k) { return (double)mg.m(k, i); };
+    auto var = [&](int k) { return (double)mg.v(k, i); };
+    auto q1 = [&](int k) -> double { // out1 of aux_posterior!
+        switch (lik.kind) {
+        case AGPL_LIK_STUDENTT: {
+            const double nu = lik.p[0], sg = lik.p[1];
+            return (nu / (sg * sg) + second_moment_y(mu(0), var(0), y(0))) / 2.0;
+        }
+        case AGPL_LIK_LAPLACE:
+            return 1.0 / (2.0 * lik.p[0] * sqrt(second_moment_y(mu(0), var(0), y(0))));
+        default:
+            return sqrt(second_moment(mu(k), var(k)));
+        }
+    };
+    auto q2 = [&](int k) -> double { // out2 of aux_posterior!
+        if (lik.kind == AGPL_LIK_POISSON) return lik.p[0] * approx_expected_logistic(-mu(0), q1(0));
+        const double den = lik.kind == AGPL_LIK_CATEGORICAL ? (double)L : (lik.cat_const + (double)L);
+        return approx_expected_logistic(-mu(k), q1(k)) / den;
+    };
+    return expected_logtilt_point(lik, y, q1, q2, mu, var) - aux_kl_point(lik, y, q1, q2);
+}
+
 struct MargArrays { // marginals latent-major [L][N]
     const float *mu, *var;
     int64_t n;
@@ -1687,7 +1753,8 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
                                                                   float *__restrict__ gamma, float *__restrict__ beta,
                                                                   float *__restrict__ c_out, float *__restrict__ gb,
                                                                   unsigned *__restrict__ scal,
-                                                                  unsigned *__restrict__ queues) {
+                                                                  unsigned *__restrict__ queues,
+                                                                  double *__restrict__ elbo_part) {
     // queues[0..7]: the marginal kernel's item queues; queues[8]: 1 + index of a gamma that is negative or not finite, kept
     // until the update's last kernel forwards it to the host (agpl_pending_resolve reports AGPL_ERR_DOMAIN)
     __shared__ unsigned red[2][kBlock / 64];
@@ -1695,9 +1762,11 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
     if (blockIdx.x == 0 && threadIdx.x < 8) queues[threadIdx.x] = 0u; // the marginal kernel's item queues, for its next launch
     const MargParts mg{resid, mu0, qpart, mpart, n, L, nb2};
     OutRecords out{gamma, beta, gb, n, npad / 32, 0u, 0u};
+    double eacc = 0.0; // (elbo_part != nullptr) this thread's ELBO terms, points in ascending order
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n) {
             fused_point(lik, n, i, yv, mg, out, c_out);
+            if (elbo_part) eacc += elbo_point(lik, i, yv, mg);
         } else { // the zero tail of the records
             for (int k = 0; k < L; ++k) {
                 float *rec = gb + ((int64_t)k * out.nrec + (i >> 5)) * 64 + (i & 31);
@@ -1728,17 +1797,43 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
             atomicMax(queues + 8, b);
         }
     }
+    if (elbo_part) { // the ELBO rides the pass: fixed-order tree over the workgroup, one partial per workgroup
+        __shared__ double esum[kBlock];
+        esum[threadIdx.x] = eacc;
+        __syncthreads();
+        for (int st = kBlock / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) esum[threadIdx.x] += esum[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) elbo_part[blockIdx.x] = esum[0];
+    }
 }
 
 // internal (agpl_update.hip): the per-point kernel of the image sweep; scal must be zero (the marginal kernel zeroes it)
 int32_t agpl_launch_fused_point(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, int64_t npad, int nb2, const void *y,
                                 const float *resid, const float *mu0, const float *qpart, const float *mpart,
-                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues) {
+                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues,
+                                double *elbo_terms_out) {
     int64_t nblk = agpl_cdiv(npad, kBlock);
     if (nblk > 1024) nblk = 1024; // (one atomic per workgroup on the max-gamma word)
+    double *part = nullptr;
+    if (elbo_terms_out) { // the sum over points of expected_logtilt_i - aux_kldivergence_i rides the pass
+        if (ld.kind == AGPL_LIK_CATEGORICAL || ld.kind == AGPL_LIK_HETEROGAUSS)
+            AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
+                      "the ELBO terms are not defined for this likelihood (categorical.jl:165-170: non-bijective link; "
+                      "heteroscedastic: not split in the reference)");
+        if (!ctx->elbo_part) {
+            AGPL_HIP(ctx, hipMalloc((void **)&ctx->elbo_part, sizeof(double) * 1024));
+        }
+        part = ctx->elbo_part;
+    }
     agpl_fused_point_kernel<<<(unsigned)nblk, kBlock, 0, ctx->stream>>>(ld, n, npad, nb2, y, resid, mu0, qpart, mpart, gamma,
-                                                                       beta, c_out, gb, scal, queues);
+                                                                       beta, c_out, gb, scal, queues, part);
     AGPL_LAUNCH_CHECK(ctx);
+    if (part) {
+        reduce_final_kernel<<<1, 64, 0, ctx->stream>>>((int)nblk, part, elbo_terms_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
     return AGPL_OK;
 }
 

@@ -33,7 +33,8 @@ __device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
 }
 
 // Phi [N][M] float32  ->  blocked hi / lo images (zero rows past N)
-__global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, const float *__restrict__ Phi,
+// (scale = 2^e: 1 for the unscaled image of agpl_split_features, the accumulate image's 2^e_A for a plan's self-scaled image)
+__global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, const float *__restrict__ Phi, float scale,
                                                              h8 *__restrict__ Ph, h8 *__restrict__ Pl) {
     const int nks = M / KS;
     const int64_t nblk = ((N + NT - 1) / NT) * nks;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, c
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 _Float16 a, b;
-                split_f16(xs[j], a, b);
+                split_f16(xs[j] * scale, a, b);
                 hi[j] = a;
                 lo[j] = b;
             }
@@ -502,7 +503,10 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
-    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues, unsigned *__restrict__ zero2) {
+    float *__restrict__ qpart, float *__restrict__ mpart, unsigned *__restrict__ queues, unsigned *__restrict__ zero2,
+    float unq, float unm) {
+    // unq, unm: the point image may carry s Phi (s = 2^e, a plan's self-scaled image): the sums come out as s^2 q and s m and are
+    // written as unq (s^2 q), unm (s m) -- exact powers of two, 1 for the unscaled image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int R = 2, KU = 2;
     if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u; // (the caller's scale words: see the launch)
@@ -627,8 +631,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
                 if (n < N) {
                     const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
                     const int64_t o = ((int64_t)prb * L + pl) * N + n;
-                    qpart[o] = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
-                    mpart[o] = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
+                    qpart[o] = unq * ((qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]));
+                    mpart[o] = unm * ((mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]));
                 }
             }
             pend = -1;
@@ -749,8 +753,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             if (n < N) {
                 const float *qr = qred + (pend & 1) * 4 * NT2, *mr = mred + (pend & 1) * 4 * NT2;
                 const int64_t o = ((int64_t)prb * L + pl) * N + n;
-                qpart[o] = (qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]);
-                mpart[o] = (mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]);
+                qpart[o] = unq * ((qr[tid_e] + qr[NT2 + tid_e]) + (qr[2 * NT2 + tid_e] + qr[3 * NT2 + tid_e]));
+                mpart[o] = unm * ((mr[tid_e] + mr[NT2 + tid_e]) + (mr[2 * NT2 + tid_e] + mr[3 * NT2 + tid_e]));
             }
         }
     }
@@ -785,7 +789,10 @@ __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L,
 __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const double *__restrict__ A,
                                                                 h8 *__restrict__ Wh, h8 *__restrict__ Wl,
                                                                 const int *__restrict__ info, int *__restrict__ info_host,
-                                                                int ninfo, unsigned *__restrict__ bad_gamma) {
+                                                                int ninfo, unsigned *__restrict__ bad_gamma, double scale) {
+    // scale = 2^e (exact): 1 for the images of agpl_pack_factor_split; a plan carries 2^15 U -- every |U[a][b]| <= 1 (I + G >= I),
+    // so 2^15 U is finite in float16 whatever G is, and entries down to 2^-29 keep a normal hi part (unscaled, an inverse
+    // factor of a strongly informed posterior, |U| ~ 1e-5, sat in the float16 subnormals)
     const int nks = M / KS, nb = M / BS;
     const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
     if (info_host && l == 0 && rb == 0 && ks == 0) {
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(256) void pack_factor_split_kernel(int M, const dou
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int b = ks * KS + plane * 8 + j;
-        const double v = b <= a ? Al[(int64_t)b * M + a] : 0.0;
+        const double v = b <= a ? Al[(int64_t)b * M + a] * scale : 0.0;
         _Float16 x, y;
         split_f16((float)v, x, y);
         hi[j] = x;
@@ -853,7 +860,16 @@ extern "C" int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, cons
     if (rc) return rc;
     int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
     if (nblk > 65535 * 16) nblk = 65535 * 16;
-    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, (h8 *)Phi_hi, (h8 *)Phi_lo);
+    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, 1.0f, (h8 *)Phi_hi, (h8 *)Phi_lo);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
+// internal (agpl_plan.hip): the same image of scale * Phi, no range check (the plan has checked the features and chosen the scale)
+int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float scale, void *Phi_hi, void *Phi_lo) {
+    int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
+    if (nblk > 65535 * 16) nblk = 65535 * 16;
+    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, scale, (h8 *)Phi_hi, (h8 *)Phi_lo);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }
@@ -904,18 +920,18 @@ extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int
 
 // internal (agpl_update.hip): the same, forwarding ninfo <= 128 info words of the factorisation to pinned host memory
 int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
-                                    const int *info, int *info_host, int ninfo) {
+                                    const int *info, int *info_host, int ninfo, int u_scale_exp) {
     if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo || ninfo > 127) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
     pack_factor_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, A, (h8 *)U_hi, (h8 *)U_lo, info, info_host, ninfo,
-                                                            (unsigned *)((char *)ctx->ws2 + 8192) + 8);
+                                                            (unsigned *)((char *)ctx->ws2 + 8192) + 8, ldexp(1.0, u_scale_exp));
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }
 
 extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    return agpl_pack_factor_split_info(ctx, M, L, A, U_hi, U_lo, nullptr, nullptr, 0);
+    return agpl_pack_factor_split_info(ctx, M, L, A, U_hi, U_lo, nullptr, nullptr, 0, 0);
 }
 
 extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
@@ -938,7 +954,7 @@ extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, co
 // (the accumulation's scale words, which no kernel between the previous accumulation and this sweep's point kernel reads).
 int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
                                     const void *U_hi, const void *U_lo, const float *v, unsigned *zero2, float **qpart_out,
-                                    float **mpart_out, unsigned **queues_out) {
+                                    float **mpart_out, unsigned **queues_out, int image_scale_exp) {
     // resident workgroups on 16x16x32 MFMA serving per-XCD queues of (tile, latent, row block) items: the row blocks of a tile
     // share its images through L2 (round 2: 6.31-6.36 against 6.67-6.78 ms for the per-tile kernel at C2 on one box, 1.92
     // against 2.63 ms at C4, 20.6 GB fetched over the fabric instead of 31.9 GB; the other forms measured then -- static
@@ -956,17 +972,18 @@ int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
     unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192); // zero between launches (agpl_ws2_reserve)
     const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
-    if (ctx->ncu <= 0) { // once per context
+    if (!ctx->queue_attr) { // once per context
         AGPL_HIP(ctx, hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_queue_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->queue_attr = 1;
     }
     // one resident workgroup per CU, and never fewer than the eight queues (a masked / partitioned device would otherwise
     // leave queues unserved and their tiles unwritten)
     const int nwg = ctx->ncu < 8 ? 8 : ctx->ncu;
     marginal_factor_queue_kernel<<<(unsigned)nwg, 1024, ldsq, ctx->stream>>>(
         N, M, L, agpl_cdiv(N, NT), (int)ntiles2, (const h8 *)Phi_hi, (const h8 *)Phi_lo, (const h8 *)U_hi, (const h8 *)U_lo,
-        v, qpart, mpart, queues, zero2);
+        v, qpart, mpart, queues, zero2, ldexpf(1.f, -2 * image_scale_exp), ldexpf(1.f, -image_scale_exp));
     AGPL_LAUNCH_CHECK(ctx);
     *qpart_out = qpart;
     *mpart_out = mpart;
@@ -974,10 +991,19 @@ int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     return AGPL_OK;
 }
 
+int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
+                                       const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
+                                       float *mu_out, float *var_out, int image_scale_exp);
 extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
                                                const void *Phi_lo, const float *resid, const float *mu0,
                                                const void *U_hi, const void *U_lo, const float *v, float *mu_out,
                                                float *var_out) {
+    return agpl_marginals_factor_internal(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu_out, var_out, 0);
+}
+// image_scale_exp: the point images hold 2^e Phi (0: the unscaled images of agpl_split_features)
+int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
+                                       const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
+                                       float *mu_out, float *var_out, int image_scale_exp) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
     if (M % NT2)
@@ -989,7 +1015,7 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
     if (rc) return rc;
     float *qpart, *mpart;
     unsigned *queues;
-    rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, nullptr, &qpart, &mpart, &queues);
+    rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, nullptr, &qpart, &mpart, &queues, image_scale_exp);
     if (rc) return rc;
     int64_t nbk = agpl_cdiv((int64_t)L * N, 256);
     if (nbk > 8192) nbk = 8192;

@@ -216,6 +216,14 @@ constexpr bool kTrace = false;
 // DMA pieces.  Diagonal tiles: strip c needs row blocks i >= 2 c; the waves of a SIMD (w, w + 4) take the strips (s, 7 - s):
 // 34 blocks per SIMD against 64 of an off-diagonal tile.
 // ------------------------------------------------------------------------------------------------
+// Measurement build (make L2PROBE=1): every step re-reads one of the slice's first four steps, i.e. every operand load hits the
+// XCD's L2 -- wrong sums, same instruction stream and data statistics.  The upper bound of what ANY scheme of sharing panels
+// between the workgroups of a slice could buy (round 4: C2 6.87 -> 6.42 ms, M = 1024 30.6 -> 26.6 ms).
+#ifdef AGPL_SYRK_L2PROBE
+#define AGPL_PROBE_T(t_) ((t_) & 3)
+#else
+#define AGPL_PROBE_T(t_) (t_)
+#endif
 #ifndef AGPL_S_PRE
 #define AGPL_S_PRE 3 // row blocks of A-fragment lead (2, 3, 4 measured: 3.73 / 3.69 / 3.74 ms at N = 4e6, M = 512)
 #endif
@@ -273,7 +281,7 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
 #define AGPL_S_DMA(t_, k_) /* piece k_ = 0..3 of step t_: (slice k_ >> 1, hi / lo k_ & 1) */                    \
     do {                                                                                                        \
         unsigned char *d_ = smem_raw + ((t_) & (kRing - 1)) * kStepBytes + ((k_) >> 1) * 16384 + a_dst + ((k_) & 1) * 4096; \
-        const h8 *src_ = a_src + (int64_t)(2 * (t_) + ((k_) >> 1)) * slice_pitch + ((k_) & 1) * 256;            \
+        const h8 *src_ = a_src + (int64_t)(2 * AGPL_PROBE_T(t_) + ((k_) >> 1)) * slice_pitch + ((k_) & 1) * 256; \
         __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);                                       \
     } while (0)
 #define AGPL_S_DMAG(t_)                                                                                         \
@@ -283,7 +291,7 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     // behind a condition -- a copy of an in-flight destination (the phi of a conditional load) would copy stale registers
 #define AGPL_S_LOADB(t_)                                                                                        \
     do {                                                                                                        \
-        const h8 *src_ = b_src + (int64_t)(2 * (t_)) * slice_pitch;                                             \
+        const h8 *src_ = b_src + (int64_t)(2 * AGPL_PROBE_T(t_)) * slice_pitch;                                 \
         const h8 *srcl_ = src_ + 256; /* the lo block follows the hi block; column block 1 = 16 rows = 256 bytes on */ \
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"                   \
                      "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256"  \
@@ -604,6 +612,39 @@ int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const floa
     return AGPL_OK;
 }
 
+// internal (also agpl_plan.hip): the scale exponent e_A for a feature matrix whose max |x| has the float32 bit pattern `hmx`:
+// 2^e_A max|Phi| in [2^13, 2^14) -- hi stays finite, and lo = f16(x - hi) is a float16 normal for |x| down to 2^-17 max|Phi|.
+// |e_A| <= 30 (2 e_A + e_B must stay an exponent of a normal float32, e_B in [-60, 60]): a larger max|Phi| (>= 2^44) would turn
+// into inf, and one below 2^-24 would leave fewer than ten of those seventeen octaves -- both AGPL_ERR_DOMAIN; between 2^-24 and
+// 2^-17 the exponent stays at 30 and the image sits up to seven octaves lower in the float16 range.
+int32_t agpl_image_scale_exp(agpl_ctx *ctx, unsigned hmx, int *eA_out) {
+    int eA = 0;
+    if (hmx) {
+        const int ex = (int)(hmx >> 23) - 127; // max_abs in [2^ex, 2^(ex+1))   (a subnormal max reads ex = -127)
+        eA = 13 - ex;
+        if (eA > 37 || eA < -30) {
+            float mx;
+            memcpy(&mx, &hmx, 4);
+            AGPL_FAIL(ctx, AGPL_ERR_DOMAIN,
+                      "max |Phi| = %g is outside the range the split-float16 images can be scaled for (2^-24 .. 2^44): rescale the "
+                      "features", (double)mx);
+        }
+        if (eA > 30) eA = 30;
+    }
+    *eA_out = eA;
+    return AGPL_OK;
+}
+// internal (also agpl_plan.hip): the image of 2^eA Phi; the features have been range-checked
+int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, int eA, unsigned hmx, void *image_out) {
+    float max_abs;
+    memcpy(&max_abs, &hmx, 4);
+    const float scale = ldexpf(1.f, eA);
+    const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2;
+    accumulate_image_kernel<<<16384, 256, 0, ctx->stream>>>(N, M, nps, scale, eA, max_abs, Phi, (unsigned char *)image_out);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
+
 extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
@@ -612,21 +653,10 @@ extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, co
     unsigned hmx = 0;
     int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, __builtin_inff(), "the accumulate image", &hmx);
     if (rc) return rc;
-    float max_abs;
-    memcpy(&max_abs, &hmx, 4);
-    // 2^e_A max|Phi| in [2^13, 2^14): hi stays finite, and lo = f16(x - hi) is a float16 normal for |x| down to 2^-17 max|Phi|
     int eA = 0;
-    if (hmx) {
-        const int ex = (int)(hmx >> 23) - 127; // max_abs in [2^ex, 2^(ex+1))   (a subnormal max reads ex = -127)
-        eA = 13 - ex;
-        if (eA > 30) eA = 30; // 2 e_A + e_B stays an exponent of a normal float32 (e_B in [-60, 60])
-        if (eA < -30) eA = -30;
-    }
-    const float scale = ldexpf(1.f, eA);
-    const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2;
-    accumulate_image_kernel<<<16384, 256, 0, ctx->stream>>>(N, M, nps, scale, eA, max_abs, Phi, (unsigned char *)image_out);
-    AGPL_LAUNCH_CHECK(ctx);
-    return AGPL_OK;
+    rc = agpl_image_scale_exp(ctx, hmx, &eA);
+    if (rc) return rc;
+    return agpl_accumulate_image_build(ctx, N, M, Phi, eA, hmx, image_out);
 }
 
 // internal (agpl_accumulate_impl): prep + accumulation kernel; slabs as agpl_mfma.hip lays them out.

@@ -16,13 +16,17 @@
 
 // agpl_ops.hip / agpl_mfma.hip internals
 int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
-                                    const int *info, int *info_host, int ninfo); // agpl_split.hip
+                                    const int *info, int *info_host, int ninfo, int u_scale_exp); // agpl_split.hip
+int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
+                                       const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
+                                       float *mu_out, float *var_out, int image_scale_exp);
 int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
                                     const void *U_hi, const void *U_lo, const float *v, unsigned *zero2, float **qpart_out,
-                                    float **mpart_out, unsigned **queues_out); // agpl_split.hip
+                                    float **mpart_out, unsigned **queues_out, int image_scale_exp); // agpl_split.hip
 int32_t agpl_launch_fused_point(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, int64_t npad, int nb2, const void *y,
                                 const float *resid, const float *mu0, const float *qpart, const float *mpart,
-                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues); // agpl_ops.hip
+                                float *gamma, float *beta, float *c_out, float *gb, unsigned *scal, unsigned *queues,
+                                double *elbo_terms_out); // agpl_ops.hip
 void agpl_accumulate_records(int64_t N, int32_t M, int32_t L, void *slab_mem, float **gb, unsigned **scal); // agpl_mfma.hip
 int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n, const void *y,
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out);
@@ -493,7 +497,7 @@ static int32_t pending_arm(agpl_ctx *ctx, const int *info_dev, int n, int L) {
 
 static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                        const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
-                                       void *U_lo, double *logdet_out, bool *armed);
+                                       void *U_lo, double *logdet_out, bool *armed, int u_scale_exp = 0);
 
 // I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
 // pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
@@ -521,9 +525,20 @@ extern "C" int32_t agpl_gaussian_factor_async(agpl_ctx *ctx, int32_t M, int32_t 
     return armed ? AGPL_OK : agpl_pending_resolve(ctx);
 }
 
+// (agpl_plan.hip) the asynchronous form with the images of 2^u_scale_exp U
+int32_t agpl_gaussian_factor_async_scaled(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                          const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
+                                          void *U_lo, double *logdet_out, int u_scale_exp) {
+    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    bool armed = false;
+    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, U_hi, U_lo, logdet_out, &armed, u_scale_exp);
+    if (rc) return rc;
+    return armed ? AGPL_OK : agpl_pending_resolve(ctx);
+}
+
 static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                        const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
-                                       void *U_lo, double *logdet_out, bool *armed) {
+                                       void *U_lo, double *logdet_out, bool *armed, int u_scale_exp) {
     if (M <= 0 || L <= 0 || L > 64 || !G || !g || !A_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if ((U_hi == nullptr) != (U_lo == nullptr)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "U_hi and U_lo go together");
     {
@@ -544,7 +559,7 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         if (U_hi) {
             rc = pending_prepare(ctx);
             if (rc) return rc;
-            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info, ctx->pend_host_dev, L);
+            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info, ctx->pend_host_dev, L, u_scale_exp);
             if (rc) return rc;
         }
         rc = pending_arm(ctx, U_hi ? nullptr : info, L, L);
@@ -559,7 +574,7 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         if (U_hi) {
             rc = pending_prepare(ctx);
             if (rc) return rc;
-            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info2, ctx->pend_host_dev, 2 * L);
+            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info2, ctx->pend_host_dev, 2 * L, u_scale_exp);
             if (rc) return rc;
         }
         rc = pending_arm(ctx, U_hi ? nullptr : info2, 2 * L, L);
@@ -591,7 +606,7 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         AGPL_LAUNCH_CHECK(ctx);
     }
     if (U_hi) {
-        rc = agpl_pack_factor_split(ctx, M, L, A_work, U_hi, U_lo);
+        rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, nullptr, nullptr, 0, u_scale_exp);
         if (rc) return rc;
     }
     rocblas_int hinfo[128];
@@ -663,7 +678,8 @@ extern "C" int32_t agpl_cavi_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64
     return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
 }
 
-static int32_t gibbs_pass_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi, const void *acc_image, bool force_split,
+// (also agpl_plan.hip)
+int32_t agpl_gibbs_pass_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi, const void *acc_image, bool force_split,
                                    const float *kdiag, const float *mu0, const void *y, const double *v,
                                    uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
                                    int64_t *n_out, uint32_t *nuni_out) {
@@ -705,7 +721,7 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
                                    const float *kdiag, const float *mu0, const void *y, const double *v,
                                    uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
                                    int64_t *n_out, uint32_t *nuni_out) {
-    return gibbs_pass_impl(ctx, lik, N, M, Phi, nullptr, false, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
+    return agpl_gibbs_pass_internal(ctx, lik, N, M, Phi, nullptr, false, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
                            n_out, nuni_out);
 }
 
@@ -713,7 +729,7 @@ extern "C" int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik
                                          const void *Phi_acc, const float *kdiag, const float *mu0, const void *y,
                                          const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
                                          double *omega_out, int64_t *n_out, uint32_t *nuni_out) {
-    return gibbs_pass_impl(ctx, lik, N, M, Phi, Phi_acc, true, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
+    return agpl_gibbs_pass_internal(ctx, lik, N, M, Phi, Phi_acc, true, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
                            n_out, nuni_out);
 }
 
@@ -907,11 +923,14 @@ extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t
                                                const void *U_hi, const void *U_lo, const float *v, float *mu_out,
                                                float *var_out);
 
-// shared body: acc_image == nullptr -> the accumulation stages the float32 Phi (syrk_split_kernel)
-static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
-                                     const void *Phi_hi, const void *Phi_lo, const void *acc_image, const float *resid,
-                                     const float *mu0, const void *y, const void *U_hi, const void *U_lo, const float *v,
-                                     double *G_out, double *g_out, float *c_out, float *gamma_out, float *beta_out) {
+// shared body (also agpl_plan.hip): acc_image == nullptr -> the accumulation stages the float32 Phi (syrk_split_kernel).
+// image_scale_exp: the marginal images hold 2^e Phi (0: agpl_split_features' unscaled images).  elbo_terms_out (device, may be
+// null; image path only): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) this pass used.
+int32_t agpl_cavi_pass_factor_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
+                                       const void *Phi_hi, const void *Phi_lo, const void *acc_image, const float *resid,
+                                       const float *mu0, const void *y, const void *U_hi, const void *U_lo, const float *v,
+                                       double *G_out, double *g_out, float *c_out, float *gamma_out, float *beta_out,
+                                       int image_scale_exp, double *elbo_terms_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     agpl_lik_dev ld;
     int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
@@ -936,7 +955,8 @@ static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, in
         agpl_accumulate_records(N, M, L, base, &gb, &scal);
         rc = agpl_timing_begin(ctx, 0);
         if (rc) return rc;
-        rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, scal, &qpart, &mpart, &queues);
+        rc = agpl_marginals_factor_parts(ctx, N, M, L, Phi_hi, Phi_lo, U_hi, U_lo, v, scal, &qpart, &mpart, &queues,
+                                         image_scale_exp);
         if (rc) return rc;
         rc = agpl_timing_end(ctx, 0);
         if (rc) return rc;
@@ -944,7 +964,7 @@ static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, in
             AGPL_FAIL(ctx, AGPL_ERR_HIP, "workspace layout: the records overlap the marginal partial sums");
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         rc = agpl_launch_fused_point(ctx, ld, N, Npad, M / 256, y, resid, mu0, qpart, mpart, gamma_out, beta_out, c_out, gb,
-                                     scal, queues);
+                                     scal, queues, elbo_terms_out);
         if (rc) return rc;
         ctx->accumulate_split = 1;
         rc = agpl_accumulate_impl(ctx, N, M, L, nullptr, acc_image, nullptr, nullptr, G_out, g_out, base, true);
@@ -952,11 +972,12 @@ static int32_t cavi_pass_factor_impl(agpl_ctx *ctx, const agpl_lik_desc *lik, in
         if (rc) return rc;
         return agpl_pending_resolve(ctx);
     }
+    if (elbo_terms_out) AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "the ELBO terms ride the image sweep only (M %% 256 == 0 and an accumulate image)");
     float *mu = (float *)(base + slab);
     float *var = (float *)(base + slab + vec);
     float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
     float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
-    rc = agpl_marginals_factor_split(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu, var);
+    rc = agpl_marginals_factor_internal(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu, var, image_scale_exp);
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
@@ -974,8 +995,8 @@ extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_des
                                                const void *U_lo, const float *v, double *G_out, double *g_out,
                                                float *c_out, float *gamma_out, float *beta_out) {
     if (ctx && !Phi) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    return cavi_pass_factor_impl(ctx, lik, N, M, Phi, Phi_hi, Phi_lo, nullptr, resid, mu0, y, U_hi, U_lo, v, G_out, g_out,
-                                 c_out, gamma_out, beta_out);
+    return agpl_cavi_pass_factor_internal(ctx, lik, N, M, Phi, Phi_hi, Phi_lo, nullptr, resid, mu0, y, U_hi, U_lo, v, G_out, g_out,
+                                          c_out, gamma_out, beta_out, 0, nullptr);
 }
 
 extern "C" int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
@@ -985,6 +1006,6 @@ extern "C" int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_des
                                                float *c_out, float *gamma_out, float *beta_out) {
     if (ctx && !Phi_acc) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     if (ctx && M % 256) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 256", M);
-    return cavi_pass_factor_impl(ctx, lik, N, M, nullptr, Phi_hi, Phi_lo, Phi_acc, resid, mu0, y, U_hi, U_lo, v, G_out,
-                                 g_out, c_out, gamma_out, beta_out);
+    return agpl_cavi_pass_factor_internal(ctx, lik, N, M, nullptr, Phi_hi, Phi_lo, Phi_acc, resid, mu0, y, U_hi, U_lo, v, G_out,
+                                          g_out, c_out, gamma_out, beta_out, 0, nullptr);
 }

@@ -88,12 +88,63 @@ def shard_range(N: int, rank: int, world: int):
     return rank * N // world, (rank + 1) * N // world
 
 
-def natural_parameter_buffers(L, M, device):
+def natural_parameter_buffers(L, M, device, extra=0):
     """(flat, G, g): G [L, M, M] and g [L, M] float64 as views of ONE flat buffer, so that the exchange step of a
-    sweep is a single collective of L (M^2 + M) doubles."""
+    sweep is a single collective of L (M^2 + M) doubles.  ``extra`` more doubles ride at its end (the ELBO terms of a sweep
+    are summed over ranks by the same collective)."""
     torch = _torch()
-    flat = torch.zeros(L * M * M + L * M, dtype=torch.float64, device=device)
-    return flat, flat[: L * M * M].view(L, M, M), flat[L * M * M:].view(L, M)
+    flat = torch.zeros(L * M * M + L * M + extra, dtype=torch.float64, device=device)
+    return flat, flat[: L * M * M].view(L, M, M), flat[L * M * M: L * M * M + L * M].view(L, M)
+
+
+class Plan:
+    """agpl_plan (include/agpl.h): the two split-float16 images of Phi (one scale), the Nystrom residual and q(v) in factor form,
+    in ONE torch-owned block of device memory; the float32 features are not referenced after construction."""
+
+    NO_MARGINALS = 1  # AGPL_PLAN_NO_MARGINALS: Gibbs passes only (no marginal image)
+
+    def __init__(self, Phi, resid, L, ctx: Context, flags: int = 0):
+        torch = _torch()
+        self.ctx = ctx
+        self.N, self.M = Phi.shape
+        self.L = L
+        self.flags = flags
+        nbytes = _ffi.lib().agpl_plan_bytes(C.c_int64(self.N), C.c_int32(self.M), C.c_int32(L), C.c_uint32(flags))
+        if nbytes <= 0:
+            raise _ffi.ArgumentError(-1, f"a plan needs a feature count that is a multiple of 256 (got {self.M}; zero-pad) and "
+                                         f"at most 64 latents (got {L})")
+        self.mem = torch.empty(nbytes, dtype=torch.uint8, device=Phi.device)
+        self._h = C.c_void_p()
+        ctx.call("agpl_plan_create", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(L), _ptr(Phi), _ptr(resid),
+                 C.c_uint32(flags), _ptr(self.mem), C.byref(self._h))
+        U, v, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(ctx._h, _ffi.lib().agpl_plan_factor(self._h, C.byref(U), C.byref(v), C.byref(r)))
+        base = self.mem.data_ptr()
+        M = self.M
+        self.U_colmajor = self.mem[U.value - base: U.value - base + 8 * L * M * M].view(torch.float64).view(L, M, M)
+        self.v = self.mem[v.value - base: v.value - base + 8 * L * M].view(torch.float64).view(L, M)
+        uh, ul, v32, ld = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(ctx._h, _ffi.lib().agpl_plan_state(self._h, C.byref(uh), C.byref(ul), C.byref(v32), C.byref(ld)))
+        view = lambda ptr, nb, dt: self.mem[ptr.value - base: ptr.value - base + nb].view(dt)
+        self.U_hi, self.U_lo = view(uh, 2 * L * M * M, torch.float16), view(ul, 2 * L * M * M, torch.float16)
+        self.v32 = view(v32, 4 * L * M, torch.float32).view(L, M)
+        self.logdet = view(ld, 8 * L, torch.float64)
+        e = C.c_int32()
+        _ffi.check(ctx._h, _ffi.lib().agpl_plan_info(self._h, None, None, None, C.byref(e), None))
+        self.scale_exp = e.value
+        self.nbytes = nbytes
+
+    def call(self, name, *args):
+        self.ctx.bind()
+        _ffi.check(self.ctx._h, getattr(_ffi.lib(), name)(self._h, *args))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().agpl_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def exchange_natural_parameters(G, g, group=None, flat=None):
@@ -122,13 +173,15 @@ class SparseCAVI:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 marginal_precision: str = "auto", accumulate_precision: str = "f16x2"):
-        """``marginal_precision``: "auto" (default) = the shipped path, i.e. "f16x2-factor" when the feature count is a
-        multiple of 256, else "f16x2"; "f32" = float32-input MFMA marginal pass; "f16x2" = the split-float16
-        pass of agpl_split.hip (3 float16 MFMA products per float32 product; costs one extra copy of Phi in HBM);
-        "f16x2-factor" = the one-pass factor form of the same (agpl_marginals_factor_split: the update keeps
-        U = chol(I + G)^-1 and v = U g instead of S and m; M % 256 == 0).
-        ``accumulate_precision``: "f16x2" (default, what bench.py measures) or "f32" for G = Phi diag(gamma) Phi'."""
+                 marginal_precision: str = "auto", accumulate_precision: str = "f16x2", track_elbo: bool = False,
+                 use_plan: bool = True):
+        """The shipped path (defaults, feature count a multiple of 256): ONE plan (agpl_plan_create: both split-float16 images
+        of Phi with one scale, q(v) in factor form) and agpl_cavi_pass_plan / agpl_plan_update per sweep.
+        ``marginal_precision`` / ``accumulate_precision`` = "f32": the float32-input MFMA kernels (agpl_cavi_pass), the
+        arithmetic SURVEY.md 8(d) prices.  The other combinations ("f16x2" marginals on W images, "f16x2-factor" without an
+        image, mixed precisions, ``use_plan=False``) drive the superseded per-generation entry points and exist for their tests.
+        ``track_elbo``: the per-point ELBO terms ride the pass and the Gaussian KL the update (plan path only); see
+        ``elbo_entering``."""
         torch = _torch()
         self.ctx = ctx or default_context()
         self.lik = lik
@@ -156,6 +209,26 @@ class SparseCAVI:
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
+        self.plan = None
+        self.track_elbo = bool(track_elbo)
+        if use_plan and self.factor and self.acc_split and M % 256 == 0:
+            self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
+            self.plan = Plan(self.Phi, self.resid, L, self.ctx)
+            self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev, extra=1 if self.track_elbo else 0)
+            self._kl = torch.zeros(2, dtype=f64, device=dev)  # KL(q(v) || p(v)) of the last two updates (q = N(0, I) at start)
+            self._elbo_terms = self._Gg[-1:] if self.track_elbo else None
+            self.A_work, self.v = self.plan.U_colmajor, self.plan.v
+            self._S = self._m = self.Wpack = self.Phi_acc = None
+            self.alpha = None
+            self.gamma = self.beta = self.c = None
+            if keep_points:
+                self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
+                self.beta = torch.empty((L, self.N), dtype=f32, device=dev)
+                self.c = torch.empty((self.N,) if L == 1 else (self.N, L), dtype=f32, device=dev)
+            self.nsweeps = 0
+            return
+        if self.track_elbo:
+            raise _ffi.ArgumentError(-1, "track_elbo rides the plan path (defaults, feature count a multiple of 256)")
         if self.split:
             nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(self.N), C.c_int32(M)) // 2
             self.Phi_hi = torch.empty(nh, dtype=torch.float16, device=dev)
@@ -213,6 +286,11 @@ class SparseCAVI:
     def accumulate(self):
         """marginals -> aux_posterior! -> expected potential/precision -> local (G, g)."""
         d = self.lik.desc()
+        if self.plan is not None:  # the shipped path
+            self.plan.call("agpl_cavi_pass_plan", C.byref(d), _ptr(self.mu0), _ptr(self.y), _ptr(self.G), _ptr(self.g),
+                           _ptr(self.c), _ptr(self.gamma), _ptr(self.beta), _ptr(self._elbo_terms))
+            return
+        # ---- superseded entry points (kept for their tests) ----
         self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
         if self.factor and self.Phi_acc is not None:
             self.ctx.call("agpl_cavi_pass_factor_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
@@ -236,16 +314,30 @@ class SparseCAVI:
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.Wpack), _ptr(self.alpha),
                       _ptr(self.G), _ptr(self.g), _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
 
+    exchange_timing = None  # a list: exchange() appends a (start, stop) pair of timing events per call (bench.py)
+
     def exchange(self):
         """Sum (G, g) over the ranks that shard N; every rank then performs the identical M x M update."""
+        if self.exchange_timing is not None and self.group is not None:
+            torch = _torch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
+            e1.record()
+            self.exchange_timing.append((e0, e1))
+            return
         exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
 
     def update(self):
         """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the factor form
         keeps U = chol(I + G)^-1 and v = U g (S = U'U, m = U'v) and packs the images of U."""
-        if self.factor:
+        if self.plan is not None:
             # enqueue only: a failed factorisation surfaces in the next accumulate() (once its kernels are queued),
             # in check(), or when S / m / elbo() are read -- the host never idles the GPU between update and pass
+            kl = self._kl[self.nsweeps & 1:(self.nsweeps & 1) + 1] if self.track_elbo else None
+            self.plan.call("agpl_plan_update", _ptr(self.G), _ptr(self.g), C.c_void_p(0), _ptr(kl))
+            return
+        if self.factor:
             self.ctx.call("agpl_gaussian_factor_async", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
                           C.c_void_p(0), _ptr(self.A_work), _ptr(self.v), _ptr(self.alpha), _ptr(self.W_hi),
                           _ptr(self.W_lo), C.c_void_p(0))
@@ -263,6 +355,18 @@ class SparseCAVI:
     def check(self):
         """Wait for the stream and raise what a deferred factorisation has to report (PosDefException, ...)."""
         self.ctx.synchronize()
+
+    def elbo_entering(self):
+        """aug_elbo (examples/bernoulli/script.jl:65-70) of the q(v) that ENTERED the last sweep, at no extra pass over the
+        features (``track_elbo=True``): the per-point terms expected_logtilt - aux_kldivergence rode that sweep's per-point kernel
+        (summed over ranks by the sweep's one all-reduce), and KL(q(v) || p(v)) rode the update that produced that q(v).
+        After sweep k this is the ELBO after k - 1 updates: a convergence monitor that lags one sweep."""
+        if not self.track_elbo or self.nsweeps == 0:
+            raise _ffi.ArgumentError(-1, "elbo_entering needs track_elbo=True and at least one sweep")
+        self.check()
+        # sweep k (1-based) wrote kl[(k - 1) & 1] for its NEW q(v); the q(v) that entered it was made by sweep k - 1 -> kl[k & 1]
+        # (k = 1: the initial N(0, I), whose slot still holds 0)
+        return float(self._elbo_terms.item()) - float(self._kl[self.nsweeps & 1].item())
 
     def run(self, niter: int = 10):
         for _ in range(niter):
@@ -301,8 +405,11 @@ class SparseCAVI:
     def marginals(self):
         """q(f_i) for the current (m, S): (mu, var) float32 [L][N]."""
         torch = _torch()
-        mu = torch.empty((self.L, self.N), dtype=torch.float32, device=self.Phi.device)
+        mu = torch.empty((self.L, self.N), dtype=torch.float32, device=self.y.device)
         var = torch.empty_like(mu)
+        if self.plan is not None:
+            self.plan.call("agpl_marginals_plan", _ptr(self.mu0), _ptr(mu), _ptr(var))
+            return mu, var
         if self.factor:
             self.ctx.call("agpl_marginals_factor_split", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L),
                           _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0), _ptr(self.W_hi),
@@ -363,7 +470,9 @@ class SparseGibbs:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 accumulate_precision: str = "f16x2", point_offset: int = 0):
+                 accumulate_precision: str = "f16x2", point_offset: int = 0, plan: "Plan | None" = None):
+        """``plan``: the plan of a SparseCAVI over the same features (its accumulate image and residual are shared); by
+        default (split accumulation, feature count a multiple of 256) a plan without the marginal image is built here."""
         torch = _torch()
         self.ctx = ctx or default_context()
         if accumulate_precision not in ("f32", "f16x2"):
@@ -382,7 +491,12 @@ class SparseGibbs:
         dev = self.Phi.device
         L, M = self.L, self.M
         f64 = torch.float64
-        self.Phi_acc = accumulate_image(self.Phi, self.ctx) if (self.acc_split and M % 256 == 0) else None
+        self.plan = None
+        self.Phi_acc = None
+        if self.acc_split and M % 256 == 0:
+            if plan is not None and (plan.N, plan.M, plan.L) != (self.N, M, L):
+                raise _ffi.ArgumentError(-1, "the plan was created for another problem size")
+            self.plan = plan if plan is not None else Plan(self.Phi, self.kdiag, L, self.ctx, flags=Plan.NO_MARGINALS)
         self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.v = torch.empty((L, M), dtype=f64, device=dev)
         self.m = torch.empty((L, M), dtype=f64, device=dev)
@@ -435,7 +549,11 @@ class SparseGibbs:
         prev_offset = self.ctx.point_offset
         self.ctx.set_point_offset(self.point_offset)
         try:  # (a raising pass must not leave the context's point offset shifted for its other users)
-            if self.acc_split:
+            if self.plan is not None:  # the shipped path
+                self.plan.call("agpl_gibbs_pass_plan", C.byref(d), _ptr(self.Phi), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
+                               C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
+                               _ptr(self.n), C.c_void_p(0))
+            elif self.acc_split:  # superseded entry point (feature counts that are not a multiple of 256)
                 self.ctx.call("agpl_gibbs_pass_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                               _ptr(self.Phi_acc), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
                               C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),

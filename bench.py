@@ -41,7 +41,8 @@ sys.path.insert(0, ROOT)
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense
-PMC_PROFILE = "r03_pmc_traffic_c2.json"  # HBM bytes per launch of the two contraction kernels (separate --pmc passes)
+PMC_PROFILE = "r04_pmc_traffic_c2.json"  # HBM bytes per launch of the two contraction kernels (separate --pmc passes)
+PMC_PROFILE_M1024 = "r04_pmc_traffic_m1024.json"  # the same at the north-star target configuration (N = 1e7, M = 1024)
 RENDEZVOUS_TIMEOUT_S = 300  # a rank that cannot join (or whose first collective hangs) exits non-zero after this
 
 
@@ -96,6 +97,7 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
     for _ in range(warmup):
         cavi.sweep()
     barrier()
+    cavi.exchange_timing = [] if cavi.group is not None else None  # hipEvent pairs around every exchange() of the timed sweeps
     _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
     read_timing(ctx, 0)  # discard what earlier legs left in the kernel timers (the sampler legs call cavi.marginals() with the
     read_timing(ctx, 1)  # timers on: two C2-size launches used to be averaged into the m1024 leg's marginal kernel: 16.8 for 20.1 ms)
@@ -116,10 +118,14 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
     gc.enable()
     kt = [read_timing(ctx, 0), read_timing(ctx, 1)]
     _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+    if cavi.exchange_timing is not None:
+        xs = [a.elapsed_time(b) for a, b in cavi.exchange_timing]
+        cavi.exchange_ms = (sum(xs) / max(len(xs), 1), max(xs) if xs else 0.0)
+        cavi.exchange_timing = None
     return dt, kt
 
 
-def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N, traffic_key=None):
+def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N, traffic_key=None, profile=None):
     """Roofline of the dominant kernel from the in-library hipEvent timings.  Algorithmic flops per launch
     (SURVEY.md 8d): marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)."""
     flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
@@ -156,9 +162,10 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc pass (cannot be taken inside this process):
     # the committed summary is attached when it was collected on exactly this configuration, else null.
     traffic = None
+    profile = profile or PMC_PROFILE
     if traffic_key is not None and world == 1:
         try:
-            with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as fh:
+            with open(os.path.join(ROOT, "profiles", profile)) as fh:
                 pm = json.load(fh)
             if pm["config"] == traffic_key:
                 traffic = pm["kernels"].get(names[dom], {}).get("traffic_bytes")
@@ -167,7 +174,7 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     return {"kernel": names[dom], "bound": "mfma", "achieved": achieved, "peak": peaks[dom], "unit": "TFLOP/s",
             "frac": round(achieved / peaks[dom], 4) if achieved else None,
             "mfma_products_per_algorithmic_product": mult[dom],
-            "traffic": traffic, "traffic_source": "profiles/" + PMC_PROFILE if traffic else None, "kernels": per,
+            "traffic": traffic, "traffic_source": "profiles/" + profile if traffic else None, "kernels": per,
             "sweep_algorithmic_tflops": round(3.0 * L * N * M * M / (ms_per_step * 1e-3) / 1e12 / world, 2)}
 
 
@@ -223,6 +230,74 @@ def parity_slice(A, ctx, lik, likname, Phi, kd, y, marginal, accumulate, nsweeps
             "pass": bool(max(dG, dg, first[0], first[1]) < 1e-5)}
 
 
+def full_size_quadratic_check(Phi, gamma, beta, G, g, nvec=4, seed=7):
+    """Size-independent properties of (G, g) = (Phi Diag(gamma) Phi', Phi beta) at ANY N, against float64 torch reductions
+    over the same gamma, beta (docs/src/index.md:154-163 in the whitened basis): g, tr G, and v'Gv = sum_n gamma_n
+    (phi_n . v)^2 for `nvec` random v -- O(N M) each, and unlike the trace they see every off-diagonal tile."""
+    import torch
+
+    L, n = gamma.shape
+    Mp = Phi.shape[1]
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    V = torch.randn((Mp, nvec), dtype=torch.float64, device="cuda", generator=gen)
+    step = max(1, (1 << 29) // Mp)
+    rel_g = rel_tr = rel_q = 0.0
+    for l in range(L):
+        tr = torch.zeros((), dtype=torch.float64, device="cuda")
+        gref = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+        qref = torch.zeros(nvec, dtype=torch.float64, device="cuda")
+        for j0 in range(0, n, step):
+            P = Phi[j0:j0 + step].double()
+            gm = gamma[l, j0:j0 + step].double()
+            tr += (gm * (P * P).sum(1)).sum()
+            gref += P.T @ beta[l, j0:j0 + step].double()
+            qref += (gm[:, None] * (P @ V) ** 2).sum(0)
+            del P
+        q = ((G[l] @ V) * V).sum(0)
+        rel_g = max(rel_g, float(((g[l] - gref).abs().max() / gref.abs().max().clamp_min(1e-300)).item()))
+        rel_tr = max(rel_tr, float(((torch.diagonal(G[l]).sum() - tr).abs() / tr.abs().clamp_min(1e-300)).item()))
+        rel_q = max(rel_q, float(((q - qref).abs() / qref.abs().clamp_min(1e-300)).max().item()))
+    return {"max_rel_dg": rel_g, "rel_d_trace_G": rel_tr, "max_rel_d_vGv": rel_q, "quadratic_forms": nvec,
+            "G_symmetric": bool(torch.equal(G, G.transpose(1, 2)))}
+
+
+def f32_contract_leg(A, ctx, lik, likname, Phi, kd, y, N, M, Mp, L, args):
+    """The same C2 sweep at the arithmetic SURVEY.md 8(d) prices: float32 features contracted by v_mfma_f32_32x32x2_f32
+    (agpl_cavi_pass: marginal_kernel<0> + syrk_kernel of agpl_mfma.hip), float64 reductions and M x M update as everywhere
+    (the reference computes in Float64, src/generic.jl:36-38; 8(d) contracts float32 K_ZX against a 157.3 TFLOP/s roof)."""
+    import torch
+
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
+    steps = 3
+    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
+    ms = dt / steps * 1e3
+    out = {"config": {"workload": f"{likname}-logistic SVGP CAVI sweep, N={N}, M={M}, L={L}, 1 GPU, float32-input MFMA kernels"},
+           "dtype": "f32", "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps,
+           "warmup": 1, "roofline": roofline_of(kt, L, N, M, Mp, "f32", "f32", ms, 1, N)}
+    del cavi
+    if not args.no_parity:
+        out["parity"] = parity_slice(A, ctx, lik, likname, Phi, kd, y, "f32", "f32")
+    return out
+
+
+def elbo_leg(A, ctx, lik, Phi, kd, y, base_ms, args):
+    """aug_elbo (examples/bernoulli/script.jl:65-70) riding the sweep: the per-point terms in the pass's one
+    per-point kernel, the Gaussian KL behind the update; what it adds to a sweep, and the values of the last sweeps."""
+    import torch
+
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, track_elbo=True)
+    steps = max(5, args.steps)
+    dt, _ = timed_sweeps(ctx, cavi, steps, 2, torch.cuda.synchronize)
+    vals = [cavi.elbo_entering()]
+    for _ in range(2):
+        cavi.sweep()
+        vals.append(cavi.elbo_entering())
+    ms = dt / steps * 1e3
+    return {"ms_per_step_with_elbo": round(ms, 3), "added_ms_per_step": round(ms - base_ms, 3), "steps": steps,
+            "elbo_entering_last_sweeps": vals,
+            "non_decreasing": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(vals, vals[1:])))}
+
+
 def m1024_leg(A, ctx, args):
     """BASELINE.json north_star's target configuration: Bernoulli-logistic CAVI, N = 1e7, M = 1024, 1 GPU -- same
     timed-loop discipline as the headline value, its own roofline, and a 10-sweep parity slice."""
@@ -241,7 +316,11 @@ def m1024_leg(A, ctx, args):
     out = {"config": {"workload": f"bernoulli-logistic SVGP CAVI sweep, N={N}, M={M}, L=1, 1 GPU", "N": N, "M": M, "L": 1,
                       "marginal_pass": "f16x2-factor", "accumulate_pass": "f16x2"},
            "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": 1,
-           "roofline": roofline_of(kt, 1, N, M, Mp, "f16x2-factor", "f16x2", ms, 1, N), "setup_s": round(t_setup, 2)}
+           "roofline": roofline_of(kt, 1, N, M, Mp, "f16x2-factor", "f16x2", ms, 1, N,
+                                   traffic_key={"lik": "bernoulli", "N": N, "M": M, "L": 1}, profile=PMC_PROFILE_M1024),
+           "setup_s": round(t_setup, 2),
+           "hbm_gb": {"plan": round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None,
+                      "float32_features": round(Phi.numel() * 4 / 1e9, 2)}}
     del cavi
     if not args.no_parity:
         out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2")
@@ -299,16 +378,41 @@ def c5_leg(A, args):
     return out
 
 
+def visible_gpu_count():
+    """GPUs visible to a rank, counted WITHOUT loading a HIP runtime into this process: the launching parent goes on to
+    start torch.distributed.run, and a process that has initialised the GPU must not start (exec) other programs on this
+    pool.  torch.cuda.device_count() only avoids hipInit when amdsmi answers; otherwise it falls back to hipGetDeviceCount.
+    So: a throw-away child counts with torch (it honours HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES exactly as the ranks
+    will) and exits; if that child fails, the kfd topology in sysfs is read (GPU nodes have simd_count > 0)."""
+    import glob
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=600)
+        if r.returncode == 0:
+            return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        pass
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(ln.split(None, 1) for ln in open(f).read().splitlines() if " " in ln)
+            n += int(props.get("simd_count", "0")) > 0
+        except Exception:
+            pass
+    return n
+
+
 def self_launch(ngpus):
     """Run this script under torch.distributed.run with one rank per GPU as a child process; returns its exit code
-    (2: fewer than `ngpus` devices are visible).  The parent never initialises a GPU (device_count() does not)."""
+    (2: fewer than `ngpus` devices are visible).  This parent never loads torch or a HIP runtime: the devices are counted
+    by a throw-away child (visible_gpu_count)."""
     import socket
     import subprocess
 
     single_dev = os.environ.get("AGPL_BENCH_SINGLE_DEVICE") == "1"  # test hook, see main()
-    import torch
-
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if have < (1 if single_dev else ngpus):
         print(f"[bench] --gpus {ngpus} but only {have} device(s) are visible: refusing to measure fewer", file=sys.stderr,
               flush=True)
@@ -340,6 +444,8 @@ def main():
     ap.add_argument("--no-m1024", action="store_true", help="skip the north-star target leg (Bernoulli N=1e7 M=1024)")
     ap.add_argument("--m1024-n", type=int, default=10_000_000)
     ap.add_argument("--no-c5", action="store_true", help="skip the full-rank StudentT Gibbs leg (BASELINE configs[4])")
+    ap.add_argument("--no-f32", action="store_true", help="skip the float32-MFMA leg (the sweep at SURVEY 8d's stated arithmetic)")
+    ap.add_argument("--no-elbo", action="store_true", help="skip the ELBO-riding-the-sweep leg")
     ap.add_argument("--c5-n", type=int, default=65_536)
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
@@ -431,10 +537,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.reset_peak_memory_stats()
     dt, kt = timed_sweeps(ctx, cavi, args.steps, args.warmup, barrier)
+    hbm_sweep_gb = round(torch.cuda.max_memory_allocated() / 1e9, 1)
     if world > 1:
         import torch.distributed as dist
 
+        # per-rank record for the diagnosis of a scaling run: this rank's own time per sweep, the exchange step as the
+        # stream saw it (hipEvents around exchange(): the wait for the slowest rank + the RCCL all-reduce), the two
+        # contraction kernels from the in-library events
+        mine = {"rank": rank, "points": n_loc, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "allreduce_ms_avg": round(cavi.exchange_ms[0], 4), "allreduce_ms_max": round(cavi.exchange_ms[1], 4),
+                "marginal_kernel_ms": round(kt[0][0] / max(kt[0][1], 1), 4),
+                "accumulate_kernel_ms": round(kt[1][0] / max(kt[1][1], 1), 4)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -443,7 +560,7 @@ def main():
         if rank != 0:
             return
         # the single-GPU extra legs (Gibbs, parity slice, CPU baseline, M = 1024, C5) are reported at N = 1 only
-        args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = True
+        args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = args.no_f32 = args.no_elbo = True
 
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
@@ -465,7 +582,20 @@ def main():
                                f"N sharded over {world} GPU(s), 1 all-reduce of L*(M^2+M) f64 per sweep",
                    "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}", "marginal_pass": args.marginal, "accumulate_pass": args.accumulate},
         "roofline": roofline, "setup_s": round(t_setup, 2),
+        "hbm_gb": {"timed_sweeps_high_water": hbm_sweep_gb,
+                   "plan": round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None,
+                   "float32_features": round(Phi.numel() * 4 / 1e9, 2),
+                   "note": "the plan (both split-float16 images + q(v)) is what a CAVI sweep reads; the float32 features stay "
+                           "resident here only because the Gibbs, parity and CPU-baseline legs of this run use them"},
     }
+    if world > 1:
+        steps_ms = [r["ms_per_step"] for r in per_rank]
+        out["allreduce_ms"] = round(sum(r["allreduce_ms_avg"] for r in per_rank) / world, 4)
+        out["allreduce_bytes"] = 8 * L * (Mp * Mp + Mp)
+        out["ms_per_step_min_rank"], out["ms_per_step_max_rank"] = min(steps_ms), max(steps_ms)
+        out["per_rank"] = per_rank
+        out["per_rank_kernels"] = [{"rank": r["rank"], "marginal_kernel_ms": r["marginal_kernel_ms"],
+                                    "accumulate_kernel_ms": r["accumulate_kernel_ms"]} for r in per_rank]
 
     # ---- Gibbs half on the same resident workload (extra legs, not the headline value) ------------------------
     if not args.no_gibbs:
@@ -546,22 +676,13 @@ def main():
         cavi.c = torch.empty((n_loc,) if L == 1 else (n_loc, L), dtype=torch.float32, device="cuda")
         cavi.accumulate()
         torch.cuda.synchronize()
-        step = max(1, (1 << 29) // Mp)
-        rel_g = rel_tr = 0.0
-        for l in range(L):
-            tr = torch.zeros((), dtype=torch.float64, device="cuda")
-            gref = torch.zeros(Mp, dtype=torch.float64, device="cuda")
-            for j0 in range(0, n_loc, step):
-                P = Phi[j0:j0 + step].double()
-                tr += (cavi.gamma[l, j0:j0 + step].double() * (P * P).sum(1)).sum()
-                gref += P.T @ cavi.beta[l, j0:j0 + step].double()
-            rel_g = max(rel_g, float(((cavi.g[l] - gref).abs().max() / gref.abs().max().clamp_min(1e-300)).item()))
-            rel_tr = max(rel_tr, float(((torch.diagonal(cavi.G[l]).sum() - tr).abs() / tr.abs().clamp_min(1e-300)).item()))
-            del P
-        sym = bool(torch.equal(cavi.G, cavi.G.transpose(1, 2)))
-        out["full_size_check"] = {"points": n_loc, "max_rel_dg": rel_g, "rel_d_trace_G": rel_tr, "G_symmetric": sym,
-                                  "reference": "float64 torch reductions over the exported gamma, beta",
-                                  "tolerance": 2e-6, "pass": bool(rel_g < 2e-6 and rel_tr < 2e-6 and sym)}
+        chk = full_size_quadratic_check(Phi, cavi.gamma, cavi.beta, cavi.G, cavi.g)
+        out["full_size_check"] = {"points": n_loc, **chk,
+                                  "reference": "float64 torch reductions over the exported gamma, beta: g, tr G, and the "
+                                               "quadratic forms v'Gv = sum_n gamma_n (phi_n . v)^2 for 4 random v (every "
+                                               "tile of G, off-diagonal ones included, enters each of them)",
+                                  "tolerance": 2e-6, "pass": bool(chk["max_rel_dg"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6
+                                                                  and chk["max_rel_d_vGv"] < 2e-6 and chk["G_symmetric"])}
         cavi.gamma = cavi.beta = cavi.c = None
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------------
@@ -618,6 +739,18 @@ def main():
                                      "operators where it is)",
             "gpu_over_cpu": round(value / cpu_value, 1), **extra}
         del Ph, kh, yh
+
+    # ---- ELBO riding the sweep, and the sweep at the contract's own arithmetic (N = 1 only) -------------------
+    if world == 1 and not args.no_elbo and getattr(cavi, "plan", None) is not None:
+        try:
+            out["elbo"] = elbo_leg(A, ctx, lik, Phi, kd, y, ms_per_step, args)
+        except Exception as e:
+            out["elbo"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_f32:
+        try:
+            out["f32_contract"] = f32_contract_leg(A, ctx, lik, args.lik, Phi, kd, y, N, M, Mp, L, args)
+        except Exception as e:
+            out["f32_contract"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the other configurations the driver should see (N = 1, default C2 run only) ------------------------
     if world == 1 and default_config and not (args.no_m1024 and args.no_c5):

@@ -382,6 +382,56 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
                                        const void *y, const double *v, uint32_t sweep, double *G_out, double *g_out,
                                        double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
 
+/* ---- the plan: the shipped sweep path (agpl_plan.hip) -------------------------------------------------------------------
+ * Everything static about one data set on one context, built once: the two split-float16 images of Phi (marginal image by
+ * 128-point tile, accumulate image point-major), BOTH carrying 2^e Phi with one e chosen from max |Phi| (domain: any finite
+ * features with max |Phi| in 2^-17 .. 2^43; a non-finite feature is AGPL_ERR_DOMAIN with its (point, feature)), a copy of the
+ * Nystrom residual, and q(v) in factor form -- U = chol(I + G)^-1, v = U (g + eta0), log det(I + G) -- which the plan's update
+ * writes and its passes read; kernels are chosen by shape.  After creation the float32 features are not read by the CAVI pass or
+ * the marginals (C2: 41 GB of images resident instead of 61 GB with the features).  These entry points supersede
+ * agpl_split_features, agpl_accumulate_image, agpl_pack_factor_split, agpl_marginals_factor_split, agpl_cavi_pass_split,
+ * agpl_cavi_pass_factor_split, agpl_cavi_pass_factor_image and agpl_gibbs_pass_image (kept below for existing callers).
+ *   agpl_plan_bytes     : device bytes a plan needs for (N, M, L, flags); 0 for sizes a plan does not take (M % 256 != 0, L > 64).
+ *   agpl_plan_create    : Phi float32 [M, N] column-major; resid float32 [N] (agpl_feature_residual); flags: 0, or
+ *                         AGPL_PLAN_NO_MARGINALS for a plan that serves Gibbs passes only (no marginal image: half the bytes);
+ *                         storage: agpl_plan_bytes bytes of caller-owned device memory that stay valid for the plan's life, or
+ *                         NULL (the library allocates and frees).  q(v) starts at N(0, I) (examples/bernoulli/script.jl:41-42).
+ *                         Synchronises once.
+ *   agpl_cavi_pass_plan : marginals of the plan's q(v) -> aux_posterior! -> expected potential / precision -> G, g
+ *                         (script.jl:32-36 up to the M x M solve; agpl_cavi_pass's contract).  elbo_terms_out (device double, may be
+ *                         NULL): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) the pass used, from
+ *                         the same marginals in float64 -- the per-point part of aug_elbo (script.jl:65-70) rides the pass's one
+ *                         per-point kernel (AGPL_ERR_UNSUPPORTED for the non-bijective categorical and the heteroscedastic
+ *                         likelihood, whose terms the reference does not define).
+ *   agpl_plan_update    : q(v) <- N(S (g + eta0), S), S = (I + G)^-1 (script.jl:35-36), kept as (U, v); asynchronous, outcome
+ *                         reported as by agpl_gaussian_factor_async.  kl_out (device double, may be NULL): KL(q(v) || N(0, I)) of
+ *                         the NEW q(v), from U and v (the kldivergence term of aug_elbo).  ELBO of a q(v) = the elbo_terms of the
+ *                         pass that used it (summed over ranks) - the kl of the update that made it.
+ *   agpl_marginals_plan : q(f_i) of the plan's q(v): mu, var float32 [L][N].
+ *   agpl_gibbs_pass_plan: agpl_gibbs_pass with the plan's residual and accumulate image (Phi: the float32 features, read by the
+ *                         projection phi_i' v only).
+ *   agpl_plan_factor    : device pointers to U (float64 [L, M, M], column-major lower triangle), v (float64 [L, M]) and the
+ *                         residual, e.g. to form S = U'U, m = U'v.   agpl_plan_info: sizes, the images' scale exponent, bytes.
+ *   agpl_plan_state     : device pointers to what an update rewrites besides U and v -- the images of 2^15 U (float16, L M M each),
+ *                         v as float32 [L, M], log det(I + G) [L] -- for repeatability checks and checkpoints. */
+typedef struct agpl_plan agpl_plan;
+#define AGPL_PLAN_NO_MARGINALS 1u
+AGPL_API int64_t agpl_plan_bytes(int64_t N, int32_t M, int32_t L, uint32_t flags);
+AGPL_API int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *resid,
+                                  uint32_t flags, void *storage, agpl_plan **plan_out);
+AGPL_API int32_t agpl_plan_destroy(agpl_plan *plan);
+AGPL_API int32_t agpl_plan_info(const agpl_plan *plan, int64_t *N, int32_t *M, int32_t *L, int32_t *scale_exp, int64_t *bytes);
+AGPL_API int32_t agpl_plan_factor(const agpl_plan *plan, const double **U_out, const double **v_out, const float **resid_out);
+AGPL_API int32_t agpl_plan_state(const agpl_plan *plan, const void **U_hi_out, const void **U_lo_out, const float **v32_out,
+                                 const double **logdet_out);
+AGPL_API int32_t agpl_cavi_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, const float *mu0, const void *y, double *G_out,
+                                     double *g_out, float *c_out, float *gamma_out, float *beta_out, double *elbo_terms_out);
+AGPL_API int32_t agpl_plan_update(agpl_plan *plan, const double *G, const double *g, const double *eta0, double *kl_out);
+AGPL_API int32_t agpl_marginals_plan(agpl_plan *plan, const float *mu0, float *mu_out, float *var_out);
+AGPL_API int32_t agpl_gibbs_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, const float *Phi, const float *mu0,
+                                      const void *y, const double *v, uint32_t sweep, double *G_out, double *g_out,
+                                      double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
+
 /* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
  *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
  *   context's stream.  For hosts that own their communicator (the Julia / C++ callers of INTEGRATION.md); the

@@ -97,7 +97,7 @@ def test_m1280_library_factor_route_ten_sweeps_match_oracle(A, ctx, oracle):
     O = oracle
     lik, olik = A.BernoulliLikelihood(), O.bernoulli()
     cavi, _ = ten_sweeps_against_oracle(A, ctx, O, lik, olik, 6_000, 1280)
-    assert cavi.Phi_acc is not None and cavi.M == 1280
+    assert cavi.plan is not None and cavi.M == 1280
     # a problem with a NaN observation-derived gamma on this route ...
     bad = A.Context(0, seed=5)
     slik = A.StudentTLikelihood(3.0, 1.0)
@@ -182,7 +182,7 @@ def test_c3_per_rank_full_size_properties(A, ctx):
 
     try:
         cavi = make()
-        assert cavi.Phi_acc is not None  # the image accumulation (M % 256 == 0)
+        assert cavi.plan is not None  # the plan path: image accumulation (M % 256 == 0)
         mu, var = cavi.marginals()
         assert mu.abs().max().item() == 0.0 and (var - 1.0).abs().max().item() < 4e-5
         cavi.accumulate()

@@ -43,12 +43,12 @@ def test_every_hot_kernel_repeats_bit_for_bit(A, likname, N, M):
     lik = bench.make_lik(A, likname)
     y, Phi, kd = bench.build_workload(A, ctx, lik, 0, N, M)
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, keep_points=True)  # the shipped path: factor marginals + image accumulation
-    assert cavi.factor and cavi.Phi_acc is not None
+    assert cavi.factor and cavi.plan is not None
     cavi.sweep()
     cavi.sweep()
     cavi.check()
     assert _count(cavi.accumulate, lambda: (cavi.G, cavi.g, cavi.gamma, cavi.beta, cavi.c)) == 0
-    assert _count(cavi.update, lambda: (cavi.A_work, cavi.v, cavi.alpha, cavi.W_hi, cavi.W_lo)) == 0
+    assert _count(cavi.update, lambda: (cavi.A_work, cavi.v, cavi.plan.v32, cavi.plan.U_hi, cavi.plan.U_lo, cavi.plan.logdet)) == 0
     mv = {}
 
     def marg():

@@ -19,19 +19,29 @@ CSRC = os.path.join(ROOT, "augmentedgplikelihoods.jl_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+KERNELS = ("syrk_strip_kernel",)
+
+
 @pytest.fixture(scope="module")
-def strip_isa(tmp_path_factory):
+def syrk_isa(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     d = tmp_path_factory.mktemp("isa")
     flags = re.search(r"^COMMON\s*:=\s*(.*)$", open(os.path.join(CSRC, "Makefile")).read(), flags=re.M).group(1)
     flags = flags.replace("$(ARCH)", "gfx950").split()
-    subprocess.check_call([HIPCC] + flags + ["-save-temps", "-c", os.path.join(CSRC, "agpl_syrk.hip"), "-o", "/dev/null"],
+    subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, "agpl_syrk.hip"), "-o", "syrk.s"],
                           cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    asm = open(os.path.join(d, "agpl_syrk-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
-    start = next(i for i, ln in enumerate(asm) if re.match(r"^_Z\w*syrk_strip_kernel\w*:", ln))
-    end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
-    return [ln.split(";")[0].rstrip() for ln in asm[start:end + 1]]
+    asm = open(os.path.join(d, "syrk.s")).read().splitlines()
+    out = {}
+    for k in KERNELS:
+        start = next(i for i, ln in enumerate(asm) if re.match(r"^_Z\w*" + k + r"\w*:", ln))
+        end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
+        out[k] = asm[start:end + 1]  # raw lines: the block labels carry the compiler's loop annotations as comments
+    return out
+
+
+def _code(lines):
+    return [ln.split(";")[0].rstrip() for ln in lines]
 
 
 def _regs(tok):
@@ -47,49 +57,74 @@ def _operands(line):
     return toks[0], [t for t in toks[1:] if t]
 
 
-def test_asm_load_destinations_are_untouched_until_the_wait(strip_isa):
-    loads = [i for i, ln in enumerate(strip_isa) if re.match(r"\s*global_load_dwordx4\s", ln)]
+def _step_loops(raw):
+    """Innermost loops that hold a whole step of MFMAs: the step loops of the off-diagonal and of the diagonal body (96 MFMAs
+    each).  A loop = the blocks the compiler annotates
+    with its header (`; =>This Inner Loop Header` on the header, `; in Loop: Header=BBx_y Depth=1` on the others); the blocks
+    of a loop need not be contiguous or in program order."""
+    loops, cur = {}, None
+    i = 0
+    while i < len(raw):
+        ln = raw[i]
+        m = re.match(r"^\.L(BB\d+_\d+):(.*)$", ln)
+        if m:
+            note = m.group(2)
+            while i + 1 < len(raw) and re.match(r"^\s*;", raw[i + 1]):  # the annotation continues on comment-only lines
+                i += 1
+                note += raw[i]
+            if re.search(r"This (Inner )?Loop Header", note):
+                cur = m.group(1)
+            else:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=\d+", note)
+                cur = h.group(1) if h else None
+        elif re.match(r"^\.L\w+:", ln):
+            cur = None
+        elif cur is not None:
+            loops.setdefault(cur, []).append(ln.split(";")[0].rstrip())
+        i += 1
+    out = []
+    for seg in loops.values():
+        n = sum("v_mfma_f32_16x16x32_f16" in x for x in seg)
+        if 90 <= n <= 110:
+            out.append(seg)
+    return out
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_asm_load_destinations_are_untouched_until_the_wait(syrk_isa, kernel):
+    isa = _code(syrk_isa[kernel])
+    loads = [i for i, ln in enumerate(isa) if re.match(r"\s*global_load_dwordx4\s", ln)]
     assert len(loads) >= 8  # prologue + step loop, four each (off-diagonal body)
     for i in loads:
-        dst = _regs(_operands(strip_isa[i])[1][0])
+        dst = _regs(_operands(isa[i])[1][0])
         assert len(dst) == 4
         j = i + 1
         # to the end of the basic block (a label, a branch, the barrier or the wait itself): exact inside a block, and the
         # failure seen was a block of v_mov copies directly behind the loads
-        while not re.search(r"s_waitcnt.*vmcnt|^\s*s_c?branch|^\s*s_barrier|^\.?\w+:\s*$|s_endpgm", strip_isa[j]):
-            if strip_isa[j].strip():
-                op, args = _operands(strip_isa[j])
+        while not re.search(r"s_waitcnt.*vmcnt|^\s*s_c?branch|^\s*s_barrier|^\.?\w+:\s*$|s_endpgm", isa[j]):
+            if isa[j].strip():
+                op, args = _operands(isa[j])
                 if not op.startswith("global_load_dwordx4"):
                     touched = set().union(*[_regs(a) for a in args]) if args else set()
-                    assert not (touched & dst), f"line {j}: `{strip_isa[j].strip()}` touches an in-flight load destination"
+                    assert not (touched & dst), f"line {j}: `{isa[j].strip()}` touches an in-flight load destination"
             j += 1
         assert j > i + 1
 
 
-def test_no_scratch_traffic_inside_the_step_loops(strip_isa):
-    # loop bodies: from a line that carries s_barrier to the next backward branch; coarse but sufficient: no scratch_*
-    # instruction may sit between the first and the last v_mfma of the kernel's loops that also hold an LDS-DMA
-    idx_dma = [i for i, ln in enumerate(strip_isa) if "global_load_lds_dwordx4" in ln]
-    idx_mfma = [i for i, ln in enumerate(strip_isa) if "v_mfma_f32_16x16x32_f16" in ln]
-    assert idx_dma and idx_mfma
-    # segments of MFMA code (two bodies: diagonal and off-diagonal tiles)
-    segs, cur = [], [idx_mfma[0], idx_mfma[0]]
-    for i in idx_mfma[1:]:
-        if i - cur[1] > 400:
-            segs.append(cur)
-            cur = [i, i]
-        cur[1] = i
-    segs.append(cur)
-    assert len(segs) >= 2
-    for a, b in segs:
-        body = strip_isa[a:b + 1]
-        assert not [ln for ln in body if "scratch_" in ln], "spill traffic inside a step loop"
-        assert sum("v_mfma_f32_16x16x32_f16" in ln for ln in body) >= 96
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_no_scratch_traffic_inside_the_step_loops(syrk_isa, kernel):
+    loops = _step_loops(syrk_isa[kernel])
+    assert len(loops) >= 2  # the off-diagonal and the diagonal body
+    for seg in loops:
+        assert not [ln for ln in seg if "scratch_" in ln], "spill traffic inside a step loop"
+        assert any("global_load_lds_dwordx4" in ln for ln in seg)
 
 
-def test_the_step_loops_wait_with_a_counted_vmcnt(strip_isa):
-    waits = [ln.strip() for ln in strip_isa if re.search(r"s_waitcnt.*vmcnt", ln)]
-    assert sum(w == "s_waitcnt vmcnt(5)" for w in waits) >= 2  # one per body: the step's five DMA pieces stay in flight
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_the_step_loops_wait_with_a_counted_vmcnt(syrk_isa, kernel):
+    for seg in _step_loops(syrk_isa[kernel]):
+        waits = [ln.strip() for ln in seg if re.search(r"s_waitcnt.*vmcnt", ln)]
+        assert "s_waitcnt vmcnt(5)" in waits  # the step's five DMA pieces stay in flight
 
 
 def test_sampler_kernels_contain_no_function_call(tmp_path):

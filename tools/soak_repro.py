@@ -42,7 +42,7 @@ for likname, N, M in (("bernoulli", 3_000_000, 512), ("negbin", 1_000_000, 1024)
     # the fused pass: marginals -> aux -> accumulation (G, g, per-point c / gamma / beta)
     case["cavi_pass_differs"] = count(cavi.accumulate, lambda: (cavi.G, cavi.g, cavi.gamma, cavi.beta, cavi.c))
     # the M x M update from the same (G, g)
-    case["factor_update_differs"] = count(cavi.update, lambda: (cavi.A_work, cavi.v, cavi.alpha, cavi.W_hi, cavi.W_lo))
+    case["factor_update_differs"] = count(cavi.update, lambda: (cavi.A_work, cavi.v, cavi.plan.v32, cavi.plan.U_hi, cavi.plan.U_lo))
     mv = {}
 
     def marg():
