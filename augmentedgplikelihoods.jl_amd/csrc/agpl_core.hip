@@ -102,13 +102,20 @@ int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes) {
     if (bytes < 16384) bytes = 16384;
     if (bytes <= ctx->ws2_bytes) return AGPL_OK;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->ws2) AGPL_HIP(ctx, hipFree(ctx->ws2));
-    ctx->ws2 = nullptr;
-    ctx->ws2_bytes = 0;
-    if (hipMalloc(&ctx->ws2, bytes) != hipSuccess)
+    void *grown = nullptr;
+    if (hipMalloc(&grown, bytes) != hipSuccess)
         AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the small workspace failed", bytes);
+    // the first 16 KB carry state ACROSS calls (a sweep's bad-gamma word waits there for the update that reports it, and that
+    // update may be the call that grows this allocation): they move with it; a first allocation starts zeroed
+    if (ctx->ws2) {
+        AGPL_HIP(ctx, hipMemcpyAsync(grown, ctx->ws2, 16384, hipMemcpyDeviceToDevice, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AGPL_HIP(ctx, hipFree(ctx->ws2));
+    } else {
+        AGPL_HIP(ctx, hipMemsetAsync(grown, 0, 16384, ctx->stream));
+    }
+    ctx->ws2 = grown;
     ctx->ws2_bytes = bytes;
-    AGPL_HIP(ctx, hipMemsetAsync(ctx->ws2, 0, 16384, ctx->stream));
     return AGPL_OK;
 }
 

@@ -101,6 +101,16 @@ __device__ __forceinline__ bool pg_series_accept(Philox &g, double x, uint32_t &
     // (x > t) or 3 exp(-4 / x) (x <= t) -- at most 0.006: 99.5 % of the proposals are accepted here, and neither a_0 nor a_1 (one
     // more exp; a log as well for x <= t) is needed to know it.  Decided through a bracket like the branch test: a u within 1e-9
     // of the boundary (or beyond it) runs the series as the reference writes it, so the outcome and the series index are its.
+    // Round 4: the bracket is first formed with ONE single-instruction float32 exponential (v_exp_f32).  rho <= 0.0058, the float32
+    // argument is off by <= 2e-7 |arg| and the exponential by <= 4e-7 relative, so |rho32 - rho| < 1e-8 everywhere (|arg| e^-|arg|
+    // is largest at the branch point |arg| = 6.25): a u more than 1e-7 below 1 - rho32 is accepted without a float64
+    // exponential or division; 1e-7 of the proposals go on to the float64 bracket, 0.6 % to the series.  Outcome, uniforms and
+    // series index are those of the plain evaluation.
+    const float rho32 = 3.0f * __expf(HI ? (float)(-(kPi * kPi)) * (float)x : -4.0f / (float)x);
+    if (u < 1.0 - (double)rho32 - 1e-7) {
+        nterms += 1u;
+        return true;
+    }
     const double rho = 3.0 * exp(HI ? -(kPi * kPi) * x : -4.0 / x);
     if (u < 1.0 - rho - 1e-9) {
         nterms += 1u;
@@ -1660,6 +1670,18 @@ template <class MG>
 __device__ __forceinline__ double elbo_point(const agpl_lik_dev &lik, int64_t i, const void *yv, const MG &mg) {
     const int L = lik.nlatent;
     const YAcc<float> y{yv, i, lik.kind, L};
+    // Bernoulli / negative binomial: with theta = E[omega] = b tanh(c / 2) / (2 c) and c^2 = mu^2 + sigma^2 the theta terms of
+    // expected_logtilt (.. - c^2 theta / 2) and of KL(PG(b, c) || PG(b, 0)) = b logcosh(c / 2) - c^2 theta / 2 cancel: what is
+    // left needs one logcosh (0.78 -> ~0.1 ms per 1e7 points against the literal expressions; equal to them to rounding)
+    if (lik.kind == AGPL_LIK_BERNOULLI_LOGISTIC) {
+        const double m = (double)mg.m(0, i), c = sqrt(second_moment(m, (double)mg.v(0, i)));
+        return -kLogTwo + (y(0) != 0.0 ? m : -m) / 2.0 - logcosh_(c / 2.0);
+    }
+    if (lik.kind == AGPL_LIK_NEGBINOMIAL) {
+        const double m = (double)mg.m(0, i), c = sqrt(second_moment(m, (double)mg.v(0, i)));
+        const double r = lik.p[0], yy = y(0);
+        return negbin_logconst(yy, r) - (yy + r) * kLogTwo + m * (yy - r) / 2.0 - (yy + r) * logcosh_(c / 2.0);
+    }
     auto mu = [&](int k) { return (double)mg.m(k, i); };
     auto var = [&](int k) { return (double)mg.v(k, i); };
     auto q1 = [&](int k) -> double { // out1 of aux_posterior!
@@ -1745,7 +1767,11 @@ struct OutRecords {
     }
 };
 
-__global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev lik, int64_t n, int64_t npad, int nb2,
+// ELBO: the instantiation that also sums the ELBO terms (float64 transcendental code: kept out of the plain kernel, whose
+// register footprint and 0.13 ms per 1e7 points it would otherwise cost -- 0.47 ms with the branch compiled in, measured)
+// (KIND: the likelihood of an ELBO instantiation, so that only its own float64 terms are compiled in; -1: taken from `lik`)
+template <bool ELBO, int KIND>
+__global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev lik_arg, int64_t n, int64_t npad, int nb2,
                                                                   const void *yv, const float *__restrict__ resid,
                                                                   const float *__restrict__ mu0,
                                                                   const float *__restrict__ qpart,
@@ -1758,6 +1784,8 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
     // queues[0..7]: the marginal kernel's item queues; queues[8]: 1 + index of a gamma that is negative or not finite, kept
     // until the update's last kernel forwards it to the host (agpl_pending_resolve reports AGPL_ERR_DOMAIN)
     __shared__ unsigned red[2][kBlock / 64];
+    agpl_lik_dev lik = lik_arg;
+    if (KIND >= 0) lik.kind = KIND; // (a compile-time constant from here on: the switches over the kind fold)
     const int L = lik.nlatent;
     if (blockIdx.x == 0 && threadIdx.x < 8) queues[threadIdx.x] = 0u; // the marginal kernel's item queues, for its next launch
     const MargParts mg{resid, mu0, qpart, mpart, n, L, nb2};
@@ -1766,7 +1794,7 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n) {
             fused_point(lik, n, i, yv, mg, out, c_out);
-            if (elbo_part) eacc += elbo_point(lik, i, yv, mg);
+            if (ELBO) eacc += elbo_point(lik, i, yv, mg);
         } else { // the zero tail of the records
             for (int k = 0; k < L; ++k) {
                 float *rec = gb + ((int64_t)k * out.nrec + (i >> 5)) * 64 + (i & 31);
@@ -1797,7 +1825,7 @@ __global__ __launch_bounds__(kBlock) void agpl_fused_point_kernel(agpl_lik_dev l
             atomicMax(queues + 8, b);
         }
     }
-    if (elbo_part) { // the ELBO rides the pass: fixed-order tree over the workgroup, one partial per workgroup
+    if (ELBO) { // the ELBO rides the pass: fixed-order tree over the workgroup, one partial per workgroup
         __shared__ double esum[kBlock];
         esum[threadIdx.x] = eacc;
         __syncthreads();
@@ -1827,8 +1855,20 @@ int32_t agpl_launch_fused_point(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t n
         }
         part = ctx->elbo_part;
     }
-    agpl_fused_point_kernel<<<(unsigned)nblk, kBlock, 0, ctx->stream>>>(ld, n, npad, nb2, y, resid, mu0, qpart, mpart, gamma,
-                                                                       beta, c_out, gb, scal, queues, part);
+#define AGPL_LAUNCH_FUSED(E_, K_)                                                                               \
+    agpl_fused_point_kernel<E_, K_><<<(unsigned)nblk, kBlock, 0, ctx->stream>>>(ld, n, npad, nb2, y, resid, mu0, qpart, mpart, \
+                                                                               gamma, beta, c_out, gb, scal, queues, part)
+    if (!part) AGPL_LAUNCH_FUSED(false, -1);
+    else
+        switch (ld.kind) {
+        case AGPL_LIK_BERNOULLI_LOGISTIC: AGPL_LAUNCH_FUSED(true, AGPL_LIK_BERNOULLI_LOGISTIC); break;
+        case AGPL_LIK_NEGBINOMIAL: AGPL_LAUNCH_FUSED(true, AGPL_LIK_NEGBINOMIAL); break;
+        case AGPL_LIK_STUDENTT: AGPL_LAUNCH_FUSED(true, AGPL_LIK_STUDENTT); break;
+        case AGPL_LIK_CATEGORICAL_BIJ: AGPL_LAUNCH_FUSED(true, AGPL_LIK_CATEGORICAL_BIJ); break;
+        case AGPL_LIK_POISSON: AGPL_LAUNCH_FUSED(true, AGPL_LIK_POISSON); break;
+        default: AGPL_LAUNCH_FUSED(true, AGPL_LIK_LAPLACE); break;
+        }
+#undef AGPL_LAUNCH_FUSED
     AGPL_LAUNCH_CHECK(ctx);
     if (part) {
         reduce_final_kernel<<<1, 64, 0, ctx->stream>>>((int)nblk, part, elbo_terms_out);

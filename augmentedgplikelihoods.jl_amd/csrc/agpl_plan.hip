@@ -105,6 +105,13 @@ __global__ void plan_identity_kernel(int M, int L, double *__restrict__ A, doubl
     if (blockIdx.x == 0 && (int)threadIdx.x < L) logdet[threadIdx.x] = 0.0;
 }
 
+__global__ void plan_residual_kernel(int64_t N, const float *__restrict__ in, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = in[i];
+        out[i] = d > 0.f ? d : (d == d ? 0.f : d); // (a NaN stays: the sweep reports it)
+    }
+}
+
 // KL(q(v_l) || N(0, I)) = (tr S + m'm - M + log det(I + G)) / 2 straight from the inverse factor: S = U'U, m = U'v, i.e.
 // tr S = sum_{a >= b} U[a][b]^2 and m_b = sum_{a >= b} U[a][b] v_a, with U[a][b] = A[b M + a] (column-major lower triangle).
 // grid (kKlBlocks, L) x 4 waves: wave w of block k takes the columns b = 4 k + w (mod kKlWaves) in ascending order, the lanes
@@ -222,8 +229,10 @@ extern "C" int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     }
     rc = agpl_accumulate_image_build(ctx, N, M, Phi, e, hmx, p->Phi_acc);
     if (rc) return fail(rc);
-    if (hipMemcpyAsync(p->resid, resid, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-        return fail(AGPL_ERR_HIP);
+    // d_i = k_ii - |phi_i|^2 >= 0 in exact arithmetic (Nystrom residual of a positive semi-definite kernel); a float32 evaluation
+    // rounds below zero by ~1e-7 k_ii, which is a NEGATIVE marginal variance once the posterior is tighter than that: clamped
+    plan_residual_kernel<<<1024, 256, 0, ctx->stream>>>(N, resid, p->resid);
+    if (hipGetLastError() != hipSuccess) return fail(AGPL_ERR_HIP);
     // q(v) = N(0, I) to start from (script.jl:41-42)
     plan_identity_kernel<<<1024, 256, 0, ctx->stream>>>(M, L, p->A_work, p->v, p->v32, p->logdet);
     if (hipGetLastError() != hipSuccess) return fail(AGPL_ERR_HIP);

@@ -14,6 +14,7 @@
 //   agpl_pack_w_split (upper-triangular, doubled off-diagonal, as the f32 Wpack).
 // The Hadamard epilogue and the output are float32 (the exact float32 Phi is read for it).
 #include <cstdlib>
+#include <type_traits>
 
 #include "agpl_common.h"
 
@@ -500,6 +501,13 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 // reproducible: no atomics on the outputs).  The next-but-one item is fetched by ONE returning atomic per item, issued in
 // the first stage of an item and written to LDS in the second: its latency hides behind a whole stage.
 // ------------------------------------------------------------------------------------------------
+#ifdef AGPL_MTRACE // diagnostic build (make MTRACE=1): per-wave cycle sums of the stage loop, tools/mtrace.py
+__device__ unsigned long long g_mtrace[256 * 16 * 4];
+__device__ unsigned long long g_mtrace_phase[256 * 16 * 18]; // per wave: cycles and count of the stages of each kind (0: full, 1..8: diagonal stage 1..8)
+constexpr bool kMTrace = true;
+#else
+constexpr bool kMTrace = false;
+#endif
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
     const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ v_all,
@@ -602,9 +610,30 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int pend = -1, pl = 0, prb = 0, ptile = 0;
     unsigned fetched = 0u; // thread 0: the queue index fetched in the first stage of the item, stored in its second
     bool fetch_pending = false;
+    [[maybe_unused]] unsigned long long mt0 = 0, mtw = 0, mtb = 0, mta = 0, mtn = 0, mtl = 0;
+    [[maybe_unused]] unsigned long long mph[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] int mkind = -1;
+    if (kMTrace) mt0 = __builtin_amdgcn_s_memtime();
     for (int t = 0; cvalid; ++t) {
+        if (kMTrace) mta = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
+        if (kMTrace) {
+            const unsigned long long x = __builtin_amdgcn_s_memtime();
+            mtw += x - mta;
+            mta = x;
+        }
         __builtin_amdgcn_s_barrier();
+        if (kMTrace) {
+            const unsigned long long x = __builtin_amdgcn_s_memtime();
+            mtb += x - mta;
+            ++mtn;
+            if (mkind >= 0) { // the stage that has just ended (barrier exit to barrier exit)
+                mph[2 * mkind] += x - mtl;
+                mph[2 * mkind + 1] += 1;
+            }
+            mtl = x;
+            mkind = ks < 16 * rb ? 0 : 1 + (ks - 16 * rb) / KU;
+        }
         if (fetch_pending) {
             if (threadIdx.x == 0) qi[(ck + 1) & 3] = (int)fetched;
             fetch_pending = false;
@@ -646,6 +675,12 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
         const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
         const int fa = fbase16 + (wr >> 1) * 512 + (wr & 1) * 64;
         const int fb = fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
+        // (Round 4 measured a CYCLIC assignment of the 16-row blocks to the four waves of a SIMD -- every wave runs out of work
+        // together in the diagonal part of an item: same MFMAs, 6.51 -> 7.55 ms at C2, not kept.  In-kernel stamps (make MTRACE=1,
+        // tools/mtrace.py; profiles/r04_mtrace_marginal.txt) show why neither form matters: EVERY stage takes 3.8-4.0 k cycles,
+        // the last diagonal ones with a quarter of the MFMAs included -- the stage is set by the CU's fill path, 64 KB per stage
+        // (32 KB of Phi from HBM at ~24 GB/s per CU + 32 KB of U from L2 at ~70 GB/s per CU: MI355X_MICROARCH.md's per-CU LDS-fill
+        // rates), not by the matrix pipe.)
         // the wave's LAST active stage covers k = its own rows 32..63 of the diagonal 64 x 64 block of U: rows 0..31 (i = 0, 1)
         // are zero there -- their MFMAs would add exact zeros and are skipped (1 + 32 / M instead of 1 + 64 / M executed).
         // One code path with wave-uniform branches around the i = 0, 1 groups (two copies of the loop body spill).
@@ -745,6 +780,17 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
 #undef AGPL_Q_ISSUE
 #undef AGPL_Q_SRC
 #undef AGPL_Q_DECODE
+#ifdef AGPL_MTRACE
+    if (blockIdx.x < 256 && lane == 0) {
+        unsigned long long *o = g_mtrace + ((size_t)blockIdx.x * 16 + wave) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - mt0; // loop cycles
+        o[1] = mtw;                                 // waiting for the DMA of the stage
+        o[2] = mtb;                                 // waiting at the barrier
+        o[3] = mtn;                                 // stages
+        unsigned long long *ph = g_mtrace_phase + ((size_t)blockIdx.x * 16 + wave) * 18;
+        for (int q = 0; q < 18; ++q) ph[q] = mph[q];
+    }
+#endif
     __syncthreads();
     if (pend >= 0) {
         const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -839,6 +885,15 @@ __global__ __launch_bounds__(256) void feature_residual_kernel(int64_t N, int M,
 }
 
 } // namespace
+
+#ifdef AGPL_MTRACE
+extern "C" __attribute__((visibility("default"))) int agpl_debug_mtrace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mtrace), sizeof(g_mtrace));
+}
+extern "C" __attribute__((visibility("default"))) int agpl_debug_mtrace_phase(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mtrace_phase), sizeof(g_mtrace_phase));
+}
+#endif
 
 extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
     if (N <= 0 || M <= 0 || M % BS) return 0;

@@ -271,9 +271,17 @@ def f32_contract_leg(A, ctx, lik, likname, Phi, kd, y, N, M, Mp, L, args):
     steps = 3
     dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
     ms = dt / steps * 1e3
+    roof = roofline_of(kt, L, N, M, Mp, "f32", "f32", ms, 1, N)
+    # SURVEY 8(d) counts the variance projection as a dense product (2 N M^2); marginal_kernel<0> uses the symmetry of W (packed
+    # triangle, doubled off-diagonal) and executes (1 + 128 / M) N M^2 -- its algorithmic rate can exceed the float32 MFMA roof.
+    # `frac` here is therefore the EXECUTED MFMA rate of the dominant kernel over the roof; the algorithmic one is kept beside it.
+    dom = max(roof["kernels"], key=lambda k: k["avg_ms"])
+    roof["frac_of_algorithmic_flops"] = roof["frac"]
+    roof["frac"] = dom["executed_frac_of_peak"]
+    roof["achieved_executed"] = dom["executed_mfma_tflops"]
     out = {"config": {"workload": f"{likname}-logistic SVGP CAVI sweep, N={N}, M={M}, L={L}, 1 GPU, float32-input MFMA kernels"},
            "dtype": "f32", "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps,
-           "warmup": 1, "roofline": roofline_of(kt, L, N, M, Mp, "f32", "f32", ms, 1, N)}
+           "warmup": 1, "roofline": roof}
     del cavi
     if not args.no_parity:
         out["parity"] = parity_slice(A, ctx, lik, likname, Phi, kd, y, "f32", "f32")

@@ -149,32 +149,21 @@ int main(int argc, char **argv) {
         HIP(hipFree(eyed)); HIP(hipFree(Wp)); HIP(hipFree(alpha0)); HIP(hipFree(kxx)); HIP(hipFree(mu));
     }
 
-    // ---- state of the sweep -- SparseCAVI.__init__ (factor form, split accumulation)
-    const int64_t img = agpl_split_features_bytes(N, M);
-    void *Phi_hi = nullptr, *Phi_lo = nullptr, *U_hi = nullptr, *U_lo = nullptr;
-    HIP(hipMalloc(&Phi_hi, (size_t)img));
-    HIP(hipMalloc(&Phi_lo, (size_t)img));
-    AGPL(agpl_split_features(ctx, N, M, Phi, Phi_hi, Phi_lo));
-    // the accumulation's own operand: the point-major split-float16 image (agpl_accumulate_image); the float32 features are
-    // not read by the sweep after this
-    void *Phi_acc = nullptr;
-    HIP(hipMalloc(&Phi_acc, (size_t)agpl_accumulate_image_bytes(N, M)));
-    AGPL(agpl_accumulate_image(ctx, N, M, Phi, Phi_acc));
-    HIP(hipMalloc(&U_hi, sizeof(uint16_t) * (size_t)M * M));
-    HIP(hipMalloc(&U_lo, sizeof(uint16_t) * (size_t)M * M));
+    // ---- state of the sweep -- SparseCAVI.__init__: ONE plan (both split-float16 images of Phi with one scale, the residual,
+    //      q(v) = N(0, I) in factor form, script.jl:41-42); the float32 features are not read by the sweep after this
+    agpl_plan *plan = nullptr;
+    AGPL(agpl_plan_create(ctx, N, M, 1, Phi, resid, 0u, nullptr, &plan));
+    AGPL(agpl_ctx_synchronize(ctx));
+    HIP(hipFree(Phi));
+    HIP(hipFree(resid));
     double *Gg = dalloc<double>((size_t)M * M + M, true); // one flat buffer: the exchange step is one collective
     double *G = Gg, *g = Gg + (size_t)M * M;
-    double *A_work = dalloc<double>((size_t)M * M), *v = dalloc<double>((size_t)M, true);
-    float *v32 = dalloc<float>((size_t)M, true);
-    // q(v) = N(0, I) (script.jl:41-42) carried as (U, v): the update of G = g = 0
-    AGPL(agpl_gaussian_factor_async(ctx, M, 1, G, g, nullptr, A_work, v, v32, U_hi, U_lo, nullptr));
 
     auto sweep = [&]() {
         // marginals -> aux_posterior! -> expected potential / precision -> (G, g)   script.jl:32-34
-        AGPL(agpl_cavi_pass_factor_image(ctx, &lik, N, M, Phi_hi, Phi_lo, Phi_acc, resid, nullptr, y, U_hi, U_lo, v32, G, g,
-                                         nullptr, nullptr, nullptr));
+        AGPL(agpl_cavi_pass_plan(plan, &lik, nullptr, y, G, g, nullptr, nullptr, nullptr, nullptr));
         // S = (I + G)^-1, m = S g   script.jl:35-36
-        AGPL(agpl_gaussian_factor_async(ctx, M, 1, G, g, nullptr, A_work, v, v32, U_hi, U_lo, nullptr));
+        AGPL(agpl_plan_update(plan, G, g, nullptr, nullptr));
     };
     for (int s = 0; s < warmup; ++s) sweep();
     AGPL(agpl_ctx_synchronize(ctx));
@@ -198,6 +187,7 @@ int main(int argc, char **argv) {
                 "\"warmup\": %d, \"seed\": %llu, \"sum_G\": %.17g, \"sum_g\": %.17g, \"G00\": %.17g, \"g0\": %.17g}\n",
                 sweeps / dt, dt / sweeps * 1e3, (long long)N, M, sweeps, warmup, (unsigned long long)seed, sumG, sumg,
                 host[0], host[(size_t)M * M]);
+    AGPL(agpl_plan_destroy(plan));
     AGPL(agpl_ctx_destroy(ctx));
     return 0;
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGPL_VERSION 100
+#define AGPL_VERSION 110
 
 #if defined(__GNUC__)
 #define AGPL_API __attribute__((visibility("default")))

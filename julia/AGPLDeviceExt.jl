@@ -9,7 +9,7 @@
 # (examples/*/script.jl, an SVGP loop over ApproximateGPs) keeps its code and gets the device path by passing
 # device arrays.  One `ccall` per operator; status codes become the exception types the reference throws.
 #
-# STATUS: written against include/agpl.h v100, not executed -- the build image has no `julia` (SURVEY.md F6).  The
+# STATUS: written against include/agpl.h v110 (the plan API), not executed -- the build image has no `julia` (SURVEY.md F6).  The
 # executed twin is the Python host (augmentedgplikelihoods.jl_amd/operators.py, sparse.py): same entry point per
 # operator, same argument order.  tests/test_julia_artifacts.py checks that every `ccall` below names an exported
 # symbol with the right number of arguments.
@@ -256,80 +256,74 @@ end
 
 # ------------------------------------------------------------------------------------------------ sparse sweep
 """
-    SparseSweep(lik, Φ, d, y)
+    SparseSweep(lik, Φ, d, y; comm=C_NULL, track_elbo=false)
 
 State of the sparse CAVI loop (`cavi!`, examples/bernoulli/script.jl:29-39, in the sparse whitened form of
-docs/src/index.md:154-163) on the shipped device path: Φ::ROCMatrix{Float32} is M x N column-major -- exactly Julia's
-layout of K_ZX (whitened: Φ = L⁻¹ K_ZX), M a multiple of 256 (zero-pad) -- `d` the Nyström residual k_nn - |φ_n|²,
-q(v) carried as (U, v) with S = UᵀU, m = Uᵀv.
+docs/src/index.md:154-163) on the shipped device path, i.e. ONE plan (include/agpl.h, agpl_plan_create): Φ::ROCMatrix{Float32}
+is M x N column-major -- exactly Julia's layout of K_ZX (whitened: Φ = L⁻¹ K_ZX), M a multiple of 256 (zero-pad) -- `d` the
+Nyström residual k_nn - |φ_n|².  The plan builds both split-float16 images of Φ (one scale) and carries q(v) as (U, v) with
+S = UᵀU, m = Uᵀv; after construction Φ itself is no longer read by the sweep and may be freed by the caller.
 """
 mutable struct SparseSweep{Tlik}
     lik::Tlik
-    Φ::ROCMatrix{Float32}
-    Φhi::ROCVector{Float16}
-    Φlo::ROCVector{Float16}
-    Φacc::ROCVector{UInt8}      # point-major split-float16 image: the accumulation's operand (agpl_accumulate_image)
-    d::ROCVector{Float32}
+    plan::Ptr{Cvoid}            # agpl_plan*
+    mem::ROCVector{UInt8}       # the plan's device memory (caller-owned storage: freed with this object)
+    N::Int
+    M::Int
     y::ROCArray
-    Gg::ROCVector{Float64}      # [G (L M M) | g (L M)]: ONE buffer, one all-reduce per sweep
-    A::ROCArray{Float64,3}      # work / U (column-major lower triangle = LowerTriangular(A[:, :, l]) is U)
-    v::ROCMatrix{Float64}
-    v32::ROCMatrix{Float32}
-    Uhi::ROCVector{Float16}
-    Ulo::ROCVector{Float16}
+    Gg::ROCVector{Float64}      # [G (L M M) | g (L M) | ELBO terms (1)]: ONE buffer, one all-reduce per sweep
+    kl::ROCVector{Float64}      # KL(q(v) || p(v)) of the last two updates
+    nsweeps::Int
+    track_elbo::Bool
     comm::Ptr{Cvoid}            # ncclComm_t when N is sharded over ranks, else C_NULL
 end
 
-function SparseSweep(lik, Φ::ROCMatrix{Float32}, d::ROCVector{Float32}, y::ROCArray; comm::Ptr{Cvoid}=C_NULL)
+function SparseSweep(lik, Φ::ROCMatrix{Float32}, d::ROCVector{Float32}, y::ROCArray; comm::Ptr{Cvoid}=C_NULL,
+                     track_elbo::Bool=false)
     c = ctx()
     M, N = size(Φ)
     L = nlatent(lik)
-    M % 256 == 0 || throw(ArgumentError("feature count $M must be a multiple of 256 (zero-pad)"))
-    nh = ccall((:agpl_split_features_bytes, libagpl), Int64, (Int64, Int32), N, M) ÷ 2
-    Φhi, Φlo = ROCVector{Float16}(undef, nh), ROCVector{Float16}(undef, nh)
-    check(c.h, ccall((:agpl_split_features, libagpl), Int32,
-        (Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), c.h, N, M, dptr(Φ), dptr(Φhi), dptr(Φlo)))
-    Φacc = ROCVector{UInt8}(undef, ccall((:agpl_accumulate_image_bytes, libagpl), Int64, (Int64, Int32), N, M))
-    check(c.h, ccall((:agpl_accumulate_image, libagpl), Int32,
-        (Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}), c.h, N, M, dptr(Φ), dptr(Φacc)))   # DomainError: a feature is not finite
-    s = SparseSweep(lik, Φ, Φhi, Φlo, Φacc, d, y, AMDGPU.zeros(Float64, L * M * M + L * M),
-                    ROCArray{Float64}(undef, M, M, L), AMDGPU.zeros(Float64, M, L), AMDGPU.zeros(Float32, M, L),
-                    ROCVector{Float16}(undef, L * M * M), ROCVector{Float16}(undef, L * M * M), comm)
-    update!(s)                                    # G = 0, g = 0: S = I, m = 0 (script.jl:41-42)
-    return s
+    nbytes = ccall((:agpl_plan_bytes, libagpl), Int64, (Int64, Int32, Int32, UInt32), N, M, L, 0)
+    nbytes > 0 || throw(ArgumentError("feature count $M must be a multiple of 256 (zero-pad) and nlatent <= 64"))
+    mem = ROCVector{UInt8}(undef, nbytes)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c.h, ccall((:agpl_plan_create, libagpl), Int32,
+        (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+        c.h, N, M, L, dptr(Φ), dptr(d), 0, dptr(mem), h))          # DomainError: a feature is not finite / out of range
+    s = SparseSweep(lik, h[], mem, N, M, y, AMDGPU.zeros(Float64, L * M * M + L * M + 1), AMDGPU.zeros(Float64, 2), 0,
+                    track_elbo, comm)
+    finalizer(x -> ccall((:agpl_plan_destroy, libagpl), Int32, (Ptr{Cvoid},), x.plan), s)
+    return s                                                       # q(v) = N(0, I) (script.jl:41-42)
 end
-Gview(s::SparseSweep) = (M = size(s.Φ, 1); L = nlatent(s.lik); reshape(view(s.Gg, 1:(L * M * M)), M, M, L))
-gview(s::SparseSweep) = (M = size(s.Φ, 1); L = nlatent(s.lik); reshape(view(s.Gg, (L * M * M + 1):length(s.Gg)), M, L))
+Gview(s::SparseSweep) = (M = s.M; L = nlatent(s.lik); reshape(view(s.Gg, 1:(L * M * M)), M, M, L))
+gview(s::SparseSweep) = (M = s.M; L = nlatent(s.lik); reshape(view(s.Gg, (L * M * M + 1):(L * M * M + L * M)), M, L))
+Gptr(s::SparseSweep) = Ptr{Cvoid}(UInt(pointer(s.Gg)))
+gptr(s::SparseSweep) = Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * nlatent(s.lik) * s.M * s.M)
+eptr(s::SparseSweep) = s.track_elbo ? Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * (length(s.Gg) - 1)) : C_NULL
 
 # S = (I + G)⁻¹, m = S g (script.jl:35-36) in factor form; enqueue only (a PosDefException surfaces in the next pass)
 function update!(s::SparseSweep)
     c = ctx()
-    M = size(s.Φ, 1)
-    L = nlatent(s.lik)
-    G, g = Ptr{Cvoid}(UInt(pointer(s.Gg))), Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * L * M * M)
-    return check(c.h, ccall((:agpl_gaussian_factor_async, libagpl), Int32,
-        (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-         Ptr{Cvoid}, Ptr{Cvoid}),
-        c.h, M, L, G, g, C_NULL, dptr(s.A), dptr(s.v), dptr(s.v32), dptr(s.Uhi), dptr(s.Ulo), C_NULL))
+    kl = s.track_elbo ? Ptr{Cvoid}(UInt(pointer(s.kl)) + 8 * (s.nsweeps & 1)) : C_NULL
+    return check(c.h, ccall((:agpl_plan_update, libagpl), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.plan, Gptr(s), gptr(s), C_NULL, kl))
 end
 
 # one sweep: marginals -> aux_posterior! -> expected potential / precision -> (G, g) -> [all-reduce] -> update
 function sweep!(s::SparseSweep)
     c = ctx()
-    M, N = size(s.Φ)
     L = nlatent(s.lik)
     dsc, keep = desc(s.lik)
-    G, g = Ptr{Cvoid}(UInt(pointer(s.Gg))), Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * L * M * M)
-    GC.@preserve keep check(c.h, ccall((:agpl_cavi_pass_factor_image, libagpl), Int32,
-        (Ptr{Cvoid}, Ref{LikDesc}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-        c.h, dsc, N, M, dptr(s.Φhi), dptr(s.Φlo), dptr(s.Φacc), dptr(s.d), C_NULL, dptr(s.y), dptr(s.Uhi), dptr(s.Ulo),
-        dptr(s.v32), G, g, C_NULL, C_NULL, C_NULL))
+    GC.@preserve keep check(c.h, ccall((:agpl_cavi_pass_plan, libagpl), Int32,
+        (Ptr{Cvoid}, Ref{LikDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+         Ptr{Cvoid}),
+        s.plan, dsc, C_NULL, dptr(s.y), Gptr(s), gptr(s), C_NULL, C_NULL, C_NULL, eptr(s)))
     if s.comm != C_NULL                           # the one exchange step of the N-sharded sweep (SURVEY.md 8e)
         check(c.h, ccall((:agpl_allreduce_nat, libagpl), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
-                         c.h, s.comm, G, L * (M * M + M)))
+                         c.h, s.comm, Gptr(s), length(s.Gg)))
     end
     update!(s)
+    s.nsweeps += 1
     return s
 end
 
@@ -344,8 +338,12 @@ end
 "q(v) = N(m, S): m = Uᵀ v, S = Uᵀ U per latent, on the host (M x M)."
 function moments(s::SparseSweep)
     synchronize()
-    A, v = Array(s.A), Array(s.v)
-    L = nlatent(s.lik)
+    L, M = nlatent(s.lik), s.M
+    U_p, v_p = Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL)
+    check(ctx().h, ccall((:agpl_plan_factor, libagpl), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ptr{Cvoid}),
+                         s.plan, U_p, v_p, C_NULL))
+    A = Array(unsafe_wrap(ROCArray, U_p[], (M, M, L)))
+    v = Array(unsafe_wrap(ROCArray, v_p[], (M, L)))
     U = [LowerTriangular(A[:, :, l]) for l in 1:L]
     return [U[l]' * v[:, l] for l in 1:L], [U[l]' * U[l] for l in 1:L]
 end
@@ -353,33 +351,38 @@ end
 "`marginals(post_u(x))` on the device (examples/bernoulli/script.jl:32-33): q(f_n) for the current (U, v)."
 function device_marginals(s::SparseSweep)
     c = ctx()
-    M, N = size(s.Φ)
     L = nlatent(s.lik)
-    μ, σ² = ROCArray{Float32}(undef, N, L), ROCArray{Float32}(undef, N, L)
-    check(c.h, ccall((:agpl_marginals_factor_split, libagpl), Int32,
-        (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-        c.h, N, M, L, dptr(s.Φhi), dptr(s.Φlo), dptr(s.d), C_NULL, dptr(s.Uhi), dptr(s.Ulo), dptr(s.v32), dptr(μ),
-        dptr(σ²)))
+    μ, σ² = ROCArray{Float32}(undef, s.N, L), ROCArray{Float32}(undef, s.N, L)
+    check(c.h, ccall((:agpl_marginals_plan, libagpl), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        s.plan, C_NULL, dptr(μ), dptr(σ²)))
     # [N, L] latent-major out; the per-point operators take [L, N] (L contiguous per point)
     qm, qv = Float64.(permutedims(μ)), Float64.(permutedims(σ²))
     return L == 1 ? DeviceNormals(vec(qm), vec(qv)) : DeviceNormals(qm, qv)
 end
 
-"`aug_elbo` of examples/bernoulli/script.jl:65-70 for the current q(v)."
+"""
+`aug_elbo` (examples/bernoulli/script.jl:65-70) of the q(v) that ENTERED the last sweep, at no extra pass over Φ
+(`track_elbo=true`): the per-point terms rode that sweep's per-point kernel (and its all-reduce), KL(q(v) ‖ p(v)) the update
+that made that q(v).
+"""
+function elbo_entering(s::SparseSweep)
+    (s.track_elbo && s.nsweeps > 0) || throw(ArgumentError("elbo_entering needs track_elbo=true and one sweep"))
+    synchronize()
+    return Array(view(s.Gg, length(s.Gg):length(s.Gg)))[1] - Array(s.kl)[(s.nsweeps & 1) + 1]
+end
+
+"`aug_elbo` of examples/bernoulli/script.jl:65-70 for the current q(v), by separate passes (the reference's own operators)."
 function aug_elbo(s::SparseSweep)
     c = ctx()
-    M = size(s.Φ, 1)
+    M = s.M
     L = nlatent(s.lik)
     qf = device_marginals(s)
-    N = size(s.Φ, 2)
-    qΩ = AugmentedGPLikelihoods.init_aux_posterior(s.lik, N)
+    qΩ = AugmentedGPLikelihoods.init_aux_posterior(s.lik, s.N)
     qΩdev = to_device(qΩ)
     aux_posterior!(qΩdev, s.lik, s.y, qf)
     kl = Ref{Float64}(0.0)
-    G, g = Ptr{Cvoid}(UInt(pointer(s.Gg))), Ptr{Cvoid}(UInt(pointer(s.Gg)) + 8 * L * M * M)
     check(c.h, ccall((:agpl_gaussian_kl, libagpl), Int32,
-        (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), c.h, M, L, G, g, C_NULL, kl))
+        (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), c.h, M, L, Gptr(s), gptr(s), C_NULL, kl))
     return expected_logtilt(s.lik, qΩdev, s.y, qf) - aux_kldivergence(s.lik, qΩdev, s.y) - kl[]
 end
 

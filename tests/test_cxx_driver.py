@@ -34,8 +34,8 @@ def test_cxx_driver_builds_links_and_rejects_bad_arguments():
     src = open(os.path.join(ROOT, "bench", "agpl_bench.cpp")).read()
     assert "torch" not in src.replace("no torch", "") and "Python.h" not in src
     # every entry point of the shipped sweep is called through the header
-    for sym in ("agpl_synth_xy", "agpl_se_features", "agpl_transform_features", "agpl_split_features",
-                "agpl_cavi_pass_factor_image", "agpl_accumulate_image", "agpl_gaussian_factor_async", "agpl_ctx_synchronize"):
+    for sym in ("agpl_synth_xy", "agpl_se_features", "agpl_transform_features", "agpl_plan_create", "agpl_cavi_pass_plan",
+                "agpl_plan_update", "agpl_plan_destroy", "agpl_ctx_synchronize"):
         assert sym + "(" in src, sym
 
 

@@ -199,6 +199,10 @@ def test_c3_per_rank_full_size_properties(A, ctx):
             gref += P.T @ bet[i0:i0 + 250_000].double()
         assert torch.diagonal(G1[0]).sum().item() == pytest.approx(tr, rel=2e-6)
         assert relmax(host(g1[0]), host(gref)) < 2e-6
+        import bench  # v'Gv = sum_n gamma_n (phi_n . v)^2 for 4 random v: every tile of G (ten 256 x 256 ones here) enters
+
+        chk = bench.full_size_quadratic_check(Phi, cavi.gamma, cavi.beta, G1, g1)
+        assert chk["max_rel_d_vGv"] < 2e-6, chk
         cavi.accumulate()
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
         for _ in range(3):  # the two-block factor route (M = 1024) inside whole sweeps
@@ -250,6 +254,10 @@ def test_c4_full_size_properties(A, ctx):
             assert torch.diagonal(G1[l]).sum().item() == pytest.approx(tr, rel=2e-6)
             assert relmax(host(g1[l]), host(P.T @ cavi.beta[l].double())) < 2e-6
         del P, n2
+        import bench  # v'G_l v = sum_n gamma_ln (phi_n . v)^2 for 4 random v, every latent
+
+        chk = bench.full_size_quadratic_check(Phi, cavi.gamma, cavi.beta, G1, g1)
+        assert chk["max_rel_d_vGv"] < 2e-6, chk
         cavi.accumulate()
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
         # one more full sweep through the ten-latent factor launch: finite, and S = U'U symmetric positive

@@ -1089,7 +1089,8 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
     """BASELINE config C2 at its full size (Bernoulli, N = 1e7, M = 512) on the path bench.py ships (split-float16
     contractions, factor-form marginals) -- sizes the oracle cannot reach, so size-independent properties:
       * G exactly symmetric, the sweep bitwise reproducible from the same state;
-      * tr G = sum_n gamma_n |phi_n|^2 and g = Phi beta against float64 torch reductions over the same gamma, beta;
+      * tr G = sum_n gamma_n |phi_n|^2, g = Phi beta and v'Gv = sum_n gamma_n (phi_n . v)^2 (4 random v: every tile of G enters)
+        against float64 torch reductions over the same gamma, beta;
       * additivity over N: G(all) = G(first half) + G(second half) (the sharding identity of the multi-GPU sweep);
       * first-sweep marginals in closed form (S = I, m = 0: mu = 0, var = d + |phi|^2 = 1 for a unit-variance kernel);
       * gamma = tanh(c/2)/(2c) in (0, 1/4] and finite everywhere."""
@@ -1130,6 +1131,11 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
             gref += P.T @ bet[i0:i0 + 1_000_000].double()
         assert torch.diagonal(G1[0]).sum().item() == pytest.approx(tr, rel=2e-6)
         assert relmax(host(g1[0]), host(gref)) < 2e-6
+        # quadratic forms v'Gv = sum_n gamma_n (phi_n . v)^2 for random v: unlike the trace they see every off-diagonal tile
+        import bench
+
+        chk = bench.full_size_quadratic_check(Phi, cavi.gamma, cavi.beta, G1, g1)
+        assert chk["max_rel_d_vGv"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6 and chk["max_rel_dg"] < 2e-6, chk
         cavi.accumulate()  # same state: bitwise identical
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
         del cavi

@@ -84,8 +84,9 @@ def test_every_julia_ccall_matches_the_header():
     # the operator surface and the sweep must all be routed
     for need in ("agpl_aux_sample", "agpl_aux_posterior", "agpl_potential_precision",
                  "agpl_expected_potential_precision", "agpl_logtilt", "agpl_aug_loglik", "agpl_expected_logtilt",
-                 "agpl_aux_kldivergence", "agpl_cavi_pass_factor_image", "agpl_accumulate_image", "agpl_gaussian_factor_async",
-                 "agpl_allreduce_nat", "agpl_gaussian_kl", "agpl_marginals_factor_split", "agpl_ctx_set_point_offset"):
+                 "agpl_aux_kldivergence", "agpl_plan_bytes", "agpl_plan_create", "agpl_plan_destroy", "agpl_cavi_pass_plan",
+                 "agpl_plan_update", "agpl_marginals_plan", "agpl_plan_factor",
+                 "agpl_allreduce_nat", "agpl_gaussian_kl", "agpl_ctx_set_point_offset"):
         assert need in used, need
 
 
@@ -123,9 +124,8 @@ int main(void) {
     d.kind = AGPL_LIK_BERNOULLI_LOGISTIC; d.nlatent = 1; d.p[0] = d.p[1] = d.p[2] = d.p[3] = 0.0; d.logtheta = 0;
     int32_t (*sample)(agpl_ctx *, const agpl_lik_desc *, int64_t, const void *, const double *, double *, int64_t *,
                       uint32_t, uint32_t *, uint32_t *) = agpl_aux_sample;
-    int32_t (*pass)(agpl_ctx *, const agpl_lik_desc *, int64_t, int32_t, const void *, const void *, const void *,
-                    const float *, const float *, const void *, const void *, const void *, const float *, double *,
-                    double *, float *, float *, float *) = agpl_cavi_pass_factor_image;
+    int32_t (*pass)(agpl_plan *, const agpl_lik_desc *, const float *, const void *, double *, double *, float *, float *,
+                    float *, double *) = agpl_cavi_pass_plan;
     int32_t rc = agpl_aux_sample((agpl_ctx *)0, &d, 0, 0, 0, 0, 0, 0u, 0, 0); /* null context: argument error */
     printf("%d %d %d %d\n", (int)agpl_version(), (int)rc, sample != 0, pass != 0);
     return (agpl_version() == AGPL_VERSION && rc == AGPL_ERR_INVALID_ARGUMENT && (int)AGPL_F64 == 1) ? 0 : 1;
@@ -152,4 +152,4 @@ def test_header_is_self_contained_for_c_and_cxx(tmp_path, lang, compiler, std):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
-    assert r.stdout.split()[0] == "100"
+    assert r.stdout.split()[0] == "110"  # AGPL_VERSION: the plan API

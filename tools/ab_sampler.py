@@ -23,10 +23,14 @@ def child():
     ctx = A.Context(0, seed=5)
     out = {"lib": os.path.basename(_ffi.LIB_PATH)}
     _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
-    for name, lik, n in (("bernoulli", A.BernoulliLikelihood(), 10_000_000), ("negbin", A.NegativeBinomialLikelihood(15.0), 4_000_000)):
+    import numpy as np
+
+    for name, lik, n in (("bernoulli", A.BernoulliLikelihood(), 10_000_000), ("negbin", A.NegativeBinomialLikelihood(15.0), 4_000_000),
+                         ("categorical", A.CategoricalLikelihood(np.zeros(10)), 1_000_000)):
         _, y = A.synth_xy(lik, 20240807, 0, n, ctx=ctx, want_x=False)
         g = torch.Generator(device="cuda").manual_seed(1)
-        f = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 1.5
+        L = A.nlatent(lik)
+        f = torch.randn((n,) if L == 1 else (n, L), dtype=torch.float64, device="cuda", generator=g) * 1.5
         Om = A.aux_sample(lik, y, f, ctx=ctx, sweep=1)
         ms, cnt = C.c_double(), C.c_int64()
         _ffi.lib().agpl_timing_read(ctx.bind(), 3, C.byref(ms), C.byref(cnt))

@@ -11,8 +11,8 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 KEEP = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "marginal_factor16_kernel", "syrk_strip_kernel",
-        "syrk_split_kernel", "factor_kernel", "reduce_slab_kernel", "aux_sample_kernel", "gibbs_project_kernel",
-        "gibbs_sample_kernel")
+        "syrk_split_kernel", "factor_kernel", "reduce_slab_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel", "gibbs_project_kernel",
+        "gibbs_sample_kernel", "agpl_fused_point_kernel")
 
 
 def short(n):
@@ -53,6 +53,11 @@ for k, d in acc.items():
         e["lds_latency_ticks"] = round(c["SQ_INST_LEVEL_LDS"] / c["SQ_INSTS_LDS"], 2)
         if "vmem_latency_ticks" in e:
             e["vmem_over_lds_latency"] = round(e["vmem_latency_ticks"] / e["lds_latency_ticks"], 1)
+    # vector-ALU occupancy of the SIMDs: SQ_ACTIVE_INST_VALU counts (per SIMD) the cycles a VALU instruction is executing
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        e["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+    if c.get("SQ_INSTS_VALU") and "SQ_WAVE_CYCLES" in c:
+        e["valu_insts_per_wave_cycle"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVE_CYCLES"], 4)
     if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
         e["lds_busy_frac_of_cu_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256), 3)
     res["kernels"][k] = e
