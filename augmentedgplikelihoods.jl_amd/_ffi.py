@@ -22,7 +22,7 @@ SYMBOLS = [
     "agpl_expected_logtilt", "agpl_aux_kldivergence", "agpl_marginals", "agpl_accumulate",
     "agpl_gaussian_update", "agpl_pack_w", "agpl_cavi_pass", "agpl_workspace_bytes", "agpl_se_features",
     "agpl_transform_features", "agpl_synth_xy", "agpl_timing_enable", "agpl_timing_read", "agpl_gibbs_pass", "agpl_gibbs_draw_v", "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_gaussian_kl", "agpl_split_features_bytes", "agpl_split_features", "agpl_pack_w_split",
-    "agpl_marginals_split", "agpl_cavi_pass_split", "agpl_set_accumulate_precision", "agpl_allreduce_nat", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_feature_residual", "agpl_gaussian_factor", "agpl_gaussian_factor_async",
+    "agpl_marginals_split", "agpl_cavi_pass_split", "agpl_allreduce_nat", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_feature_residual", "agpl_gaussian_factor", "agpl_gaussian_factor_async",
     "agpl_pack_factor_split", "agpl_marginals_factor_split", "agpl_cavi_pass_factor_split", "agpl_probe_mfma_f64", "agpl_probe_mfma_f16",
     "agpl_accumulate_image_bytes", "agpl_accumulate_image", "agpl_accumulate_split", "agpl_cavi_pass_factor_image",
     "agpl_gibbs_pass_image", "agpl_debug_force_factor_rescue",

@@ -32,10 +32,11 @@ struct agpl_ctx {
     double logtheta_host[128];      // last uploaded values (skip the copy when unchanged)
     int logtheta_n = 0;
     // optional kernel timing (agpl_timing_*): event pairs per kernel family
-    int accumulate_split = 0; // 0: f32-input MFMA accumulation, 1: split-float16 (agpl_set_accumulate_precision)
+    int accumulate_split = 0; // internal: 1 while a *_split / *_image / plan entry point runs its accumulation (split-float16), else 0 (f32-input MFMA)
     int ncu = 0;              // compute units of `device` (queried once, by the first queue-served launch)
     int strip_attr = 0;       // the accumulation kernels' dynamic-LDS attributes are set (once)
     int queue_attr = 0;       // marginal_factor_queue_kernel's dynamic-LDS attribute is set (once)
+    const void *checked_image = nullptr; // the accumulate image whose header agpl_syrk_image_launch has validated last
     double *elbo_part = nullptr;  // per-workgroup partial sums of the ELBO terms that ride the per-point kernel (1024 doubles)
     bool debug_force_rescue = false; // agpl_debug_force_factor_rescue (test hook)
     bool timing = false;

@@ -1035,9 +1035,3 @@ extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mod
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (mode != 0 && mode != 1) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA) or 1 (split float16 MFMA)");
-    ctx->accumulate_split = mode;
-    return AGPL_OK;
-}

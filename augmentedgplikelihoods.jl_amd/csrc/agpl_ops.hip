@@ -2090,8 +2090,93 @@ __global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
     }
 }
 
+// The same projection from the accumulate image (agpl_syrk.hip: 4 KB blocks [point slice of 16][feature block of 128][hi | lo] =
+// [plane 2 of 8 points][feature 128][8 halves], the image holding 2^e Phi), so that a plan's Gibbs pass reads nothing but its
+// images: x = (hi + lo) 2^-e is the feature the accumulation multiplies (Phi to 2^-22 relative).  One wave per 16-point slice:
+// lanes 0-31 take plane 0 (points 0..7), lanes 32-63 plane 1; a lane walks the features (lane & 31) + 32 j, j = 0..3, of every
+// feature block in ascending order and keeps the partial sums of its 8 points; the 32 lanes of a plane are then added by an
+// exchange tree (a lane hands half of its points to its partner at distances 16, 8, 4 -- 4, 2, 1 values left -- and the last two
+// steps add the remaining value): fixed order, bitwise reproducible.  float64 accumulation; several latents share the loads.
+typedef _Float16 gp_h8 __attribute__((ext_vector_type(8)));
+template <int LB> // latents per pass over the slice
+__device__ __forceinline__ void gibbs_project_slice(int64_t N, int M, int Lf, int l0, const gp_h8 *__restrict__ blocks, int64_t ps,
+                                                    double unscale, const double *__restrict__ v_s, double *__restrict__ proj,
+                                                    int lane) {
+    const int nb = M / 128;
+    const int plane = lane >> 5, fl = lane & 31;
+    double acc[LB][8];
+#pragma unroll
+    for (int l = 0; l < LB; ++l)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[l][p] = 0.0;
+    for (int fb = 0; fb < nb; ++fb) {
+        const gp_h8 *bh = blocks + ((ps * nb + fb) * 2) * 256 + plane * 128 + fl; // hi block; the lo block follows (+ 256 granules)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const gp_h8 h = bh[32 * j], lo = bh[256 + 32 * j];
+            const int f = fb * 128 + fl + 32 * j;
+            double x[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) x[p] = (double)((float)h[p] + (float)lo[p]); // exact: hi and lo do not overlap
+#pragma unroll
+            for (int l = 0; l < LB; ++l) {
+                const double vv = v_s[(size_t)(l0 + l) * M + f];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) acc[l][p] += x[p] * vv;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+        // exchange tree over the 32 lanes of the plane: after distance d a lane keeps the points whose bit (d >> 2 ... ) matches it
+        double a4[4], a2[2], a1;
+        const bool up16 = fl & 16, up8 = fl & 8, up4 = fl & 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { // keep points 4..7 in the upper half of the 16-pairs, 0..3 in the lower
+            const double mine = up16 ? acc[l][4 + p] : acc[l][p], give = up16 ? acc[l][p] : acc[l][4 + p];
+            a4[p] = mine + __shfl_xor(give, 16);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const double mine = up8 ? a4[2 + p] : a4[p], give = up8 ? a4[p] : a4[2 + p];
+            a2[p] = mine + __shfl_xor(give, 8);
+        }
+        {
+            const double mine = up4 ? a2[1] : a2[0], give = up4 ? a2[0] : a2[1];
+            a1 = mine + __shfl_xor(give, 4);
+        }
+        a1 += __shfl_xor(a1, 2);
+        a1 += __shfl_xor(a1, 1);
+        // the lane with (fl & 3) == 0 holds point 4 [fl & 16] + 2 [fl & 8] + [fl & 4] of its plane
+        if ((fl & 3) == 0) {
+            const int pt = plane * 8 + (up16 ? 4 : 0) + (up8 ? 2 : 0) + (up4 ? 1 : 0);
+            const int64_t n = ps * 16 + pt;
+            if (n < N) proj[n * Lf + l0 + l] = a1 * unscale;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void gibbs_project_image_kernel(int64_t N, int M, int Lf, const unsigned char *__restrict__ image,
+                                                                  const double *__restrict__ v, double *__restrict__ proj) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *v_s = sh; // [Lf][M]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = threadIdx.x; a < Lf * M; a += blockDim.x) v_s[a] = v[a];
+    __syncthreads();
+    const int e = reinterpret_cast<const int32_t *>(image)[1]; // header word 1: the image holds 2^e Phi
+    const double unscale = __hiloint2double((1023 - e) << 20, 0);
+    const gp_h8 *blocks = reinterpret_cast<const gp_h8 *>(image + 256);
+    const int64_t nslices = (N + 15) >> 4;
+    for (int64_t ps = (int64_t)blockIdx.x * 4 + wave; ps < nslices; ps += (int64_t)gridDim.x * 4) {
+        int l = 0;
+        for (; l + 4 <= Lf; l += 4) gibbs_project_slice<4>(N, M, Lf, l, blocks, ps, unscale, v_s, proj, lane);
+        for (; l + 2 <= Lf; l += 2) gibbs_project_slice<2>(N, M, Lf, l, blocks, ps, unscale, v_s, proj, lane);
+        for (; l < Lf; ++l) gibbs_project_slice<1>(N, M, Lf, l, blocks, ps, unscale, v_s, proj, lane);
+    }
+}
+
+// Phi == nullptr: the projection reads `image` (the accumulate image of the same features) instead
 int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
-                                         const float *kdiag, const float *mu0, const void *y, const double *v,
+                                         const void *image, const float *kdiag, const float *mu0, const void *y, const double *v,
                                          uint32_t sweep, float *gamma, float *beta, double *f_out,
                                          double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad,
                                          double *proj_work /* N * L doubles of scratch */) {
@@ -2114,7 +2199,15 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));                 \
         gibbs_project_kernel<NV_><<<(unsigned)nbp, 256, lds_p, ctx->stream>>>(N, M, Lf, Phi, v, proj_work);         \
     } while (0)
-        if (Lf > 1 && M == 256) AGPL_LAUNCH_PROJECT(4); // several latents: the row stays in registers (M = 64 NV)
+        if (!Phi) {
+            if (!image) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "Gibbs point pass: neither features nor their image");
+            AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_project_image_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+            int64_t nbi = agpl_cdiv(agpl_cdiv(N, 16), 4);
+            if (nbi > 256 * 16) nbi = 256 * 16;
+            gibbs_project_image_kernel<<<(unsigned)nbi, 256, lds_p, ctx->stream>>>(N, M, Lf, (const unsigned char *)image, v,
+                                                                                proj_work);
+        } else if (Lf > 1 && M == 256) AGPL_LAUNCH_PROJECT(4); // several latents: the row stays in registers (M = 64 NV)
         else if (Lf > 1 && M == 512) AGPL_LAUNCH_PROJECT(8);
         else if (Lf > 1 && M == 1024) AGPL_LAUNCH_PROJECT(16);
         else AGPL_LAUNCH_PROJECT(0);

@@ -10,8 +10,8 @@
 //   * a copy of the Nystrom residual d_i = k_ii - |phi_i|^2 (agpl_feature_residual);
 //   * q(v) in factor form: U = chol(I + G)^-1 (float64, and split-float16 images of 2^15 U: |U| <= 1 always, so the scale is
 //     fixed and the images keep normal float16 parts down to |U| ~ 2^-29), v = U (g + eta0), log det(I + G);
-// and picks the kernels by shape.  After agpl_plan_create the float32 features are not read again by the CAVI sweep or the
-// marginals (the Gibbs pass still projects from them: it takes the pointer as an argument).
+// and picks the kernels by shape.  After agpl_plan_create the float32 features are not read again: the CAVI sweep, the marginals
+// and the Gibbs pass (projection phi_i' v from the accumulate image) read the images only.
 // Reference: the loop bodies of examples/bernoulli/script.jl:29-39 (cavi!) and :76-87 (gibbs_sample) in the sparse form of
 // docs/src/index.md:154-163; the ELBO pieces are those of aug_elbo, script.jl:65-70.
 #include "agpl_common.h"
@@ -313,7 +313,7 @@ extern "C" int32_t agpl_marginals_plan(agpl_plan *p, const float *mu0, float *mu
                                           mu_out, var_out, p->scale_exp + kUExp);
 }
 
-extern "C" int32_t agpl_gibbs_pass_plan(agpl_plan *p, const agpl_lik_desc *lik, const float *Phi, const float *mu0, const void *y,
+extern "C" int32_t agpl_gibbs_pass_plan(agpl_plan *p, const agpl_lik_desc *lik, const float *mu0, const void *y,
                                         const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out) {
     int32_t rc = plan_check(p);
@@ -321,6 +321,6 @@ extern "C" int32_t agpl_gibbs_pass_plan(agpl_plan *p, const agpl_lik_desc *lik, 
     if (!lik) AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "null likelihood descriptor");
     if (lik->nlatent != p->L)
         AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "the likelihood has %d latents, the plan was created for %d", lik->nlatent, p->L);
-    return agpl_gibbs_pass_internal(p->ctx, lik, p->N, p->M, Phi, p->Phi_acc, true, p->resid, mu0, y, v, sweep, G_out, g_out,
+    return agpl_gibbs_pass_internal(p->ctx, lik, p->N, p->M, nullptr, p->Phi_acc, true, p->resid, mu0, y, v, sweep, G_out, g_out,
                                     f_out, omega_out, n_out, nuni_out);
 }

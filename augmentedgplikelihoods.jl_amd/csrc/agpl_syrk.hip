@@ -642,6 +642,7 @@ int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const f
     const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2;
     accumulate_image_kernel<<<16384, 256, 0, ctx->stream>>>(N, M, nps, scale, eA, max_abs, Phi, (unsigned char *)image_out);
     AGPL_LAUNCH_CHECK(ctx);
+    if (ctx->checked_image == image_out) ctx->checked_image = nullptr; // (rebuilt in place: its header is looked at again)
     return AGPL_OK;
 }
 
@@ -666,6 +667,19 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
                                float *slabg, int ns, bool records_ready) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
+    if (ctx->checked_image != image) {
+        // the header, once per image: an image of another (N, M), or a buffer that never was one, would otherwise give
+        // out-of-range DMA reads and a garbage scale.  One small copy and one synchronisation, at the first sweep only.
+        AccImageHeader h;
+        AGPL_HIP(ctx, hipMemcpyAsync(&h, image, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h.magic != kImageMagic || h.N != N || h.M != M)
+            AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
+                      "not an accumulate image of this problem (agpl_accumulate_image / agpl_plan_create): header says N = %lld, "
+                      "M = %d, magic %#x; the call has N = %lld, M = %d",
+                      (long long)h.N, (int)h.M, (unsigned)h.magic, (long long)N, (int)M);
+        ctx->checked_image = image;
+    }
     const int nb2 = M / kPanel;
     const int npairs2 = nb2 * (nb2 + 1) / 2;
     const int64_t nwg = (int64_t)L * npairs2 * ((ns + 7) / 8) * 8;

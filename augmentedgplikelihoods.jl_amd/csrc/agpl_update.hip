@@ -32,7 +32,7 @@ int32_t agpl_launch_fused_elementwise(agpl_ctx *ctx, const agpl_lik_dev &ld, int
                                       const float *mu, const float *var, float *gamma, float *beta, float *c_out);
 int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const void *acc_image, const float *beta,
                              const float *gamma, double *G_out, double *g_out, void *slab_mem, bool records_ready = false);
-int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi,
+int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, int64_t N, int M, const float *Phi, const void *image,
                                          const float *kdiag, const float *mu0, const void *y, const double *v,
                                          uint32_t sweep, float *gamma, float *beta, double *f_out,
                                          double *omega_out, int64_t *n_out, uint32_t *nuni_out, int *bad,
@@ -690,7 +690,9 @@ int32_t agpl_gibbs_pass_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_
     const int L = ld.nlatent;
     if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
     if (M % 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 128 (zero-pad the features)", M);
-    if (!Phi || !kdiag || !v || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    // Phi == nullptr (a plan's pass): projection and accumulation both read the accumulate image
+    if ((!Phi && !(acc_image && M % 256 == 0)) || !kdiag || !v || !G_out || !g_out)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     if (ld.kind != AGPL_LIK_BERNOULLI_LOGISTIC && !y) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null y");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
     const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
@@ -706,7 +708,7 @@ int32_t agpl_gibbs_pass_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_
     float *bet = (float *)(base + slab + vec);
     // the slab region (>= 16 L N bytes) is free until the accumulation starts: it lends the N x L doubles of the
     // projections between the two kernels of the point pass
-    rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
+    rc = agpl_launch_gibbs_project_sample(ctx, ld, N, M, Phi, acc_image, kdiag, mu0, y, v, sweep, gam, bet, f_out, omega_out,
                                           n_out, nuni_out, bad, (double *)base);
     if (rc) return rc;
     const int keep_split = ctx->accumulate_split;
@@ -910,7 +912,7 @@ extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik,
     if (rc) return rc;
     rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
     if (rc) return rc;
-    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
+    // a split entry point implies the split-float16 accumulation (ctx->accumulate_split is internal: the float32-named entry points leave it 0)
     const int keep = ctx->accumulate_split;
     ctx->accumulate_split = 1;
     rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
@@ -944,7 +946,7 @@ int32_t agpl_cavi_pass_factor_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, 
     rc = agpl_ws_reserve(ctx, slab + 4 * vec);
     if (rc) return rc;
     char *base = (char *)ctx->ws;
-    // a split entry point implies the split-float16 accumulation, whatever agpl_set_accumulate_precision says
+    // a split entry point implies the split-float16 accumulation (ctx->accumulate_split is internal: the float32-named entry points leave it 0)
     const int keep = ctx->accumulate_split;
     if (acc_image && M % 256 == 0) {
         // three launches up to the slabs: marginal partial sums (MFMA) -> ONE per-point kernel (q(f_i), aux_posterior!,

@@ -206,6 +206,10 @@ class SparseCAVI:
         if accumulate_precision not in ("f32", "f16x2"):
             raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
         self.acc_split = 1 if accumulate_precision == "f16x2" else 0
+        if self.split != bool(self.acc_split):
+            # the entry points come in two arithmetics: float32-input MFMA for both contractions (agpl_cavi_pass), or
+            # split-float16 for both (the plan and the superseded *_split calls, which always accumulate split)
+            raise _ffi.ArgumentError(-1, "marginal_precision and accumulate_precision must both be 'f32' or both be split-float16")
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
@@ -291,7 +295,6 @@ class SparseCAVI:
                            _ptr(self.c), _ptr(self.gamma), _ptr(self.beta), _ptr(self._elbo_terms))
             return
         # ---- superseded entry points (kept for their tests) ----
-        self.ctx.call("agpl_set_accumulate_precision", C.c_int32(self.acc_split))
         if self.factor and self.Phi_acc is not None:
             self.ctx.call("agpl_cavi_pass_factor_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
                           _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.Phi_acc), _ptr(self.resid), _ptr(self.mu0),
@@ -550,7 +553,7 @@ class SparseGibbs:
         self.ctx.set_point_offset(self.point_offset)
         try:  # (a raising pass must not leave the context's point offset shifted for its other users)
             if self.plan is not None:  # the shipped path
-                self.plan.call("agpl_gibbs_pass_plan", C.byref(d), _ptr(self.Phi), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
+                self.plan.call("agpl_gibbs_pass_plan", C.byref(d), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
                                C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
                                _ptr(self.n), C.c_void_p(0))
             elif self.acc_split:  # superseded entry point (feature counts that are not a multiple of 256)
@@ -559,7 +562,6 @@ class SparseGibbs:
                               C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
                               _ptr(self.n), C.c_void_p(0))
             else:
-                self.ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
                 self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                               _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),
                               _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega), _ptr(self.n), C.c_void_p(0))

@@ -593,8 +593,8 @@ def main():
         "hbm_gb": {"timed_sweeps_high_water": hbm_sweep_gb,
                    "plan": round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None,
                    "float32_features": round(Phi.numel() * 4 / 1e9, 2),
-                   "note": "the plan (both split-float16 images + q(v)) is what a CAVI sweep reads; the float32 features stay "
-                           "resident here only because the Gibbs, parity and CPU-baseline legs of this run use them"},
+                   "note": "the plan (both split-float16 images + q(v)) is all that CAVI and Gibbs sweeps read; the float32 features "
+                           "stay resident here only because the parity, float32-contract and CPU-baseline legs of this run use them"},
     }
     if world > 1:
         steps_ms = [r["ms_per_step"] for r in per_rank]
@@ -608,7 +608,8 @@ def main():
     # ---- Gibbs half on the same resident workload (extra legs, not the headline value) ------------------------
     if not args.no_gibbs:
         yg = y.to(torch.float64) if lik.ykind == "real" else y
-        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None, accumulate_precision=args.accumulate)
+        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=None, accumulate_precision=args.accumulate,
+                            plan=getattr(cavi, "plan", None))  # (the CAVI leg's plan: its accumulate image and residual are shared)
         for _ in range(2):
             gib.sweep()
         torch.cuda.synchronize()
@@ -624,10 +625,12 @@ def main():
         proj_ms = pms / max(pcnt, 1)
         out["gibbs"] = {
             "sweeps_per_s": round(1.0 / tg, 3), "ms_per_sweep": round(tg * 1e3, 3),
-            "point_pass": {"kernel": "gibbs_project_kernel + " + ("aux_sample_pg1_kernel<gibbs>" if args.lik == "bernoulli"
+            "point_pass": {"kernel": ("gibbs_project_image_kernel + " if gib.plan is not None else "gibbs_project_kernel + ") + ("aux_sample_pg1_kernel<gibbs>" if args.lik == "bernoulli"
                                                                   else "gibbs_sample_kernel"), "avg_ms": round(proj_ms, 3), "bound": "hbm",
                            "algorithmic_bytes": n_loc * (Mp * 4 + 16),
-                           "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000}}
+                           "achieved_GBps": round(n_loc * (Mp * 4 + 16) / (proj_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000,
+                           "projection_reads": "the plan's accumulate image (hi | lo float16 = 4 bytes per feature and point)"
+                                               if gib.plan is not None else "the float32 features"}}
         del gib
 
         # standalone aux_sample! (src/generic.jl:5-12) at the marginal means: the PG sampler kernel alone, for the

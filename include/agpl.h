@@ -351,7 +351,7 @@ AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc 
  *   agpl_accumulate_image_bytes : bytes of the image (256-byte header + blocks) for N points, M features (M % 128 == 0).
  *   agpl_accumulate_image       : Phi (float32 [M,N] col-major) -> image.  AGPL_ERR_DOMAIN (with the offending point and
  *                                 feature in agpl_last_error) if a feature is not finite.  Synchronises the stream once.
- *   agpl_accumulate_split       : agpl_accumulate on the float16 matrix cores, whatever agpl_set_accumulate_precision says:
+ *   agpl_accumulate_split       : agpl_accumulate on the float16 matrix cores:
  *                                 from the image when acc_image != NULL and M % 256 == 0 (Phi may then be NULL), else from
  *                                 the float32 Phi (psi = sqrt(gamma) phi split while staging; |sqrt(gamma) phi| < 6e4).
  *                                 gamma >= 0 (TestUtils.jl:88).                                                        */
@@ -366,7 +366,7 @@ AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int3
  *                                 agpl_accumulate_image) -- the float32 features are not an argument; M % 256 == 0.
  *   agpl_gibbs_pass_image       : agpl_gibbs_pass with the split-float16 accumulation, from Phi_acc when it is given
  *                                 and M % 256 == 0 (Phi is still read by the projection phi_i' v).
- * Every *_split / *_image entry point runs the split-float16 accumulation whatever agpl_set_accumulate_precision says.
+ * Every *_split / *_image entry point runs the split-float16 accumulation.
  * agpl_cavi_pass_factor_image is three launches up to the slabs (marginal partial sums; ONE per-point kernel: q(f_i),
  * aux_posterior!, expected potential / precision, written straight into the accumulation's gamma | beta records; the
  * accumulation) -- gamma_out / beta_out / c_out may be NULL and are then never materialised.  A gamma that is negative or not
@@ -387,8 +387,8 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  * 128-point tile, accumulate image point-major), BOTH carrying 2^e Phi with one e chosen from max |Phi| (domain: any finite
  * features with max |Phi| in 2^-17 .. 2^43; a non-finite feature is AGPL_ERR_DOMAIN with its (point, feature)), a copy of the
  * Nystrom residual, and q(v) in factor form -- U = chol(I + G)^-1, v = U (g + eta0), log det(I + G) -- which the plan's update
- * writes and its passes read; kernels are chosen by shape.  After creation the float32 features are not read by the CAVI pass or
- * the marginals (C2: 41 GB of images resident instead of 61 GB with the features).  These entry points supersede
+ * writes and its passes read; kernels are chosen by shape.  After creation the float32 features are not read by any plan entry
+ * point (C2: 41 GB of images resident instead of 61 GB with the features; 20.5 GB for a Gibbs-only plan).  These entry points supersede
  * agpl_split_features, agpl_accumulate_image, agpl_pack_factor_split, agpl_marginals_factor_split, agpl_cavi_pass_split,
  * agpl_cavi_pass_factor_split, agpl_cavi_pass_factor_image and agpl_gibbs_pass_image (kept below for existing callers).
  *   agpl_plan_bytes     : device bytes a plan needs for (N, M, L, flags); 0 for sizes a plan does not take (M % 256 != 0, L > 64).
@@ -408,8 +408,9 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *                         the NEW q(v), from U and v (the kldivergence term of aug_elbo).  ELBO of a q(v) = the elbo_terms of the
  *                         pass that used it (summed over ranks) - the kl of the update that made it.
  *   agpl_marginals_plan : q(f_i) of the plan's q(v): mu, var float32 [L][N].
- *   agpl_gibbs_pass_plan: agpl_gibbs_pass with the plan's residual and accumulate image (Phi: the float32 features, read by the
- *                         projection phi_i' v only).
+ *   agpl_gibbs_pass_plan: agpl_gibbs_pass with the plan's residual and accumulate image; the projection phi_i' v is formed from the
+ *                         image too (x = (hi + lo) 2^-e: the features to 2^-22 relative, float64 accumulation in a fixed order),
+ *                         so a Gibbs chain needs the float32 features at plan creation only.
  *   agpl_plan_factor    : device pointers to U (float64 [L, M, M], column-major lower triangle), v (float64 [L, M]) and the
  *                         residual, e.g. to form S = U'U, m = U'v.   agpl_plan_info: sizes, the images' scale exponent, bytes.
  *   agpl_plan_state     : device pointers to what an update rewrites besides U and v -- the images of 2^15 U (float16, L M M each),
@@ -428,9 +429,9 @@ AGPL_API int32_t agpl_cavi_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, 
                                      double *g_out, float *c_out, float *gamma_out, float *beta_out, double *elbo_terms_out);
 AGPL_API int32_t agpl_plan_update(agpl_plan *plan, const double *G, const double *g, const double *eta0, double *kl_out);
 AGPL_API int32_t agpl_marginals_plan(agpl_plan *plan, const float *mu0, float *mu_out, float *var_out);
-AGPL_API int32_t agpl_gibbs_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, const float *Phi, const float *mu0,
-                                      const void *y, const double *v, uint32_t sweep, double *G_out, double *g_out,
-                                      double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
+AGPL_API int32_t agpl_gibbs_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, const float *mu0, const void *y,
+                                      const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
+                                      double *omega_out, int64_t *n_out, uint32_t *nuni_out);
 
 /* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
  *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
@@ -438,13 +439,9 @@ AGPL_API int32_t agpl_gibbs_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik,
  *   Python host reaches the same RCCL through torch.distributed.  librccl is loaded at the first call.          */
 AGPL_API int32_t agpl_allreduce_nat(agpl_ctx *ctx, void *rccl_comm, double *buf, int64_t count);
 
-/* agpl_set_accumulate_precision: which kernel the float32-named entry points agpl_accumulate / agpl_cavi_pass /
- *   agpl_gibbs_pass use for G = Phi Diag(gamma) Phi': 0 = float32-input MFMA (default: what their names promise),
- *   1 = split-float16 MFMA (psi = sqrt(gamma) phi split into hi/lo float16 while staging; 3 float16 products per
- *   float32 product; needs gamma >= 0 and |sqrt(gamma) phi| < 6e4).  Same slabs, same fixed-order float64 reduction.
- *   The *_split / *_image entry points (agpl_accumulate_split, agpl_cavi_pass_split, agpl_cavi_pass_factor_split,
- *   agpl_cavi_pass_factor_image, agpl_gibbs_pass_image) do not read this setting: they are the split path.      */
-AGPL_API int32_t agpl_set_accumulate_precision(agpl_ctx *ctx, int32_t mode);
+/* (agpl_set_accumulate_precision, v100: removed in v110.  The float32-named entry points -- agpl_accumulate, agpl_cavi_pass,
+ * agpl_gibbs_pass -- always contract on the float32-input MFMA; the split-float16 arithmetic is the plan API's, and the
+ * superseded *_split / *_image entry points'.  There is no per-context precision state any more.) */
 
 /* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
 AGPL_API int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L);

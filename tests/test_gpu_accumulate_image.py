@@ -183,9 +183,11 @@ def test_sparse_cavi_default_path_uses_the_image(A, ctx, oracle):
     assert relmax(cavi.g.cpu().numpy(), g) < 1e-5
 
 
-def test_gibbs_pass_image_equals_gibbs_pass(A, ctx):
-    """The Gibbs point pass draws the same chain whichever kernel accumulates: same f, omega bit for bit, (G, g) within
-    the split-float16 bound of each other."""
+def test_gibbs_pass_on_a_plan_follows_the_float32_pass(A, ctx):
+    """The plan's Gibbs point pass projects phi_i' v from the accumulate image (features to 2^-22 relative) where the float32
+    pass reads Phi itself: the draws of f agree to that precision, (G, g) within the split-float16 bound of each other.  (Exact
+    parity of the plan's pass -- f, omega, counts, uniforms consumed -- is against the oracle on the image's own features:
+    tests/test_gpu_plan.py.)"""
     import bench
 
     lik = A.NegativeBinomialLikelihood(15.0)
@@ -193,9 +195,29 @@ def test_gibbs_pass_image_equals_gibbs_pass(A, ctx):
     ga = A.SparseGibbs(lik, Phi, kd, y, ctx=A.Context(0, seed=3), keep_points=True, accumulate_precision="f16x2")
     gb = A.SparseGibbs(lik, Phi, kd, y, ctx=A.Context(0, seed=3), keep_points=True, accumulate_precision="f32")
     assert ga.plan is not None and gb.plan is None
-    for _ in range(3):
-        ga.sweep()
-        gb.sweep()
-        assert torch.equal(ga.omega, gb.omega) and torch.equal(ga.f, gb.f)
-        assert relmax(ga.G.cpu().numpy(), gb.G.cpu().numpy()) < 5e-6
-        gb.G.copy_(ga.G), gb.g.copy_(ga.g), gb.v.copy_(ga.v)  # keep the chains on one trajectory
+    ga.accumulate()
+    gb.accumulate()  # (one pass from the same v: later sweeps draw different v from slightly different G)
+    assert (ga.f - gb.f).abs().max().item() < 2e-6 * max(1.0, gb.f.abs().max().item())
+    same = (ga.omega - gb.omega).abs() < 1e-5 * gb.omega.abs().clamp_min(1e-30)
+    assert same.float().mean().item() > 0.999  # (a 1e-7 change of |f| moves a PG draw continuously, bar a rare accept / reject flip)
+
+
+def test_image_of_another_problem_is_refused(A, ctx):
+    """The accumulation checks the image's header (magic, N, M) once per image: a buffer that is not an image of THIS problem
+    would otherwise be read out of range."""
+    N, M = 4000, 256
+    Phi = torch.randn((N, M), device="cuda")
+    img = A.sparse.accumulate_image(Phi, ctx)
+    gam = torch.rand((1, N), device="cuda")
+    bet = torch.randn((1, N), device="cuda")
+    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
+    ok = (C.c_int64(N), C.c_int32(M), C.c_int32(1), _p(None), _p(img), _p(bet), _p(gam), _p(G), _p(g))
+    ctx.call("agpl_accumulate_split", *ok)
+    with pytest.raises(A.ArgumentError, match="not an accumulate image of this problem"):
+        ctx.call("agpl_accumulate_split", C.c_int64(N - 64), C.c_int32(M), C.c_int32(1), _p(None), _p(img), _p(bet[:, :N - 64].contiguous()),
+                 _p(gam[:, :N - 64].contiguous()), _p(G), _p(g))
+    junk = torch.zeros_like(img)
+    with pytest.raises(A.ArgumentError, match="not an accumulate image of this problem"):
+        ctx.call("agpl_accumulate_split", C.c_int64(N), C.c_int32(M), C.c_int32(1), _p(None), _p(junk), _p(bet), _p(gam), _p(G), _p(g))
+    ctx.call("agpl_accumulate_split", *ok)  # the context is still usable

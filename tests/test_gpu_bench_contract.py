@@ -48,6 +48,14 @@ def test_bench_line_single_gpu_small_workload():
     assert d["parity"]["pass"] and d["parity"]["max_rel_dG"] < 1e-5 and d["parity"]["max_rel_dg"] < 1e-5
     fc = d["full_size_check"]
     assert fc["pass"] and fc["points"] == 300000 and fc["G_symmetric"]
+    assert fc["max_rel_d_vGv"] < 2e-6 and fc["quadratic_forms"] == 4  # the check that sees the off-diagonal tiles
+    # the sweep at the contract's own arithmetic (float32-input MFMA), priced by what it executes against the 157.3 TFLOP/s roof
+    f32 = d["f32_contract"]
+    assert f32["dtype"] == "f32" and f32["ms_per_step"] > 0 and 0 < f32["roofline"]["frac"] < 1
+    assert f32["parity"]["pass"]
+    # aug_elbo riding the sweep: the last values do not decrease
+    assert d["elbo"]["non_decreasing"] and len(d["elbo"]["elbo_entering_last_sweeps"]) == 3
+    assert d["hbm_gb"]["plan"] > 0
 
 
 @pytest.mark.timeout(600)
@@ -64,6 +72,12 @@ def test_bench_line_two_ranks_through_the_driver_launcher():
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    # the diagnosis a scaling run needs: the exchange step as the stream saw it, and every rank's own numbers
+    assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] == 8 * (256 * 256 + 256)
+    assert len(d["per_rank"]) == 2 and {r["rank"] for r in d["per_rank"]} == {0, 1}
+    assert all(r["points"] == 150000 and r["ms_per_step"] > 0 and r["allreduce_ms_avg"] > 0 for r in d["per_rank"])
+    assert d["ms_per_step_min_rank"] <= d["ms_per_step_max_rank"] <= d["ms_per_step"] * 1.001
+    assert len(d["per_rank_kernels"]) == 2 and all(k["accumulate_kernel_ms"] > 0 for k in d["per_rank_kernels"])
 
 
 @pytest.mark.timeout(600)

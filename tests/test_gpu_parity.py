@@ -717,17 +717,17 @@ def test_cavi_with_split_f16_marginals_matches_oracle(A, ctx, oracle, name, N, M
 # --------------------------------------------------------------------------------------- split-float16 accumulation
 @pytest.fixture()
 def split_accumulate(ctx):
+    """agpl_accumulate's arguments -> agpl_accumulate_split without an image: the float32-staged split-float16 kernel
+    (syrk_split_kernel), which serves feature counts that are not a multiple of 256."""
     import ctypes as C
 
-    ctx.call("agpl_set_accumulate_precision", C.c_int32(1))
-    yield
-    ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+    return lambda *a: ctx.call("agpl_accumulate_split", *a[:4], C.c_void_p(0), *a[4:])
 
 
 @pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (70001, 128, 2), (31, 128, 1), (5000, 384, 1),
                                    (300000, 128, 1), (4097, 128, 1), (16, 128, 1), (100003, 512, 1)])
 def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M, L):
-    """agpl_accumulate with agpl_set_accumulate_precision(1): sqrt(gamma) phi split into hi/lo float16 while
+    """agpl_accumulate_split without an image: sqrt(gamma) phi split into hi/lo float16 while
     staging, 3 float16 MFMA products per float32 product; the same bound, symmetry and reproducibility as f32."""
     import ctypes as C
 
@@ -741,13 +741,13 @@ def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M,
     args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
             C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
             C.c_void_p(g.data_ptr()))
-    ctx.call("agpl_accumulate", *args)
+    split_accumulate(*args)
     G1 = host(G).copy()
     Gr, gr = oracle.accumulate(Phi, beta, gamma)
     assert relmax(G1, Gr) < 5e-6
     assert relmax(host(g), gr) < 5e-6
     assert np.array_equal(G1, G1.transpose(0, 2, 1))
-    ctx.call("agpl_accumulate", *args)
+    split_accumulate(*args)
     assert np.array_equal(host(G), G1)
 
 
@@ -765,7 +765,7 @@ def test_split_accumulate_with_every_cu_shared(A, ctx, split_accumulate, N, M):
     g = torch.empty((1, M), dtype=torch.float64, device="cuda")
     args = (C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(Phi.data_ptr()), C.c_void_p(beta.data_ptr()),
             C.c_void_p(gamma.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()))
-    ctx.call("agpl_accumulate", *args)
+    split_accumulate(*args)
     G1, g1 = G.clone(), g.clone()
     Gr = torch.zeros((M, M), dtype=torch.float64, device="cuda")
     gr = torch.zeros(M, dtype=torch.float64, device="cuda")
@@ -776,7 +776,7 @@ def test_split_accumulate_with_every_cu_shared(A, ctx, split_accumulate, N, M):
     assert ((G1[0] - Gr).abs().max() / Gr.abs().max()).item() < 2e-6
     assert ((g1[0] - gr).abs().max() / gr.abs().max()).item() < 2e-6
     for _ in range(3):  # and bitwise reproducible under the same load
-        ctx.call("agpl_accumulate", *args)
+        split_accumulate(*args)
         assert torch.equal(G, G1) and torch.equal(g, g1)
 
 
@@ -793,19 +793,12 @@ def test_split_accumulate_wide_dynamic_range(A, ctx, oracle, split_accumulate):
     G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
     g = torch.empty((1, M), dtype=torch.float64, device="cuda")
     dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
-    ctx.call("agpl_accumulate", C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(dPhi.data_ptr()),
-             C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
-             C.c_void_p(g.data_ptr()))
+    split_accumulate(C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(dPhi.data_ptr()),
+                     C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
+                     C.c_void_p(g.data_ptr()))
     Gr, gr = oracle.accumulate(Phi, beta, gamma)
     assert relmax(host(G), Gr) < 5e-6
     assert relmax(host(g), gr) < 5e-6
-
-
-def test_set_accumulate_precision_rejects_unknown_mode(A, ctx):
-    import ctypes as C
-
-    with pytest.raises(A.ArgumentError):
-        ctx.call("agpl_set_accumulate_precision", C.c_int32(7))
 
 
 @pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("cat", 4_000, 64),
@@ -825,9 +818,7 @@ def test_cavi_with_split_f16_both_passes_matches_oracle(A, ctx, oracle, name, N,
             G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
             S, m = O.gaussian_update(G, g)
     finally:
-        import ctypes as C
-
-        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+        pass
     assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
     assert relmax(host(cavi.g), g) < NAT_TOL
 
@@ -915,9 +906,7 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
             G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
             S, m = O.gaussian_update(G, g)
     finally:
-        import ctypes as C
-
-        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+        pass
     assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
     assert relmax(host(cavi.g), g) < NAT_TOL
     # moments from (U, v): the M x M solve amplifies the natural-parameter difference by cond(I + G)
@@ -1149,7 +1138,7 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
         assert relmax(host(parts[0][0] + parts[1][0]), host(G1)) < 2e-6
         assert relmax(host(parts[0][1] + parts[1][1]), host(g1)) < 2e-6
     finally:
-        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+        pass
 
 
 @pytest.mark.timeout(120)

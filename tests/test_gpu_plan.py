@@ -105,7 +105,7 @@ def test_power_of_two_feature_scales_give_the_same_bits(A):
     _, y, Phi, kd = _svgp(A, ctx, lik, N, M)
     kd = kd.clamp_min(0)
     ref = None
-    for k in (0, -20, 10, 30):
+    for k in (0, -16, 10, 30):  # e = 14 - k stays inside the unclamped range -30 .. 30 of the image exponent
         s = 2.0 ** k
         cavi = A.SparseCAVI(lik, (Phi * s).contiguous(), (kd * s * s).contiguous(), y, ctx=ctx, keep_points=True)
         assert cavi.plan.scale_exp == A.SparseCAVI(lik, Phi, kd, y, ctx=ctx).plan.scale_exp - k
@@ -230,3 +230,55 @@ def test_plan_argument_and_domain_errors(A):
     rc = lib.agpl_cavi_pass_plan(h, C.byref(lik), C.c_void_p(0), p(y), p(G), p(g), None, None, None, None)
     assert rc == A._ffi.ERR_INVALID_ARGUMENT  # 4 latents against a plan for 1
     assert lib.agpl_plan_destroy(h) == 0
+
+
+def image_features(Phi):
+    """The features the plan's images hold: x' = (hi + lo) 2^-e with hi = f16(2^e x), lo = f16(2^e x - hi), e from max |Phi|
+    (agpl_syrk.hip agpl_image_scale_exp / accumulate_image_kernel), restated in numpy."""
+    Phi = np.asarray(Phi, dtype=np.float32)
+    mx = float(np.abs(Phi).max())
+    e = min(13 - int(np.floor(np.log2(mx))), 30) if mx > 0 else 0
+    xs = Phi * np.float32(2.0 ** e)
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    return ((hi.astype(np.float32) + lo.astype(np.float32)).astype(np.float64) * 2.0 ** -e), e
+
+
+@pytest.mark.parametrize("name,M", [("bernoulli", 256), ("negbin", 512), ("cat", 256), ("studentt", 256)])
+def test_gibbs_pass_plan_matches_oracle_on_the_image_features(A, oracle, name, M):
+    """agpl_gibbs_pass_plan: projection from the accumulate image + per-point Philox streams + aux_sample! + accumulation
+    (examples/bernoulli/script.jl:81-84 in sparse form) against the oracle's pass on the SAME features (the image's): f to 1e-12,
+    omega to 1e-9, counts and uniforms consumed bit for bit."""
+    O = oracle
+    liks = {"bernoulli": (A.BernoulliLikelihood(), O.bernoulli()), "negbin": (A.NegativeBinomialLikelihood(15.0), O.negbinomial(15.0)),
+            "cat": (A.CategoricalLikelihood(np.array([0.1, -0.2, 0.3, 0.0])), O.categorical([0.1, -0.2, 0.3, 0.0])),
+            "studentt": (A.StudentTLikelihood(3.5, 2.0), O.studentt(3.5, 2.0))}
+    lik, olik = liks[name]
+    rng = np.random.default_rng(17)
+    N, L = 3001, olik.nlatent
+    Phi = (rng.standard_normal((N, M)) * 0.15).astype(np.float32)
+    kd = rng.uniform(0.0, 0.3, size=N).astype(np.float32)
+    if name == "bernoulli":
+        y = (rng.uniform(size=N) < 0.5).astype(np.uint8)
+    elif name == "negbin":
+        y = rng.poisson(4.0, size=N).astype(np.int32)
+    elif name == "cat":
+        y = (rng.integers(0, L, size=N)[:, None] == np.arange(L)[None, :]).astype(np.uint8)
+    else:
+        y = rng.normal(size=N)
+    ctx = A.Context(0, seed=SEED)
+    gib = A.SparseGibbs(lik, torch.from_numpy(Phi).cuda(), torch.from_numpy(kd).cuda(), torch.from_numpy(y).cuda(), ctx=ctx,
+                        keep_points=True)
+    assert gib.plan is not None
+    v = rng.normal(size=(L, M))
+    gib.v.copy_(torch.from_numpy(v).cuda())
+    gib.accumulate()
+    Phi_img, e = image_features(Phi)
+    assert gib.plan.scale_exp == e
+    Gr, gr, pts = O.gibbs_pass(olik, Phi_img.astype(np.float32), kd.astype(np.float64), y, v, seed=SEED, sweep=gib.sweep_index)
+    f = host(gib.f)
+    assert np.abs(f - pts["f"]).max() < 1e-12 * max(1.0, np.abs(pts["f"]).max())
+    assert np.allclose(host(gib.omega), pts["omega"], rtol=1e-9, atol=0)
+    if name == "cat":
+        assert np.array_equal(host(gib.n), pts["n"])
+    assert relmax(host(gib.G), Gr) < 5e-6 and relmax(host(gib.g), gr) < 5e-6

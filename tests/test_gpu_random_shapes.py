@@ -111,16 +111,12 @@ def test_split_accumulate_random_shape(A, ctx, N, M, L):
     dPhi, dbeta, dgamma = (torch.from_numpy(a).cuda() for a in (Phi, beta, gamma))
     G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
     g = torch.empty((L, M), dtype=torch.float64, device="cuda")
-    args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), p(dPhi), p(dbeta), p(dgamma), p(G), p(g))
-    ctx.call("agpl_set_accumulate_precision", C.c_int32(1))
-    try:
-        ctx.call("agpl_accumulate", *args)
-        ctx.synchronize()
-        G1, g1 = G.cpu().numpy().copy(), g.cpu().numpy().copy()
-        ctx.call("agpl_accumulate", *args)
-        ctx.synchronize()
-    finally:
-        ctx.call("agpl_set_accumulate_precision", C.c_int32(0))
+    args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), p(dPhi), C.c_void_p(0), p(dbeta), p(dgamma), p(G), p(g))  # (no image)
+    ctx.call("agpl_accumulate_split", *args)
+    ctx.synchronize()
+    G1, g1 = G.cpu().numpy().copy(), g.cpu().numpy().copy()
+    ctx.call("agpl_accumulate_split", *args)
+    ctx.synchronize()
     P = Phi.astype(np.float64)
     for l in range(L):
         Gr = (P * gamma[l].astype(np.float64)[:, None]).T @ P

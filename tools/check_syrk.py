@@ -9,7 +9,6 @@ if os.environ.get("AGPL_LIB_AB"):
     _ffi.LIB_PATH = os.environ["AGPL_LIB_AB"]
 N, M = int(sys.argv[1]), int(sys.argv[2])
 ctx = A.Context(0, seed=1)
-ctx.call("agpl_set_accumulate_precision", C.c_int32(int(os.environ.get("AGPL_ASPLIT", "0"))))
 g = torch.Generator(device="cuda").manual_seed(0)
 Phi = torch.randn((N, M), device="cuda", generator=g) * 0.1
 gam = torch.rand((1, N), device="cuda", generator=g) * 0.25
