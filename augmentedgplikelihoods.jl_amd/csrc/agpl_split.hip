@@ -23,6 +23,7 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BS = 128;
 constexpr int KS = 16;  // reduction slice per stage
@@ -501,12 +502,106 @@ __global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
 // reproducible: no atomics on the outputs).  The next-but-one item is fetched by ONE returning atomic per item, issued in
 // the first stage of an item and written to LDS in the second: its latency hides behind a whole stage.
 // ------------------------------------------------------------------------------------------------
-#ifdef AGPL_MTRACE // diagnostic build (make MTRACE=1): per-wave cycle sums of the stage loop, tools/mtrace.py
+// x over the lanes l, l ^ 16, l ^ 32, l ^ 48 (in every one of them), as (x_l + x_{l^16}) + (the same of l ^ 32): two VALU swaps
+// (gfx950 v_permlane16_swap / v_permlane32_swap), no LDS crossbar round trip
+__device__ __forceinline__ float kgroup_sum(float x) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned v = __float_as_uint(y);
+    const u32x2 t = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
+// A wave's share of an item's per-point sums, q_n = sum_a T[a,n]^2 and m_n = sum_a v_a T[a,n], over the 16-row blocks I0 .. I1 - 1
+// of its 64 rows (lane rows a = 16 i + 4 kg + 0..3), into the item's parity buffers qr, mr ([row group][256 points]); those
+// accumulators are cleared.
+// Round 4 (in-kernel stamps and probe builds, profiles/r04_mtrace_marginal.txt): all sixteen waves used to do this behind the
+// item's last stage, with the matrix pipe idle -- ~250 VALU instructions each in three-deep dependent runs behind a vmcnt(0) the
+// compiler put in front of the LDS read of v (= the wait for the DMA pieces just issued): with the sums compiled out the kernel
+// ran 14-17 % faster.  Now
+//  * row groups 0..2 take their sums in the first stage in which they have nothing else to do (stages 3, 5, 7 of the item's
+//    diagonal block), beside the MFMAs of the waves still at work on their SIMD; row group 3, whose rows are complete with the
+//    item, behind the last stage.  (Not free beside MFMAs -- the stages that carry a wave's sums are 350-450 cycles longer --
+//    but the item's last stage lost 2 k.  Tried and measured slower: at the END of a wave's last active stage (the stage waits for
+//    that wave); row group 3's in the first stage of the next item, behind its DMA issue (that stage then waits for row group 3:
+//    +1.7-2.8 k cycles against -1.3 k); two halves in two idle stages (three instances of this routine: spills).)
+//  * v comes from LDS by inline-asm reads (no vmcnt(0): the buffer is not a DMA target of this or the previous stage);
+//  * sixteen independent chains of scalar FMAs (v_pk_fma_f32 measured: -1 % at M = 512, +0.5 % at M = 1024 -- and the library keeps
+//    packed-float32 arithmetic out of its sums: DESIGN 4.4e, Reproducibility);
+//  * the sums over the four k-groups of a column (lanes l, l ^ 16, l ^ 32, l ^ 48) by v_permlane16/32_swap: no LDS round trip.
+template <int I0, int I1, bool NOSUMS>
+__device__ __forceinline__ void item_sums_rows(f32x4 (&acc)[4][4], const float *vrow, float *qr, float *mr) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    f32x4 a0[I1 - I0];
+    {
+        const unsigned aaddr = (unsigned)(uintptr_t)(lds_void *)(vrow + 16 * I0);
+        if (I1 - I0 == 1)
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a0[0]) : "v"(aaddr));
+        else if (I1 - I0 == 2)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0[0]), "=&v"(a0[(I1 - I0) > 1 ? 1 : 0])
+                         : "v"(aaddr));
+        else
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                         "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0[0]), "=&v"(a0[(I1 - I0) > 1 ? 1 : 0]), "=&v"(a0[(I1 - I0) > 2 ? 2 : 0]), "=&v"(a0[(I1 - I0) > 3 ? 3 : 0])
+                         : "v"(aaddr));
+    }
+    f32x2 q2[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q2[j] = m2[j] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const f32x2 alo = {a0[i - I0][0], a0[i - I0][1]}, ahi = {a0[i - I0][2], a0[i - I0][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 lo = {acc[i][j][0], acc[i][j][1]};
+            if (!NOSUMS) {
+                q2[j][0] = fmaf(lo[0], lo[0], q2[j][0]), q2[j][1] = fmaf(lo[1], lo[1], q2[j][1]);
+                m2[j][0] = fmaf(alo[0], lo[0], m2[j][0]), m2[j][1] = fmaf(alo[1], lo[1], m2[j][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 hi = {acc[i][j][2], acc[i][j][3]};
+            if (!NOSUMS) {
+                q2[j][0] = fmaf(hi[0], hi[0], q2[j][0]), q2[j][1] = fmaf(hi[1], hi[1], q2[j][1]);
+                m2[j][0] = fmaf(ahi[0], hi[0], m2[j][0]), m2[j][1] = fmaf(ahi[1], hi[1], m2[j][1]);
+            }
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    float qacc[4], macc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qacc[j] = kgroup_sum(q2[j][0] + q2[j][1]);
+        macc[j] = kgroup_sum(m2[j][0] + m2[j][1]);
+    }
+    if (lane_e < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qr[16 * j + lane_e] = qacc[j];
+            mr[16 * j + lane_e] = macc[j];
+        }
+    }
+}
+
+#if defined(AGPL_MCLOCK) && !defined(AGPL_MTRACE) // diagnostic build: two stamps around the stage loop only (the in-kernel clock of the kernel as shipped)
 __device__ unsigned long long g_mtrace[256 * 16 * 4];
-__device__ unsigned long long g_mtrace_phase[256 * 16 * 18]; // per wave: cycles and count of the stages of each kind (0: full, 1..8: diagonal stage 1..8)
+__device__ unsigned long long g_mtrace_phase[256 * 16 * 24];
+constexpr bool kMTrace = false;
+constexpr bool kMClock = true;
+#elif defined(AGPL_MTRACE) // diagnostic build (make MTRACE=1): per-wave cycle sums of the stage loop, tools/mtrace.py
+__device__ unsigned long long g_mtrace[256 * 16 * 4];
+__device__ unsigned long long g_mtrace_phase[256 * 16 * 24]; // per wave: [kind 3][segment 7 + count]: kind 0 full stage, 1 diagonal stage 1..6, 2 diagonal stage 7, 8
 constexpr bool kMTrace = true;
+constexpr bool kMClock = true;
 #else
 constexpr bool kMTrace = false;
+constexpr bool kMClock = false;
 #endif
 __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     int64_t N, int M, int L, int64_t ntiles128, int ntiles2, const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
@@ -525,7 +620,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
     float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
     float *mred = qred + 2 * 4 * NT2;                                  // [2][4 x 256]
-    int *qi = reinterpret_cast<int *>(mred + 2 * 4 * NT2);             // [4] queue indices of this workgroup's items
+    int *qi = reinterpret_cast<int *>(mred + 2 * 4 * NT2);             // [4][4] this workgroup's items, decoded
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
@@ -537,7 +632,24 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int nitems = ntq * L * nb2;
     unsigned *queue = queues + qn;
 
-    if (threadIdx.x == 0) qi[0] = (int)atomicAdd(queue, 1u);
+    // item k of this workgroup = queue index j: (tile, latent, 256-row block), longest row block first.  Thread 0 decodes an index
+    // once, when it stores it (two integer divisions: by every wave they cost the SIMDs ~1.5 k cycles per item); the waves read
+    // qi[k & 3] = {tile, latent, row block, valid}
+#define AGPL_Q_STORE(k_, j_)                                                                                \
+    do {                                                                                                    \
+        const int jj_ = (int)(j_);                                                                          \
+        const int jl_ = jj_ / nb2;                                                                          \
+        const int tq_ = jl_ / L;                                                                            \
+        int4 e_;                                                                                            \
+        e_.x = tq_ * 8 + qn;                                                                                \
+        e_.y = jl_ - tq_ * L;                                                                               \
+        e_.z = nb2 - 1 - (jj_ - jl_ * nb2);                                                                 \
+        e_.w = jj_ >= 0 && jj_ < nitems;                                                                    \
+        *reinterpret_cast<int4 *>(qi + 4 * ((k_) & 3)) = e_;                                                \
+    } while (0)
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    if (threadIdx.x == 0) AGPL_Q_STORE(0, atomicAdd(queue, 1u));
     __syncthreads();
 
     const int ia = wave >> 2, qd = wave & 3;
@@ -546,16 +658,16 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int wra_ = 2 * (ia >> 1) + (qd & 1);          // the 64-row block of the item this wave stages (image layout: quarter qd = k half qd >> 1 of rows 64 (qd & 1) ..)
     constexpr bool skip_zero_rows = true; // (-3.5 % at C2 with / without: profiles/r02_ab_marginal_zero_row_skip.jsonl)
 
-    // item k of this workgroup = queue index qi[k & 3]: (tile, latent, 256-row block), longest row block first
 #define AGPL_Q_DECODE(k_, valid_, tile_, l_, rb_)                                                           \
     do {                                                                                                    \
-        const int j_ = __builtin_amdgcn_readfirstlane(qi[(k_) & 3]);                                        \
-        valid_ = j_ >= 0 && j_ < nitems;                                                                    \
-        const int jl_ = j_ / nb2;                                                                           \
-        rb_ = nb2 - 1 - (j_ - jl_ * nb2);                                                                   \
-        const int tq_ = jl_ / L;                                                                            \
-        l_ = jl_ - tq_ * L;                                                                                 \
-        tile_ = tq_ * 8 + qn;                                                                               \
+        /* (inline asm: in front of a plain LDS read the compiler waits for vmcnt(0) -- the DMA pieces just issued) */ \
+        const unsigned qaddr_ = (unsigned)(uintptr_t)(lds_void *)(qi + 4 * ((k_) & 3));                     \
+        i32x4 e_;                                                                                           \
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e_) : "v"(qaddr_));               \
+        tile_ = __builtin_amdgcn_readfirstlane(e_[0]);                                                      \
+        l_ = __builtin_amdgcn_readfirstlane(e_[1]);                                                         \
+        rb_ = __builtin_amdgcn_readfirstlane(e_[2]);                                                        \
+        valid_ = __builtin_amdgcn_readfirstlane(e_[3]) != 0;                                                \
     } while (0)
 
     int ik = 0, irb = 0, iks = 0, il = 0, itile = 0; // issue pointer
@@ -565,15 +677,45 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const h8 *a_src, *b_src;
 #define AGPL_Q_SRC()                                                                                        \
     do {                                                                                                    \
-        const int64_t t128_ = 2 * (int64_t)itile + (ia >> 1) < ntiles128 ? 2 * (int64_t)itile + (ia >> 1)   \
-                                                                         : ntiles128 - 1;                   \
+        const int64_t t128_ = AGPL_MPROBE == 2 ? (ia >> 1)                                                  \
+                              : 2 * (int64_t)itile + (ia >> 1) < ntiles128 ? 2 * (int64_t)itile + (ia >> 1) \
+                                                                           : ntiles128 - 1;                 \
         a_src = a_img + ((int64_t)il * nb + 2 * irb + (ia >> 1)) * nks * 256 + qd * 64;                     \
         b_src = b_img + t128_ * nks * 256 + qd * 64;                                                        \
     } while (0)
-    typedef __attribute__((address_space(3))) void lds_void;
-#define AGPL_Q_ISSUE(t_)                                                                                    \
+    // Measurement builds (tools/build_variant.sh ... -DAGPL_MPROBE=k; wrong sums, same instruction stream otherwise):
+    //   1  no DMA after the first two stages (the stage loop's compute side alone)
+    //   2  every point image read is tile 0's (all of B from L2: the loop without its HBM stream)
+    //   3  the 64 pieces of a stage issued by four waves (one per SIMD, 16 pieces each) instead of 4 by each of the 16
+    //   4  no per-point sums at the end of an item (the accumulators are only cleared)
+    //   5  every stage multiplied in full (no zero block of U skipped)
+#ifndef AGPL_MPROBE
+#define AGPL_MPROBE 0
+#endif
+#if AGPL_MPROBE == 3
+#define AGPL_Q_PIECES(t_)                                                                                   \
     do {                                                                                                    \
-        if (ivalid) {                                                                                       \
+        if (wave < 4) {                                                                                     \
+            _Pragma("unroll") for (int ia_ = 0; ia_ < 4; ++ia_) {                                           \
+                const int64_t t128_ = 2 * (int64_t)itile + (ia_ >> 1) < ntiles128 ? 2 * (int64_t)itile + (ia_ >> 1) : ntiles128 - 1; \
+                const h8 *as_ = ((ia_ & 1) ? Wl : Wh) + ((int64_t)il * nb + 2 * irb + (ia_ >> 1)) * nks * 256 + wave * 64; \
+                const h8 *bs_ = ((ia_ & 1) ? Pl : Ph) + t128_ * nks * 256 + wave * 64;                      \
+                unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + ia_ * 4096 + wave * 1024;            \
+                const int wr2_ = 2 * (ia_ >> 1) + (wave & 1);                                               \
+                _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                         \
+                    if (!skip_zero_rows || iks + u_ < 16 * irb + 4 * (wr2_ + 1))                            \
+                        __builtin_amdgcn_global_load_lds(as_ + (int64_t)(iks + u_) * 256 + lane_v,          \
+                                                         (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);    \
+                    __builtin_amdgcn_global_load_lds(bs_ + (int64_t)(iks + u_) * 256 + lane_v,              \
+                                                     (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0); \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#else
+#define AGPL_Q_PIECES(t_)                                                                                   \
+    do {                                                                                                    \
+        if (AGPL_MPROBE != 1 || (t_) < 2) {                                                                 \
             unsigned char *slot_ = smem_raw + ((t_) & 1) * kSlot + dma_off;                                 \
             _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                             \
                 /* U is lower triangular: the 64 rows x 8 k this wave stages are the 64-row block wra_ of the item,  */  \
@@ -584,6 +726,13 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
                 __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256 + lane_v,                \
                                                  (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0); \
             }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#endif
+#define AGPL_Q_ISSUE(t_)                                                                                    \
+    do {                                                                                                    \
+        if (ivalid) {                                                                                       \
+            AGPL_Q_PIECES(t_);                                                                              \
             iks += KU;                                                                                      \
             if (iks == 16 * (irb + 1)) {                                                                    \
                 iks = 0;                                                                                    \
@@ -597,7 +746,6 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     AGPL_Q_SRC();
     AGPL_Q_ISSUE(0);
 
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f}, macc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -611,47 +759,79 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     unsigned fetched = 0u; // thread 0: the queue index fetched in the first stage of the item, stored in its second
     bool fetch_pending = false;
     [[maybe_unused]] unsigned long long mt0 = 0, mtw = 0, mtb = 0, mta = 0, mtn = 0, mtl = 0;
-    [[maybe_unused]] unsigned long long mph[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    [[maybe_unused]] int mkind = -1;
-    if (kMTrace) mt0 = __builtin_amdgcn_s_memtime();
+    // segment sums by stage kind (scalars: every one of them is wave-uniform and lives in SGPRs)
+    //   seg 0 dma wait | 1 barrier | 2 barrier exit -> before the DMA issue (bookkeeping, first fragment reads, first MFMAs) |
+    //   3 the DMA issue | 4 the rest of the MFMAs | 5 item-end work | 6 (unused)
+#define AGPL_MT_DECL(k_) [[maybe_unused]] unsigned long long mp##k_##0 = 0, mp##k_##1 = 0, mp##k_##2 = 0, mp##k_##3 = 0, mp##k_##4 = 0, mp##k_##5 = 0, mp##k_##n = 0
+    AGPL_MT_DECL(0);
+    AGPL_MT_DECL(1);
+    AGPL_MT_DECL(2);
+#undef AGPL_MT_DECL
+    [[maybe_unused]] int mkind = 0;
+    [[maybe_unused]] unsigned long long mtx = 0;
+#define AGPL_MT_SEG(seg_)                                                                                   \
+    do {                                                                                                    \
+        if (kMTrace) {                                                                                      \
+            const unsigned long long y_ = __builtin_amdgcn_s_memtime();                                     \
+            const unsigned long long d_ = y_ - mtx;                                                         \
+            mtx = y_;                                                                                       \
+            if (mkind == 0) mp0##seg_ += d_;                                                                \
+            else if (mkind == 1) mp1##seg_ += d_;                                                           \
+            else mp2##seg_ += d_;                                                                           \
+        }                                                                                                   \
+    } while (0)
+    [[maybe_unused]] unsigned long long mr0 = 0, mkl = 0;
+    [[maybe_unused]] int mkp = -1;
+    [[maybe_unused]] unsigned long long mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0, mk4 = 0, mk5 = 0, mk6 = 0, mk7 = 0, mk8 = 0;
+    [[maybe_unused]] unsigned long long mn0 = 0, mn1 = 0, mn2 = 0, mn3 = 0, mn4 = 0, mn5 = 0, mn6 = 0, mn7 = 0, mn8 = 0;
+    if (kMClock) {
+        mt0 = __builtin_amdgcn_s_memtime();
+        mr0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int t = 0; cvalid; ++t) {
-        if (kMTrace) mta = __builtin_amdgcn_s_memtime();
+        if (kMTrace) {
+            mta = __builtin_amdgcn_s_memtime();
+            mtx = mta;
+            mkind = ks < 16 * rb ? 0 : (ks - 16 * rb < 12 ? 1 : 2);
+            if (mkind == 0) mp0n += 1;
+            else if (mkind == 1) mp1n += 1;
+            else mp2n += 1;
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): stage t has landed (R = 2: nothing younger is in flight)
         if (kMTrace) {
             const unsigned long long x = __builtin_amdgcn_s_memtime();
             mtw += x - mta;
             mta = x;
         }
+        AGPL_MT_SEG(0);
         __builtin_amdgcn_s_barrier();
         if (kMTrace) {
             const unsigned long long x = __builtin_amdgcn_s_memtime();
             mtb += x - mta;
             ++mtn;
-            if (mkind >= 0) { // the stage that has just ended (barrier exit to barrier exit)
-                mph[2 * mkind] += x - mtl;
-                mph[2 * mkind + 1] += 1;
-            }
-            mtl = x;
-            mkind = ks < 16 * rb ? 0 : 1 + (ks - 16 * rb) / KU;
+        }
+        AGPL_MT_SEG(1);
+        // (AGPL_MCLOCK build) one stamp per stage at the barrier exit, consumed at the bottom of the loop body, where this wave's
+        // LDS reads have all been waited for anyway: the stage lengths by kind without a wait the shipped kernel does not have
+        [[maybe_unused]] unsigned long long mks = 0;
+        [[maybe_unused]] int mkk = 0;
+        if (kMClock && !kMTrace) {
+            mks = __builtin_amdgcn_s_memtime();
+            mkk = ks < 16 * rb ? 0 : 1 + (ks - 16 * rb) / KU;
         }
         if (fetch_pending) {
-            if (threadIdx.x == 0) qi[(ck + 1) & 3] = (int)fetched;
+            if (threadIdx.x == 0) AGPL_Q_STORE(ck + 1, fetched);
             fetch_pending = false;
         }
-        if (ks == 0) {
-            // first stage of an item: v of its latent into the item's parity buffer
-            float *as = alpha_s + (ck & 1) * M;
-            for (int a = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); a < M;
-                 a += 1024)
-                as[a] = v_all[(int64_t)cl * M + a];
+        if (ks == 0 && wave < M / NT2) {
+            // first stage of an item: v of its latent into the item's parity buffer, 1 KB per wave by the DMA path (in LDS behind
+            // the next barrier; first read at the end of the item's second stage)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(v_all + (int64_t)cl * M + wave * NT2) + lane_v,
+                                             (lds_void *)(alpha_s + (ck & 1) * M + wave * NT2), 16, 0, 0);
         }
-        if (ks == 16 * (rb + 1) - 4 * KU) {
-            // four stages before the item ends: take the NEXT item of the queue -- as late as the pipeline allows (its
-            // index is stored next stage, visible the stage after, decoded by the issue pointer in the stage after that),
-            // so that the workgroups that take the row blocks of one tile start them within a stage or two of each other
-            if (threadIdx.x == 0) fetched = atomicAdd(queue, 1u);
-            fetch_pending = true;
-        }
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int kg = ln >> 4;
         if (pend >= 0) {
             // the previous item's per-wave partial sums are in LDS (written before this barrier): rows out
             const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -667,25 +847,24 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             pend = -1;
         }
         // U is lower triangular: this wave's rows 64 wr .. 64 wr + 63 of block rb are zero from slice 16 rb + 4 (wr + 1)
-        const bool act = ks < rb * 16 + 4 * (wr + 1);
+        const bool act = AGPL_MPROBE == 5 || ks < rb * 16 + 4 * (wr + 1);
         const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & 1) * kSlot);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int kg = ln >> 4;
         const int fbase16 = (kg >> 1) * 2048 + (kg & 1) * 128 + (ln & 15);
         const int fa = fbase16 + (wr >> 1) * 512 + (wr & 1) * 64;
         const int fb = fbase16 + 1024 + (wc >> 1) * 512 + (wc & 1) * 64;
         // (Round 4 measured a CYCLIC assignment of the 16-row blocks to the four waves of a SIMD -- every wave runs out of work
-        // together in the diagonal part of an item: same MFMAs, 6.51 -> 7.55 ms at C2, not kept.  In-kernel stamps (make MTRACE=1,
-        // tools/mtrace.py; profiles/r04_mtrace_marginal.txt) show why neither form matters: EVERY stage takes 3.8-4.0 k cycles,
-        // the last diagonal ones with a quarter of the MFMAs included -- the stage is set by the CU's fill path, 64 KB per stage
-        // (32 KB of Phi from HBM at ~24 GB/s per CU + 32 KB of U from L2 at ~70 GB/s per CU: MI355X_MICROARCH.md's per-CU LDS-fill
-        // rates), not by the matrix pipe.)
+        // together in the diagonal part of an item: same MFMAs, 6.51 -> 7.55 ms at C2, not kept.  What the stage loop spends its
+        // time on (stamps and probe builds -DAGPL_MPROBE=k, tools/mtrace.py; profiles/r04_mtrace_marginal.txt): a stage takes
+        // ~3.9 k cycles whether full (3.07 k of MFMA per SIMD) or diagonal (0.8-2.3 k); without ANY DMA after the prologue (probe 1)
+        // still ~3.6 k (-9 % cycles, -5 % time: the clock drops); with all of Phi served by L2 (probe 2) -5 %; the 64 pieces of a stage
+        // issued by four waves instead of sixteen (probe 3) no change; without the per-point sums at item ends (probe 4) -14..17 %.
+        // I.e. neither HBM nor the DMA path bounds it: every barrier costs the SIMD ~0.5-0.9 k cycles of fragment-read latency,
+        // bookkeeping and waiting for the slowest wave, and the item-end sums were serial VALU work -- the part that was cut.)
         // the wave's LAST active stage covers k = its own rows 32..63 of the diagonal 64 x 64 block of U: rows 0..31 (i = 0, 1)
         // are zero there -- their MFMAs would add exact zeros and are skipped (1 + 32 / M instead of 1 + 64 / M executed).
         // One code path with wave-uniform branches around the i = 0, 1 groups (two copies of the loop body spill).
         if (act) {
-            const bool lo_rows = !(skip_zero_rows && ks + KU == rb * 16 + 4 * (wr + 1));
+            const bool lo_rows = AGPL_MPROBE == 5 || !(skip_zero_rows && ks + KU == rb * 16 + 4 * (wr + 1));
             h8 ah[4], al[4];
             if (lo_rows) {
                 ah[0] = st[fa];
@@ -701,7 +880,9 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             acc[2][0] = mfma32(ah[2], bh, acc[2][0]);
             acc[3][0] = mfma32(ah[3], bh, acc[3][0]);
             __builtin_amdgcn_sched_barrier(0);
+            AGPL_MT_SEG(2);
             AGPL_Q_ISSUE(t + 1); // into the slot read in iteration t - 1, behind the first MFMAs
+            AGPL_MT_SEG(3);
             __builtin_amdgcn_sched_barrier(0);
             if (lo_rows) {
                 al[0] = st[256 + fa];
@@ -733,41 +914,33 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
                 acc[3][j] = mfma32(al[3], bh, acc[3][j]);
             }
         } else {
+            AGPL_MT_SEG(2);
             AGPL_Q_ISSUE(t + 1);
+            AGPL_MT_SEG(3);
+        }
+        if (kMTrace) __builtin_amdgcn_sched_barrier(0);
+        AGPL_MT_SEG(4);
+        if (ks == 16 * (rb + 1) - 4 * KU) {
+            // four stages before the item ends: take the NEXT item of the queue -- as late as the pipeline allows (its
+            // index is stored next stage, visible the stage after, decoded by the issue pointer in the stage after that),
+            // so that the workgroups that take the row blocks of one tile start them within a stage or two of each other.
+            // Behind the stage's DMA issue: the compiler waits for the returned value at once (vmcnt(0)), and wave 0 -- idle in
+            // this stage -- must have its pieces of the next stage out before it sits in that wait.
+            if (threadIdx.x == 0) fetched = atomicAdd(queue, 1u);
+            fetch_pending = true;
+        }
+        {
+            // row groups 0..2: in their first idle stage of the item's diagonal block (their rows are complete); row group 3: behind
+            // its (= the item's) last stage
+            const int s_idle = ks - (rb * 16 + 4 * (wr + 1));
+            const float *vrow = alpha_s + (ck & 1) * M + rb * NT2 + wr * 64 + 4 * kg;
+            float *qr = qred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64, *mr = mred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64;
+            constexpr bool kNoSums = AGPL_MPROBE == 4;
+            if (wr < 3 ? s_idle == 0 : ks + KU == 16 * (rb + 1)) item_sums_rows<0, 4, kNoSums>(acc, vrow, qr, mr);
         }
         ks += KU;
         if (ks == 16 * (rb + 1)) {
-            // item finished: q_n = sum_a T[a,n]^2, m_n = sum_a v_a T[a,n] over this row block; lane rows a = 16 i + 4 kg + 0..3
-            const float *asrc = alpha_s + (ck & 1) * M + rb * NT2 + wr * 64 + 4 * kg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 a0 = *reinterpret_cast<const float4 *>(asrc + 16 * i);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 &c = acc[i][j];
-                    qacc[j] += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
-                    macc[j] += a0.x * c[0] + a0.y * c[1] + a0.z * c[2] + a0.w * c[3];
-                    c = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            float *qr = qred + (ck & 1) * 4 * NT2, *mr = mred + (ck & 1) * 4 * NT2;
-            const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                qacc[j] += __shfl_xor(qacc[j], 16);
-                qacc[j] += __shfl_xor(qacc[j], 32);
-                macc[j] += __shfl_xor(macc[j], 16);
-                macc[j] += __shfl_xor(macc[j], 32);
-            }
-            if (lane_e < 16) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    qr[wr * NT2 + wc * 64 + 16 * j + lane_e] = qacc[j];
-                    mr[wr * NT2 + wc * 64 + 16 * j + lane_e] = macc[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qacc[j] = macc[j] = 0.f;
+            // item finished: every wave's partial sums are in LDS behind the next barrier
             pend = ck;
             pl = cl;
             prb = rb;
@@ -776,19 +949,45 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             ++ck;
             AGPL_Q_DECODE(ck, cvalid, ctile, cl, rb);
         }
+        AGPL_MT_SEG(5);
+        if (kMClock && !kMTrace) {
+            // mks - mkl = the length of the PREVIOUS stage (barrier exit to barrier exit), of kind mkp
+            if (mkp >= 0) {
+                const unsigned long long d = mks - mkl;
+#define AGPL_MK(k_) if (mkp == k_) { mk##k_ += d; mn##k_ += 1; }
+                AGPL_MK(0) else AGPL_MK(1) else AGPL_MK(2) else AGPL_MK(3) else AGPL_MK(4) else AGPL_MK(5) else AGPL_MK(6) else AGPL_MK(7) else AGPL_MK(8)
+#undef AGPL_MK
+            }
+            mkl = mks;
+            mkp = mkk;
+        }
     }
 #undef AGPL_Q_ISSUE
+#undef AGPL_Q_PIECES
 #undef AGPL_Q_SRC
 #undef AGPL_Q_DECODE
-#ifdef AGPL_MTRACE
+#undef AGPL_Q_STORE
+#undef AGPL_MT_SEG
+#if defined(AGPL_MTRACE) || defined(AGPL_MCLOCK)
     if (blockIdx.x < 256 && lane == 0) {
         unsigned long long *o = g_mtrace + ((size_t)blockIdx.x * 16 + wave) * 4;
         o[0] = __builtin_amdgcn_s_memtime() - mt0; // loop cycles
         o[1] = mtw;                                 // waiting for the DMA of the stage
         o[2] = mtb;                                 // waiting at the barrier
-        o[3] = mtn;                                 // stages
-        unsigned long long *ph = g_mtrace_phase + ((size_t)blockIdx.x * 16 + wave) * 18;
-        for (int q = 0; q < 18; ++q) ph[q] = mph[q];
+        o[3] = kMTrace ? mtn : 1;                   // stages
+        unsigned long long *ph = g_mtrace_phase + ((size_t)blockIdx.x * 16 + wave) * 24;
+#define AGPL_MT_OUT(k_)                                                                                     \
+    ph[8 * k_ + 0] = mp##k_##0, ph[8 * k_ + 1] = mp##k_##1, ph[8 * k_ + 2] = mp##k_##2, ph[8 * k_ + 3] = mp##k_##3,          \
+                ph[8 * k_ + 4] = mp##k_##4, ph[8 * k_ + 5] = mp##k_##5, ph[8 * k_ + 6] = 0, ph[8 * k_ + 7] = mp##k_##n
+        AGPL_MT_OUT(0);
+        AGPL_MT_OUT(1);
+        AGPL_MT_OUT(2);
+        if (!kMTrace) { // stage lengths by kind: sums in [0..8] (but [6], moved to [18]), counts in [9..17]
+            ph[0] = mk0, ph[1] = mk1, ph[2] = mk2, ph[3] = mk3, ph[4] = mk4, ph[5] = mk5, ph[18] = mk6, ph[7] = mk7, ph[8] = mk8;
+            ph[9] = mn0, ph[10] = mn1, ph[11] = mn2, ph[12] = mn3, ph[13] = mn4, ph[14] = mn5, ph[15] = mn6, ph[16] = mn7, ph[17] = mn8;
+        }
+        ph[6] = __builtin_amdgcn_s_memrealtime() - mr0; // 100 MHz ticks of the loop (in-kernel clock = o[0] / ph[6] x 100 MHz)
+#undef AGPL_MT_OUT
     }
 #endif
     __syncthreads();
@@ -886,7 +1085,7 @@ __global__ __launch_bounds__(256) void feature_residual_kernel(int64_t N, int M,
 
 } // namespace
 
-#ifdef AGPL_MTRACE
+#if defined(AGPL_MTRACE) || defined(AGPL_MCLOCK)
 extern "C" __attribute__((visibility("default"))) int agpl_debug_mtrace(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mtrace), sizeof(g_mtrace));
 }
@@ -1026,7 +1225,7 @@ int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     if (rc) return rc;
     float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
     unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192); // zero between launches (agpl_ws2_reserve)
-    const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64;
+    const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64; // (+ 64: the four decoded items)
     if (!ctx->queue_attr) { // once per context
         AGPL_HIP(ctx, hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_queue_kernel),

@@ -219,10 +219,16 @@ constexpr bool kTrace = false;
 // Measurement build (make L2PROBE=1): every step re-reads one of the slice's first four steps, i.e. every operand load hits the
 // XCD's L2 -- wrong sums, same instruction stream and data statistics.  The upper bound of what ANY scheme of sharing panels
 // between the workgroups of a slice could buy (round 4: C2 6.87 -> 6.42 ms, M = 1024 30.6 -> 26.6 ms).
+// (make NODMA: -DAGPL_SYRK_NODMA: no operand load at all after the first steps -- the step loop's compute side alone.)
 #ifdef AGPL_SYRK_L2PROBE
 #define AGPL_PROBE_T(t_) ((t_) & 3)
 #else
 #define AGPL_PROBE_T(t_) (t_)
+#endif
+#ifdef AGPL_SYRK_NODMA
+#define AGPL_PROBE_LOAD(t_) ((t_) < 3)
+#else
+#define AGPL_PROBE_LOAD(t_) true
 #endif
 #ifndef AGPL_S_PRE
 #define AGPL_S_PRE 3 // row blocks of A-fragment lead (2, 3, 4 measured: 3.73 / 3.69 / 3.74 ms at N = 4e6, M = 512)
@@ -282,9 +288,10 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     do {                                                                                                        \
         unsigned char *d_ = smem_raw + ((t_) & (kRing - 1)) * kStepBytes + ((k_) >> 1) * 16384 + a_dst + ((k_) & 1) * 4096; \
         const h8 *src_ = a_src + (int64_t)(2 * AGPL_PROBE_T(t_) + ((k_) >> 1)) * slice_pitch + ((k_) & 1) * 256; \
-        __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);                                       \
+        if (AGPL_PROBE_LOAD(t_)) __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);              \
     } while (0)
 #define AGPL_S_DMAG(t_)                                                                                         \
+    if (AGPL_PROBE_LOAD(t_))                                                                                    \
     __builtin_amdgcn_global_load_lds(gb_src + (int64_t)(t_) * 64, (lds_void *)(gbuf + ((t_) & (kRing - 1)) * 64), 4, 0, 0)
     // The compiler does not see these loads in the memory queue (it believes their results are there at once): the waits
     // are written out below, and the destinations are read-write operands of every statement that touches them and are never
@@ -293,6 +300,7 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     do {                                                                                                        \
         const h8 *src_ = b_src + (int64_t)(2 * AGPL_PROBE_T(t_)) * slice_pitch;                                 \
         const h8 *srcl_ = src_ + 256; /* the lo block follows the hi block; column block 1 = 16 rows = 256 bytes on */ \
+        if (AGPL_PROBE_LOAD(t_))                                                                                \
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"                   \
                      "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256"  \
                      : "+v"(rh0), "+v"(rl0), "+v"(rh1), "+v"(rl1)                                               \
@@ -667,8 +675,8 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
                                float *slabg, int ns, bool records_ready) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
-    if (ctx->checked_image != image) {
-        // the header, once per image: an image of another (N, M), or a buffer that never was one, would otherwise give
+    if (ctx->checked_image != image || ctx->checked_image_N != N || ctx->checked_image_M != M) {
+        // the header, once per (image, N, M): an image of another (N, M), or a buffer that never was one, would otherwise give
         // out-of-range DMA reads and a garbage scale.  One small copy and one synchronisation, at the first sweep only.
         AccImageHeader h;
         AGPL_HIP(ctx, hipMemcpyAsync(&h, image, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -679,6 +687,8 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                       "M = %d, magic %#x; the call has N = %lld, M = %d",
                       (long long)h.N, (int)h.M, (unsigned)h.magic, (long long)N, (int)M);
         ctx->checked_image = image;
+        ctx->checked_image_N = N;
+        ctx->checked_image_M = M;
     }
     const int nb2 = M / kPanel;
     const int npairs2 = nb2 * (nb2 + 1) / 2;

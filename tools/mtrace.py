@@ -27,9 +27,29 @@ for wr in range(4):
     sel = a[:, wr * 4:(wr + 1) * 4, :]
     s2 = sel[:, :, 3].clip(min=1)
     print(f"  row group {wr}: total {np.mean(sel[:, :, 0] / s2):.0f}  dma wait {np.mean(sel[:, :, 1] / s2):.0f}  barrier {np.mean(sel[:, :, 2] / s2):.0f}")
-buf2 = (C.c_ulonglong * (256 * 16 * 18))()
+buf2 = (C.c_ulonglong * (256 * 16 * 24))()
 lib.agpl_debug_mtrace_phase(buf2)
-ph = np.frombuffer(buf2, dtype=np.uint64).reshape(256, 16, 9, 2).astype(np.float64)
-tot, cnt = ph[:, :, :, 0].sum((0, 1)), ph[:, :, :, 1].sum((0, 1)).clip(min=1)
-print("  stage length by kind (barrier exit to barrier exit), cycles: full", round(tot[0] / cnt[0]), " diagonal 1..8:",
-      [int(round(tot[k] / cnt[k])) for k in range(1, 9)], " share of stages: full %.2f" % (cnt[0] / cnt.sum()))
+ph = np.frombuffer(buf2, dtype=np.uint64).reshape(256, 16, 3, 8).astype(np.float64)
+rt = ph[:, :, 0, 6]
+print(f"  stage loop of a workgroup, median: {np.median(rt[rt > 0]) / 100:.1f} us = {np.median(a[:, :, 0][rt > 0]) / 1e6:.3f} M cycles")
+print(f"  in-kernel clock (s_memtime / s_memrealtime x 100 MHz), median over waves: {np.median(a[:, :, 0][rt > 0] / rt[rt > 0]) * 0.1:.3f} GHz")
+if a[:, :, 3].max() <= 1:  # the clock-only build (-DAGPL_MCLOCK): stage lengths by kind from one stamp per stage
+    raw = np.frombuffer(buf2, dtype=np.uint64).reshape(256, 16, 24).astype(np.float64)
+    for wr in (None, 0, 3):
+        sel = raw if wr is None else raw[:, wr * 4:(wr + 1) * 4]
+        sums = [sel[:, :, q].sum() for q in (0, 1, 2, 3, 4, 5, 18, 7, 8)]
+        cnts = [max(sel[:, :, 9 + q].sum(), 1) for q in range(9)]
+        print(f"  stage length by kind, barrier exit to barrier exit ({'all waves' if wr is None else 'row group %d' % wr}): full {sums[0] / cnts[0]:.0f}  diagonal 1..8: "
+              + " ".join(f"{sums[q] / cnts[q]:.0f}" for q in range(1, 9)) + f"   share of full stages {cnts[0] / sum(cnts):.2f}")
+    sys.exit(0)
+SEG = ["dma wait", "barrier", "to issue", "dma issue", "mfma rest", "item end"]
+KIND = ["full stage", "diagonal stage 1..6", "diagonal stage 7, 8"]
+print("  cycles per stage by stage kind, row group and segment (barrier exit -> DMA issue = bookkeeping + first fragment reads + first MFMAs):")
+for k in range(3):
+    cnt = ph[:, :, k, 7]
+    print(f"   {KIND[k]} (share of stages {cnt.sum() / ph[:, :, :, 7].sum():.2f})")
+    for wr in range(4):
+        sel = ph[:, wr * 4:(wr + 1) * 4, k, :]
+        c = sel[:, :, 7].sum().clip(min=1)
+        segs = [sel[:, :, q].sum() / c for q in range(6)]
+        print(f"     row group {wr}: " + "  ".join(f"{SEG[q]} {segs[q]:.0f}" for q in range(6)) + f"  = {sum(segs):.0f}")
