@@ -959,7 +959,22 @@ extern "C" int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, in
     ctx->accumulate_split = 1;
     rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, beta, gamma, G_out, g_out, ctx->ws, false);
     ctx->accumulate_split = keep;
-    return rc;
+    if (rc) return rc;
+    if (acc_image && M % 256 == 0) {
+        // the image path takes gamma as it is (no square root that would turn a negative one into a NaN): the record kernel's
+        // "bad gamma" word is read back here -- this stand-alone entry point has no update behind it that would forward it
+        // (a sweep's passes do: agpl_pending_resolve).  One 4-byte copy and one synchronisation per call.
+        float *gb;
+        unsigned *scal, bad = 0;
+        agpl_accumulate_records(N, M, L, ctx->ws, &gb, &scal);
+        AGPL_HIP(ctx, hipMemcpyAsync(&bad, scal + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad)
+            AGPL_FAIL(ctx, AGPL_ERR_DOMAIN,
+                      "gamma is negative or not finite (first at flat index %u of the [latent][point] array): G and g hold the "
+                      "sums with it", bad - 1u);
+    }
+    return AGPL_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -354,7 +354,9 @@ AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc 
  *   agpl_accumulate_split       : agpl_accumulate on the float16 matrix cores:
  *                                 from the image when acc_image != NULL and M % 256 == 0 (Phi may then be NULL), else from
  *                                 the float32 Phi (psi = sqrt(gamma) phi split while staging; |sqrt(gamma) phi| < 6e4).
- *                                 gamma >= 0 (TestUtils.jl:88).                                                        */
+ *                                 gamma >= 0 (TestUtils.jl:88): from the image, a negative or non-finite gamma is
+ *                                 AGPL_ERR_DOMAIN with its index (the call then synchronises the stream once; inside a
+ *                                 sweep the same report comes with the next update, without a synchronisation).        */
 AGPL_API int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M);
 AGPL_API int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out);
 AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,

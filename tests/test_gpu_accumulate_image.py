@@ -221,3 +221,23 @@ def test_image_of_another_problem_is_refused(A, ctx):
     with pytest.raises(A.ArgumentError, match="not an accumulate image of this problem"):
         ctx.call("agpl_accumulate_split", C.c_int64(N), C.c_int32(M), C.c_int32(1), _p(None), _p(junk), _p(bet), _p(gam), _p(G), _p(g))
     ctx.call("agpl_accumulate_split", *ok)  # the context is still usable
+
+
+@pytest.mark.parametrize("badval", [float("nan"), -0.5, float("inf")])
+def test_stand_alone_image_accumulation_reports_a_bad_gamma(A, ctx, badval):
+    """agpl_accumulate_split from an image takes gamma without a square root, so a negative one gives plausible
+    sums; the record kernel's flag word is read back by the stand-alone call (a sweep gets the same report with its update)."""
+    N, M = 3000, 256
+    Phi = torch.randn((N, M), device="cuda")
+    img = A.sparse.accumulate_image(Phi, ctx)
+    gam = torch.rand((1, N), device="cuda")
+    bet = torch.randn((1, N), device="cuda")
+    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
+    gam[0, 1234] = badval
+    with pytest.raises(A.DomainError, match="flat index 1234"):
+        ctx.call("agpl_accumulate_split", C.c_int64(N), C.c_int32(M), C.c_int32(1), _p(None), _p(img), _p(bet), _p(gam), _p(G), _p(g))
+    gam[0, 1234] = 0.25
+    ctx.call("agpl_accumulate_split", C.c_int64(N), C.c_int32(M), C.c_int32(1), _p(None), _p(img), _p(bet), _p(gam), _p(G), _p(g))
+    ref = (Phi.double().T * gam[0].double()) @ Phi.double()
+    assert (G[0] - ref).abs().max().item() < 1e-5 * ref.abs().max().item()

@@ -12,7 +12,7 @@ def means(root, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 KNOWN = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "syrk_gang_kernel", "syrk_strip_kernel", "syrk_split_kernel",
-         "agpl_fused_point_kernel", "reduce_slab_kernel", "reduce_G_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_kernel",
+         "agpl_fused_point_kernel", "reduce_slab_kernel", "reduce_G_kernel", "gibbs_project_image_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_kernel",
          "split_prep_kernel", "acc_prep_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel")
 
 
@@ -30,7 +30,7 @@ N, M = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (10_000_00
 LIK, L = (sys.argv[7], int(sys.argv[8])) if len(sys.argv) > 8 else ("bernoulli", 1)
 alg = {"marginal_split256_kernel": N * M * 4, "syrk_split_kernel": N * M * 4,
        "marginal_factor_persist_kernel": N * M * 4, "marginal_factor_queue_kernel": N * M * 4, "syrk_strip_kernel": N * M * 4,
-       "syrk_gang_kernel": N * M * 4, "gibbs_project_kernel": N * (M * 4 + 8),
+       "syrk_gang_kernel": N * M * 4, "gibbs_project_kernel": N * (M * 4 + 8), "gibbs_project_image_kernel": N * (M * 4 + 8),
        "gibbs_sample_kernel": N * 24, "reduce_slab_kernel": None, "agpl_fused_point_kernel": N * (2 * 2 * 4 + 4 + 1 + 8),
        "aux_sample_pg1_kernel": N * 16}
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-cpu "
