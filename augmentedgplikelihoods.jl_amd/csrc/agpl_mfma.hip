@@ -1017,12 +1017,78 @@ __global__ __launch_bounds__(256, 4) void mfma_f16_probe_kernel(int iters, float
     for (int k = 0; k < 16; ++k) t += s[k];
     if (t == 1.2345e30f) sink[0] = t; // never true: keeps the chain alive
 }
+
+// The same for the shape the shipped kernels issue (round 4): v_mfma_f32_16x16x32_f16, 48 per step into sixteen 16 x 16
+// accumulators = one 32-deep stage of marginal_factor_queue_kernel's wave (4 x 4 blocks x hi hi' + hi lo' + lo hi'), with
+// (MODE 1) or without (MODE 0) the stage's sixteen 16-byte fragment reads from LDS; operands are hashed bit patterns of
+// float16 normals in [-2, 2) (the clock a matrix loop holds depends on how the operand bits toggle: MI355X_MICROARCH.md, DVFS).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void mfma_f16_probe32_kernel(int iters, float *__restrict__ sink) {
+    __shared__ h8v frag[16][64 * 4];
+    for (int f = 0; f < 16; ++f) {
+        h8v v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned x = (unsigned)(threadIdx.x * 8 + k) * 2654435761u + (unsigned)f * 40503u + blockIdx.x * 97u;
+            x ^= x >> 15, x *= 2246822519u, x ^= x >> 13;
+            const unsigned short bits = (unsigned short)((x & 0x8000u) | (((x >> 16) & 0x3FFu)) | ((12u + ((x >> 26) & 3u)) << 10));
+            v[k] = __builtin_bit_cast(_Float16, bits);
+        }
+        frag[f][threadIdx.x] = v;
+    }
+    __syncthreads();
+    h8v ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ah[q] = frag[q][threadIdx.x], al[q] = frag[4 + q][threadIdx.x];
+        bh[q] = frag[8 + q][threadIdx.x], bl[q] = frag[12 + q][threadIdx.x];
+    }
+    typedef float f32x4p __attribute__((ext_vector_type(4)));
+    f32x4p acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 1) {
+            const int o = (threadIdx.x + it) & 255; // a changing address: the reads cannot be hoisted
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ah[q] = frag[q][o], al[q] = frag[4 + q][o];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (MODE == 1) {
+                const int o = (threadIdx.x + it + j) & 255;
+                bh[j] = frag[8 + j][o], bl[j] = frag[12 + j][o];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        if (MODE == 0) { ah[0] = -ah[0]; bl[3] = -bl[3]; al[2] = -al[2]; } // bounded sums, changing operands
+        else if ((it & 63) == 63) { // (random-sign products: a random walk; rescaled now and then so that nothing reaches inf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] *= 0.03125f;
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 1.2345e30f) sink[0] = t;
+}
 } // namespace
 
 extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
                                        double *tflops_host, double *ms_host) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (iters <= 0 || !tflops_host || (mode != 0 && mode != 1) || workgroups_per_cu < 1 || workgroups_per_cu > 4)
+    if (iters <= 0 || !tflops_host || mode < 0 || mode > 3 || workgroups_per_cu < 1 || workgroups_per_cu > 4)
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     int32_t rc = agpl_ws2_reserve(ctx, 4096);
     if (rc) return rc;
@@ -1035,7 +1101,9 @@ extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mod
     for (int rep = 0; rep < 2 + reps; ++rep) { // two untimed launches settle the clocks, `reps` launches are one timed region
         if (rep == 2) AGPL_HIP(ctx, hipEventRecord(e0, ctx->stream));
         if (mode == 0) mfma_f16_probe_kernel<0><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
-        else mfma_f16_probe_kernel<1><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
+        else if (mode == 1) mfma_f16_probe_kernel<1><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
+        else if (mode == 2) mfma_f16_probe32_kernel<0><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
+        else mfma_f16_probe32_kernel<1><<<blocks, 256, 0, ctx->stream>>>(iters, (float *)ctx->ws2);
     }
     AGPL_HIP(ctx, hipEventRecord(e1, ctx->stream));
     AGPL_HIP(ctx, hipEventSynchronize(e1));
@@ -1044,7 +1112,8 @@ extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mod
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     AGPL_LAUNCH_CHECK(ctx);
-    const double flop = (double)reps * blocks * 4.0 * (double)iters * 12.0 * (2.0 * 32 * 32 * 16);
+    // per wave and iteration: modes 0, 1: 12 x 32x32x16; modes 2, 3: 48 x 16x16x32
+    const double flop = (double)reps * blocks * 4.0 * (double)iters * (mode < 2 ? 12.0 * (2.0 * 32 * 32 * 16) : 48.0 * (2.0 * 16 * 16 * 32));
     *tflops_host = flop / ((double)ms * 1e-3) / 1e12;
     if (ms_host) *ms_host = ms / reps;
     return AGPL_OK;

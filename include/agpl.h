@@ -259,9 +259,12 @@ AGPL_API int32_t agpl_debug_force_factor_rescue(agpl_ctx *ctx, int32_t on);
 /* agpl_probe_mfma_f16: SUSTAINED float16 MFMA rate of this device [TFLOP/s]: v_mfma_f32_32x32x16_f16 in the instruction
  *   mix of one stage of the split accumulation's wave (12 per step into four 32 x 32 accumulators), six launches of
  *   `iters` steps per wave timed as one region after two that settle the clocks, `workgroups_per_cu` (1..4) 4-wave
- *   workgroups per CU.  mode 0: MFMA only; mode 1: with that stage's eight 16-byte LDS fragment reads.  The ceiling
- *   bench.py reports next to the data-sheet peak (the clock under MFMA load is below the boost clock).  ms_host (may be
- *   NULL): average launch duration.  Synchronous.                                                              */
+ *   workgroups per CU.  mode 0: MFMA only; mode 1: with that stage's eight 16-byte LDS fragment reads; modes 2, 3: the
+ *   same for v_mfma_f32_16x16x32_f16 in the mix of one stage of the shipped marginal kernel's wave (48 per step into
+ *   sixteen 16 x 16 accumulators, hashed operands, at most 2 workgroups per CU; 3: with the stage's sixteen fragment reads)
+ *   -- the shape the shipped
+ *   contractions issue.  The ceiling bench.py reports next to the data-sheet peak (the clock under MFMA load is below the
+ *   boost clock).  ms_host (may be NULL): average launch duration.  Synchronous.                                  */
 AGPL_API int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
                                      double *tflops_host, double *ms_host);
 
