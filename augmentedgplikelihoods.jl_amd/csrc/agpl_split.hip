@@ -752,22 +752,6 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // The last MFMA of a wave's stage (al[3] x the last column block's bh; two would spill) is held back and issued at the START of its
-    // next stage, behind that stage's first fragment reads: after every barrier all sixteen waves read LDS at once and the matrix
-    // pipe would idle for the reads' latency; the accumulator they add to (column block 3) is not touched again before the next
-    // stage's last column block, so the order of the additions -- and every bit of the result -- is unchanged.
-#ifndef AGPL_M_CARRY
-#define AGPL_M_CARRY 1
-#endif
-    [[maybe_unused]] h8 cA3 = {0, 0, 0, 0, 0, 0, 0, 0}, cB = cA3;
-    [[maybe_unused]] bool carry = false;
-#define AGPL_Q_CARRY()                                                                                      \
-    do {                                                                                                    \
-        if (AGPL_M_CARRY && carry) {                                                                        \
-            acc[3][3] = mfma32(cA3, cB, acc[3][3]);                                                         \
-            carry = false;                                                                                  \
-        }                                                                                                   \
-    } while (0)
     int ck = 0, rb = 0, ks = 0, cl = 0, ctile = 0; // consume pointer
     bool cvalid;
     AGPL_Q_DECODE(0, cvalid, ctile, cl, rb);
@@ -889,7 +873,6 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             ah[2] = st[fa + 32];
             ah[3] = st[fa + 48];
             h8 bh = st[fb], bl = st[256 + fb];
-            AGPL_Q_CARRY(); // (operands in registers since the previous stage: issued while the reads above are in flight)
             if (lo_rows) {
                 acc[0][0] = mfma32(ah[0], bh, acc[0][0]);
                 acc[1][0] = mfma32(ah[1], bh, acc[1][0]);
@@ -927,19 +910,10 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
                 }
                 acc[2][j] = mfma32(ah[2], bl, acc[2][j]);
                 acc[3][j] = mfma32(ah[3], bl, acc[3][j]);
-                // (row group 3's sums follow its last stage at once: nothing is held back there)
-                if (AGPL_M_CARRY && j == 3 && !(wr == 3 && ks + KU == 16 * (rb + 1))) {
-                    acc[2][j] = mfma32(al[2], bh, acc[2][j]);
-                    cA3 = al[3];
-                    cB = bh;
-                    carry = true;
-                } else {
-                    acc[2][j] = mfma32(al[2], bh, acc[2][j]);
-                    acc[3][j] = mfma32(al[3], bh, acc[3][j]);
-                }
+                acc[2][j] = mfma32(al[2], bh, acc[2][j]);
+                acc[3][j] = mfma32(al[3], bh, acc[3][j]);
             }
         } else {
-            AGPL_Q_CARRY();
             AGPL_MT_SEG(2);
             AGPL_Q_ISSUE(t + 1);
             AGPL_MT_SEG(3);
@@ -988,7 +962,6 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             mkp = mkk;
         }
     }
-#undef AGPL_Q_CARRY
 #undef AGPL_Q_ISSUE
 #undef AGPL_Q_PIECES
 #undef AGPL_Q_SRC
