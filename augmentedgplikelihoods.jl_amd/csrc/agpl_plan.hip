@@ -5,7 +5,8 @@
 // and keep consistent.  A plan owns them:
 //   * the marginal image of Phi (split-float16, blocks by 128-point tile: the B operand of U Phi, agpl_split.hip) and the
 //     accumulate image (point-major: both operands of Phi Diag(gamma) Phi', agpl_syrk.hip), BOTH scaled by the same 2^e chosen
-//     from max |Phi| -- one domain (any finite feature range that can be scaled into float16: max |Phi| in 2^-17 .. 2^43) instead
+//     from max |Phi| -- one domain (any finite feature range that can be scaled into float16: max |Phi| in 2^-24 .. 2^44, see
+//     agpl_image_scale_exp) instead
 //     of an unscaled marginal image that refused |x| >= 65504 and lost precision below 2^-14 beside a self-scaling accumulate image;
 //   * a copy of the Nystrom residual d_i = k_ii - |phi_i|^2 (agpl_feature_residual);
 //   * q(v) in factor form: U = chol(I + G)^-1 (float64, and split-float16 images of 2^15 U: |U| <= 1 always, so the scale is

@@ -345,8 +345,8 @@ AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc 
  * G_l = Phi Diag(gamma_l) Phi', g_l = Phi beta_l (the accumulators of docs/src/index.md:154-163: S = (K_Z^-1 +
  * kappa Diag(r) kappa')^-1, m = S (kappa t + ...), in the whitened basis; script.jl:35-36 in sparse form).  The reduction
  * index of this product is the POINT, the strided index of the float32 features; the image stores, once per data set,
- * hi = f16(s phi), lo = f16(s phi - hi) (s = 2^e chosen from max |Phi|: any finite feature range is representable, error
- * <= 2^-22 |phi| down to 2^-17 max |Phi|) in 4 KB blocks [point slice of 16][feature block of 128][hi | lo] =
+ * hi = f16(s phi), lo = f16(s phi - hi) (s = 2^e chosen from max |Phi|, -30 <= e <= 30: max |Phi| in 2^-24 .. 2^44, else
+ * AGPL_ERR_DOMAIN; error <= 2^-22 |phi| down to 2^-17 max |Phi|) in 4 KB blocks [point slice of 16][feature block of 128][hi | lo] =
  * [2 planes of 8 points][128 features][8 halves], whose 16-byte granule (one feature, 8 consecutive points) is one MFMA
  * operand fragment.  The accumulation then reads ONLY the image: A = the image (HBM -> LDS by DMA), B = gamma_n x the
  * image (rebuilt, scaled and re-split in registers), three float16 MFMA products per float32 product, float32
@@ -390,7 +390,8 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
 /* ---- the plan: the shipped sweep path (agpl_plan.hip) -------------------------------------------------------------------
  * Everything static about one data set on one context, built once: the two split-float16 images of Phi (marginal image by
  * 128-point tile, accumulate image point-major), BOTH carrying 2^e Phi with one e chosen from max |Phi| (domain: any finite
- * features with max |Phi| in 2^-17 .. 2^43; a non-finite feature is AGPL_ERR_DOMAIN with its (point, feature)), a copy of the
+ * features with max |Phi| in 2^-24 .. 2^44, else AGPL_ERR_DOMAIN; a non-finite feature is AGPL_ERR_DOMAIN with its (point,
+ * feature)), a copy of the
  * Nystrom residual, and q(v) in factor form -- U = chol(I + G)^-1, v = U (g + eta0), log det(I + G) -- which the plan's update
  * writes and its passes read; kernels are chosen by shape.  After creation the float32 features are not read by any plan entry
  * point (C2: 41 GB of images resident instead of 61 GB with the features; 20.5 GB for a Gibbs-only plan).  These entry points supersede
