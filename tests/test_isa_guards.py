@@ -144,3 +144,33 @@ def test_sampler_kernels_contain_no_function_call(tmp_path):
     assert len(kernels) >= 16  # 8 + 7 likelihood instantiations + the two PG(1) kernels
     for name, body in kernels:
         assert "s_swappc" not in body and "s_call" not in body, name
+
+
+def test_marginal_kernel_stage_loop_has_no_spill_and_no_stray_vmcnt0(tmp_path):
+    """marginal_factor_queue_kernel (agpl_split.hip), round 4: with LDS-DMA pieces in flight the compiler puts `s_waitcnt vmcnt(0)`
+    in front of every plain LDS read it cannot prove disjoint from them -- i.e. it waits for the whole flight of the next stage's
+    pieces.  The item-end sums and the queue decode read LDS through inline asm for that reason; what must remain in the stage loop
+    is the loop's own wait at its top and the wait behind the queue's returning atomic (wave 0, behind its DMA issue).  Also: no
+    scratch (the kernel sits at the 128-VGPR cap of a 1024-thread workgroup), and one copy of the 48-MFMA stage body."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    flags = re.search(r"^COMMON\s*:=\s*(.*)$", open(os.path.join(CSRC, "Makefile")).read(), flags=re.M).group(1)
+    flags = flags.replace("$(ARCH)", "gfx950").split()
+    subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, "agpl_split.hip"), "-o", "split.s"],
+                          cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asm = open(os.path.join(tmp_path, "split.s")).read().splitlines()
+    start = next(i for i, ln in enumerate(asm) if re.match(r"^_Z\w*marginal_factor_queue_kernel\w*:", ln))
+    end = next(i for i in range(start, len(asm)) if ".end_amdhsa_kernel" in asm[i])
+    body = asm[start:end]
+    assert any(".amdhsa_private_segment_fixed_size 0" in ln for ln in body), "the marginal kernel spills"
+    code = _code(body)
+    assert not [ln for ln in code if "scratch_" in ln]
+    assert sum("v_mfma_f32_16x16x32_f16" in ln for ln in code) == 48
+    # the stage loop: from the first barrier that follows a vmcnt(0) (its top) to the kernel's last barrier
+    bars = [i for i, ln in enumerate(code) if re.match(r"\s*s_barrier", ln)]
+    assert len(bars) == 3  # the queue's first item, the stage loop's, the one in front of the last rows out
+    loop = code[bars[1]:bars[2]]
+    waits = [ln.strip() for ln in loop if re.search(r"s_waitcnt.*vmcnt\(0\)", ln)]
+    # behind the atomic + (at the loop bottom, in front of the last barrier) the drain of the final item
+    assert len(waits) <= 2, waits
+    assert sum("global_load_lds_dwordx4" in ln for ln in loop) >= 8
