@@ -22,7 +22,7 @@ from .likelihoods import (BernoulliLikelihood, CategoricalLikelihood, Heterosced
 from .operators import (AuxPosterior, Context, TupleVector, aug_loglik, aux_prior_logpdf, auglik_potential,
                         auglik_potential_and_precision, auglik_precision, aux_kldivergence, aux_posterior,
                         aux_posterior_, aux_sample, aux_sample_, default_context, expected_auglik_potential,
-                        expected_auglik_potential_and_precision, expected_auglik_precision, expected_logtilt,
+                        expected_auglik_potential_and_precision, expected_auglik_precision, expected_aug_loglik, expected_logtilt,
                         init_aux_posterior, init_aux_variables, logtilt, rand_polyagamma)
 from . import sparse
 from .sparse import (DenseGibbs, SparseCAVI, SparseGibbs, exchange_natural_parameters, se_features, shard_range, synth_xy,
@@ -36,7 +36,7 @@ __all__ = [
     "init_aux_variables", "init_aux_posterior", "aux_sample", "aux_sample_", "aux_posterior", "aux_posterior_",
     "auglik_potential", "auglik_precision", "auglik_potential_and_precision",
     "expected_auglik_potential", "expected_auglik_precision", "expected_auglik_potential_and_precision",
-    "logtilt", "expected_logtilt", "aux_kldivergence", "aug_loglik", "aux_prior_logpdf", "rand_polyagamma",
+    "logtilt", "expected_logtilt", "aux_kldivergence", "aug_loglik", "expected_aug_loglik", "aux_prior_logpdf", "rand_polyagamma",
     "SparseCAVI", "SparseGibbs", "DenseGibbs", "se_features", "whiten_features", "synth_xy", "shard_range",
     "exchange_natural_parameters",
 ]

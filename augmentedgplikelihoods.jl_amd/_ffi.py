@@ -19,7 +19,7 @@ SYMBOLS = [
     "agpl_version", "agpl_ctx_create", "agpl_ctx_destroy", "agpl_ctx_set_stream", "agpl_ctx_set_seed", "agpl_ctx_set_point_offset",
     "agpl_ctx_synchronize", "agpl_last_error", "agpl_aux_sample", "agpl_rand_polyagamma",
     "agpl_potential_precision", "agpl_aux_posterior", "agpl_expected_potential_precision", "agpl_logtilt",
-    "agpl_expected_logtilt", "agpl_aux_kldivergence", "agpl_marginals", "agpl_accumulate",
+    "agpl_expected_logtilt", "agpl_aux_kldivergence", "agpl_expected_aug_loglik", "agpl_marginals", "agpl_accumulate",
     "agpl_gaussian_update", "agpl_pack_w", "agpl_cavi_pass", "agpl_workspace_bytes", "agpl_se_features",
     "agpl_transform_features", "agpl_synth_xy", "agpl_timing_enable", "agpl_timing_read", "agpl_gibbs_pass", "agpl_gibbs_draw_v", "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_gaussian_kl", "agpl_split_features_bytes", "agpl_split_features", "agpl_pack_w_split",
     "agpl_marginals_split", "agpl_cavi_pass_split", "agpl_allreduce_nat", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_feature_residual", "agpl_gaussian_factor", "agpl_gaussian_factor_async",

@@ -1103,7 +1103,7 @@ __device__ double pg_logpdf(double b, double c, double x) {
     return ext + log(acc);
 }
 
-enum { RED_LOGTILT = 0, RED_EXPECTED_LOGTILT = 1, RED_KL = 2, RED_AUX_PRIOR_LOGPDF = 3, RED_AUG_LOGLIK = 4 };
+enum { RED_LOGTILT = 0, RED_EXPECTED_LOGTILT = 1, RED_KL = 2, RED_AUX_PRIOR_LOGPDF = 3, RED_AUG_LOGLIK = 4, RED_EXPECTED_AUG_LOGLIK = 5 };
 
 struct RedArgs {
     const void *y;
@@ -1230,10 +1230,17 @@ struct YAcc {
 
 __device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A);
 
+// logpdf(Poisson(lam), n) -- Distributions.jl closed form (upstream, unpinned)
+__device__ __forceinline__ double poisson_logpdf(double lam, double n) {
+    if (lam == 0.0) return n == 0.0 ? 0.0 : -__builtin_inf();
+    return n * log(lam) - lam - lgamma(n + 1.0);
+}
 // logdensity_def(aux_prior(lik, y), Omega) per point -- the second half of aug_loglik (generic.jl:48-50).
-// PG(1, 0) bernoulli.jl:9-11 ; PG(y + r, 0) negativebinomial.jl:14-18 ; Gamma(nu/2, scale 2 sigma^2/nu) studentt.jl:91.
-// The categorical / Poisson priors go through the reference's broken logdensity_def and the others are
-// never evaluated by it: unsupported here.
+// PG(1, 0) bernoulli.jl:51-57 ; PG(y + r, 0) negativebinomial.jl:67-73 ; Gamma(nu/2, scale 2 sigma^2/nu) studentt.jl:91 ;
+// PolyaGammaPoisson(y, 0, lambda) poisson.jl:67-76 with the joint density of polyagammapoisson.jl:29-33 ;
+// InverseGamma(1/2, (2 beta)^-2) laplace.jl:90-96.  The categorical prior goes through the reference's broken logdensity_def
+// (polyagammanegativemultinomial.jl:33-39): unsupported.  The heteroscedastic likelihood has no aux_prior
+// (its aug_loglik is its own method, below).
 __device__ double aux_prior_logpdf_term(const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
     const double *omega = A.a1;
     switch (lik.kind) {
@@ -1245,16 +1252,46 @@ __device__ double aux_prior_logpdf_term(const agpl_lik_dev &lik, int64_t i, cons
         const double a = lik.p[0] / 2.0, th = lik.p[1] * lik.p[1] / a;
         return -lgamma(a) - a * log(th) + (a - 1.0) * log(omega[i]) - omega[i] / th;
     }
+    case AGPL_LIK_POISSON: {
+        const double nk = (double)A.nn[i];
+        return poisson_logpdf(lik.p[0], nk) + pg_logpdf((double)((const int32_t *)A.y)[i] + nk, 0.0, omega[i]);
+    }
+    case AGPL_LIK_LAPLACE: {
+        const double lam = 1.0 / ((2.0 * lik.p[0]) * (2.0 * lik.p[0]));
+        return 0.5 * log(lam) - lgamma(0.5) - 1.5 * log(omega[i]) - lam / omega[i];
+    }
     default:
         return __builtin_nan("");
     }
+}
+// aug_loglik(lik::AugHeteroGaussian, (omega, n), y, (f, g)) heteroscedasticgaussian.jl:118-128 ; fg = [2, N]
+__device__ double hetero_aug_loglik_term(const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
+    const double ff = A.f[2 * i], gg = A.f[2 * i + 1], yy = ((const double *)A.y)[i];
+    const double nk = (double)A.nn[i], om = A.a1[i];
+    return -(0.5 + nk) * kLogTwo + ((0.5 - nk) * gg - gg * gg * om) / 2.0 + pg_logpdf(0.5 + nk, 0.0, om) +
+           poisson_logpdf(lik.p[0] / 2.0 * (yy - ff) * (yy - ff), nk);
+}
+// expected_aug_loglik(lik::AugHeteroGaussian, qOmega, y, qfg) heteroscedasticgaussian.jl:130-145 ; q1 = c, q2 = lambda of
+// aux_posterior!, (mu, var) = q(f), q(g) as [2, N]; `var(first(qg))` is read as var(qg)
+__device__ double hetero_expected_aug_loglik_term(const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
+    const double lam = lik.p[0], yy = ((const double *)A.y)[i];
+    const double mf = A.f[2 * i], vf = A.var[2 * i], g = A.f[2 * i + 1], vg = A.var[2 * i + 1];
+    const double tn = A.a2[i], tw = pg_mean(0.5 + tn, A.a1[i]);
+    const double lp = lam / 2.0 * ((yy - mf) * (yy - mf) + vf);
+    const double klp = tn > 0 ? tn * (log(tn) - log(lp)) - tn + lp : lp;
+    return 0.5 * (log(lam) + log(2.0 / kPi)) - (0.5 + tn) * kLogTwo + ((0.5 - tn) * g - (g * g + vg) * tw) / 2.0 +
+           pg_kl(0.5 + tn, A.a1[i]) + klp;
 }
 
 __device__ double red_term(int mode, const agpl_lik_dev &lik, int64_t i, const RedArgs &A) {
     const int L = lik.nlatent;
     const double nanv = __builtin_nan("");
     if (mode == RED_AUX_PRIOR_LOGPDF) return aux_prior_logpdf_term(lik, i, A);
+    if (lik.kind == AGPL_LIK_HETEROGAUSS) // the two methods the reference defines for it; everything else is refused on the host
+        return mode == RED_AUG_LOGLIK ? hetero_aug_loglik_term(lik, i, A) : hetero_expected_aug_loglik_term(lik, i, A);
     if (mode == RED_AUG_LOGLIK) return red_term(RED_LOGTILT, lik, i, A) + aux_prior_logpdf_term(lik, i, A);
+    if (mode == RED_EXPECTED_AUG_LOGLIK) // generic.jl:52-54: expected_logtilt + aux_kldivergence (the sign is the reference's)
+        return red_term(RED_EXPECTED_LOGTILT, lik, i, A) + red_term(RED_KL, lik, i, A);
     if (mode == RED_LOGTILT) {
         const double *omega = A.a1, *f = A.f;
         switch (lik.kind) {
@@ -1335,17 +1372,22 @@ int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t
     agpl_lik_dev ld;
     int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
     if (rc) return rc;
-    if (mode == RED_KL && lik->kind == AGPL_LIK_CATEGORICAL)
+    if ((mode == RED_KL || mode == RED_EXPECTED_AUG_LOGLIK) && lik->kind == AGPL_LIK_CATEGORICAL)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
                   "the kl-divergence cannot be computed for the non-bijective LogisticSoftMaxLink "
                   "(categorical.jl:165-170); use the bijective link");
-    if (lik->kind == AGPL_LIK_HETEROGAUSS)
-        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "heteroscedastic ELBO terms are not split in the reference");
-    if ((mode == RED_AUX_PRIOR_LOGPDF || mode == RED_AUG_LOGLIK) && lik->kind != AGPL_LIK_BERNOULLI_LOGISTIC &&
-        lik->kind != AGPL_LIK_NEGBINOMIAL && lik->kind != AGPL_LIK_STUDENTT)
+    if (lik->kind == AGPL_LIK_HETEROGAUSS && mode != RED_AUG_LOGLIK && mode != RED_EXPECTED_AUG_LOGLIK)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
-                  "aug_loglik / the aux-prior log-density is available for the Bernoulli, negative-binomial and "
-                  "Student-t likelihoods (the reference's logdensity_def of the other priors is broken or absent)");
+                  "the heteroscedastic likelihood defines aug_loglik and expected_aug_loglik only "
+                  "(heteroscedasticgaussian.jl:106-145): its tilt, prior and KL are not split in the reference");
+    if ((mode == RED_AUX_PRIOR_LOGPDF || mode == RED_AUG_LOGLIK) &&
+        (lik->kind == AGPL_LIK_CATEGORICAL || lik->kind == AGPL_LIK_CATEGORICAL_BIJ))
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
+                  "aug_loglik / the aux-prior log-density of the categorical likelihood: the reference's logdensity_def of "
+                  "PolyaGammaNegativeMultinomial is broken (polyagammanegativemultinomial.jl:33-39, SURVEY App. B)");
+    const bool wants_n = lik->kind == AGPL_LIK_POISSON || lik->kind == AGPL_LIK_HETEROGAUSS;
+    if ((mode == RED_AUX_PRIOR_LOGPDF || mode == RED_AUG_LOGLIK) && wants_n && n > 0 && !A.nn)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "this likelihood's prior density needs the counts n_aux");
     if (n <= 0) {
         *out_host = 0.0;
         return AGPL_OK;
@@ -1538,8 +1580,8 @@ extern "C" int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t
     return run_reduction(ctx, RED_LOGTILT, lik, n, A, out_host);
 }
 extern "C" int32_t agpl_aux_prior_logpdf(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
-                                         const double *omega, double *out_host) {
-    RedArgs A{y, omega, nullptr, nullptr, nullptr, nullptr};
+                                         const double *omega, const int64_t *n_aux, double *out_host) {
+    RedArgs A{y, omega, nullptr, n_aux, nullptr, nullptr};
     return run_reduction(ctx, RED_AUX_PRIOR_LOGPDF, lik, n, A, out_host);
 }
 extern "C" int32_t agpl_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
@@ -1557,6 +1599,12 @@ extern "C" int32_t agpl_aux_kldivergence(agpl_ctx *ctx, const agpl_lik_desc *lik
                                          const double *q1, const double *q2, double *out_host) {
     RedArgs A{y, q1, q2, nullptr, nullptr, nullptr};
     return run_reduction(ctx, RED_KL, lik, n, A, out_host);
+}
+extern "C" int32_t agpl_expected_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                            const double *q1, const double *q2, const double *mu, const double *var,
+                                            double *out_host) {
+    RedArgs A{y, q1, q2, nullptr, mu, var};
+    return run_reduction(ctx, RED_EXPECTED_AUG_LOGLIK, lik, n, A, out_host);
 }
 
 // fused elementwise step of a sweep: aux_posterior! + expected potential / precision of point i from its marginals.

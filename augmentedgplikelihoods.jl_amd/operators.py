@@ -383,8 +383,9 @@ def logtilt(lik, Ω: TupleVector, y, f, ctx: Context | None = None) -> float:
 
 
 def aug_loglik(lik, Ω: TupleVector, y, f, ctx: Context | None = None) -> float:
-    """aug_loglik(lik, Ω, y, f) = logtilt + logdensity_def(aux_prior(lik, y), Ω) -- src/generic.jl:48-50
-    (Bernoulli, negative binomial, Student-t)."""
+    """aug_loglik(lik, Ω, y, f) = logtilt + logdensity_def(aux_prior(lik, y), Ω) -- src/generic.jl:48-50; the
+    heteroscedastic likelihood's own method heteroscedasticgaussian.jl:106-128 (f = fg [N, 2]).  Categorical: UnsupportedError
+    (the reference's prior density is broken)."""
     torch = _torch()
     ctx = ctx or default_context()
     f = _prep(f, torch.float64, "f")
@@ -398,14 +399,35 @@ def aug_loglik(lik, Ω: TupleVector, y, f, ctx: Context | None = None) -> float:
 
 
 def aux_prior_logpdf(lik, Ω: TupleVector, y, ctx: Context | None = None) -> float:
-    """logdensity_def(aux_prior(lik, y), Ω): the second term of aug_loglik."""
+    """logdensity_def(aux_prior(lik, y), Ω): the second term of aug_loglik (priors: bernoulli.jl:51-57,
+    negativebinomial.jl:67-73, studentt.jl:85-91, poisson.jl:67-76, laplace.jl:90-96)."""
     torch = _torch()
     ctx = ctx or default_context()
     y = _prep_y(lik, y, torch.float64)
     ω = _prep(Ω.ω, torch.float64, "ω")
+    nn = Ω.n if lik.kind in _HAS_N else None
     out = C.c_double()
     d = lik.desc()
-    ctx.call("agpl_aux_prior_logpdf", C.byref(d), C.c_int64(ω.numel()), _ptr(y), _ptr(ω), C.byref(out))
+    ctx.call("agpl_aux_prior_logpdf", C.byref(d), C.c_int64(ω.numel()), _ptr(y), _ptr(ω), _ptr(nn), C.byref(out))
+    return out.value
+
+
+def expected_aug_loglik(lik, qΩ: AuxPosterior, y, qf, ctx: Context | None = None) -> float:
+    """expected_aug_loglik(lik, qΩ, y, qf) = expected_logtilt + aux_kldivergence -- src/generic.jl:52-54 (sign as coded);
+    heteroscedastic: heteroscedasticgaussian.jl:130-145."""
+    torch = _torch()
+    ctx = ctx or default_context()
+    φ = qΩ.inds[0]
+    names = [k for k in _POSTERIOR_FIELDS[lik.kind] if k != "y"]
+    q1 = _prep(φ[names[0]], torch.float64, "q1")
+    q2 = _prep(φ[names[1]], torch.float64, "q2") if len(names) > 1 else None
+    mu, var = _qf_parts(qf)
+    mu, var = _prep(mu, torch.float64, "mean(qf)"), _prep(var, torch.float64, "var(qf)")
+    y = _prep_y(lik, y, torch.float64)
+    out = C.c_double()
+    d = lik.desc()
+    ctx.call("agpl_expected_aug_loglik", C.byref(d), C.c_int64(_npoints(lik, mu)), _ptr(y), _ptr(q1), _ptr(q2),
+             _ptr(mu), _ptr(var), C.byref(out))
     return out.value
 
 

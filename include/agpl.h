@@ -137,17 +137,22 @@ AGPL_API int32_t agpl_expected_potential_precision(agpl_ctx *ctx, const agpl_lik
                                           const void *mu_g, void *beta_out, void *gamma_out);
 
 /* ---- ELBO terms (N-reductions, float64, result to host) ----------------------------------------
- * logtilt generic.jl:40-46 ; expected_logtilt api.jl:219-223 ; aux_kldivergence generic.jl:56-62.  */
+ * logtilt generic.jl:40-46 ; expected_logtilt api.jl:219-223 ; aux_kldivergence generic.jl:56-62 ;
+ * aug_loglik generic.jl:48-50 ; expected_aug_loglik generic.jl:52-54.                               */
 AGPL_API int32_t agpl_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                      const double *omega, const int64_t *n_aux, const double *f, double *out_host);
 /* agpl_aug_loglik: aug_loglik(lik, Omega, y, f) = logtilt + logdensity_def(aux_prior(lik, y), Omega), src/generic.jl:48-50;
  *   the PG prior density is the 101-term series of src/SpecialDistributions/polyagamma.jl:37-91 (log-domain for
- *   omega < 1e-2), evaluated per point in float64.  agpl_aux_prior_logpdf is the second term alone.
- *   Bernoulli (bernoulli.jl:9-11), negative binomial (negativebinomial.jl:14-18), Student-t (studentt.jl:91);
- *   AGPL_ERR_UNSUPPORTED for the others (the reference's own logdensity_def of those priors is broken or absent,
- *   SURVEY.md Appendix B).                                                                                      */
+ *   omega < 1e-2), evaluated per point in float64.  agpl_aux_prior_logpdf is the second term alone.  Priors:
+ *   Bernoulli PG(1,0) (bernoulli.jl:51-57), negative binomial PG(y+r,0) (negativebinomial.jl:67-73), Student-t
+ *   Gamma(nu/2, 2 sigma^2/nu) (studentt.jl:85-91), Poisson PolyaGammaPoisson(y,0,lambda) (poisson.jl:67-76, joint density
+ *   polyagammapoisson.jl:29-33: needs the counts n_aux), Laplace InverseGamma(1/2, (2 beta)^-2) (laplace.jl:90-96).
+ *   Heteroscedastic Gaussian: agpl_aug_loglik is the likelihood's own method (heteroscedasticgaussian.jl:106-128; f = fg
+ *   [2,N], n_aux required); it has no aux_prior (agpl_aux_prior_logpdf, agpl_logtilt: AGPL_ERR_UNSUPPORTED).
+ *   Categorical: AGPL_ERR_UNSUPPORTED -- the reference's logdensity_def of PolyaGammaNegativeMultinomial is broken
+ *   (polyagammanegativemultinomial.jl:33-39 sums over the NamedTuple's 2 fields; its tests are skipped). */
 AGPL_API int32_t agpl_aux_prior_logpdf(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
-                                       const double *omega, double *out_host);
+                                       const double *omega, const int64_t *n_aux, double *out_host);
 AGPL_API int32_t agpl_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                                  const double *omega, const int64_t *n_aux, const double *f, double *out_host);
 AGPL_API int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
@@ -155,6 +160,14 @@ AGPL_API int32_t agpl_expected_logtilt(agpl_ctx *ctx, const agpl_lik_desc *lik, 
                               const double *var, double *out_host);
 AGPL_API int32_t agpl_aux_kldivergence(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                               const double *q1, const double *q2, double *out_host);
+/* agpl_expected_aug_loglik: expected_aug_loglik(lik, qOmega, y, qf) = expected_logtilt + aux_kldivergence, src/generic.jl:52-54
+ *   (the PLUS is the reference's; its example ELBOs subtract the KL themselves, examples/bernoulli/script.jl:65-70).
+ *   Heteroscedastic Gaussian: the likelihood's own method, heteroscedasticgaussian.jl:130-145 (q1 = c, q2 = lambda of
+ *   aux_posterior!; mu, var = q(f), q(g) as [2,N]; `var(first(qg))` read as var(q(g)), Appendix B).  Non-bijective
+ *   categorical: AGPL_ERR_UNSUPPORTED (categorical.jl:165-170). */
+AGPL_API int32_t agpl_expected_aug_loglik(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
+                                          const double *q1, const double *q2, const double *mu, const double *var,
+                                          double *out_host);
 
 /* ---- the sparse Gaussian half of a sweep -------------------------------------------------------
  * Feature matrix Phi: float32, [M, N] column-major (M contiguous per point; ld = M), M % 128 == 0

@@ -970,10 +970,30 @@ AGPLO_API double agplo_aux_kl(const agplo_lik *lik, int64_t n, const void *yv, c
     return acc;
 }
 
-/* logdensity of aux_prior at Omega, summed (second half of aug_loglik generic.jl:48-50).
- * PG-only families (bernoulli, negbin); others are not needed by the restated identities. */
+/* logpdf of the upstream scalar families the priors / conditionals are built from (Distributions.jl 0.25 closed forms,
+ * "upstream, unpinned"): Poisson, Gamma(shape, scale), InverseGamma(shape, scale), InverseGaussian(mu, lambda). */
+static double poisson_logpdf(double lam, double n) {
+    if (lam == 0.0) return n == 0.0 ? 0.0 : -INFINITY;
+    return n * log(lam) - lam - lgamma(n + 1.0);
+}
+static double gamma_logpdf(double a, double th, double x) {
+    return -lgamma(a) - a * log(th) + (a - 1.0) * log(x) - x / th;
+}
+static double invgamma_logpdf(double a, double th, double x) {
+    return a * log(th) - lgamma(a) - (a + 1.0) * log(x) - th / x;
+}
+static double invgaussian_logpdf(double mu, double lam, double x) {
+    return (log(lam) - (LOG2PI + 3.0 * log(x)) - lam * (x - mu) * (x - mu) / (mu * mu * x)) / 2.0;
+}
+
+/* logdensity_def(aux_prior(lik, y), Omega), summed (second half of aug_loglik generic.jl:48-50):
+ *   bernoulli.jl:51-57 PG(1,0); negativebinomial.jl:67-73 PG(y+r,0); studentt.jl:85-91 Gamma(nu/2, scale sigma^2/(nu/2));
+ *   poisson.jl:67-76 PolyaGammaPoisson(y,0,lambda) with the joint density of polyagammapoisson.jl:29-33
+ *   (logpdf(Poisson(lambda), n) + logpdf(PG(y+n,0), omega)); laplace.jl:90-96 InverseGamma(1/2, (2 beta)^-2).
+ * Categorical: the reference's logdensity_def of PolyaGammaNegativeMultinomial is broken -> NAN.
+ * Heteroscedastic: there is no aux_prior; aug_loglik is its own method (agplo_aug_loglik). */
 AGPLO_API double agplo_aux_prior_logpdf(const agplo_lik *lik, int64_t n, const void *yv,
-                                        const double *omega) {
+                                        const double *omega, const int64_t *nn) {
     double acc = 0.0;
     for (int64_t i = 0; i < n; ++i) {
         switch (lik->kind) {
@@ -986,13 +1006,108 @@ AGPLO_API double agplo_aux_prior_logpdf(const agplo_lik *lik, int64_t n, const v
         } break;
         case LIK_STUDENTT: { /* logpdf(Gamma(nu/2, scale 2 sigma^2/nu), omega) studentt.jl:91 */
             double a = lik->p[0] / 2.0, th = lik->p[1] * lik->p[1] / a;
-            acc += -lgamma(a) - a * log(th) + (a - 1.0) * log(omega[i]) - omega[i] / th;
+            acc += gamma_logpdf(a, th, omega[i]);
+        } break;
+        case LIK_POISSON: { /* polyagammapoisson.jl:29-33 at (y, c = 0, lambda) */
+            const int32_t *y = (const int32_t *)yv;
+            if (!nn) return NAN;
+            acc += poisson_logpdf(lik->p[0], (double)nn[i]) +
+                   agplo_pg_logpdf((double)y[i] + (double)nn[i], 0.0, omega[i]);
+        } break;
+        case LIK_LAPLACE: { /* laplace.jl:96 */
+            double lam = 1.0 / ((2.0 * lik->p[0]) * (2.0 * lik->p[0]));
+            acc += invgamma_logpdf(0.5, lam, omega[i]);
         } break;
         default:
             return NAN;
         }
     }
     return acc;
+}
+
+/* aug_loglik(lik, Omega, y, f): generic.jl:48-50 (logtilt + logdensity_def(aux_prior)); the heteroscedastic likelihood
+ * has its own method, heteroscedasticgaussian.jl:106-128, with f = fg [2,N] column-major (f_i = fg[2i], g_i = fg[2i+1]). */
+AGPLO_API double agplo_aug_loglik(const agplo_lik *lik, int64_t n, const void *yv, const double *omega,
+                                  const int64_t *nn, const double *f) {
+    if (lik->kind == LIK_HETEROGAUSS) {
+        const double *y = (const double *)yv;
+        double acc = 0.0;
+        if (!nn) return NAN;
+        for (int64_t i = 0; i < n; ++i) {
+            double ff = f[2 * i], gg = f[2 * i + 1], nk = (double)nn[i];
+            acc += -(0.5 + nk) * LOGTWO + ((0.5 - nk) * gg - gg * gg * omega[i]) / 2.0 +
+                   agplo_pg_logpdf(0.5 + nk, 0.0, omega[i]) +
+                   poisson_logpdf(lik->p[0] / 2.0 * (y[i] - ff) * (y[i] - ff), nk);
+        }
+        return acc;
+    }
+    return agplo_logtilt(lik, n, yv, omega, nn, f) + agplo_aux_prior_logpdf(lik, n, yv, omega, nn);
+}
+
+/* logdensity_def(aux_full_conditional(lik, y, f), Omega), summed -- the second term of the full-conditional-Omega identity
+ * of src/TestUtils.jl:107-116.  Conditionals: bernoulli.jl:13-15, negativebinomial.jl:20-22, studentt.jl:46-48,
+ * poisson.jl:26-28, laplace.jl:40-42, heteroscedasticgaussian.jl:28-32 (joint densities polyagammapoisson.jl:29-33;
+ * NTDist -> logpdf of the wrapped distribution, ntdist.jl). */
+AGPLO_API double agplo_full_conditional_logpdf(const agplo_lik *lik, int64_t n, const void *yv, const double *f,
+                                               const double *omega, const int64_t *nn) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        switch (lik->kind) {
+        case LIK_BERNOULLI_LOGISTIC:
+            acc += agplo_pg_logpdf(1.0, fabs(f[i]), omega[i]);
+            break;
+        case LIK_NEGBINOMIAL:
+            acc += agplo_pg_logpdf((double)((const int32_t *)yv)[i] + lik->p[0], fabs(f[i]), omega[i]);
+            break;
+        case LIK_STUDENTT: {
+            double nu = lik->p[0], sg = lik->p[1], d = ((const double *)yv)[i] - f[i];
+            acc += gamma_logpdf((nu + 1.0) / 2.0, 2.0 / (nu / (sg * sg) + d * d), omega[i]);
+        } break;
+        case LIK_POISSON: {
+            if (!nn) return NAN;
+            double yy = (double)((const int32_t *)yv)[i], nk = (double)nn[i];
+            acc += poisson_logpdf(lik->p[0] * logistic_(-f[i]), nk) + agplo_pg_logpdf(yy + nk, fabs(f[i]), omega[i]);
+        } break;
+        case LIK_LAPLACE: {
+            double beta = lik->p[0], lam = 1.0 / ((2.0 * beta) * (2.0 * beta));
+            acc += invgaussian_logpdf(1.0 / (2.0 * beta * fabs(((const double *)yv)[i] - f[i])), 2.0 * lam, omega[i]);
+        } break;
+        case LIK_HETEROGAUSS: {
+            if (!nn) return NAN;
+            double ff = f[2 * i], gg = f[2 * i + 1], yy = ((const double *)yv)[i], nk = (double)nn[i];
+            acc += poisson_logpdf(lik->p[0] * logistic_(-gg) * (ff - yy) * (ff - yy) / 2.0, nk) +
+                   agplo_pg_logpdf(0.5 + nk, fabs(gg), omega[i]);
+        } break;
+        default:
+            return NAN;
+        }
+    }
+    return acc;
+}
+
+/* expected_aug_loglik(lik, qOmega, y, qf): generic.jl:52-54 = expected_logtilt + aux_kldivergence (the PLUS sign is the
+ * reference's; its ELBO examples subtract the KL themselves, examples/bernoulli/script.jl:65-70); the heteroscedastic
+ * likelihood has its own method, heteroscedasticgaussian.jl:130-145: q1 = c, q2 = lambda of aux_posterior!, (mu, var) =
+ * q(f), q(g) as [2,N].  `var(first(qg))` there is taken as var(qg) (first() of a scalar Normal does not exist upstream:
+ * SURVEY App. B). */
+AGPLO_API double agplo_expected_aug_loglik(const agplo_lik *lik, int64_t n, const void *yv, const double *q1,
+                                           const double *q2, const double *mu, const double *var) {
+    if (lik->kind == LIK_HETEROGAUSS) {
+        const double *y = (const double *)yv;
+        const double lam = lik->p[0];
+        const double Cst = 0.5 * (log(lam) + log(2.0 / PI_));
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double mf = mu[2 * i], vf = var[2 * i], g = mu[2 * i + 1], vg = var[2 * i + 1];
+            double tn = q2[i], tw = agplo_pg_mean(0.5 + tn, q1[i]);
+            double lp = lam / 2.0 * ((y[i] - mf) * (y[i] - mf) + vf);
+            double klp = tn > 0 ? tn * (log(tn) - log(lp)) - tn + lp : lp;
+            acc += Cst - (0.5 + tn) * LOGTWO + ((0.5 - tn) * g - (g * g + vg) * tw) / 2.0 +
+                   agplo_pg_kl(0.5 + tn, q1[i]) + klp;
+        }
+        return acc;
+    }
+    return agplo_expected_logtilt(lik, n, yv, q1, q2, mu, var) + agplo_aux_kl(lik, n, yv, q1, q2);
 }
 
 /* ------------------------------------------------------------------------------------------ */

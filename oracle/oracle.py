@@ -112,7 +112,8 @@ def lib():
         ]:
             f = getattr(_lib, name)
             f.restype, f.argtypes = res, args
-        for name in ("agplo_logtilt", "agplo_expected_logtilt", "agplo_aux_kl", "agplo_aux_prior_logpdf"):
+        for name in ("agplo_logtilt", "agplo_expected_logtilt", "agplo_aux_kl", "agplo_aux_prior_logpdf",
+                     "agplo_aug_loglik", "agplo_full_conditional_logpdf", "agplo_expected_aug_loglik"):
             getattr(_lib, name).restype = d
     return _lib
 
@@ -291,16 +292,41 @@ def aux_kl(lik: Lik, y, q1, q2=None):
     return lib().agplo_aux_kl(C.byref(lc), C.c_int64(q1.size // lik.nlatent), _p(y), _p(q1), _p(q2))
 
 
-def aux_prior_logpdf(lik: Lik, y, omega):
+def _i64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+def aux_prior_logpdf(lik: Lik, y, omega, nn=None):
+    """logdensity_def(aux_prior(lik, y), Omega): the second half of aug_loglik, src/generic.jl:48-50."""
     y = _ycast(lik, y)
-    omega = _f64(omega)
+    omega, nn = _f64(omega), _i64(nn)
     lc = lik.c()
-    return lib().agplo_aux_prior_logpdf(C.byref(lc), C.c_int64(omega.size), _p(y), _p(omega))
+    return lib().agplo_aux_prior_logpdf(C.byref(lc), C.c_int64(omega.size), _p(y), _p(omega), _p(nn))
 
 
-def aug_loglik(lik: Lik, y, omega, f):
-    """aug_loglik src/generic.jl:48-50."""
-    return logtilt(lik, y, omega, f) + aux_prior_logpdf(lik, y, omega)
+def aug_loglik(lik: Lik, y, omega, f, nn=None):
+    """aug_loglik src/generic.jl:48-50; heteroscedastic: heteroscedasticgaussian.jl:106-128 (f = fg [N,2])."""
+    y = _ycast(lik, y)
+    omega, f, nn = _f64(omega), _f64(f), _i64(nn)
+    lc = lik.c()
+    return lib().agplo_aug_loglik(C.byref(lc), C.c_int64(omega.size), _p(y), _p(omega), _p(nn), _p(f))
+
+
+def full_conditional_logpdf(lik: Lik, y, f, omega, nn=None):
+    """logdensity_def(aux_full_conditional(lik, y, f), Omega) -- src/TestUtils.jl:110-114."""
+    y = _ycast(lik, y)
+    omega, f, nn = _f64(omega), _f64(f), _i64(nn)
+    lc = lik.c()
+    return lib().agplo_full_conditional_logpdf(C.byref(lc), C.c_int64(omega.size), _p(y), _p(f), _p(omega), _p(nn))
+
+
+def expected_aug_loglik(lik: Lik, y, q1, q2, mu, var):
+    """expected_aug_loglik src/generic.jl:52-54; heteroscedastic: heteroscedasticgaussian.jl:130-145."""
+    y = _ycast(lik, y)
+    q1, q2, mu, var = _f64(q1), _f64(q2), _f64(mu), _f64(var)
+    lc = lik.c()
+    return lib().agplo_expected_aug_loglik(C.byref(lc), C.c_int64(q1.size // (1 if lik.kind == HETEROGAUSS else lik.nlatent)),
+                                           _p(y), _p(q1), _p(q2), _p(mu), _p(var))
 
 
 # ---------------------------------------------------------------- sparse sweep

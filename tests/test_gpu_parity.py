@@ -139,14 +139,27 @@ def test_aux_sample_matches_oracle(A, ctx, oracle, name):
     if name not in ("hetero",):
         lt = A.logtilt(lik, Om, dev(y), dev(f), ctx=ctx)
         assert lt == pytest.approx(O.logtilt(olik, y, ref["omega"], f, ref.get("n")), rel=1e-11)
-    if name in ("bernoulli", "negbin", "negbin_real", "studentt"):
-        # aug_loglik = logtilt + log-density of the aux prior at the draw (generic.jl:48-50; PG series polyagamma.jl:37-91)
+    if name in ("bernoulli", "negbin", "negbin_real", "studentt", "poisson", "laplace", "hetero"):
+        # aug_loglik = logtilt + log-density of the aux prior at the draw (generic.jl:48-50; PG series polyagamma.jl:37-91;
+        # priors poisson.jl:67-76 / polyagammapoisson.jl:29-33, laplace.jl:90-96); heteroscedasticgaussian.jl:106-128 its own
         al = A.aug_loglik(lik, Om, dev(y), dev(f), ctx=ctx)
-        assert al == pytest.approx(O.aug_loglik(olik, y, ref["omega"], f), rel=1e-10)
+        ral = O.aug_loglik(olik, y, ref["omega"], f, ref.get("n"))
+        assert np.isfinite(ral)
+        assert al == pytest.approx(ral, rel=1e-10)
+        # the full-conditional-Omega identity of TestUtils.jl:107-116 with the DEVICE's aug_loglik on both draws
+        Om2 = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(f), ctx=ctx, sweep=8)
+        ref2 = O.aux_sample(olik, y, f, seed=SEED, sweep=8)
+        c1 = al - O.full_conditional_logpdf(olik, y, f, ref["omega"], ref.get("n"))
+        c2 = A.aug_loglik(lik, Om2, dev(y), dev(f), ctx=ctx) - O.full_conditional_logpdf(olik, y, f, ref2["omega"], ref2.get("n"))
+        assert c1 == pytest.approx(c2, abs=1e-6)  # (1e-5 for n = 10 in the reference; measured ~1e-11 at n = 3000)
+    if name in ("bernoulli", "negbin", "negbin_real", "studentt", "poisson", "laplace"):
         pl = A.aux_prior_logpdf(lik, Om, dev(y), ctx=ctx)
-        assert pl == pytest.approx(O.aux_prior_logpdf(olik, y, ref["omega"]), rel=1e-10)
-    elif name != "hetero":
-        with pytest.raises(A.AGPLError):
+        assert pl == pytest.approx(O.aux_prior_logpdf(olik, y, ref["omega"], ref.get("n")), rel=1e-10)
+    elif name == "hetero":
+        with pytest.raises(A.AGPLError):  # no aux_prior for this likelihood in the reference
+            A.aux_prior_logpdf(lik, Om, dev(y), ctx=ctx)
+    else:
+        with pytest.raises(A.AGPLError):  # categorical: the reference's logdensity_def is broken
             A.aug_loglik(lik, Om, dev(y), dev(f), ctx=ctx)
 
 
@@ -238,6 +251,16 @@ def test_aux_posterior_and_expectations(A, ctx, oracle, name, dtype):
         else:
             kl = A.aux_kldivergence(lik, q, yd, ctx=ctx)
             assert kl == pytest.approx(O.aux_kl(olik, y, r1, r2), rel=1e-10)
+            # expected_aug_loglik generic.jl:52-54 (the reference ADDS the KL)
+            eal = A.expected_aug_loglik(lik, q, yd, (dev(mu), dev(var)), ctx=ctx)
+            assert eal == pytest.approx(O.expected_aug_loglik(olik, y, r1, r2, mu, var), rel=1e-10)
+            assert eal == pytest.approx(el + kl, rel=1e-12)
+    if dtype == "f64" and name == "hetero":
+        # the heteroscedastic likelihood defines expected_aug_loglik only (heteroscedasticgaussian.jl:130-145)
+        eal = A.expected_aug_loglik(lik, q, yd, (dev(mu), dev(var)), ctx=ctx)
+        assert eal == pytest.approx(O.expected_aug_loglik(olik, y, r1, r2, mu, var), rel=1e-10)
+        with pytest.raises(A.AGPLError):
+            A.expected_logtilt(lik, q, yd, (dev(mu), dev(var)), ctx=ctx)
 
 
 def test_closed_form_means_on_device(A, ctx):
