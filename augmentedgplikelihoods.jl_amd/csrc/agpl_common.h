@@ -40,6 +40,7 @@ struct agpl_ctx {
     int64_t checked_image_N = 0;
     int32_t checked_image_M = 0;
     double *elbo_part = nullptr;  // per-workgroup partial sums of the ELBO terms that ride the per-point kernel (1024 doubles)
+    int live_plans = 0;           // agpl_plan objects created on this context and not yet destroyed (agpl_ctx_destroy refuses while > 0)
     bool debug_force_rescue = false; // agpl_debug_force_factor_rescue (test hook)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; // 0 marginal, 1 syrk, 2 gibbs point pass, 3 aux_sample

@@ -29,6 +29,9 @@ extern "C" int32_t agpl_ctx_create(agpl_ctx **out, int32_t device_id, uint64_t s
 
 extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     if (!ctx) return AGPL_OK;
+    if (ctx->live_plans > 0) // a plan enqueues on, and reports through, its context: destroy the plans first (include/agpl.h)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "%d plan(s) created on this context are still alive: agpl_plan_destroy them first",
+                  ctx->live_plans);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     agpl_update_release(ctx);

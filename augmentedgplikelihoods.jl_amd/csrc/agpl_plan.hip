@@ -106,10 +106,30 @@ __global__ void plan_identity_kernel(int M, int L, double *__restrict__ A, doubl
     if (blockIdx.x == 0 && (int)threadIdx.x < L) logdet[threadIdx.x] = 0.0;
 }
 
-__global__ void plan_residual_kernel(int64_t N, const float *__restrict__ in, float *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const float d = in[i];
-        out[i] = d > 0.f ? d : (d == d ? 0.f : d); // (a NaN stays: the sweep reports it)
+// The plan's copy of d_i = k_ii - |phi_i|^2.  d_i >= 0 in exact arithmetic (Nystrom residual of a positive semi-definite
+// kernel); a float32 evaluation rounds below zero by ~1e-7 (k_ii + |phi_i|^2), which is a NEGATIVE marginal variance once the
+// posterior is tighter than that: such round-off is clamped to 0.  Anything more negative than 1e-5 (|d_i| + |phi_i|^2) is not
+// round-off (a wrong kdiag / resid array, a wrong sign): its smallest index goes to *bad.  One wave per point at a
+// time, |phi_i|^2 from the float32 features (read once more, at plan creation only).  A NaN stays: the sweep reports it.
+__global__ __launch_bounds__(256) void plan_residual_kernel(int64_t N, int M, const float *__restrict__ Phi,
+                                                            const float *__restrict__ in, float *__restrict__ out,
+                                                            unsigned long long *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < N; i += nwaves) {
+        const float4 *row = (const float4 *)(Phi + i * M);
+        float s = 0.f;
+        for (int q = lane; q < M / 4; q += 64) {
+            const float4 x = row[q];
+            s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const float d = in[i];
+            if (d < -1e-5f * (fabsf(d) + s)) atomicMin(bad, (unsigned long long)i);
+            out[i] = d > 0.f ? d : (d == d ? 0.f : d);
+        }
     }
 }
 
@@ -230,22 +250,47 @@ extern "C" int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     }
     rc = agpl_accumulate_image_build(ctx, N, M, Phi, e, hmx, p->Phi_acc);
     if (rc) return fail(rc);
-    // d_i = k_ii - |phi_i|^2 >= 0 in exact arithmetic (Nystrom residual of a positive semi-definite kernel); a float32 evaluation
-    // rounds below zero by ~1e-7 k_ii, which is a NEGATIVE marginal variance once the posterior is tighter than that: clamped
-    plan_residual_kernel<<<1024, 256, 0, ctx->stream>>>(N, resid, p->resid);
+    rc = agpl_ws2_reserve(ctx, 16384);
+    if (rc) return fail(rc);
+    unsigned long long *bad = (unsigned long long *)((char *)ctx->ws2 + 32); // (bytes 8..63 of the small scratch are nobody's)
+    if (hipMemsetAsync(bad, 0xff, sizeof(*bad), ctx->stream) != hipSuccess) return fail(AGPL_ERR_HIP);
+    plan_residual_kernel<<<2048, 256, 0, ctx->stream>>>(N, M, Phi, resid, p->resid, bad);
     if (hipGetLastError() != hipSuccess) return fail(AGPL_ERR_HIP);
     // q(v) = N(0, I) to start from (script.jl:41-42)
     plan_identity_kernel<<<1024, 256, 0, ctx->stream>>>(M, L, p->A_work, p->v, p->v32, p->logdet);
     if (hipGetLastError() != hipSuccess) return fail(AGPL_ERR_HIP);
     rc = agpl_pack_factor_split_info(ctx, M, L, p->A_work, p->U_hi, p->U_lo, nullptr, nullptr, 0, kUExp);
     if (rc) return fail(rc);
+    // The image builds and the residual copy above READ the caller's Phi and resid: wait for them, so that "Phi is not read
+    // after agpl_plan_create returns" holds for a host that frees it stream-ordered on another stream.  One
+    // synchronisation per data set.
+    unsigned long long hbad = ~0ull;
+    if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "agpl_plan_create: waiting for the image builds failed: %s",
+                 hipGetErrorString(hipGetLastError()));
+        return fail(AGPL_ERR_HIP);
+    }
+    if (hbad != ~0ull) {
+        snprintf(ctx->err, sizeof(ctx->err),
+                 "resid[%llu] is negative beyond the float32 round-off of k_ii - |phi_i|^2 (tolerance 1e-5 (|d| + |phi|^2)): "
+                 "not a Nystrom residual (agpl_feature_residual)", hbad);
+        return fail(AGPL_ERR_DOMAIN);
+    }
+    ctx->live_plans += 1;
     *plan_out = p;
     return AGPL_OK;
 }
 
 extern "C" int32_t agpl_plan_destroy(agpl_plan *p) {
     if (!p) return AGPL_OK;
-    if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
+    // Lifetime rule (include/agpl.h): a plan is destroyed BEFORE its context; agpl_ctx_destroy refuses while plans are alive.
+    if (p->ctx) {
+        (void)hipStreamSynchronize(p->ctx->stream);
+        // the accumulation skips the header check of the image it validated last: forget it, the memory may be reused
+        if (p->ctx->checked_image == p->Phi_acc) p->ctx->checked_image = nullptr;
+        p->ctx->live_plans -= 1;
+    }
     if (p->own && p->base) (void)hipFree(p->base);
     delete p;
     return AGPL_OK;

@@ -499,6 +499,10 @@ class SparseGibbs:
         if self.acc_split and M % 256 == 0:
             if plan is not None and (plan.N, plan.M, plan.L) != (self.N, M, L):
                 raise _ffi.ArgumentError(-1, "the plan was created for another problem size")
+            if plan is not None and plan.ctx is not self.ctx:
+                # the pass runs on the PLAN's context (its seed, its point offset): a plan from another Context would draw that
+                # context's Philox streams while this object sets the offset on its own
+                raise _ffi.ArgumentError(-1, "the plan belongs to another Context: pass ctx=plan.ctx (or build the plan on this one)")
             self.plan = plan if plan is not None else Plan(self.Phi, self.kdiag, L, self.ctx, flags=Plan.NO_MARGINALS)
         self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
         self.v = torch.empty((L, M), dtype=f64, device=dev)

@@ -271,6 +271,60 @@ def full_size_quadratic_check(Phi, gamma, beta, G, g, nvec=4, seed=7):
             "G_symmetric": bool(torch.equal(G, G.transpose(1, 2)))}
 
 
+def marginal_sample_indices(n, seed=11, ntiles=64, nrandom=4096):
+    """Point indices for a sampled check of the marginal kernel at any N: whole 128-point tiles -- one from each of `ntiles`
+    strata of the tile range, its index chosen so that every residue mod 8 (= the kernel's eight per-XCD item queues, tile t in
+    queue t mod 8) occurs --, the first tile, the last full tile and the ragged tail tile, plus `nrandom` single points."""
+    import torch
+
+    T = (n + 127) // 128
+    rng = np.random.default_rng(seed)
+    tiles = {0, max(T - 1, 0), max(T - 2, 0)}
+    for k in range(ntiles):
+        lo, hi = k * T // ntiles, max((k + 1) * T // ntiles, k * T // ntiles + 1)
+        t = int(rng.integers(lo, hi))
+        t = min(T - 1, t - (t % 8) + (k % 8)) if hi - lo >= 8 else t
+        tiles.add(max(t, 0))
+    idx = [np.arange(t * 128, min(n, t * 128 + 128)) for t in sorted(tiles)]
+    idx.append(rng.integers(0, n, size=nrandom))
+    idx = np.unique(np.concatenate(idx))
+    return torch.from_numpy(idx).cuda(), sorted(tiles)
+
+
+def full_size_marginal_check(cavi, Phi, mu=None, var=None):
+    """The marginal kernel of the plan path at ANY N with the REAL posterior factor: after >= 1 update, q(v) = (U, v) is pulled from
+    the plan (agpl_plan_factor: U float64, column-major lower triangle), and mu_n = sum_a v_a T[a,n], var_n = d_n + sum_a T[a,n]^2,
+    T = U Phi (the `marginals(post_u(x))` of examples/bernoulli/script.jl:32-33 in factor form, include/agpl.h) is evaluated in
+    float64 from the float32 feature rows of a sample of points (marginal_sample_indices) and compared with agpl_marginals_plan's
+    float32 mu, var.  Then gamma, beta of those points (if the object exports them) against the float64 Bernoulli / NegBin / ...
+    operators is left to the tests; here: max |d mu| / max |mu|, max |d var| / max |var|."""
+    import torch
+
+    assert cavi.plan is not None, "full_size_marginal_check is for the plan path"
+    cavi.check()
+    if mu is None:
+        mu, var = cavi.marginals()
+    idx, tiles = marginal_sample_indices(cavi.N)
+    L = cavi.L
+    rel_mu = rel_var = 0.0
+    P = Phi[idx].double()
+    d = cavi.kdiag[idx].double().clamp_min(0.0)  # (the plan stores round-off below zero as 0)
+    for l in range(L):
+        Ut = torch.triu(cavi.plan.U_colmajor[l])  # row-major view of the column-major lower triangle = U'
+        T = P @ Ut  # T[n, a] = sum_b phi_n[b] U[a][b]
+        mref = T @ cavi.plan.v[l]
+        vref = d + (T * T).sum(1)
+        if cavi.mu0 is not None:
+            mref = mref + cavi.mu0[l][idx].double()
+        rel_mu = max(rel_mu, float(((mu[l][idx].double() - mref).abs().max() / mref.abs().max().clamp_min(1e-300)).item()))
+        rel_var = max(rel_var, float(((var[l][idx].double() - vref).abs().max() / vref.abs().max().clamp_min(1e-300)).item()))
+    U0 = cavi.plan.U_colmajor[0]
+    offdiag = float((torch.triu(U0, 1).abs().max()).item())
+    return {"max_rel_d_mu": rel_mu, "max_rel_d_var": rel_var, "sampled_points": int(idx.numel()), "sampled_tiles": len(tiles),
+            "tile_residues_mod_8": sorted({t % 8 for t in tiles}), "last_tile_points": int(cavi.N - (tiles[-1]) * 128),
+            "max_abs_offdiag_U": offdiag, "sweeps_before": int(cavi.nsweeps)}
+
+
 def f32_contract_leg(A, ctx, lik, likname, Phi, kd, y, N, M, Mp, L, args):
     """The same C2 sweep at the arithmetic SURVEY.md 8(d) prices: float32 features contracted by v_mfma_f32_32x32x2_f32
     (agpl_cavi_pass: marginal_kernel<0> + syrk_kernel of agpl_mfma.hip), float64 reductions and M x M update as everywhere
@@ -714,6 +768,14 @@ def main():
                                   "tolerance": 2e-6, "pass": bool(chk["max_rel_dg"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6
                                                                   and chk["max_rel_d_vGv"] < 2e-6 and chk["G_symmetric"])}
         cavi.gamma = cavi.beta = cavi.c = None
+        if getattr(cavi, "plan", None) is not None and cavi.nsweeps > 0:
+            # ... and the marginal kernel at the measured size with the REAL q(v) of the timed sweeps (not U = I, v = 0)
+            mchk = full_size_marginal_check(cavi, Phi)
+            out["full_size_check"]["marginals"] = {
+                **mchk, "reference": "float64 T = U Phi from the float32 feature rows of the sampled points, U, v from "
+                                     "agpl_plan_factor after the timed sweeps", "tolerance": 2e-5,
+                "pass": bool(mchk["max_rel_d_mu"] < 2e-5 and mchk["max_rel_d_var"] < 2e-5 and mchk["max_abs_offdiag_U"] > 1e-3)}
+            out["full_size_check"]["pass"] = bool(out["full_size_check"]["pass"] and out["full_size_check"]["marginals"]["pass"])
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------------
     if world == 1 and not args.no_cpu:

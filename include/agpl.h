@@ -415,7 +415,12 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *                         AGPL_PLAN_NO_MARGINALS for a plan that serves Gibbs passes only (no marginal image: half the bytes);
  *                         storage: agpl_plan_bytes bytes of caller-owned device memory that stay valid for the plan's life, or
  *                         NULL (the library allocates and frees).  q(v) starts at N(0, I) (examples/bernoulli/script.jl:41-42).
- *                         Synchronises once.
+ *                         Waits for its own kernels before returning (one synchronisation per data set): Phi and resid are not
+ *                         read after the call returns and may be freed on any stream.  A resid entry more negative than the
+ *                         float32 round-off of k_ii - |phi_i|^2 (d < -1e-5 (|d| + |phi|^2)) is AGPL_ERR_DOMAIN with its index;
+ *                         round-off below zero is stored as 0.
+ *   lifetime            : a plan enqueues on, and reports through, the context it was created on: agpl_plan_destroy it BEFORE
+ *                         agpl_ctx_destroy (which returns AGPL_ERR_INVALID_ARGUMENT, and destroys nothing, while plans are alive).
  *   agpl_cavi_pass_plan : marginals of the plan's q(v) -> aux_posterior! -> expected potential / precision -> G, g
  *                         (script.jl:32-36 up to the M x M solve; agpl_cavi_pass's contract).  elbo_terms_out (device double, may be
  *                         NULL): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) the pass used, from

@@ -208,3 +208,108 @@ def test_sparse_gibbs_refuses_ranks_with_different_seed_or_draw_counter():
     for p in procs:
         p.join(60)
     assert res[0] == res[1] == ["ok", "refused", "refused"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the real rank count of BASELINE config C3 (8 ranks), whole sweeps: CAVI (pass -> one all-reduce -> the identical update on
+# every rank) and Gibbs (global-index Philox streams, identical v everywhere), the oracle standing in for the device pass
+# ---------------------------------------------------------------------------------------------------------------------
+def _sweeps_worker(rank, world, port, N, M, nsweeps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="1")
+    import torch
+    import torch.distributed as dist
+
+    torch.set_num_threads(1)
+    import agpl_amd as A
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = 20240807
+        olik = O.negbinomial(15.0)  # C3's likelihood
+        i0, i1 = A.shard_range(N, rank, world)
+        x = O.synth_x(seed, i0, i1 - i0)
+        y = O.synth_y(olik, seed, i0, i1 - i0)
+        z = np.linspace(-10, 10, M)
+        Phi = O.se_kernel_f32(x, z, 1.5 * (z[1] - z[0]))
+        kd = np.full(i1 - i0, 0.3)
+        # ---- CAVI: examples/bernoulli/script.jl:29-39 sharded over N
+        S, m = np.eye(M)[None].copy(), np.zeros((1, M))
+        flat, Gf, gf = A.sparse.natural_parameter_buffers(1, M, "cpu")
+        for _ in range(nsweeps):
+            G, g = O.cavi_pass(olik, Phi, kd, y, -S, m)
+            Gf.copy_(torch.from_numpy(G)); gf.copy_(torch.from_numpy(g))
+            A.exchange_natural_parameters(Gf, gf, dist.group.WORLD, flat=flat)  # ONE collective of M^2 + M doubles
+            S, m = O.gaussian_update(Gf.numpy(), gf.numpy())  # every rank, identical inputs -> identical (S, m): no broadcast
+        cavi = (Gf.numpy().copy(), gf.numpy().copy(), S.copy(), m.copy())
+        # ---- Gibbs: script.jl:76-87 sharded; streams keyed on the GLOBAL point index, v on the same key everywhere
+        v, _ = O.gibbs_draw_v(np.zeros((1, M, M)), np.zeros((1, M)), seed=seed, sweep=0)
+        fs, oms, nunis = [], [], []
+        for sw in range(1, nsweeps + 1):
+            G, g, pts = O.gibbs_pass(olik, Phi, kd, y, v, seed=seed, sweep=sw, i0=i0)
+            Gf.copy_(torch.from_numpy(G)); gf.copy_(torch.from_numpy(g))
+            A.exchange_natural_parameters(Gf, gf, dist.group.WORLD, flat=flat)
+            v, _ = O.gibbs_draw_v(Gf.numpy(), gf.numpy(), seed=seed, sweep=sw)
+            fs.append(pts["f"]); oms.append(pts["omega"]); nunis.append(pts["nuni"])
+        q.put((rank, i0, i1, cavi, v.copy(), fs[-1], oms[-1], nunis[-1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [8])
+def test_eight_rank_sharded_cavi_and_gibbs_sweeps_are_the_single_process_sweeps(oracle, world):
+    """BASELINE config C3's rank count on CPU (gloo, world size 8): shard_range at the real
+    world size (ragged: N = 4003 is not a multiple of 8), three whole CAVI sweeps and three whole Gibbs sweeps.  Every rank ends
+    every sweep with bit-identical (G, g) and hence the bit-identical M x M update / inducing draw; the sharded result equals
+    the single-process one (sums to float64 round-off, the per-point draws of the last Gibbs sweep bit for bit once
+    concatenated in rank order -- which they can only be if the chains agreed in every earlier sweep to the last bit of v...
+    they agree to round-off of the reduced G, so f is compared to 1e-9 and the integer bookkeeping exactly)."""
+    import torch.multiprocessing as mp
+
+    O = oracle
+    N, M, nsweeps = 4003, 32, 3
+    port = 30100 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweeps_worker, args=(r, world, port, N, M, nsweeps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[-1][2] == N and all(res[i][2] == res[i + 1][1] for i in range(world - 1))
+    assert {r[2] - r[1] for r in res} == {N // world, N // world + 1}
+    # identical on every rank, bit for bit: the reduced accumulators, the update, the inducing draw
+    for r in res[1:]:
+        for a, b in zip(r[3], res[0][3]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(r[4], res[0][4])
+    # single-process reference
+    seed = 20240807
+    olik = O.negbinomial(15.0)
+    x, y = O.synth_x(seed, 0, N), O.synth_y(olik, seed, 0, N)
+    z = np.linspace(-10, 10, M)
+    Phi = O.se_kernel_f32(x, z, 1.5 * (z[1] - z[0]))
+    kd = np.full(N, 0.3)
+    S, m = np.eye(M)[None].copy(), np.zeros((1, M))
+    for _ in range(nsweeps):
+        G, g = O.cavi_pass(olik, Phi, kd, y, -S, m)
+        S, m = O.gaussian_update(G, g)
+    assert np.allclose(res[0][3][0], G, rtol=1e-10, atol=1e-12) and np.allclose(res[0][3][1], g, rtol=1e-10, atol=1e-12)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(res[0][3][2], S) < 1e-7 and rel(res[0][3][3], m) < 1e-7  # (round-off of the reduced G times cond(I + G))
+    v, _ = O.gibbs_draw_v(np.zeros((1, M, M)), np.zeros((1, M)), seed=seed, sweep=0)
+    for sw in range(1, nsweeps + 1):
+        G, g, pts = O.gibbs_pass(olik, Phi, kd, y, v, seed=seed, sweep=sw)
+        v, _ = O.gibbs_draw_v(G, g, seed=seed, sweep=sw)
+    assert rel(res[0][4], v) < 1e-6
+    f_all = np.concatenate([r[5] for r in res])
+    assert rel(f_all, pts["f"]) < 1e-6
+    # integer bookkeeping of the last sweep: uniforms consumed per point (the chains have not branched apart)
+    nuni_all = np.concatenate([r[7] for r in res])
+    assert (nuni_all == pts["nuni"]).mean() > 0.99
+    # first sweep is exact by construction (same v): covered bit for bit by the two-rank test above

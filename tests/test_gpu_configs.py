@@ -64,6 +64,35 @@ def shipped(A, lik, Phi, kd, y, ctx, **kw):
     return A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2-factor", accumulate_precision="f16x2", **kw)
 
 
+def sampled_marginals_and_operators_match_float64(A, cavi, Phi, lik_name, r=None):
+    """the marginal kernel at full size with a REAL posterior factor.  After >= 2 sweeps: U, v from
+    agpl_plan_factor, a sample of >= 1e4 points over every per-XCD item queue and the last (ragged) tile, mu / var of
+    agpl_marginals_plan against float64 from the float32 feature rows (2e-5 of max, the bar of test_gpu_random_shapes),
+    then gamma, beta of the next pass at those points against the float64 operators on the float64 marginals."""
+    import bench
+
+    assert cavi.nsweeps >= 2 and cavi.plan is not None
+    chk = bench.full_size_marginal_check(cavi, Phi)
+    assert chk["sampled_points"] >= 10_000 and chk["tile_residues_mod_8"] == list(range(8)), chk
+    assert chk["max_abs_offdiag_U"] > 1e-3, chk  # a real factor, not the identity
+    assert chk["max_rel_d_mu"] < 2e-5 and chk["max_rel_d_var"] < 2e-5, chk
+    # gamma, beta of the next pass at the sampled points, from float64 marginals
+    idx, _ = bench.marginal_sample_indices(cavi.N)
+    P = Phi[idx].double()
+    T = P @ torch.triu(cavi.plan.U_colmajor[0])
+    mu = T @ cavi.plan.v[0]
+    var = cavi.kdiag[idx].double().clamp_min(0.0) + (T * T).sum(1)
+    c = torch.sqrt(mu * mu + var)
+    cavi.accumulate()  # exports gamma, beta (keep_points=True) for the q(v) just checked
+    y = cavi.y[idx].double()
+    b = 1.0 if lik_name == "bernoulli" else y + r  # bernoulli.jl:35-45 / negativebinomial.jl:43-49
+    gref = b * torch.tanh(c / 2) / (2 * c)
+    bref = (y - 0.5) if lik_name == "bernoulli" else (y - r) / 2
+    assert ((cavi.gamma[0][idx].double() - gref).abs().max() / gref.abs().max()).item() < 2e-5
+    assert torch.equal(cavi.beta[0][idx].double(), bref)
+    return chk
+
+
 def ten_sweeps_against_oracle(A, ctx, O, lik, olik, N, M):
     x, y, Phi, kd = setup_svgp(A, ctx, lik, N, M)
     cavi = shipped(A, lik, Phi, kd, y, ctx)
@@ -118,6 +147,15 @@ def test_m1280_library_factor_route_ten_sweeps_match_oracle(A, ctx, oracle):
         c2.sweep()
     c2.check()
     assert torch.isfinite(c2.G).all()
+
+
+@pytest.mark.timeout(900)
+def test_c2_bernoulli_m512_ten_sweeps_match_oracle(A, ctx, oracle):
+    """C2's likelihood and M (Bernoulli-logistic, M = 512: the one-launch factor kernel, the 2 x 2-panel image accumulation):
+    ten plan sweeps (agpl_cavi_pass_plan + agpl_plan_update) against the oracle, at a size it finishes in seconds."""
+    O = oracle
+    cavi, _ = ten_sweeps_against_oracle(A, ctx, O, A.BernoulliLikelihood(), O.bernoulli(), 20_000, 512)
+    assert cavi.plan is not None and cavi.M == 512
 
 
 @pytest.mark.timeout(900)
@@ -205,10 +243,13 @@ def test_c3_per_rank_full_size_properties(A, ctx):
         assert chk["max_rel_d_vGv"] < 2e-6, chk
         cavi.accumulate()
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
-        for _ in range(3):  # the two-block factor route (M = 1024) inside whole sweeps
+        for _ in range(3):  # the M = 1024 factor route inside whole sweeps
             cavi.sweep()
         cavi.check()
         assert torch.isfinite(cavi.G).all() and torch.isfinite(cavi.v).all()
+        # N = 1.25e6 = 9765 full tiles + a ragged one of 80 points; M = 1024: four 256-row blocks of U per tile
+        chk = sampled_marginals_and_operators_match_float64(A, cavi, Phi, "negbin", r=r)
+        assert chk["last_tile_points"] == 80
         del cavi
         h = N // 2
         acc = None

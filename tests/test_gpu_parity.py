@@ -1150,7 +1150,23 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
         assert chk["max_rel_d_vGv"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6 and chk["max_rel_dg"] < 2e-6, chk
         cavi.accumulate()  # same state: bitwise identical
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
-        del cavi
+        # the marginal kernel at this size with a REAL factor: two sweeps, then U, v from agpl_plan_factor and
+        # a sampled float64 evaluation over every per-XCD queue and the last tile; then gamma, beta from those marginals
+        cavi.sweep()
+        cavi.sweep()
+        mchk = bench.full_size_marginal_check(cavi, Phi)
+        assert mchk["sampled_points"] >= 10_000 and mchk["tile_residues_mod_8"] == list(range(8)), mchk
+        assert mchk["max_abs_offdiag_U"] > 1e-3 and mchk["max_rel_d_mu"] < 2e-5 and mchk["max_rel_d_var"] < 2e-5, mchk
+        idx, _ = bench.marginal_sample_indices(N)
+        Ps = Phi[idx].double()
+        T = Ps @ torch.triu(cavi.plan.U_colmajor[0])
+        mu64 = T @ cavi.plan.v[0]
+        c64 = torch.sqrt(mu64 * mu64 + kd[idx].double().clamp_min(0.0) + (T * T).sum(1))
+        cavi.accumulate()
+        gref = torch.tanh(c64 / 2) / (2 * c64)  # bernoulli.jl:41-45
+        assert ((cavi.gamma[0][idx].double() - gref).abs().max() / gref.max()).item() < 2e-5
+        assert torch.equal(cavi.beta[0][idx].double(), y[idx].double() - 0.5)
+        del cavi, Ps, T
         h = N // 2
         parts = []
         for sl in (slice(0, h), slice(h, N)):
