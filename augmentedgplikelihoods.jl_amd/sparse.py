@@ -138,6 +138,24 @@ class Plan:
         self.ctx.bind()
         _ffi.check(self.ctx._h, getattr(_ffi.lib(), name)(self._h, *args))
 
+    _STATE = ("U_colmajor", "v", "U_hi", "U_lo", "v32", "logdet")
+
+    def state(self):
+        """Checkpoint of what an update rewrites (agpl_plan_factor + agpl_plan_state: U, v, their float16 / float32 images,
+        log det(I + G)) as host tensors.  The images of Phi are static: a restoring process rebuilds them from the same features."""
+        self.ctx.synchronize()
+        return {k: getattr(self, k).detach().cpu().clone() for k in self._STATE}
+
+    def load_state(self, st):
+        """Restore a checkpoint into a plan created for the same data: the next pass is bit for bit the saved run's."""
+        self.ctx.synchronize()
+        for k in self._STATE:
+            dst = getattr(self, k)
+            if tuple(st[k].shape) != tuple(dst.shape) or st[k].dtype != dst.dtype:
+                raise _ffi.ArgumentError(-1, f"checkpoint field {k}: {tuple(st[k].shape)} {st[k].dtype}, the plan holds "
+                                             f"{tuple(dst.shape)} {dst.dtype}")
+            dst.copy_(st[k])
+
     def __del__(self):
         try:
             if self._h:
@@ -359,6 +377,30 @@ class SparseCAVI:
         """Wait for the stream and raise what a deferred factorisation has to report (PosDefException, ...)."""
         self.ctx.synchronize()
 
+    def state_dict(self):
+        """Checkpoint of the sweep loop (SURVEY.md 5 "checkpoint / resume"; the reference's state is the (m, S, qΩ) of
+        examples/bernoulli/script.jl:41-43): q(v) in the plan's factor form, the reduced (G, g) of the last sweep, the sweep count
+        and the context's Philox key / draw counter.  qΩ is a function of q(v) and is not stored.  Plan path only."""
+        if self.plan is None:
+            raise _ffi.ArgumentError(-1, "state_dict is the plan path's (defaults, feature count a multiple of 256)")
+        self.check()
+        return {"plan": self.plan.state(), "Gg": self._Gg.detach().cpu().clone(), "kl": self._kl.detach().cpu().clone(),
+                "nsweeps": self.nsweeps, "seed": int(self.ctx.seed), "sweep_counter": int(self.ctx.sweep),
+                "shape": (self.N, self.M, self.L)}
+
+    def load_state_dict(self, st, restore_rng: bool = True):
+        if self.plan is None:
+            raise _ffi.ArgumentError(-1, "load_state_dict is the plan path's")
+        if tuple(st["shape"]) != (self.N, self.M, self.L):
+            raise _ffi.ArgumentError(-1, f"the checkpoint is of a {tuple(st['shape'])} problem, this one is {(self.N, self.M, self.L)}")
+        self.plan.load_state(st["plan"])
+        self._Gg[: st["Gg"].numel()].copy_(st["Gg"][: self._Gg.numel()])
+        self._kl.copy_(st["kl"])
+        self.nsweeps = int(st["nsweeps"])
+        if restore_rng:
+            self.ctx.set_seed(int(st["seed"]))
+            self.ctx.sweep = int(st["sweep_counter"])
+
     def elbo_entering(self):
         """aug_elbo (examples/bernoulli/script.jl:65-70) of the q(v) that ENTERED the last sweep, at no extra pass over the
         features (``track_elbo=True``): the per-point terms expected_logtilt - aux_kldivergence rode that sweep's per-point kernel
@@ -574,6 +616,26 @@ class SparseGibbs:
 
     def exchange(self):
         exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
+
+    def state_dict(self):
+        """Checkpoint of the chain (the reference's state is the (f, Ω) of examples/bernoulli/script.jl:89-90; here f and Ω are
+        redrawn from v every sweep): the inducing draw v, and the context's Philox key and draw counter -- counter-based streams
+        make the resumed chain the uninterrupted one, bit for bit."""
+        self.ctx.synchronize()
+        return {"v": self.v.detach().cpu().clone(), "m": self.m.detach().cpu().clone(), "seed": int(self.ctx.seed),
+                "sweep_counter": int(self.ctx.sweep), "sweep_index": int(self.sweep_index), "point_offset": self.point_offset,
+                "shape": (self.N, self.M, self.L)}
+
+    def load_state_dict(self, st):
+        if tuple(st["shape"]) != (self.N, self.M, self.L):
+            raise _ffi.ArgumentError(-1, f"the checkpoint is of a {tuple(st['shape'])} problem, this one is {(self.N, self.M, self.L)}")
+        self.ctx.synchronize()
+        self.v.copy_(st["v"])
+        self.m.copy_(st["m"])
+        self.ctx.set_seed(int(st["seed"]))
+        self.ctx.sweep = int(st["sweep_counter"])
+        self.sweep_index = int(st["sweep_index"])
+        self._check_ranks_agree()
 
     def sweep(self):
         self.accumulate()

@@ -16,6 +16,9 @@ At N = 1 the same JSON line also carries (each skippable by a --no-... flag):
   "gibbs"  the Gibbs half on the resident workload (point pass, PG sampler rates for Bernoulli AND NegBin r = 15);
   "parity" 10 sweeps on a 20 000-point slice against the oracle; "full_size_check"; "cpu_baseline";
   "c5"     BASELINE configs[4]: StudentT full-rank Gibbs step at N = 65 536 (float64).
+  "n8", "c3r" (+ "n8_m1024"), "c4"  one rank's share of C2 / of C3 and the north-star configuration at 8 GPUs (N / 8 points), and
+           BASELINE configs[3] (categorical K = 10, N = 1e6, M = 256): ms_per_step, roofline.kernels, ten-sweep parity, Gibbs
+           sweep, projected_scaling_8 = full-N ms / per-rank ms (--no-extra skips them and the full-N CPU sweep).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000000] [--m 512] [--lik bernoulli]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -379,6 +382,41 @@ def elbo_leg(A, ctx, lik, Phi, kd, y, base_ms, args, plain=None):
             "non_decreasing": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(vals, vals[1:])))}
 
 
+def config_leg(A, ctx, likname, N, M, steps=5, gibbs=False, parity_points=10_000, no_parity=False, workload=None, label=None):
+    """One more BASELINE configuration on this GPU with the headline's timed-loop discipline: `steps` plan sweeps after one
+    warm-up, the two contraction kernels from the in-library events (roofline.kernels), a ten-sweep parity slice against the
+    oracle, optionally the sparse Gibbs sweep on the same plan.  `workload`: (y, Phi, kd) to reuse instead of building one."""
+    import torch
+
+    lik = make_lik(A, likname)
+    L = A.nlatent(lik)
+    t0 = time.time()
+    y, Phi, kd = workload if workload is not None else build_workload(A, ctx, lik, 0, N, M)
+    Mp = Phi.shape[1]
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    t_setup = time.time() - t0
+    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
+    ms = dt / steps * 1e3
+    out = {"config": {"workload": label or f"{likname} SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, 1 GPU", "N": N, "M": M, "L": L},
+           "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": 1,
+           "roofline": roofline_of(kt, L, N, M, Mp, "f16x2-factor", "f16x2", ms, 1, N), "setup_s": round(t_setup, 2)}
+    if gibbs:
+        yg = y.to(torch.float64) if lik.ykind == "real" else y
+        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, plan=cavi.plan)
+        gib.sweep()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(steps):
+            gib.sweep()
+        torch.cuda.synchronize()
+        out["gibbs_ms_per_sweep"] = round((time.perf_counter() - tg) / steps * 1e3, 3)
+        del gib
+    del cavi
+    if not no_parity:
+        out["parity"] = parity_slice(A, ctx, lik, likname, Phi, kd, y, "f16x2-factor", "f16x2", ns=parity_points)
+    return out, (y, Phi, kd)
+
+
 def m1024_leg(A, ctx, args):
     """BASELINE.json north_star's target configuration: Bernoulli-logistic CAVI, N = 1e7, M = 1024, 1 GPU -- same
     timed-loop discipline as the headline value, its own roofline, and a 10-sweep parity slice."""
@@ -405,6 +443,19 @@ def m1024_leg(A, ctx, args):
     del cavi
     if not args.no_parity:
         out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2")
+    if not args.no_extra:
+        # BASELINE configs[2] (C3: NegBin r = 15, N = 1e7, M = 1024) on ONE GPU, on the same features (x_i depends on (seed, i)
+        # only): the numerator of c3r's projected 8-GPU scaling
+        try:
+            nlik = make_lik(A, "negbin")
+            _, yn = A.synth_xy(nlik, SEED, 0, N, ctx=ctx, want_x=False)
+            torch.cuda.empty_cache()
+            c3, _ = config_leg(A, ctx, "negbin", N, M, steps=3, no_parity=True, workload=(yn, Phi, kd),
+                               label=f"C3 on one GPU: NegBin(r=15) SVGP CAVI sweep, N={N}, M={M}, L=1")
+            out["c3_full_one_gpu"] = c3
+            del yn
+        except Exception as e:
+            out["c3_full_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
     del Phi, kd, y
     torch.cuda.empty_cache()
     return out
@@ -527,6 +578,10 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the full-rank StudentT Gibbs leg (BASELINE configs[4])")
     ap.add_argument("--no-f32", action="store_true", help="skip the float32-MFMA leg (the sweep at SURVEY 8d's stated arithmetic)")
     ap.add_argument("--no-elbo", action="store_true", help="skip the ELBO-riding-the-sweep leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the per-rank / other-configuration legs (n8, c3r, c4) and the full-N CPU sweep")
+    ap.add_argument("--cpu-full", dest="cpu_full", action="store_true", default=None,
+                    help="time ONE full-N sweep of the CPU twin (default: on for the default configuration)")
     ap.add_argument("--c5-n", type=int, default=65_536)
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
@@ -641,7 +696,7 @@ def main():
         if rank != 0:
             return
         # the single-GPU extra legs (Gibbs, parity slice, CPU baseline, M = 1024, C5) are reported at N = 1 only
-        args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = args.no_f32 = args.no_elbo = True
+        args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = args.no_f32 = args.no_elbo = args.no_extra = True
 
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
@@ -819,6 +874,36 @@ def main():
                         f"(float64) and the oracle's per-point operators, {t_blas:.2f} s (the oracle's own scalar pass: "
                         f"{t_cpu:.2f} s; both agree to 1e-9); value extrapolated linearly in N (labelled extrapolation)")
             del P
+        full = None
+        want_full = args.cpu_full if args.cpu_full is not None else (default_config and not args.no_extra)
+        if want_full and L == 1 and extra.get("blas_twin_matches_oracle"):
+            # ONE sweep of the BLAS twin over ALL n_loc points, in chunks of the sample's size (the float32 features live on the
+            # device: each chunk is copied to the host outside the timed regions; only the CPU work is timed) -- a measured
+            # figure, the 1e6-point sample above stays as its cross-check
+            Gf, gf = np.zeros((Mp, Mp)), np.zeros(Mp)
+            t_full = 0.0
+            for c0 in range(0, n_loc, ns):
+                c1 = min(n_loc, c0 + ns)
+                Pc, kc, yc = Phi[c0:c1].cpu().numpy(), kd[c0:c1].cpu().numpy().astype(np.float64), y[c0:c1].cpu().numpy()
+                t0 = time.perf_counter()
+                P = Pc.astype(np.float64)
+                q = np.einsum("ij,ij->i", P @ (-S0[0]), P)
+                q1, q2, _ = O.aux_posterior(olik, yc, P @ m0[0], kc - q)
+                bt, gm = O.expected_potential_precision(olik, yc, q1, q2)
+                Gf += (P * gm[0][:, None]).T @ P
+                gf += P.T @ bt[0]
+                t_full += time.perf_counter() - t0
+                del P, Pc
+            t0 = time.perf_counter()
+            O.gaussian_update(Gf[None], gf[None])
+            t_full += time.perf_counter() - t0
+            full = {"value": 1.0 / t_full, "seconds": round(t_full, 2), "points": n_loc, "chunks": -(-n_loc // ns),
+                    "extrapolated_from_sample": blas_value, "measured_over_extrapolated": round((1.0 / t_full) / blas_value, 3)}
+            cpu_value = full["value"]
+            note = (f"MEASURED: one full sweep over all {n_loc} points with the two contractions through numpy/OpenBLAS (float64) "
+                    f"and the oracle's per-point operators, {t_full:.1f} s of CPU time in {full['chunks']} chunks (host copies of the "
+                    f"device-resident features not timed); the {ns}-point sample extrapolates to {1.0 / blas_value:.1f} s")
+            extra["full_sweep"] = full
         try:
             with open("/proc/cpuinfo") as fh:
                 phys = {ln.split(":")[1].strip() for ln in fh if ln.startswith("physical id")}
@@ -845,10 +930,34 @@ def main():
             out["f32_contract"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the other configurations the driver should see (N = 1, default C2 run only) ------------------------
-    if world == 1 and default_config and not (args.no_m1024 and args.no_c5):
+    if world == 1 and default_config and not (args.no_m1024 and args.no_c5 and args.no_extra):
         del cavi, Phi, kd, y
         gc.collect()
         torch.cuda.empty_cache()
+        t_legs = time.time()
+
+        def leg(name, fn):  # an extra leg must not take the headline line down with it
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+            gc.collect()
+            torch.cuda.empty_cache()
+
+        if not args.no_extra:
+            # one rank's share of C2 at 8 GPUs (N / 8 points, everything but the all-reduce): the per-rank fixed cost decides scaling
+            def n8():
+                o, _ = config_leg(A, ctx, "bernoulli", N // 8, 512, steps=10, no_parity=args.no_parity)
+                o["projected_scaling_8"] = round(ms_per_step / o["ms_per_step"], 3)
+                o["projected_scaling_8_note"] = "ms_per_step of the full-N headline / ms_per_step of one rank's N/8 share, before the all-reduce (2 MB of float64)"
+                return o
+            leg("n8", n8)
+
+            # BASELINE configs[3] (C4): categorical K = 10, N = 1e6, M = 256 -- CAVI and Gibbs
+            def c4():
+                o, _ = config_leg(A, ctx, "categorical", 1_000_000, 256, steps=5, gibbs=True, no_parity=args.no_parity, parity_points=20_000)
+                return o
+            leg("c4", c4)
         if not args.no_m1024:
             try:
                 out["m1024"] = m1024_leg(A, ctx, args)
@@ -857,11 +966,31 @@ def main():
                     out["m1024"]["gpu_over_cpu_estimate"] = round(out["m1024"]["value"] / (out["cpu_baseline"]["value"] / 4.0), 1)
             except Exception as e:  # an extra leg must not take the headline line down with it
                 out["m1024"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_extra:
+            # one rank's share of the north-star configuration (Bernoulli, N = 1.25e6, M = 1024) and of C3 (NegBin r = 15, same
+            # features): CAVI (+ Gibbs for C3), ten-sweep parity, projected 8-GPU scaling against the full-N single-GPU legs above
+            def n8_m1024():
+                o, wl = config_leg(A, ctx, "bernoulli", N // 8, 1024, steps=6, no_parity=args.no_parity)
+                full = out.get("m1024", {}).get("ms_per_step")
+                o["projected_scaling_8"] = round(full / o["ms_per_step"], 3) if full else None
+                out["n8_m1024"] = o
+                nlik = make_lik(A, "negbin")
+                _, yn = A.synth_xy(nlik, SEED, 0, N // 8, ctx=ctx, want_x=False)
+                o3, _ = config_leg(A, ctx, "negbin", N // 8, 1024, steps=6, gibbs=True, no_parity=args.no_parity,
+                                   workload=(yn, wl[1], wl[2]),
+                                   label=f"one rank's share of C3: NegBin(r=15) SVGP CAVI sweep, N={N // 8}, M=1024, L=1")
+                full3 = out.get("m1024", {}).get("c3_full_one_gpu", {}).get("ms_per_step")
+                o3["projected_scaling_8"] = round(full3 / o3["ms_per_step"], 3) if full3 else None
+                o3["projected_scaling_8_note"] = ("ms_per_step of C3 at its full N on one GPU (m1024.c3_full_one_gpu) / this leg, before the "
+                                                  "all-reduce (8.4 MB of float64 per sweep)")
+                return o3
+            leg("c3r", n8_m1024)
         if not args.no_c5:
             try:
                 out["c5"] = c5_leg(A, args)
             except Exception as e:
                 out["c5"] = {"error": f"{type(e).__name__}: {e}"}
+        out["extra_legs_s"] = round(time.time() - t_legs, 1)
     print(json.dumps(out), flush=True)
 
 
