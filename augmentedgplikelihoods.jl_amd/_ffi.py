@@ -17,17 +17,19 @@ F32, F64 = 0, 1
 # exported symbols of include/agpl.h (tests/test_abi.py checks this list against the header and the .so)
 SYMBOLS = [
     "agpl_version", "agpl_ctx_create", "agpl_ctx_destroy", "agpl_ctx_set_stream", "agpl_ctx_set_seed", "agpl_ctx_set_point_offset",
-    "agpl_ctx_synchronize", "agpl_last_error", "agpl_aux_sample", "agpl_rand_polyagamma",
-    "agpl_potential_precision", "agpl_aux_posterior", "agpl_expected_potential_precision", "agpl_logtilt",
-    "agpl_expected_logtilt", "agpl_aux_kldivergence", "agpl_expected_aug_loglik", "agpl_marginals", "agpl_accumulate",
-    "agpl_gaussian_update", "agpl_pack_w", "agpl_cavi_pass", "agpl_workspace_bytes", "agpl_se_features",
-    "agpl_transform_features", "agpl_synth_xy", "agpl_timing_enable", "agpl_timing_read", "agpl_gibbs_pass", "agpl_gibbs_draw_v", "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_gaussian_kl", "agpl_split_features_bytes", "agpl_split_features", "agpl_pack_w_split",
-    "agpl_marginals_split", "agpl_cavi_pass_split", "agpl_allreduce_nat", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_feature_residual", "agpl_gaussian_factor", "agpl_gaussian_factor_async",
-    "agpl_pack_factor_split", "agpl_marginals_factor_split", "agpl_cavi_pass_factor_split", "agpl_probe_mfma_f64", "agpl_probe_mfma_f16",
-    "agpl_accumulate_image_bytes", "agpl_accumulate_image", "agpl_accumulate_split", "agpl_cavi_pass_factor_image",
-    "agpl_gibbs_pass_image", "agpl_debug_force_factor_rescue",
-    "agpl_plan_bytes", "agpl_plan_create", "agpl_plan_destroy", "agpl_plan_info", "agpl_plan_factor", "agpl_plan_state", "agpl_cavi_pass_plan",
-    "agpl_plan_update", "agpl_marginals_plan", "agpl_gibbs_pass_plan",
+    "agpl_ctx_synchronize", "agpl_last_error",
+    # the operator surface of src/AugmentedGPLikelihoods.jl:18-30
+    "agpl_aux_sample", "agpl_rand_polyagamma", "agpl_potential_precision", "agpl_aux_posterior",
+    "agpl_expected_potential_precision", "agpl_logtilt", "agpl_aux_prior_logpdf", "agpl_aug_loglik", "agpl_expected_logtilt",
+    "agpl_aux_kldivergence", "agpl_expected_aug_loglik",
+    # the sweep at SURVEY.md 8(d)'s float32-input arithmetic
+    "agpl_marginals", "agpl_accumulate", "agpl_gaussian_update", "agpl_cavi_pass", "agpl_gibbs_pass", "agpl_gibbs_draw_v",
+    # the shipped sweep: factor-form update + the plan (split-float16 images)
+    "agpl_gaussian_factor", "agpl_feature_residual", "agpl_plan_bytes", "agpl_plan_create", "agpl_plan_destroy", "agpl_plan_info",
+    "agpl_plan_state", "agpl_cavi_pass_plan", "agpl_plan_update", "agpl_marginals_plan", "agpl_gibbs_pass_plan",
+    # full-rank Gibbs step, multi-GPU exchange, features / synthetic data, diagnostics
+    "agpl_dense_cholesky", "agpl_dense_gibbs_step", "agpl_allreduce_nat", "agpl_se_features", "agpl_transform_features",
+    "agpl_synth_xy", "agpl_probe_mfma", "agpl_timing", "agpl_debug_force_factor_rescue",
 ]
 
 
@@ -85,9 +87,6 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.agpl_last_error.restype = C.c_char_p
         _lib.agpl_last_error.argtypes = [C.c_void_p]
-        _lib.agpl_workspace_bytes.restype = C.c_int64
-        _lib.agpl_split_features_bytes.restype = C.c_int64
-        _lib.agpl_accumulate_image_bytes.restype = C.c_int64
         _lib.agpl_plan_bytes.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # raises AttributeError if the library does not export the ABI

@@ -106,4 +106,8 @@ struct agpl_lik_dev {
 };
 int32_t agpl_lik_to_device(agpl_ctx *ctx, const agpl_lik_desc *lik, agpl_lik_dev *out);
 
+// bytes of the plan's two kinds of image (agpl_split.hip, agpl_syrk.hip)
+int64_t agpl_split_features_bytes(int64_t N, int32_t M);
+int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M);
+
 static inline int64_t agpl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

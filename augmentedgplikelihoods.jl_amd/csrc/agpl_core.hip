@@ -193,13 +193,13 @@ int32_t agpl_timing_end(agpl_ctx *ctx, int which) {
     AGPL_HIP(ctx, hipEventRecord(ctx->ev[which].back().second, ctx->stream));
     return AGPL_OK;
 }
-extern "C" int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on) {
+extern "C" int32_t agpl_timing(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    ctx->timing = on != 0;
-    return AGPL_OK;
-}
-extern "C" int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host) {
-    if (!ctx || which < 0 || which > 3 || !total_ms_host || !launches_host) return AGPL_ERR_INVALID_ARGUMENT;
+    if (which == -1 || which == -2) { // switch the event pairs around the hot kernels on / off
+        ctx->timing = which == -1;
+        return AGPL_OK;
+    }
+    if (which < 0 || which > 3 || !total_ms_host || !launches_host) return AGPL_ERR_INVALID_ARGUMENT;
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
     for (auto &pr : ctx->ev[which]) {

@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(int iters, double *
 }
 } // namespace
 
-extern "C" int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host) {
+// the float64 half of agpl_probe_mfma (agpl_mfma.hip holds the entry point)
+int32_t agpl_probe_mfma_f64_impl(agpl_ctx *ctx, int32_t iters, double *tflops_host) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (iters <= 0 || !tflops_host) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     int32_t rc = agpl_ws2_reserve(ctx, 4096);

@@ -366,17 +366,7 @@ __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npai
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// syrk_split_kernel: the same tile / slice decomposition and slab output as syrk_kernel, on the float16 matrix
-// cores.  psi = sqrt(gamma_n) phi_n is formed in float32 while staging, split into hi = f16(psi),
-// lo = f16(psi - hi), and  G += psi psi'  runs as hi hi' + hi lo' + lo hi'  (3 x v_mfma_f32_32x32x16_f16 per
-// 32x32x16 sub-product, float32 accumulation; the lo lo' term, <= 2^-22 relative, is dropped).
-// The reduction index is the point index, which is the strided one in Phi [point][feature]: every thread stages a
-// 4-feature x 4-point micro-tile (4 coalesced float4 loads), transposes it in registers and writes 4 + 4
-// 8-byte pieces into LDS images [plane h][feature row 128][8 points] -- the fragment layout of the MFMA
-// (lane (row r, h) reads the 16 bytes of points 8h..8h+7 of its feature row; conflict-free ds_read_b128).
-// g = Phi beta rides the staging registers of the diagonal tiles (float32 VALU, exact float32 phi).
-// ------------------------------------------------------------------------------------------------
+// float16 fragment types of the matrix-core probe kernels below
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -384,297 +374,6 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mfma16(h8v a, h8v b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-
-// psi is staged as 2^8 sqrt(gamma) phi so that hi AND lo are float16 normals for |psi| in [2^-11, 2^8) (the
-// unscaled lo of a psi ~ 0.05 is a float16 subnormal and loses bits); the accumulators carry 2^16 G and are
-// rescaled (exactly) when the slab is written.
-constexpr float kPsiScale = 256.f;
-constexpr float kPsiUnscale = 1.f / (256.f * 256.f);
-
-// padded copies for the split kernel: sg[l][Npad] = 2^8 sqrt(gamma) (0 beyond N), bp[l][Npad] = beta (0 beyond N);
-// Npad = N rounded up to 16, so a stage's float4 of scales needs neither a clamp nor an alignment case.
-__global__ void split_prep_kernel(int64_t N, int64_t Npad, int L, const float *__restrict__ gamma,
-                                  const float *__restrict__ beta, float *__restrict__ sg, float *__restrict__ bp) {
-    const int64_t total = (int64_t)L * Npad;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t l = i / Npad, n = i - l * Npad;
-        const bool in = n < N;
-        sg[i] = in ? kPsiScale * sqrtf(fmaxf(gamma[l * N + n], 0.f)) : 0.f; // gamma >= 0 by construction (TestUtils.jl:88)
-        bp[i] = in ? beta[l * N + n] : 0.f;
-    }
-}
-
-// LDS image of one operand part (hi or lo) of one 128-row panel for one 16-point stage:
-//   [plane h = points 8h..8h+7][slot][8 halves], slot(row r) = (r & 3) * 36 + (r >> 2), 148 slots per plane.
-// The stagers write 8-byte (4-byte on diagonal tiles) pieces of rows 4 fq + e at fixed e: consecutive fq are
-// consecutive slots and the plane pitch is 16 banks mod 32, so a lane group covers all 32 banks once; the fragment
-// reads (ds_read_b128, lane li -> row base + li) hit 16 distinct bank quads per lane group (36 = 4 mod 16).
-constexpr int kImgSlots = 2 * 148;            // 16-byte slots per image
-constexpr int kImgBytes = kImgSlots * 16;     // 4736
-constexpr int kStageBytes = 4 * kImgBytes;    // A hi | A lo | B hi | B lo
-
-// hi / lo float16 pair of two scaled values, packed: H = (f16(x0 s0), f16(x1 s1)), L = (f16(x0 s0 - H.lo), ...).
-// v_fma_mix{lo,hi}_f16 rounds the exact fma once and writes one half of the destination, so the four
-// instructions leave both words packed (the compiler's own lowering of the same arithmetic needs 2-3x as many).
-#define AGPL_SPLIT2(CS, x0_, s0_, x1_, s1_, H_, L_)                                                            \
-    do {                                                                                                       \
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(H_) : "v"(x0_), CS(s0_));                                   \
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(H_) : "v"(x1_), CS(s1_));                                   \
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(L_) : "v"(x0_), CS(s0_), "v"(H_));      \
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"                                 \
-            : "+v"(L_)                                                                                         \
-            : "v"(x1_), CS(s1_), "v"(H_));                                                                     \
-    } while (0)
-
-// g = Phi beta rides the staging registers: one v_fmac_f32 per term, written out (volatile asm, in program order).  Left to
-// the compiler the same sums become v_pk_mul_f32 / v_pk_fma_f32 chains scheduled among the MFMAs, and in some shapes of the
-// surrounding code (an extra wave-uniform branch in the MFMA block; two staging register sets) g then differed from run to
-// run at the 1e-4 level on the hardware while G stayed bit-identical -- root cause open (an isolated
-// replay of the instruction sequence computes correctly); the explicit sequence is bitwise reproducible in every shape tried
-// (tests/test_gpu_repeat.py soaks it).
-#define AGPL_GFMA(acc_, b_, x_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(b_), "v"(x_))
-
-// Staging geometry: a 16-lane group of a store must fill whole 16-byte slots (both 8-byte point halves) of
-// consecutive rows to touch every LDS bank once, so the point half is the lane's low bit.
-// DIAG = false: wave w -> (panel = w >> 1, plane = w & 1); lane -> (half = lane & 1, feature quad fq = lane >> 1);
-//               4 features x 4 points (8 plane + 4 half + 0..3) per thread: 4 float4 loads, 8 ds_write_b64.
-// DIAG = true : both panels are the same 128 rows: only panel A is staged; wave w -> (plane = w & 1, features
-//               64 (w >> 1) ..); lane -> (half = lane & 1, pp = (lane >> 1) & 1, fq = 16 (w >> 1) + (lane >> 2));
-//               4 features x 2 points (8 plane + 4 half + 2 pp + 0..1): 2 float4 loads, 8 ds_write_b32; B fragments
-//               read panel A; g = Phi beta is accumulated from the float32 staging registers.
-template <bool DIAG>
-__device__ __forceinline__ void syrk_split_body(unsigned char *smem_raw, const float *__restrict__ sbase, int M,
-                                                int bi, int bj, int nstage, int plast,
-                                                const float *__restrict__ sgs, const float *__restrict__ bps,
-                                                f32x16 (&acc)[2][2], float (&gacc)[4]) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
-    const bool active = !(DIAG && wr < wc); // the sub-tile above the diagonal of a diagonal tile is not multiplied
-    // the 32 x 32 block above the diagonal of a diagonal sub-tile (rows 0..31 x columns 32..63 of sub-tile (w, w) of a
-    // diagonal tile) is never read back: reduce_G_kernel mirrors element-wise from the lower triangle
-    const bool upper = !(DIAG && wr == wc);
-    constexpr int PQ = DIAG ? 2 : 4; // points per thread
-    const int panel = DIAG ? 0 : (wave >> 1);
-    const int plane = wave & 1;
-    const int half = lane & 1;
-    const int pp = DIAG ? ((lane >> 1) & 1) : 0;
-    const int fq = DIAG ? (16 * (wave >> 1) + (lane >> 2)) : (lane >> 1);
-    const int p0 = 8 * plane + 4 * half + 2 * pp; // first point (within the stage) of this thread
-    const unsigned colofs = (unsigned)((panel ? bj : bi) * BS + (fq << 2));
-    // byte offsets of this thread's PQ rows from the stage's first row; voffc: the same for the last stage, whose
-    // rows beyond the slice end are clamped to the slice's last point (their scale is 0)
-    unsigned voff[PQ], voffc[PQ];
-    const int lastbase = (nstage - 1) * 16;
-#pragma unroll
-    for (int q = 0; q < PQ; ++q) {
-        voff[q] = ((unsigned)((p0 + q) * M) + colofs) * 4u;
-        const int pc = (lastbase + p0 + q) < plast ? (p0 + q) : (plast - lastbase);
-        voffc[q] = ((unsigned)(pc * M) + colofs) * 4u;
-    }
-    const size_t stage_pitch = (size_t)16 * M * sizeof(float);
-    const unsigned soff = (unsigned)p0 * 4u; // byte offset of this thread's scales within the stage's 16
-    // destination of (feature 4 fq + e, points p0..): plane, slot e * 36 + fq, byte (p0 & 7) * 2
-    const unsigned dst0 = (unsigned)(panel * 2 * kImgBytes + plane * 148 * 16 + fq * 16 + (p0 & 7) * 2);
-    // fragment slots (16-byte units)
-    const int fslot = lk * 148 + (li & 3) * 36 + (li >> 2);
-    const int fa = fslot + wr * 16;
-    const int fb = (DIAG ? 0 : 2 * kImgSlots) + fslot + wc * 16;
-
-    float4 x[PQ];
-    float sv[PQ], bv[PQ];
-
-#define AGPL_SS_LOAD(st_)                                                                          \
-    do {                                                                                           \
-        const int sti_ = (st_);                                                                    \
-        const char *sb_ = reinterpret_cast<const char *>(sbase) + (size_t)sti_ * stage_pitch;     \
-        const bool lastst_ = sti_ == nstage - 1;                                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < PQ; ++q_)                                          \
-            x[q_] = *reinterpret_cast<const float4 *>(sb_ + (lastst_ ? voffc[q_] : voff[q_]));     \
-        const char *ss_ = reinterpret_cast<const char *>(sgs + sti_ * 16);                         \
-        if (DIAG) {                                                                                \
-            const float2 s2_ = *reinterpret_cast<const float2 *>(ss_ + soff);                      \
-            const float2 b2_ = *reinterpret_cast<const float2 *>(                                  \
-                reinterpret_cast<const char *>(bps + sti_ * 16) + soff);                           \
-            sv[0] = s2_.x; sv[1] = s2_.y; bv[0] = b2_.x; bv[1] = b2_.y;                            \
-        } else {                                                                                   \
-            const float4 s4_ = *reinterpret_cast<const float4 *>(ss_ + soff);                      \
-            sv[0] = s4_.x; sv[1] = s4_.y; sv[PQ - 2] = s4_.z; sv[PQ - 1] = s4_.w;                            \
-        }                                                                                          \
-    } while (0)
-#define AGPL_SS_STORE(buf_, gkeep_)                                                                \
-    do {                                                                                           \
-        unsigned char *dst_ = smem_raw + (buf_) * kStageBytes + dst0;                              \
-        if (DIAG) {                                                                                \
-            float ba_ = bv[0] * (gkeep_), bb2_ = bv[1] * (gkeep_);                                 \
-            AGPL_GFMA(gacc[0], ba_, x[0].x); AGPL_GFMA(gacc[0], bb2_, x[1].x);                       \
-            AGPL_GFMA(gacc[1], ba_, x[0].y); AGPL_GFMA(gacc[1], bb2_, x[1].y);                       \
-            AGPL_GFMA(gacc[2], ba_, x[0].z); AGPL_GFMA(gacc[2], bb2_, x[1].z);                       \
-            AGPL_GFMA(gacc[3], ba_, x[0].w); AGPL_GFMA(gacc[3], bb2_, x[1].w);                       \
-            unsigned h_, l_;                                                                       \
-            AGPL_SPLIT2("v", x[0].x, sv[0], x[1].x, sv[1], h_, l_);                                \
-            *reinterpret_cast<unsigned *>(dst_ + 0 * 36 * 16) = h_;                                \
-            *reinterpret_cast<unsigned *>(dst_ + kImgBytes + 0 * 36 * 16) = l_;                    \
-            AGPL_SPLIT2("v", x[0].y, sv[0], x[1].y, sv[1], h_, l_);                                \
-            *reinterpret_cast<unsigned *>(dst_ + 1 * 36 * 16) = h_;                                \
-            *reinterpret_cast<unsigned *>(dst_ + kImgBytes + 1 * 36 * 16) = l_;                    \
-            AGPL_SPLIT2("v", x[0].z, sv[0], x[1].z, sv[1], h_, l_);                                \
-            *reinterpret_cast<unsigned *>(dst_ + 2 * 36 * 16) = h_;                                \
-            *reinterpret_cast<unsigned *>(dst_ + kImgBytes + 2 * 36 * 16) = l_;                    \
-            AGPL_SPLIT2("v", x[0].w, sv[0], x[1].w, sv[1], h_, l_);                                \
-            *reinterpret_cast<unsigned *>(dst_ + 3 * 36 * 16) = h_;                                \
-            *reinterpret_cast<unsigned *>(dst_ + kImgBytes + 3 * 36 * 16) = l_;                    \
-        } else {                                                                                   \
-            uint2 h_, l_;                                                                          \
-            AGPL_SPLIT2("v", x[0].x, sv[0], x[1].x, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[PQ - 2].x, sv[PQ - 2], x[PQ - 1].x, sv[PQ - 1], h_.y, l_.y);                            \
-            *reinterpret_cast<uint2 *>(dst_ + 0 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 0 * 36 * 16) = l_;                       \
-            AGPL_SPLIT2("v", x[0].y, sv[0], x[1].y, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[PQ - 2].y, sv[PQ - 2], x[PQ - 1].y, sv[PQ - 1], h_.y, l_.y);                            \
-            *reinterpret_cast<uint2 *>(dst_ + 1 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 1 * 36 * 16) = l_;                       \
-            AGPL_SPLIT2("v", x[0].z, sv[0], x[1].z, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[PQ - 2].z, sv[PQ - 2], x[PQ - 1].z, sv[PQ - 1], h_.y, l_.y);                            \
-            *reinterpret_cast<uint2 *>(dst_ + 2 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 2 * 36 * 16) = l_;                       \
-            AGPL_SPLIT2("v", x[0].w, sv[0], x[1].w, sv[1], h_.x, l_.x);                            \
-            AGPL_SPLIT2("v", x[PQ - 2].w, sv[PQ - 2], x[PQ - 1].w, sv[PQ - 1], h_.y, l_.y);                            \
-            *reinterpret_cast<uint2 *>(dst_ + 3 * 36 * 16) = h_;                                   \
-            *reinterpret_cast<uint2 *>(dst_ + kImgBytes + 3 * 36 * 16) = l_;                       \
-        }                                                                                          \
-    } while (0)
-
-    AGPL_SS_LOAD(0);
-    AGPL_SS_STORE(0, 1.f);
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        // unconditional (the last iteration re-loads its own stage): a conditional load would make x a phi of
-        // loaded / not-loaded values and the copies would wait for the loads before the MFMAs
-        const bool more = st + 1 < nstage;
-        AGPL_SS_LOAD(more ? st + 1 : st);
-        __builtin_amdgcn_sched_barrier(0); // keep the loads above the MFMA block
-        if (active) {
-            const h8v *I = reinterpret_cast<const h8v *>(smem_raw + buf * kStageBytes);
-            const h8v ah0 = I[fa], ah1 = I[fa + 8], bh0 = I[fb], bh1 = I[fb + 8];
-            acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-            if (upper) acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
-            const h8v bl0 = I[kImgSlots + fb], bl1 = I[kImgSlots + fb + 8];
-            acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-            if (upper) acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
-            const h8v al0 = I[kImgSlots + fa], al1 = I[kImgSlots + fa + 8];
-            acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-            if (upper) acc[0][1] = mfma16(al0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(al1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(al1, bh1, acc[1][1]);
-        }
-        __builtin_amdgcn_sched_barrier(0); // ... and the wait for them below it
-        // slot buf^1 was last read in iteration st-1, which every wave left through the barrier below
-        // (unconditional as well: the compiler sinks loads whose only use is conditional below the MFMAs;
-        //  the duplicate of the last stage lands in the slot nobody reads again, with its g contribution zeroed)
-        AGPL_SS_STORE(buf ^ 1, more ? 1.f : 0.f);
-        __syncthreads();
-    }
-#undef AGPL_SS_LOAD
-#undef AGPL_SS_STORE
-}
-
-__global__ __launch_bounds__(256, 4) void syrk_split_kernel(int64_t N, int64_t Npad, int M, int npairs, int nsplit,
-                                                            const float *__restrict__ Phi,
-                                                            const float *__restrict__ sg_all,
-                                                            const float *__restrict__ bp_all,
-                                                            float *__restrict__ slabG, float *__restrict__ slabg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x;
-    const int nsplit8 = (nsplit + 7) / 8;
-    const int per_l = npairs * nsplit8 * 8;
-    const int l = blockIdx.x / per_l;
-    const int id = blockIdx.x - l * per_l;
-    const int xcd = id & 7, j = id >> 3;
-    const int s = (j / npairs) * 8 + xcd;
-    const int p = j % npairs;
-    if (s >= nsplit) return;
-    // static issue priorities that differ between groups of 256 consecutive workgroup ids: the four waves on a SIMD (one per
-    // co-resident workgroup) otherwise interleave their MFMA blocks instruction by instruction, finish together and convert
-    // together (round 2: -1 % at C2, -4.5 % at M = 1024; priorities by hardware slot, slice or tile pair change nothing)
-    switch ((blockIdx.x >> 8) & 3u) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-    const int nb = M / BS;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
-    const int bj = p - bi * (bi + 1) / 2;
-    const bool diag = (bi == bj);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
-    float gacc[4] = {0.f, 0.f, 0.f, 0.f};
-
-    // the tile kind is decided once: one call per body instance (a branch around the stage loop's body would make the
-    // accumulators a merge of both bodies' and spill them)
-    const int64_t nbeg = (int64_t)s * agpl_chunk_points(M);
-    int64_t nend = nbeg + agpl_chunk_points(M);
-    if (nend > N) nend = N;
-    const int nstage = (int)((nend - nbeg + 15) / 16);
-    const int plast = (int)(nend - 1 - nbeg);
-    if (diag)
-        syrk_split_body<true>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast, sg_all + (int64_t)l * Npad + nbeg,
-                              bp_all + (int64_t)l * Npad + nbeg, acc, gacc);
-    else
-        syrk_split_body<false>(smem_raw, Phi + nbeg * (int64_t)M, M, bi, bj, nstage, plast, sg_all + (int64_t)l * Npad + nbeg,
-                               bp_all + (int64_t)l * Npad + nbeg, acc, gacc);
-    if (diag) {
-        // lanes 4k..4k+3 hold the four point pairs of feature quad 16 (w >> 1) + k over this wave's plane
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gacc[e] += __shfl_xor(gacc[e], 1);
-            gacc[e] += __shfl_xor(gacc[e], 2);
-        }
-    }
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
-    float *slab = slabG + (((int64_t)l * npairs + p) * nsplit + s) * (int64_t)(BS * BS);
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int col = wc * 64 + jj * 32 + li;
-                slab[row * BS + col] = acc[ii][jj][r] * kPsiUnscale;
-            }
-    if (diag) {
-        // wave w, lane 4k: features 64 (w >> 1) + 4k .. + 3 over plane w & 1; sum the two planes through LDS
-        float *gw = reinterpret_cast<float *>(smem_raw); // [2 planes][128] (the stage images are dead by now)
-        __syncthreads();
-        if ((lane & 3) == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gw[(wave & 1) * 128 + (wave >> 1) * 64 + lane + e] = gacc[e];
-        }
-        __syncthreads();
-        if (tid < 128) slabg[(((int64_t)l * nb + bi) * nsplit + s) * BS + tid] = gw[tid] + gw[128 + tid];
-    }
-}
-
-size_t syrk_split_lds_bytes() { return 2 * kStageBytes; }
 
 
 
@@ -802,11 +501,6 @@ inline int syrk_nsplit(int64_t N, int M) { return (int)agpl_cdiv(N, agpl_chunk_p
 
 size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L);
 
-extern "C" int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L) {
-    if (N <= 0 || M <= 0 || M % BS || L <= 0) return 0;
-    return (int64_t)agpl_slab_bytes(N, M, L) + (int64_t)sizeof(float) * 4 * L * N + 2048;
-}
-
 extern "C" int32_t agpl_marginals(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
                                   const float *kdiag, const float *mu0, const float *Wpack, const float *alpha,
                                   float *mu_out, float *var_out) {
@@ -912,13 +606,8 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
         launch_rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
                                            (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, records_ready);
     } else if (ctx->accumulate_split) {
-        const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
-        float *sg = (float *)((char *)slab_mem + lo.sgam);
-        float *bp = sg + (int64_t)L * Npad;
-        split_prep_kernel<<<2048, 256, 0, ctx->stream>>>(N, Npad, L, gamma, beta, sg, bp);
-        // the float32-staged split kernel: M % 256 != 0, or no image (agpl_accumulate with precision 1)
-        syrk_split_kernel<<<(unsigned)nwg, 256, syrk_split_lds_bytes(), ctx->stream>>>(N, Npad, M, npairs, ns, Phi, sg, bp,
-                                                                                       slabG, slabg);
+        launch_rc = AGPL_ERR_INVALID_ARGUMENT; // (internal: the split-float16 accumulation exists on the image only)
+        snprintf(ctx->err, sizeof(ctx->err), "the split-float16 accumulation needs the accumulate image and M %% 256 == 0");
     } else
         syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, Phi, gamma, beta, slabG, slabg);
     rc = agpl_timing_end(ctx, 1);
@@ -946,41 +635,10 @@ extern "C" int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t 
     return agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, beta, gamma, G_out, g_out, ctx->ws, false);
 }
 
-extern "C" int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
-                                         const void *acc_image, const float *beta, const float *gamma, double *G_out,
-                                         double *g_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (N <= 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
-    if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
-    if ((!Phi && !acc_image) || !beta || !gamma || !G_out || !g_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    int32_t rc = agpl_ws_reserve(ctx, agpl_slab_bytes(N, M, L));
-    if (rc) return rc;
-    const int keep = ctx->accumulate_split;
-    ctx->accumulate_split = 1;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, beta, gamma, G_out, g_out, ctx->ws, false);
-    ctx->accumulate_split = keep;
-    if (rc) return rc;
-    if (acc_image && M % 256 == 0) {
-        // the image path takes gamma as it is (no square root that would turn a negative one into a NaN): the record kernel's
-        // "bad gamma" word is read back here -- this stand-alone entry point has no update behind it that would forward it
-        // (a sweep's passes do: agpl_pending_resolve).  One 4-byte copy and one synchronisation per call.
-        float *gb;
-        unsigned *scal, bad = 0;
-        agpl_accumulate_records(N, M, L, ctx->ws, &gb, &scal);
-        AGPL_HIP(ctx, hipMemcpyAsync(&bad, scal + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (bad)
-            AGPL_FAIL(ctx, AGPL_ERR_DOMAIN,
-                      "gamma is negative or not finite (first at flat index %u of the [latent][point] array): G and g hold the "
-                      "sums with it", bad - 1u);
-    }
-    return AGPL_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Measured float16 MFMA rate under sustained load (the ceiling the split contractions are priced against next to the
 // data-sheet peak): v_mfma_f32_32x32x16_f16 back to back, 12 per step into four 32 x 32 accumulators -- the instruction
-// mix of one 16-point stage of syrk_split_kernel's wave -- with (mode 1) or without (mode 0) the stage's eight 16-byte
+// mix of one 16-point stage of the accumulation's wave -- with (mode 1) or without (mode 0) the stage's eight 16-byte
 // fragment reads from LDS.  Launches are long (milliseconds) and repeated so that the clock the power management
 // settles on is the one measured.
 // ------------------------------------------------------------------------------------------------
@@ -1085,9 +743,16 @@ __global__ __launch_bounds__(256, 2) void mfma_f16_probe32_kernel(int iters, flo
 }
 } // namespace
 
-extern "C" int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
-                                       double *tflops_host, double *ms_host) {
+int32_t agpl_probe_mfma_f64_impl(agpl_ctx *ctx, int32_t iters, double *tflops_host); // agpl_dense.hip
+
+extern "C" int32_t agpl_probe_mfma(agpl_ctx *ctx, int32_t dtype, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
+                                   double *tflops_host, double *ms_host) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
+    if (dtype == AGPL_F64) {
+        if (ms_host) *ms_host = 0.0;
+        return agpl_probe_mfma_f64_impl(ctx, iters, tflops_host);
+    }
+    if (dtype != AGPL_F32) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "dtype must be AGPL_F64 or AGPL_F32 (float16 operands, float32 accumulate)");
     if (iters <= 0 || !tflops_host || mode < 0 || mode > 3 || workgroups_per_cu < 1 || workgroups_per_cu > 4)
         AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     int32_t rc = agpl_ws2_reserve(ctx, 4096);

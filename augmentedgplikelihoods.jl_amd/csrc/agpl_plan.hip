@@ -2,7 +2,7 @@
 //
 // Rounds 1-3 grew four generations of sweep entry points (agpl_cavi_pass, _split, _factor_split, _factor_image; the same for
 // the Gibbs pass and the accumulation), each with its own list of images and work arrays a host had to build in the right order
-// and keep consistent.  A plan owns them:
+// and keep consistent; round 5 removed all but the float32 one.  A plan owns the images:
 //   * the marginal image of Phi (split-float16, blocks by 128-point tile: the B operand of U Phi, agpl_split.hip) and the
 //     accumulate image (point-major: both operands of Phi Diag(gamma) Phi', agpl_syrk.hip), BOTH scaled by the same 2^e chosen
 //     from max |Phi| -- one domain (any finite feature range that can be scaled into float16: max |Phi| in 2^-24 .. 2^44, see
@@ -306,21 +306,16 @@ extern "C" int32_t agpl_plan_info(const agpl_plan *p, int64_t *N, int32_t *M, in
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_plan_factor(const agpl_plan *p, const double **U_out, const double **v_out, const float **resid_out) {
+extern "C" int32_t agpl_plan_state(const agpl_plan *p, double **U_out, double **v_out, void **U_hi_out, void **U_lo_out,
+                                   float **v32_out, double **logdet_out, const float **resid_out) {
     if (!p) return AGPL_ERR_INVALID_ARGUMENT;
     if (U_out) *U_out = p->A_work;
     if (v_out) *v_out = p->v;
-    if (resid_out) *resid_out = p->resid;
-    return AGPL_OK;
-}
-
-extern "C" int32_t agpl_plan_state(const agpl_plan *p, const void **U_hi_out, const void **U_lo_out, const float **v32_out,
-                                   const double **logdet_out) {
-    if (!p) return AGPL_ERR_INVALID_ARGUMENT;
     if (U_hi_out) *U_hi_out = p->U_hi;
     if (U_lo_out) *U_lo_out = p->U_lo;
     if (v32_out) *v32_out = p->v32;
     if (logdet_out) *logdet_out = p->logdet;
+    if (resid_out) *resid_out = p->resid;
     return AGPL_OK;
 }
 

@@ -66,29 +66,6 @@ __global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, c
     }
 }
 
-// W [L][M][M] float64 symmetric -> blocked hi / lo images of scale * W' (W'[a][b] = 2 W[a][b] for b > a, W[a][a], 0 below)
-__global__ __launch_bounds__(256) void pack_w_split_kernel(int M, const double *__restrict__ W, double scale,
-                                                           h8 *__restrict__ Wh, h8 *__restrict__ Wl) {
-    const int nks = M / KS, nb = M / BS;
-    const int l = blockIdx.z, rb = blockIdx.y, ks = blockIdx.x;
-    const int plane = threadIdx.x >> 7, row = threadIdx.x & 127;
-    const int a = rb * BS + row;
-    const double *Wr = W + ((int64_t)l * M + a) * M;
-    h8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int b = ks * KS + plane * 8 + j;
-        double v = b > a ? 2.0 * Wr[b] : (b == a ? Wr[b] : 0.0);
-        _Float16 x, y;
-        split_f16((float)(scale * v), x, y);
-        hi[j] = x;
-        lo[j] = y;
-    }
-    const int64_t blk = ((int64_t)l * nb + rb) * nks + ks;
-    Wh[blk * 256 + threadIdx.x] = hi;
-    Wl[blk * 256 + threadIdx.x] = lo;
-}
-
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -98,396 +75,7 @@ __device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// grid = (tiles of 128 points, L); 256 threads = 4 waves, each a 64 x 64 sub-tile (2 x 2 accumulators)
-__global__ __launch_bounds__(256, 4) void marginal_split_kernel(int64_t N, int M, const float *__restrict__ Phi,
-                                                                const h8 *__restrict__ Ph, const h8 *__restrict__ Pl,
-                                                                const float *__restrict__ kdiag,
-                                                                const float *__restrict__ mu0,
-                                                                const h8 *__restrict__ Wh, const h8 *__restrict__ Wl,
-                                                                const float *__restrict__ alpha_all,
-                                                                float *__restrict__ mu_out,
-                                                                float *__restrict__ var_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    h8 *stage = reinterpret_cast<h8 *>(smem_raw);                 // [2 buf][4 operand][256]
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + 2 * 4 * 4096); // M floats
-    float *qred = alpha_s + M;                                     // 2 x 128
-    float *mred = qred + 2 * NT;                                   // 2 x 128
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
-    const int l = blockIdx.y;
-    const int nb = M / BS, nks = M / KS;
-    const int64_t tile = blockIdx.x;
-    const int64_t n0 = tile * NT;
-    const h8 *Wh_l = Wh + (int64_t)l * nb * nks * 256;
-    const h8 *Wl_l = Wl + (int64_t)l * nb * nks * 256;
-    const h8 *Ph_t = Ph + tile * nks * 256;
-    const h8 *Pl_t = Pl + tile * nks * 256;
-
-    const float *alpha = alpha_all + (int64_t)l * M;
-    for (int a = tid; a < M; a += 256) alpha_s[a] = alpha[a];
-
-    const int nlim = (int)((N - 1 - n0) < (NT - 1) ? (N - 1 - n0) : (NT - 1));
-    const float *tile32 = Phi + n0 * (int64_t)M;
-    float qacc[2] = {0.f, 0.f};
-    float macc[2] = {0.f, 0.f};
-    h8 r0, r1, r2, r3;
-
-#define AGPL_SPLIT_LOAD(rb_, ks_)                                     \
-    do {                                                              \
-        const int64_t wb_ = ((int64_t)(rb_) * nks + (ks_)) * 256 + tid; \
-        const int64_t pb_ = (int64_t)(ks_) * 256 + tid;               \
-        r0 = Wh_l[wb_];                                               \
-        r1 = Wl_l[wb_];                                               \
-        r2 = Ph_t[pb_];                                               \
-        r3 = Pl_t[pb_];                                               \
-    } while (0)
-#define AGPL_SPLIT_STORE(buf_)                                        \
-    do {                                                              \
-        h8 *st_ = stage + (buf_) * 4 * 256;                           \
-        st_[tid] = r0;                                                \
-        st_[256 + tid] = r1;                                          \
-        st_[512 + tid] = r2;                                          \
-        st_[768 + tid] = r3;                                          \
-    } while (0)
-
-    for (int rb = 0; rb < nb; ++rb) {
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
-
-        const int ks_first = rb * (BS / KS);
-        const int nstage = nks - ks_first;
-        AGPL_SPLIT_LOAD(rb, ks_first);
-        __syncthreads(); // previous row block's readers of slot 0 are done
-        AGPL_SPLIT_STORE(0);
-        __syncthreads();
-        for (int s = 0; s < nstage; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nstage) AGPL_SPLIT_LOAD(rb, ks_first + s + 1);
-            const h8 *st = stage + buf * 4 * 256;
-            // fragments: plane lk, row (sub-tile base + li)
-            const int fa = lk * 128 + wr * 64 + li;
-            const int fb = lk * 128 + wc * 64 + li;
-            const h8 ah0 = st[fa], ah1 = st[fa + 32], al0 = st[256 + fa], al1 = st[256 + fa + 32];
-            const h8 bh0 = st[512 + fb], bh1 = st[512 + fb + 32], bl0 = st[768 + fb], bl1 = st[768 + fb + 32];
-            acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
-            acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-            acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
-            acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
-            acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
-            acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-            acc[0][1] = mfma16(al0, bh1, acc[0][1]);
-            acc[1][0] = mfma16(al1, bh0, acc[1][0]);
-            acc[1][1] = mfma16(al1, bh1, acc[1][1]);
-            if (s + 1 < nstage) AGPL_SPLIT_STORE(buf ^ 1);
-            __syncthreads();
-        }
-
-        // Hadamard epilogue with the exact float32 Phi: q_n += sum_{a in rb} Phi[a, n] T[a, n], and the mean
-        // mu_n += sum_{a in rb} alpha_a Phi[a, n] from the same registers (lane rows a = .. + 8 g + 4 lk + 0..3)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            int nl = wc * 64 + jj * 32 + li;
-            nl = nl > nlim ? nlim : nl;
-            const float *hsrc = tile32 + nl * M + rb * BS + wr * 64 + 4 * lk;
-            const float *asrc = alpha_s + rb * BS + wr * 64 + 4 * lk;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int g2 = 0; g2 < 4; g2 += 2) {
-                    const float4 h0 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2);
-                    const float4 h1 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2 + 8);
-                    const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2);
-                    const float4 a1 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2 + 8);
-                    qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
-                                acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
-                    qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
-                                acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
-                    macc[jj] += a0.x * h0.x + a0.y * h0.y + a0.z * h0.z + a0.w * h0.w;
-                    macc[jj] += a1.x * h1.x + a1.y * h1.y + a1.z * h1.z + a1.w * h1.w;
-                }
-        }
-    }
-#undef AGPL_SPLIT_LOAD
-#undef AGPL_SPLIT_STORE
-
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        qacc[jj] += __shfl_xor(qacc[jj], 32);
-        macc[jj] += __shfl_xor(macc[jj], 32);
-    }
-    __syncthreads();
-    if (lk == 0) {
-        qred[wr * NT + wc * 64 + li] = qacc[0];
-        qred[wr * NT + wc * 64 + 32 + li] = qacc[1];
-        mred[wr * NT + wc * 64 + li] = macc[0];
-        mred[wr * NT + wc * 64 + 32 + li] = macc[1];
-    }
-    __syncthreads();
-    if (tid < NT) {
-        const int64_t n = n0 + tid;
-        if (n < N) {
-            float q = qred[tid] + qred[NT + tid];
-            float m = mred[tid] + mred[NT + tid];
-            if (mu0) m += mu0[(int64_t)l * N + n];
-            mu_out[(int64_t)l * N + n] = m;
-            var_out[(int64_t)l * N + n] = kdiag[n] - q;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// marginal_split256_kernel: the same product on 256 (rows of W') x 256 (points) tiles, ONE 1024-thread workgroup
-// (16 waves, each a 64 x 64 sub-tile) per CU.  Against four independent 128 x 128 workgroups per CU this halves
-// the operand bytes pulled from L2 per MFMA (the 128-tile kernel moves ~117 GB per launch at C2, ~9 TB/s: it sits
-// at the L2 -> CU rate, not at the matrix cores), and one barrier now covers the MFMAs of four waves per SIMD.
-// Operand blocks travel global -> LDS by the DMA path (global_load_lds_dwordx4; the 4 KB images are already the
-// LDS layout: no staging VGPRs, no ds_write) through a ring of R stage slots of 32 KB:
-//   slot = [A blk0 hi | A blk0 lo | A blk1 hi | A blk1 lo | B tile0 hi | B tile0 lo | B tile1 hi | B tile1 lo]
-//   per stage:  wait(stage t landed) ; barrier ; issue(stage t + R - 1 -> the slot read in iteration t - 1) ; MFMAs(t)
-// The flat stage list runs over 256-row blocks rb2 and k-slices ks = 16 rb2 .. M/16 - 1 (W' is upper triangular);
-// in the first 8 slices of a row block its lower 128 rows are still zero and their waves issue no MFMA.
-//
-// FACTOR = true is the one-pass form:  I + G = R R', U = R^-1 (lower triangular), T = U Phi,
-//   var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2,   mu_n = mu0_n + sum_a v_a T[a,n],  v = U (g + eta0)
-// (S = U'U, m = U'v): the epilogue needs T only, so the float32 features are not read at all -- the launch reads
-// the feature images once per 256-row block and nothing else from HBM.  A-operand images hold U (k-slices
-// 0 .. 16 (rb2 + 1) - 1 of row block rb2; the upper 128 rows are zero in the block's last 8 slices), `alpha` holds v
-// and `kdiag` holds the residual k_nn - |phi_n|^2.
-// ------------------------------------------------------------------------------------------------
-constexpr int NT2 = 256;
-
-template <int R, bool FACTOR, int KU>
-__global__ __launch_bounds__(1024, 1) void marginal_split256_kernel(
-    int64_t N, int M, int64_t ntiles128, const float *__restrict__ Phi, const h8 *__restrict__ Ph,
-    const h8 *__restrict__ Pl, const float *__restrict__ kdiag, const float *__restrict__ mu0,
-    const h8 *__restrict__ Wh, const h8 *__restrict__ Wl, const float *__restrict__ alpha_all,
-    float *__restrict__ mu_out, float *__restrict__ var_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int kSlot = KU * 8 * 4096; // KU 16-deep k-slices per stage (= per barrier)
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // M floats
-    float *qred = alpha_s + M;                                         // 4 x 256
-    float *mred = qred + 4 * NT2;                                      // 4 x 256
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..15
-    const int wr = wave >> 2, wc = wave & 3;
-    const int li = lane & 31, lk = lane >> 5;
-    const int l = blockIdx.y;
-    const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
-    const int64_t tile2 = blockIdx.x;
-    const int64_t n0 = tile2 * NT2;
-
-    // this wave's two DMA pieces per stage: image ia of the A half and of the B half, quarter qd
-    const int ia = wave >> 2, qd = wave & 3;
-    const int64_t t128 = 2 * tile2 + (ia >> 1) < ntiles128 ? 2 * tile2 + (ia >> 1) : ntiles128 - 1;
-    const h8 *a_src = ((ia & 1) ? Wl : Wh) + ((int64_t)l * nb + (ia >> 1)) * nks * 256 + qd * 64 + lane;
-    const h8 *b_src = ((ia & 1) ? Pl : Ph) + t128 * nks * 256 + qd * 64 + lane;
-    const int dma_off = ia * 4096 + qd * 1024;
-
-    const float *alpha = alpha_all + (int64_t)l * M;
-    for (int a = tid; a < M; a += 1024) alpha_s[a] = alpha[a];
-
-    const int nlim = (int)((N - 1 - n0) < (NT2 - 1) ? (N - 1 - n0) : (NT2 - 1));
-    const float *tile32 = FACTOR ? nullptr : Phi + n0 * (int64_t)M;
-    float qacc[2] = {0.f, 0.f};
-    float macc[2] = {0.f, 0.f};
-
-    const int T = (nb2 * nks - 16 * nb2 * (nb2 - 1) / 2) / KU; // slices: 8 nb2 (nb2 + 1) in both forms; 16 % KU == 0
-    int irb = 0, iks = 0; // issue pointer
-    typedef __attribute__((address_space(3))) void lds_void;
-#define AGPL_DMA_ISSUE(t_)                                                                                  \
-    do {                                                                                                    \
-        unsigned char *slot_ = smem_raw + ((t_) % R) * kSlot + dma_off;                                     \
-        _Pragma("unroll") for (int u_ = 0; u_ < KU; ++u_) {                                                 \
-            __builtin_amdgcn_global_load_lds(a_src + ((int64_t)(2 * irb) * nks + iks + u_) * 256,          \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds(b_src + (int64_t)(iks + u_) * 256,                             \
-                                             (lds_void *)(slot_ + u_ * 8 * 4096 + 4 * 4096), 16, 0, 0);     \
-        }                                                                                                   \
-        iks += KU;                                                                                          \
-        if (iks == (FACTOR ? 16 * (irb + 1) : nks)) {                                                       \
-            ++irb;                                                                                          \
-            iks = FACTOR ? 0 : irb * 16;                                                                    \
-        }                                                                                                   \
-    } while (0)
-
-#pragma unroll
-    for (int t = 0; t < R - 1; ++t)
-        if (t < T) AGPL_DMA_ISSUE(t);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
-
-    // fragment indices (16-byte units within a slot)
-    const int fa = (wr >> 1) * 512 + lk * 128 + (wr & 1) * 64 + li;        // A blk (wr >> 1): hi at +0, lo at +256
-    const int fb = 1024 + (wc >> 1) * 512 + lk * 128 + (wc & 1) * 64 + li; // B tile (wc >> 1)
-
-    int rb = 0, ks = 0; // consume pointer
-    for (int t = 0; t < T; ++t) {
-        // stage t has landed once at most the stages issued after it are outstanding (2 KU DMAs each)
-        if (t + R - 2 < T) {
-            constexpr int kOut = 2 * KU * (R - 2);
-            static_assert(kOut < 16, "vmcnt immediate");
-            __builtin_amdgcn_s_waitcnt(0x0F70 | kOut); // vmcnt(kOut)
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        __builtin_amdgcn_s_barrier();
-        // rows 128..255 of the block are zero for the block's first 8 slices (strictly lower part of W');
-        // FACTOR: U is lower triangular, so this wave's rows 64 wr .. 64 wr + 63 of the block are zero from slice
-        // 16 rb + 4 (wr + 1) on (KU divides 4: a stage is skipped whole).  The four waves of a SIMD have the four
-        // values of wr, so every SIMD sheds the same share of the diagonal block's products.
-        const bool act = FACTOR ? ks < rb * 16 + 4 * (wr + 1) : !((wr >> 1) && ks < rb * 16 + 8);
-        // The DMA for stage t + R - 1 (into the slot read in iteration t - 1) is issued AFTER the first four MFMAs: its
-        // issue cost (~100 cycles per piece with 16 waves issuing at once) then overlaps matrix work instead of
-        // delaying the first MFMA of every wave behind the barrier.
-        // Fragment reads run one MFMA group ahead of their use (the lo parts of B are read with the hi parts, the lo
-        // parts of A and the next slice's hi parts while the previous group's MFMAs execute): the compiler's counted
-        // lgkmcnt waits then leave the LDS latency behind matrix work instead of in front of every group.
-        {
-            const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t % R) * kSlot);
-            h8 ah0, ah1, bh0, bh1, bl0, bl1;
-            if (act) {
-                ah0 = st[fa]; ah1 = st[fa + 32]; bh0 = st[fb]; bh1 = st[fb + 32];
-                bl0 = st[256 + fb]; bl1 = st[256 + fb + 32];
-                acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-                acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
-                acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
-                acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + R - 1 < T) AGPL_DMA_ISSUE(t + R - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (act) {
-#pragma unroll
-                for (int u = 0; u < KU; ++u) {
-                    const h8 *su = st + u * 8 * 256;
-                    const h8 al0 = su[256 + fa], al1 = su[256 + fa + 32];
-                    // the next slice's hi parts and lo(B), read before this slice's last two groups are issued
-                    h8 nah0, nah1, nbh0, nbh1, nbl0, nbl1;
-                    if (u + 1 < KU) {
-                        const h8 *sn = su + 8 * 256;
-                        nah0 = sn[fa]; nah1 = sn[fa + 32]; nbh0 = sn[fb]; nbh1 = sn[fb + 32];
-                        nbl0 = sn[256 + fb]; nbl1 = sn[256 + fb + 32];
-                    }
-                    acc[0][0] = mfma16(ah0, bl0, acc[0][0]);
-                    acc[0][1] = mfma16(ah0, bl1, acc[0][1]);
-                    acc[1][0] = mfma16(ah1, bl0, acc[1][0]);
-                    acc[1][1] = mfma16(ah1, bl1, acc[1][1]);
-                    acc[0][0] = mfma16(al0, bh0, acc[0][0]);
-                    acc[0][1] = mfma16(al0, bh1, acc[0][1]);
-                    acc[1][0] = mfma16(al1, bh0, acc[1][0]);
-                    acc[1][1] = mfma16(al1, bh1, acc[1][1]);
-                    if (u + 1 < KU) {
-                        ah0 = nah0; ah1 = nah1; bh0 = nbh0; bh1 = nbh1; bl0 = nbl0; bl1 = nbl1;
-                        acc[0][0] = mfma16(ah0, bh0, acc[0][0]);
-                        acc[0][1] = mfma16(ah0, bh1, acc[0][1]);
-                        acc[1][0] = mfma16(ah1, bh0, acc[1][0]);
-                        acc[1][1] = mfma16(ah1, bh1, acc[1][1]);
-                    }
-                }
-            }
-        }
-        ks += KU;
-        if (ks == (FACTOR ? 16 * (rb + 1) : nks)) {
-            if (FACTOR) {
-                // row block finished: q_n += sum_a T[a,n]^2, mu_n += sum_a v_a T[a,n] (lane rows a = .. + 8 g + 4 lk + 0..3)
-                const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * lk;
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g);
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const float t0 = acc[ii][jj][4 * g + 0], t1 = acc[ii][jj][4 * g + 1];
-                            const float t2 = acc[ii][jj][4 * g + 2], t3 = acc[ii][jj][4 * g + 3];
-                            qacc[jj] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-                            macc[jj] += a0.x * t0 + a0.y * t1 + a0.z * t2 + a0.w * t3;
-                        }
-                    }
-            } else {
-            // row block finished: Hadamard epilogue with the exact float32 Phi, and the mean from the same registers
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                int nl = wc * 64 + jj * 32 + li;
-                nl = nl > nlim ? nlim : nl;
-                const float *hsrc = tile32 + (int64_t)nl * M + rb * NT2 + wr * 64 + 4 * lk;
-                const float *asrc = alpha_s + rb * NT2 + wr * 64 + 4 * lk;
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int g2 = 0; g2 < 4; g2 += 2) {
-                        const float4 h0 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2);
-                        const float4 h1 = *reinterpret_cast<const float4 *>(hsrc + ii * 32 + 8 * g2 + 8);
-                        const float4 a0 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2);
-                        const float4 a1 = *reinterpret_cast<const float4 *>(asrc + ii * 32 + 8 * g2 + 8);
-                        qacc[jj] += acc[ii][jj][4 * g2 + 0] * h0.x + acc[ii][jj][4 * g2 + 1] * h0.y +
-                                    acc[ii][jj][4 * g2 + 2] * h0.z + acc[ii][jj][4 * g2 + 3] * h0.w;
-                        qacc[jj] += acc[ii][jj][4 * g2 + 4] * h1.x + acc[ii][jj][4 * g2 + 5] * h1.y +
-                                    acc[ii][jj][4 * g2 + 6] * h1.z + acc[ii][jj][4 * g2 + 7] * h1.w;
-                        macc[jj] += a0.x * h0.x + a0.y * h0.y + a0.z * h0.z + a0.w * h0.w;
-                        macc[jj] += a1.x * h1.x + a1.y * h1.y + a1.z * h1.z + a1.w * h1.w;
-                    }
-            }
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.f;
-            ++rb;
-            ks = FACTOR ? 0 : rb * 16;
-        }
-    }
-#undef AGPL_DMA_ISSUE
-
-    // the lane indices are re-derived here: kept live across the loop they are what the 128-VGPR cap spills
-    // (3 dwords per thread = 0.5 GB of scratch traffic per launch at C2)
-    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int li_e = lane_e & 31, lk_e = lane_e >> 5, tid_e = wave * 64 + lane_e;
-
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        qacc[jj] += __shfl_xor(qacc[jj], 32);
-        macc[jj] += __shfl_xor(macc[jj], 32);
-    }
-    if (lk_e == 0) {
-        qred[wr * NT2 + wc * 64 + li_e] = qacc[0];
-        qred[wr * NT2 + wc * 64 + 32 + li_e] = qacc[1];
-        mred[wr * NT2 + wc * 64 + li_e] = macc[0];
-        mred[wr * NT2 + wc * 64 + 32 + li_e] = macc[1];
-    }
-    __syncthreads();
-    if (tid_e < NT2) {
-        const int64_t n = n0 + tid_e;
-        if (n < N) {
-            float q = (qred[tid_e] + qred[NT2 + tid_e]) + (qred[2 * NT2 + tid_e] + qred[3 * NT2 + tid_e]);
-            float m = (mred[tid_e] + mred[NT2 + tid_e]) + (mred[2 * NT2 + tid_e] + mred[3 * NT2 + tid_e]);
-            if (mu0) m += mu0[(int64_t)l * N + n];
-            mu_out[(int64_t)l * N + n] = m;
-            var_out[(int64_t)l * N + n] = FACTOR ? kdiag[n] + q : kdiag[n] - q;
-        }
-    }
-}
+constexpr int NT2 = 256; // points per item of the queue kernel (two 128-point tiles of the image)
 
 // ------------------------------------------------------------------------------------------------
 // marginal_factor_queue_kernel: marginal_factor_persist_kernel<true> with the work cut one level finer and handed out
@@ -1094,7 +682,8 @@ extern "C" __attribute__((visibility("default"))) int agpl_debug_mtrace_phase(un
 }
 #endif
 
-extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
+// internal (agpl_plan.hip): bytes of ONE marginal image (hi or lo) for N points, M features
+int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
     if (N <= 0 || M <= 0 || M % BS) return 0;
     return (int64_t)sizeof(_Float16) * ((N + NT - 1) / NT) * NT * M; // per image (hi and lo each)
 }
@@ -1102,24 +691,7 @@ extern "C" int64_t agpl_split_features_bytes(int64_t N, int32_t M) {
 int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float limit, const char *what,
                                  unsigned *max_bits_out); // agpl_syrk.hip
 
-extern "C" int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *Phi_hi,
-                                       void *Phi_lo) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (N <= 0 || M <= 0 || M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need N > 0 and M %% 128 == 0");
-    if (!Phi || !Phi_hi || !Phi_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    // the marginal image is UNSCALED float16 hi / lo (its partner, the inverse factor U, has entries in [-1, 1]): a feature at or
-    // beyond the float16 range would become inf and every marginal behind it NaN -- refused here, with its position
-    unsigned max_bits = 0;
-    int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, 65504.0f, "the unscaled float16 marginal image", &max_bits);
-    if (rc) return rc;
-    int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
-    if (nblk > 65535 * 16) nblk = 65535 * 16;
-    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, 1.0f, (h8 *)Phi_hi, (h8 *)Phi_lo);
-    AGPL_LAUNCH_CHECK(ctx);
-    return AGPL_OK;
-}
-
-// internal (agpl_plan.hip): the same image of scale * Phi, no range check (the plan has checked the features and chosen the scale)
+// internal (agpl_plan.hip): the marginal image of scale * Phi (the plan has checked the features and chosen the scale)
 int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float scale, void *Phi_hi, void *Phi_lo) {
     int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
     if (nblk > 65535 * 16) nblk = 65535 * 16;
@@ -1128,51 +700,8 @@ int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, const flo
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_pack_w_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
-                                     void *W_hi, void *W_lo) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (M <= 0 || M % BS || L <= 0 || !W || !W_hi || !W_lo) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
-    dim3 grid((unsigned)(M / KS), (unsigned)(M / BS), (unsigned)L);
-    pack_w_split_kernel<<<grid, 256, 0, ctx->stream>>>(M, W, scale, (h8 *)W_hi, (h8 *)W_lo);
-    AGPL_LAUNCH_CHECK(ctx);
-    return AGPL_OK;
-}
-
-extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
-                                        const void *Phi_hi, const void *Phi_lo, const float *kdiag,
-                                        const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
-                                        float *mu_out, float *var_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (N < 0 || M <= 0 || L <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
-    if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
-    if (N == 0) return AGPL_OK;
-    if (!Phi || !Phi_hi || !Phi_lo || !kdiag || !W_hi || !W_lo || !alpha || !mu_out || !var_out)
-        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    const size_t lds = 2 * 4 * 4096 + sizeof(float) * (size_t)(M + 4 * NT);
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((unsigned)agpl_cdiv(N, NT), (unsigned)L);
-    int32_t rc = agpl_timing_begin(ctx, 0);
-    if (rc) return rc;
-    if (M % NT2 == 0) {
-        constexpr int R = 4;
-        const size_t lds2 = (size_t)R * 8 * 4096 + sizeof(float) * (size_t)(M + 8 * NT2);
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_split256_kernel<R, false, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        dim3 grid2((unsigned)agpl_cdiv(N, NT2), (unsigned)L);
-        marginal_split256_kernel<R, false, 1><<<grid2, 1024, lds2, ctx->stream>>>(
-            N, M, agpl_cdiv(N, NT), Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag, mu0, (const h8 *)W_hi,
-            (const h8 *)W_lo, alpha, mu_out, var_out);
-    } else {
-        marginal_split_kernel<<<grid, 256, lds, ctx->stream>>>(N, M, Phi, (const h8 *)Phi_hi, (const h8 *)Phi_lo, kdiag,
-                                                               mu0, (const h8 *)W_hi, (const h8 *)W_lo, alpha, mu_out,
-                                                               var_out);
-    }
-    AGPL_LAUNCH_CHECK(ctx);
-    return agpl_timing_end(ctx, 0);
-}
-
-// internal (agpl_update.hip): the same, forwarding ninfo <= 128 info words of the factorisation to pinned host memory
+// internal (agpl_update.hip, agpl_plan.hip): split-float16 images of 2^u_scale_exp U from A_work, forwarding ninfo <= 128 info words
+// of the factorisation to pinned host memory
 int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo,
                                     const int *info, int *info_host, int ninfo, int u_scale_exp) {
     if (M <= 0 || M % BS || L <= 0 || !A || !U_hi || !U_lo || ninfo > 127) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
@@ -1181,11 +710,6 @@ int32_t agpl_pack_factor_split_info(agpl_ctx *ctx, int32_t M, int32_t L, const d
                                                             (unsigned *)((char *)ctx->ws2 + 8192) + 8, ldexp(1.0, u_scale_exp));
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
-}
-
-extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    return agpl_pack_factor_split_info(ctx, M, L, A, U_hi, U_lo, nullptr, nullptr, 0, 0);
 }
 
 extern "C" int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
@@ -1245,16 +769,7 @@ int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     return AGPL_OK;
 }
 
-int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
-                                       const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
-                                       float *mu_out, float *var_out, int image_scale_exp);
-extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
-                                               const void *Phi_lo, const float *resid, const float *mu0,
-                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
-                                               float *var_out) {
-    return agpl_marginals_factor_internal(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu_out, var_out, 0);
-}
-// image_scale_exp: the point images hold 2^e Phi (0: the unscaled images of agpl_split_features)
+// (agpl_plan.hip) image_scale_exp: the point images hold 2^e Phi
 int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
                                        const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
                                        float *mu_out, float *var_out, int image_scale_exp) {

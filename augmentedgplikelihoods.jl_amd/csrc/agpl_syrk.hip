@@ -581,7 +581,8 @@ extern "C" __attribute__((visibility("default"))) int agpl_debug_qtrace(unsigned
 #endif
 
 
-extern "C" int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M) {
+// internal (agpl_plan.hip): bytes of the accumulate image (256-byte header + 4 KB blocks) for N points, M features
+int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M) {
     if (N <= 0 || M <= 0 || M % BS) return 0;
     const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2; // whole 32-point stages
     return (int64_t)sizeof(AccImageHeader) + nps * (M / BS) * 2 * 4096;
@@ -654,20 +655,6 @@ int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const f
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
-    if (M % BS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of %d (zero-pad the features)", M, BS);
-    if (!Phi || !image_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    unsigned hmx = 0;
-    int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, __builtin_inff(), "the accumulate image", &hmx);
-    if (rc) return rc;
-    int eA = 0;
-    rc = agpl_image_scale_exp(ctx, hmx, &eA);
-    if (rc) return rc;
-    return agpl_accumulate_image_build(ctx, N, M, Phi, eA, hmx, image_out);
-}
-
 // internal (agpl_accumulate_impl): prep + accumulation kernel; slabs as agpl_mfma.hip lays them out.
 // gb: 2 L Npad floats (the gamma | beta records), Npad = N rounded up to 32 (+ 32); scal: 2 words (max gamma bits, 1 + index
 // of a gamma that is negative or not finite).  records_ready: both are filled already; gamma / beta are not read.
@@ -683,7 +670,7 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
         AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (h.magic != kImageMagic || h.N != N || h.M != M)
             AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
-                      "not an accumulate image of this problem (agpl_accumulate_image / agpl_plan_create): header says N = %lld, "
+                      "not an accumulate image of this problem (agpl_plan_create): header says N = %lld, "
                       "M = %d, magic %#x; the call has N = %lld, M = %d",
                       (long long)h.N, (int)h.M, (unsigned)h.magic, (long long)N, (int)M);
         ctx->checked_image = image;

@@ -135,15 +135,6 @@ extern "C" void agpl_update_release(agpl_ctx *ctx) {
     }
 }
 
-extern "C" int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale, float *Wpack_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (M <= 0 || L <= 0 || !W || !Wpack_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
-    dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    pack_w_kernel<<<grid, 128, 0, ctx->stream>>>(M, W, scale, Wpack_out);
-    AGPL_LAUNCH_CHECK(ctx);
-    return AGPL_OK;
-}
-
 namespace {
 // logdet[l] = 2 sum_i log C_ii of the Cholesky factor (read between potrf and potri), fixed-order tree
 __global__ __launch_bounds__(256) void logdet_kernel(int M, const double *__restrict__ A, double *__restrict__ out) {
@@ -177,6 +168,13 @@ __global__ __launch_bounds__(256) void gauss_kl_kernel(int M, const double *__re
         __syncthreads();
     }
     if (threadIdx.x == 0) out[l] = 0.5 * (sm[0] - (double)M + logdet[l]);
+}
+__global__ void sum_latents_kernel(int L, const double *__restrict__ per, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int l = 0; l < L; ++l) t += per[l]; // fixed order
+        *out = t;
+    }
 }
 } // namespace
 
@@ -326,9 +324,6 @@ __global__ __launch_bounds__(256) void factor_apply_kernel(int M, const double *
     }
 }
 } // namespace
-
-extern "C" int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi,
-                                          void *U_lo);
 
 namespace {
 // 512 < M <= 1024: the same factorisation as two block rows (m1 = 512, m2 = M - 512) around the one-launch kernel:
@@ -500,27 +495,15 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
                                        void *U_lo, double *logdet_out, bool *armed, int u_scale_exp = 0);
 
 // I + G = R R' ; U = R^-1 ; v = U (g + eta0).  S = U'U and m = U'v are never formed: the factor form of the marginal
-// pass (agpl_marginals_factor_split) consumes U and v directly -- potrf + trtri instead of potrf + potri.
-extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                        const double *eta0, double *A_work, double *v_out, float *v32_out,
-                                        void *U_hi, void *U_lo, double *logdet_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    bool armed = false;
-    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, U_hi, U_lo, logdet_out, &armed);
-    if (rc) return rc;
-    return agpl_pending_resolve(ctx);
-}
-
-// The same, without waiting: the outcome (AGPL_ERR_NOT_POSDEF, ...) is reported by the next agpl_cavi_pass_factor_split
-// (after it has enqueued its own kernels -- the host never idles the GPU between the update and the next pass),
-// agpl_gaussian_factor[_async] or agpl_ctx_synchronize on this context.  Everything enqueued behind a failed
+// pass consumes U and v directly.  Asynchronous: the outcome (AGPL_ERR_NOT_POSDEF, ...) is reported by the next plan pass
+// (after it has enqueued its own kernels -- the host never idles the GPU between the update and the next pass), the next
+// agpl_gaussian_factor / agpl_plan_update, or agpl_ctx_synchronize on this context.  Everything enqueued behind a failed
 // factorisation computes on NaNs; nothing is lost but the timing of the report.
-extern "C" int32_t agpl_gaussian_factor_async(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                              const double *eta0, double *A_work, double *v_out, float *v32_out,
-                                              void *U_hi, void *U_lo, double *logdet_out) {
+extern "C" int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                        const double *eta0, double *A_work, double *v_out, double *logdet_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     bool armed = false;
-    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, U_hi, U_lo, logdet_out, &armed);
+    int32_t rc = gaussian_factor_enqueue(ctx, M, L, G, g, eta0, A_work, v_out, nullptr, nullptr, nullptr, logdet_out, &armed);
     if (rc) return rc;
     return armed ? AGPL_OK : agpl_pending_resolve(ctx);
 }
@@ -622,30 +605,23 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
 
 extern "C" int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                         const double *eta0, double *S_out, double *m_out, float *Wpack_out,
-                                        float *alpha_out) {
-    return gaussian_update_impl(ctx, M, L, G, g, eta0, S_out, m_out, Wpack_out, alpha_out, nullptr);
-}
-
-extern "C" int32_t agpl_gaussian_kl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                    const double *eta0, double *kl_out_host) {
+                                        float *alpha_out, double *kl_out) {
+    if (!kl_out) return gaussian_update_impl(ctx, M, L, G, g, eta0, S_out, m_out, Wpack_out, alpha_out, nullptr);
+    // KL(q(v) || N(0, I)) = sum_l (tr S_l + m_l'm_l - M + logdet(I + G_l)) / 2 of the q(v) just formed: needs S, m and the
+    // log-determinant read off the Cholesky factor; what the caller does not take lives in the large workspace
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    if (M <= 0 || L <= 0 || L > 64 || !G || !g || !kl_out_host) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
-    // scratch in the large workspace: S [L,M,M] | m [L,M] | logdet [L] | kl [L]
+    if (M <= 0 || L <= 0 || L > 64 || !G || !g) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     const size_t mat = sizeof(double) * (size_t)L * M * M, vec = sizeof(double) * (size_t)L * M;
     int32_t rc = agpl_ws_reserve(ctx, mat + vec + 4096);
     if (rc) return rc;
-    double *S = (double *)ctx->ws, *m = (double *)((char *)ctx->ws + mat);
+    double *S = S_out ? S_out : (double *)ctx->ws, *m = m_out ? m_out : (double *)((char *)ctx->ws + mat);
     double *ld = (double *)((char *)ctx->ws + mat + vec), *kl = ld + 64;
-    rc = gaussian_update_impl(ctx, M, L, G, g, eta0, S, m, nullptr, nullptr, ld);
+    rc = gaussian_update_impl(ctx, M, L, G, g, eta0, S, m, Wpack_out, alpha_out, ld);
     if (rc) return rc;
     gauss_kl_kernel<<<(unsigned)L, 256, 0, ctx->stream>>>(M, S, m, ld, kl);
     AGPL_LAUNCH_CHECK(ctx);
-    double h[64];
-    AGPL_HIP(ctx, hipMemcpyAsync(h, kl, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
-    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double tot = 0.0;
-    for (int l = 0; l < L; ++l) tot += h[l];
-    *kl_out_host = tot;
+    sum_latents_kernel<<<1, 64, 0, ctx->stream>>>(L, kl, kl_out);
+    AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }
 
@@ -724,14 +700,6 @@ extern "C" int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
                                    uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
                                    int64_t *n_out, uint32_t *nuni_out) {
     return agpl_gibbs_pass_internal(ctx, lik, N, M, Phi, nullptr, false, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
-                           n_out, nuni_out);
-}
-
-extern "C" int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
-                                         const void *Phi_acc, const float *kdiag, const float *mu0, const void *y,
-                                         const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
-                                         double *omega_out, int64_t *n_out, uint32_t *nuni_out) {
-    return agpl_gibbs_pass_internal(ctx, lik, N, M, Phi, Phi_acc, true, kdiag, mu0, y, v, sweep, G_out, g_out, f_out, omega_out,
                            n_out, nuni_out);
 }
 
@@ -880,53 +848,7 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     return AGPL_OK;
 }
 
-extern "C" int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
-                                        const void *Phi_hi, const void *Phi_lo, const float *kdiag,
-                                        const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
-                                        float *mu_out, float *var_out);
-
-extern "C" int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                        const float *Phi, const void *Phi_hi, const void *Phi_lo,
-                                        const float *kdiag, const float *mu0, const void *y, const void *W_hi,
-                                        const void *W_lo, const float *alpha, double *G_out, double *g_out,
-                                        float *c_out, float *gamma_out, float *beta_out) {
-    if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
-    agpl_lik_dev ld;
-    int32_t rc = agpl_lik_to_device(ctx, lik, &ld);
-    if (rc) return rc;
-    const int L = ld.nlatent;
-    if (N <= 0 || M <= 0) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d", (long long)N, M);
-    if (M % 128) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 128 (zero-pad the features)", M);
-    if (!Phi || !Phi_hi || !Phi_lo || !kdiag || !y || !W_hi || !W_lo || !alpha || !G_out || !g_out)
-        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    const size_t slab = (agpl_slab_bytes(N, M, L) + 255) & ~(size_t)255;
-    const size_t vec = (sizeof(float) * (size_t)L * N + 255) & ~(size_t)255;
-    rc = agpl_ws_reserve(ctx, slab + 4 * vec);
-    if (rc) return rc;
-    char *base = (char *)ctx->ws;
-    float *mu = (float *)(base + slab);
-    float *var = (float *)(base + slab + vec);
-    float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
-    float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
-    rc = agpl_marginals_split(ctx, N, M, L, Phi, Phi_hi, Phi_lo, kdiag, mu0, W_hi, W_lo, alpha, mu, var);
-    if (rc) return rc;
-    rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
-    if (rc) return rc;
-    // a split entry point implies the split-float16 accumulation (ctx->accumulate_split is internal: the float32-named entry points leave it 0)
-    const int keep = ctx->accumulate_split;
-    ctx->accumulate_split = 1;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, nullptr, bet, gam, G_out, g_out, base);
-    ctx->accumulate_split = keep;
-    return rc;
-}
-
-extern "C" int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
-                                               const void *Phi_lo, const float *resid, const float *mu0,
-                                               const void *U_hi, const void *U_lo, const float *v, float *mu_out,
-                                               float *var_out);
-
-// shared body (also agpl_plan.hip): acc_image == nullptr -> the accumulation stages the float32 Phi (syrk_split_kernel).
-// image_scale_exp: the marginal images hold 2^e Phi (0: agpl_split_features' unscaled images).  elbo_terms_out (device, may be
+// the plan's CAVI pass (agpl_plan.hip).  image_scale_exp: the marginal images hold 2^e Phi (times the U images' 2^15).  elbo_terms_out (device, may be
 // null; image path only): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) this pass used.
 int32_t agpl_cavi_pass_factor_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M, const float *Phi,
                                        const void *Phi_hi, const void *Phi_lo, const void *acc_image, const float *resid,
@@ -948,6 +870,8 @@ int32_t agpl_cavi_pass_factor_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, 
     char *base = (char *)ctx->ws;
     // a split entry point implies the split-float16 accumulation (ctx->accumulate_split is internal: the float32-named entry points leave it 0)
     const int keep = ctx->accumulate_split;
+    (void)slab;
+    (void)vec;
     if (acc_image && M % 256 == 0) {
         // three launches up to the slabs: marginal partial sums (MFMA) -> ONE per-point kernel (q(f_i), aux_posterior!,
         // expected potential / precision, written as the accumulation's gamma | beta records, and max gamma) -> accumulation.
@@ -974,40 +898,6 @@ int32_t agpl_cavi_pass_factor_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, 
         if (rc) return rc;
         return agpl_pending_resolve(ctx);
     }
-    if (elbo_terms_out) AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "the ELBO terms ride the image sweep only (M %% 256 == 0 and an accumulate image)");
-    float *mu = (float *)(base + slab);
-    float *var = (float *)(base + slab + vec);
-    float *gam = gamma_out ? gamma_out : (float *)(base + slab + 2 * vec);
-    float *bet = beta_out ? beta_out : (float *)(base + slab + 3 * vec);
-    rc = agpl_marginals_factor_internal(ctx, N, M, L, Phi_hi, Phi_lo, resid, mu0, U_hi, U_lo, v, mu, var, image_scale_exp);
-    if (rc) return rc;
-    rc = agpl_launch_fused_elementwise(ctx, ld, N, y, mu, var, gam, bet, c_out);
-    if (rc) return rc;
-    ctx->accumulate_split = 1;
-    rc = agpl_accumulate_impl(ctx, N, M, L, Phi, acc_image, bet, gam, G_out, g_out, base);
-    ctx->accumulate_split = keep;
-    if (rc) return rc;
-    // everything of this pass is enqueued: now is the free moment to look at the outcome of the factorisation before it
-    return agpl_pending_resolve(ctx);
+    AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the plan sweep needs the accumulate image and M %% 256 == 0");
 }
 
-extern "C" int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                               const float *Phi, const void *Phi_hi, const void *Phi_lo,
-                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
-                                               const void *U_lo, const float *v, double *G_out, double *g_out,
-                                               float *c_out, float *gamma_out, float *beta_out) {
-    if (ctx && !Phi) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    return agpl_cavi_pass_factor_internal(ctx, lik, N, M, Phi, Phi_hi, Phi_lo, nullptr, resid, mu0, y, U_hi, U_lo, v, G_out, g_out,
-                                          c_out, gamma_out, beta_out, 0, nullptr);
-}
-
-extern "C" int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                               const void *Phi_hi, const void *Phi_lo, const void *Phi_acc,
-                                               const float *resid, const float *mu0, const void *y, const void *U_hi,
-                                               const void *U_lo, const float *v, double *G_out, double *g_out,
-                                               float *c_out, float *gamma_out, float *beta_out) {
-    if (ctx && !Phi_acc) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
-    if (ctx && M % 256) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "M = %d must be a multiple of 256", M);
-    return agpl_cavi_pass_factor_internal(ctx, lik, N, M, nullptr, Phi_hi, Phi_lo, Phi_acc, resid, mu0, y, U_hi, U_lo, v, G_out,
-                                          g_out, c_out, gamma_out, beta_out, 0, nullptr);
-}

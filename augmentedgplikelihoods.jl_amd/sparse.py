@@ -117,15 +117,14 @@ class Plan:
         self._h = C.c_void_p()
         ctx.call("agpl_plan_create", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(L), _ptr(Phi), _ptr(resid),
                  C.c_uint32(flags), _ptr(self.mem), C.byref(self._h))
-        U, v, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _ffi.check(ctx._h, _ffi.lib().agpl_plan_factor(self._h, C.byref(U), C.byref(v), C.byref(r)))
+        U, v, uh, ul, v32, ld = (C.c_void_p() for _ in range(6))
+        _ffi.check(ctx._h, _ffi.lib().agpl_plan_state(self._h, C.byref(U), C.byref(v), C.byref(uh), C.byref(ul), C.byref(v32),
+                                                      C.byref(ld), None))
         base = self.mem.data_ptr()
         M = self.M
-        self.U_colmajor = self.mem[U.value - base: U.value - base + 8 * L * M * M].view(torch.float64).view(L, M, M)
-        self.v = self.mem[v.value - base: v.value - base + 8 * L * M].view(torch.float64).view(L, M)
-        uh, ul, v32, ld = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _ffi.check(ctx._h, _ffi.lib().agpl_plan_state(self._h, C.byref(uh), C.byref(ul), C.byref(v32), C.byref(ld)))
         view = lambda ptr, nb, dt: self.mem[ptr.value - base: ptr.value - base + nb].view(dt)
+        self.U_colmajor = view(U, 8 * L * M * M, torch.float64).view(L, M, M)
+        self.v = view(v, 8 * L * M, torch.float64).view(L, M)
         self.U_hi, self.U_lo = view(uh, 2 * L * M * M, torch.float16), view(ul, 2 * L * M * M, torch.float16)
         self.v32 = view(v32, 4 * L * M, torch.float32).view(L, M)
         self.logdet = view(ld, 8 * L, torch.float64)
@@ -141,7 +140,7 @@ class Plan:
     _STATE = ("U_colmajor", "v", "U_hi", "U_lo", "v32", "logdet")
 
     def state(self):
-        """Checkpoint of what an update rewrites (agpl_plan_factor + agpl_plan_state: U, v, their float16 / float32 images,
+        """Checkpoint of what an update rewrites (agpl_plan_state: U, v, their float16 / float32 images,
         log det(I + G)) as host tensors.  The images of Phi are static: a restoring process rebuilds them from the same features."""
         self.ctx.synchronize()
         return {k: getattr(self, k).detach().cpu().clone() for k in self._STATE}
@@ -191,13 +190,13 @@ class SparseCAVI:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 marginal_precision: str = "auto", accumulate_precision: str = "f16x2", track_elbo: bool = False,
-                 use_plan: bool = True):
-        """The shipped path (defaults, feature count a multiple of 256): ONE plan (agpl_plan_create: both split-float16 images
-        of Phi with one scale, q(v) in factor form) and agpl_cavi_pass_plan / agpl_plan_update per sweep.
-        ``marginal_precision`` / ``accumulate_precision`` = "f32": the float32-input MFMA kernels (agpl_cavi_pass), the
-        arithmetic SURVEY.md 8(d) prices.  The other combinations ("f16x2" marginals on W images, "f16x2-factor" without an
-        image, mixed precisions, ``use_plan=False``) drive the superseded per-generation entry points and exist for their tests.
+                 marginal_precision: str = "auto", accumulate_precision: str = "auto", track_elbo: bool = False):
+        """Two arithmetics, chosen for both contractions together:
+          * the shipped path ("f16x2-factor" marginals + "f16x2" accumulation; "auto" when the feature count is a multiple of
+            256): ONE plan (agpl_plan_create: both split-float16 images of Phi with one scale, q(v) in factor form) and
+            agpl_cavi_pass_plan / agpl_plan_update per sweep;
+          * "f32" / "f32" ("auto" otherwise): the float32-input MFMA kernels (agpl_cavi_pass + agpl_gaussian_update), the
+            arithmetic SURVEY.md 8(d) prices.
         ``track_elbo``: the per-point ELBO terms ride the pass and the Gaussian KL the update (plan path only); see
         ``elbo_entering``."""
         torch = _torch()
@@ -212,86 +211,56 @@ class SparseCAVI:
         self.y = _prep_y(lik, y, torch.float32)
         self.mu0 = _prep(mu0, torch.float32, "mu0")
         self.group = group
+        split_names = ("f16x2", "f16x2-factor")
         if marginal_precision == "auto":
-            marginal_precision = "f16x2-factor" if self.M % 256 == 0 else "f16x2"
-        if marginal_precision not in ("f32", "f16x2", "f16x2-factor"):
-            raise _ffi.ArgumentError(-1, "marginal_precision must be 'auto', 'f32', 'f16x2' or 'f16x2-factor'")
+            marginal_precision = ("f16x2-factor" if self.M % 256 == 0 else "f32") if accumulate_precision == "auto" \
+                else ("f32" if accumulate_precision == "f32" else "f16x2-factor")
+        if accumulate_precision == "auto":
+            accumulate_precision = "f32" if marginal_precision == "f32" else "f16x2"
+        if marginal_precision not in ("f32", "f16x2-factor") or accumulate_precision not in ("f32", "f16x2"):
+            raise _ffi.ArgumentError(-1, "marginal_precision must be 'auto', 'f32' or 'f16x2-factor', accumulate_precision 'auto', "
+                                         "'f32' or 'f16x2'")
+        if (marginal_precision in split_names) != (accumulate_precision == "f16x2"):
+            # the entry points come in two arithmetics: float32-input MFMA for both contractions (agpl_cavi_pass), or
+            # split-float16 for both (the plan)
+            raise _ffi.ArgumentError(-1, "marginal_precision and accumulate_precision must both be 'f32' or both be split-float16")
         self.marginal_precision = marginal_precision
         self.factor = marginal_precision == "f16x2-factor"
         if self.factor and self.M % 256:
-            raise _ffi.ArgumentError(-1, f"the factor form needs a feature count that is a multiple of 256 (got {self.M})")
-        self.split = marginal_precision in ("f16x2", "f16x2-factor")
-        if accumulate_precision not in ("f32", "f16x2"):
-            raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
-        self.acc_split = 1 if accumulate_precision == "f16x2" else 0
-        if self.split != bool(self.acc_split):
-            # the entry points come in two arithmetics: float32-input MFMA for both contractions (agpl_cavi_pass), or
-            # split-float16 for both (the plan and the superseded *_split calls, which always accumulate split)
-            raise _ffi.ArgumentError(-1, "marginal_precision and accumulate_precision must both be 'f32' or both be split-float16")
+            raise _ffi.ArgumentError(-1, f"the plan needs a feature count that is a multiple of 256 (got {self.M}; zero-pad)")
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
         self.plan = None
         self.track_elbo = bool(track_elbo)
-        if use_plan and self.factor and self.acc_split and M % 256 == 0:
-            self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
-            self.plan = Plan(self.Phi, self.resid, L, self.ctx)
-            self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev, extra=1 if self.track_elbo else 0)
-            self._kl = torch.zeros(2, dtype=f64, device=dev)  # KL(q(v) || p(v)) of the last two updates (q = N(0, I) at start)
-            self._elbo_terms = self._Gg[-1:] if self.track_elbo else None
-            self.A_work, self.v = self.plan.U_colmajor, self.plan.v
-            self._S = self._m = self.Wpack = self.Phi_acc = None
-            self.alpha = None
-            self.gamma = self.beta = self.c = None
-            if keep_points:
-                self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
-                self.beta = torch.empty((L, self.N), dtype=f32, device=dev)
-                self.c = torch.empty((self.N,) if L == 1 else (self.N, L), dtype=f32, device=dev)
-            self.nsweeps = 0
-            return
-        if self.track_elbo:
-            raise _ffi.ArgumentError(-1, "track_elbo rides the plan path (defaults, feature count a multiple of 256)")
-        if self.split:
-            nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(self.N), C.c_int32(M)) // 2
-            self.Phi_hi = torch.empty(nh, dtype=torch.float16, device=dev)
-            self.Phi_lo = torch.empty(nh, dtype=torch.float16, device=dev)
-            self.ctx.call("agpl_split_features", C.c_int64(self.N), C.c_int32(M), _ptr(self.Phi), _ptr(self.Phi_hi),
-                          _ptr(self.Phi_lo))
-            self.W_hi = torch.empty(L * M * M, dtype=torch.float16, device=dev)
-            self.W_lo = torch.empty(L * M * M, dtype=torch.float16, device=dev)
-        # the accumulation's own operand: the point-major split-float16 image (agpl_accumulate_image), M % 256 == 0
-        self.Phi_acc = accumulate_image(self.Phi, self.ctx) if (self.acc_split and M % 256 == 0) else None
-        self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev)
-        self.alpha = torch.zeros((L, M), dtype=f32, device=dev)
-        if self.factor:
-            # q(v) is carried as (U, v): S = U'U = I, m = U'v = 0 at the start (script.jl:41-42)
-            self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
-            self.A_work = torch.empty((L, M, M), dtype=f64, device=dev)
-            self.v = torch.zeros((L, M), dtype=f64, device=dev)
-            self._S = self._m = self.Wpack = None
-            self.update()
-        else:
-            self._S = torch.eye(M, dtype=f64, device=dev).repeat(L, 1, 1).contiguous()  # script.jl:42
-            self._m = torch.zeros((L, M), dtype=f64, device=dev)  # script.jl:41
-            self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
-            self.ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), _ptr(self._S), C.c_double(-1.0), _ptr(self.Wpack))
-            self._pack_split()
         self.gamma = self.beta = self.c = None
         if keep_points:
             self.gamma = torch.empty((L, self.N), dtype=f32, device=dev)
             self.beta = torch.empty((L, self.N), dtype=f32, device=dev)
             self.c = torch.empty((self.N,) if L == 1 else (self.N, L), dtype=f32, device=dev)
         self.nsweeps = 0
-
-    def _pack_split(self):
-        if self.split:
-            self.ctx.call("agpl_pack_w_split", C.c_int32(self.M), C.c_int32(self.L), _ptr(self._S), C.c_double(-1.0),
-                          _ptr(self.W_hi), _ptr(self.W_lo))
+        self._Gg, self.G, self.g = natural_parameter_buffers(L, M, dev, extra=1 if (self.track_elbo and self.factor) else 0)
+        self._kl = torch.zeros(2, dtype=f64, device=dev)  # KL(q(v) || p(v)) of the last two updates (q = N(0, I) at start)
+        if self.factor:
+            self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
+            self.plan = Plan(self.Phi, self.resid, L, self.ctx)
+            self._elbo_terms = self._Gg[-1:] if self.track_elbo else None
+            self.A_work, self.v = self.plan.U_colmajor, self.plan.v
+            self._S = self._m = self.Wpack = self.alpha = None
+            return
+        if self.track_elbo:
+            raise _ffi.ArgumentError(-1, "track_elbo rides the plan path (defaults, feature count a multiple of 256)")
+        # q(v) = N(0, I) (script.jl:41-42): the update of G = 0, g = 0 gives S = I, m = 0 and the packed -I the first pass reads
+        self._S = torch.empty((L, M, M), dtype=f64, device=dev)
+        self._m = torch.empty((L, M), dtype=f64, device=dev)
+        self.Wpack = torch.empty((L, M, M), dtype=f32, device=dev)
+        self.alpha = torch.empty((L, M), dtype=f32, device=dev)
+        self.update()
 
     @property
     def S(self):
         """Covariance of q(v).  In the factor form it is materialised on demand: S = U'U, U' = triu of A_work viewed
-        row-major (rocSOLVER leaves U in the column-major lower triangle)."""
+        row-major (the column-major lower triangle holds U)."""
         if not self.factor:
             return self._S
         self.check()
@@ -312,25 +281,6 @@ class SparseCAVI:
             self.plan.call("agpl_cavi_pass_plan", C.byref(d), _ptr(self.mu0), _ptr(self.y), _ptr(self.G), _ptr(self.g),
                            _ptr(self.c), _ptr(self.gamma), _ptr(self.beta), _ptr(self._elbo_terms))
             return
-        # ---- superseded entry points (kept for their tests) ----
-        if self.factor and self.Phi_acc is not None:
-            self.ctx.call("agpl_cavi_pass_factor_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
-                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.Phi_acc), _ptr(self.resid), _ptr(self.mu0),
-                          _ptr(self.y), _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g),
-                          _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
-            return
-        if self.factor:
-            self.ctx.call("agpl_cavi_pass_factor_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M),
-                          _ptr(self.Phi), _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0),
-                          _ptr(self.y), _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g),
-                          _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
-            return
-        if self.split:
-            self.ctx.call("agpl_cavi_pass_split", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
-                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y),
-                          _ptr(self.W_hi), _ptr(self.W_lo), _ptr(self.alpha), _ptr(self.G), _ptr(self.g), _ptr(self.c),
-                          _ptr(self.gamma), _ptr(self.beta))
-            return
         self.ctx.call("agpl_cavi_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.Wpack), _ptr(self.alpha),
                       _ptr(self.G), _ptr(self.g), _ptr(self.c), _ptr(self.gamma), _ptr(self.beta))
@@ -350,22 +300,16 @@ class SparseCAVI:
         exchange_natural_parameters(self.G, self.g, self.group, flat=getattr(self, "_Gg", None))
 
     def update(self):
-        """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the factor form
-        keeps U = chol(I + G)^-1 and v = U g (S = U'U, m = U'v) and packs the images of U."""
+        """S = (I + G)^-1, m = S g (examples/bernoulli/script.jl:35-36 in sparse whitened form); the plan keeps
+        U = chol(I + G)^-1 and v = U g (S = U'U, m = U'v) and the images of U."""
         if self.plan is not None:
             # enqueue only: a failed factorisation surfaces in the next accumulate() (once its kernels are queued),
             # in check(), or when S / m / elbo() are read -- the host never idles the GPU between update and pass
             kl = self._kl[self.nsweeps & 1:(self.nsweeps & 1) + 1] if self.track_elbo else None
             self.plan.call("agpl_plan_update", _ptr(self.G), _ptr(self.g), C.c_void_p(0), _ptr(kl))
             return
-        if self.factor:
-            self.ctx.call("agpl_gaussian_factor_async", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
-                          C.c_void_p(0), _ptr(self.A_work), _ptr(self.v), _ptr(self.alpha), _ptr(self.W_hi),
-                          _ptr(self.W_lo), C.c_void_p(0))
-            return
         self.ctx.call("agpl_gaussian_update", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
-                      C.c_void_p(0), _ptr(self._S), _ptr(self._m), _ptr(self.Wpack), _ptr(self.alpha))
-        self._pack_split()
+                      C.c_void_p(0), _ptr(self._S), _ptr(self._m), _ptr(self.Wpack), _ptr(self.alpha), _ptr(self._kl[:1]))
 
     def sweep(self):
         self.accumulate()
@@ -422,7 +366,7 @@ class SparseCAVI:
     def elbo(self):
         """aug_elbo of examples/bernoulli/script.jl:65-70 for the current q(v):
         expected_logtilt(lik, qΩ, y, qf) - aux_kldivergence(lik, qΩ, y) - KL(q(v) || p(v)), with qf the current
-        marginals and qΩ = aux_posterior(lik, y, qf) (float64 operator kernels + agpl_gaussian_kl).  Local points
+        marginals and qΩ = aux_posterior(lik, y, qf) (float64 operator kernels; the Gaussian KL from the factor).  Local points
         only: with N sharded, sum the first two terms over ranks and count the KL once."""
         from . import operators as ops
 
@@ -436,10 +380,14 @@ class SparseCAVI:
         qΩ = ops.aux_posterior(self.lik, y, qf, ctx=self.ctx)
         elt = ops.expected_logtilt(self.lik, qΩ, y, qf, ctx=self.ctx)
         kl_aux = ops.aux_kldivergence(self.lik, qΩ, y, ctx=self.ctx)
-        kl = C.c_double()
-        self.ctx.call("agpl_gaussian_kl", C.c_int32(self.M), C.c_int32(self.L), _ptr(self.G), _ptr(self.g),
-                      C.c_void_p(0), C.byref(kl))
-        return elt - kl_aux - kl.value
+        if self.plan is not None:
+            self.check()
+            Ut = torch.triu(self.A_work)  # U' (row-major view of the column-major lower triangle)
+            m = (Ut @ self.v.unsqueeze(-1)).squeeze(-1)
+            kl = 0.5 * float(((Ut * Ut).sum() + (m * m).sum() - self.L * self.M + self.plan.logdet.sum()).item())
+        else:
+            kl = float(self._kl[0].item())  # of the last agpl_gaussian_update (its kl_out)
+        return elt - kl_aux - kl
 
     def natural_parameters(self):
         """(Lambda_v, eta_v) = (I + G, g): the whitened natural parameters of q(v)."""
@@ -455,48 +403,21 @@ class SparseCAVI:
         if self.plan is not None:
             self.plan.call("agpl_marginals_plan", _ptr(self.mu0), _ptr(mu), _ptr(var))
             return mu, var
-        if self.factor:
-            self.ctx.call("agpl_marginals_factor_split", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L),
-                          _ptr(self.Phi_hi), _ptr(self.Phi_lo), _ptr(self.resid), _ptr(self.mu0), _ptr(self.W_hi),
-                          _ptr(self.W_lo), _ptr(self.alpha), _ptr(mu), _ptr(var))
-            return mu, var
         self.ctx.call("agpl_marginals", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(self.L), _ptr(self.Phi),
                       _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.Wpack), _ptr(self.alpha), _ptr(mu), _ptr(var))
         return mu, var
 
 
-def accumulate_image(Phi, ctx: Context | None = None):
-    """The accumulation's operand (agpl_accumulate_image): Phi float32 [N, Mp] -> the point-major split-float16 image
-    (uint8 tensor, 256-byte header + 4 KB blocks [point slice of 16][feature block of 128][hi | lo]).  Raises DomainError if
-    a feature is not finite."""
-    torch = _torch()
-    ctx = ctx or default_context()
-    Phi = _prep(Phi, torch.float32, "Phi")
-    N, M = Phi.shape
-    nbytes = _ffi.lib().agpl_accumulate_image_bytes(C.c_int64(N), C.c_int32(M))
-    if nbytes <= 0:
-        raise _ffi.ArgumentError(-1, f"feature count {M} must be a multiple of {PAD} (zero-pad)")
-    img = torch.empty(nbytes, dtype=torch.uint8, device=Phi.device)
-    ctx.call("agpl_accumulate_image", C.c_int64(N), C.c_int32(M), _ptr(Phi), _ptr(img))
-    return img
-
-
 def nystrom_residual(Phi, kxx, ctx: Context | None = None):
-    """d_i = k_ii - |phi_i|^2 through agpl_marginals with W = I, alpha = 0."""
+    """d_i = k_ii - |phi_i|^2 (agpl_feature_residual: float64 accumulation), the `resid` of a plan / `kdiag` of the sweeps."""
     torch = _torch()
     ctx = ctx or default_context()
     Phi = _prep(Phi, torch.float32, "Phi")
     N, M = Phi.shape
     kxx = _prep(kxx, torch.float32, "kxx")
-    eye = torch.eye(M, dtype=torch.float64, device=Phi.device).unsqueeze(0).contiguous()
-    Wp = torch.empty((1, M, M), dtype=torch.float32, device=Phi.device)
-    ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(1), _ptr(eye), C.c_double(1.0), _ptr(Wp))
-    alpha = torch.zeros((1, M), dtype=torch.float32, device=Phi.device)
-    mu = torch.empty((1, N), dtype=torch.float32, device=Phi.device)
-    var = torch.empty_like(mu)
-    ctx.call("agpl_marginals", C.c_int64(N), C.c_int32(M), C.c_int32(1), _ptr(Phi), _ptr(kxx), C.c_void_p(0),
-             _ptr(Wp), _ptr(alpha), _ptr(mu), _ptr(var))
-    return var[0].contiguous()
+    out = torch.empty(N, dtype=torch.float32, device=Phi.device)
+    ctx.call("agpl_feature_residual", C.c_int64(N), C.c_int32(M), _ptr(Phi), _ptr(kxx), _ptr(out))
+    return out
 
 
 class SparseGibbs:
@@ -515,13 +436,16 @@ class SparseGibbs:
     """
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
-                 accumulate_precision: str = "f16x2", point_offset: int = 0, plan: "Plan | None" = None):
-        """``plan``: the plan of a SparseCAVI over the same features (its accumulate image and residual are shared); by
-        default (split accumulation, feature count a multiple of 256) a plan without the marginal image is built here."""
+                 accumulate_precision: str = "auto", point_offset: int = 0, plan: "Plan | None" = None):
+        """``accumulate_precision``: "f16x2" (the plan's split-float16 image accumulation; "auto" when the feature count is a
+        multiple of 256) or "f32" (agpl_gibbs_pass: float32-input MFMA).  ``plan``: the plan of a SparseCAVI over the same
+        features (its accumulate image and residual are shared); by default a plan without the marginal image is built here."""
         torch = _torch()
         self.ctx = ctx or default_context()
+        if accumulate_precision == "auto":
+            accumulate_precision = "f16x2" if (Phi.shape[1] % 256 == 0 or plan is not None) else "f32"
         if accumulate_precision not in ("f32", "f16x2"):
-            raise _ffi.ArgumentError(-1, "accumulate_precision must be 'f32' or 'f16x2'")
+            raise _ffi.ArgumentError(-1, "accumulate_precision must be 'auto', 'f32' or 'f16x2'")
         self.acc_split = 1 if accumulate_precision == "f16x2" else 0
         self.lik = lik
         self.Phi = _prep(Phi, torch.float32, "Phi")
@@ -537,8 +461,10 @@ class SparseGibbs:
         L, M = self.L, self.M
         f64 = torch.float64
         self.plan = None
-        self.Phi_acc = None
-        if self.acc_split and M % 256 == 0:
+        if self.acc_split and M % 256:
+            raise _ffi.ArgumentError(-1, f"the split-float16 accumulation needs a feature count that is a multiple of 256 (got {M}; "
+                                         "zero-pad, or accumulate_precision='f32')")
+        if self.acc_split:
             if plan is not None and (plan.N, plan.M, plan.L) != (self.N, M, L):
                 raise _ffi.ArgumentError(-1, "the plan was created for another problem size")
             if plan is not None and plan.ctx is not self.ctx:
@@ -602,11 +528,6 @@ class SparseGibbs:
                 self.plan.call("agpl_gibbs_pass_plan", C.byref(d), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
                                C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
                                _ptr(self.n), C.c_void_p(0))
-            elif self.acc_split:  # superseded entry point (feature counts that are not a multiple of 256)
-                self.ctx.call("agpl_gibbs_pass_image", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
-                              _ptr(self.Phi_acc), _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v),
-                              C.c_uint32(self.sweep_index), _ptr(self.G), _ptr(self.g), _ptr(self.f), _ptr(self.omega),
-                              _ptr(self.n), C.c_void_p(0))
             else:
                 self.ctx.call("agpl_gibbs_pass", C.byref(d), C.c_int64(self.N), C.c_int32(self.M), _ptr(self.Phi),
                               _ptr(self.kdiag), _ptr(self.mu0), _ptr(self.y), _ptr(self.v), C.c_uint32(self.sweep_index),

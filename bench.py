@@ -88,7 +88,7 @@ def read_timing(ctx, which):
     from agpl_amd import _ffi
 
     ms, cnt = C.c_double(), C.c_int64()
-    _ffi.check(ctx.bind(), _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt)))
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(which), C.byref(ms), C.byref(cnt)))
     return ms.value, cnt.value
 
 
@@ -101,7 +101,7 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
         cavi.sweep()
     barrier()
     cavi.exchange_timing = [] if cavi.group is not None else None  # hipEvent pairs around every exchange() of the timed sweeps
-    _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-1), None, None)
     read_timing(ctx, 0)  # discard what earlier legs left in the kernel timers (the sampler legs call cavi.marginals() with the
     read_timing(ctx, 1)  # timers on: two C2-size launches used to be averaged into the m1024 leg's marginal kernel: 16.8 for 20.1 ms)
     # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
@@ -120,7 +120,7 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
     dt = time.perf_counter() - t0
     gc.enable()
     kt = [read_timing(ctx, 0), read_timing(ctx, 1)]
-    _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+    _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-2), None, None)
     if cavi.exchange_timing is not None:
         xs = [a.elapsed_time(b) for a, b in cavi.exchange_timing]
         cavi.exchange_ms = (sum(xs) / max(len(xs), 1), max(xs) if xs else 0.0)
@@ -133,7 +133,7 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     (SURVEY.md 8d): marginal pass 2 L n M^2, accumulation L n M^2 (n = local points)."""
     flops = (2.0 * L * n_loc * M * M, 1.0 * L * n_loc * M * M)
     nbk = Mp // 128
-    msplit = marginal in ("f16x2", "f16x2-factor")
+    msplit = marginal == "f16x2-factor"
     # executed flops: factor-form marginal kernel -- a wave (64 rows) stops at its own diagonal and skips the all-zero upper
     # half of its last stage -> (1 + 32 / M) M^2 per point; accumulation -- lower tile pairs only, on a diagonal tile the
     # sub-tile above the diagonal idles and (split tile kernel) the two diagonal sub-tiles skip their upper 32 x 32 block
@@ -141,13 +141,11 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
     image_acc = accumulate == "f16x2" and Mp % 256 == 0  # syrk_strip_kernel (agpl_syrk.hip): 16 x 16 blocks on or below the diagonal
     ex_s = (1.0 + 16.0 / Mp) if image_acc else (nbk + (0.25 if accumulate == "f16x2" else 0.5)) / nbk
     executed = (ex_m * L * n_loc * Mp * Mp, ex_s * L * n_loc * Mp * Mp)
-    # kernel names as the library picks them (agpl_split.hip / agpl_mfma.hip defaults): the factor form runs resident
-    # workgroups on 16x16x32 MFMA serving per-XCD item queues; the split accumulation reads the point-major image
-    # (syrk_strip_kernel) when the padded M is a multiple of 256, else stages the float32 features (syrk_split_kernel)
-    names = (("marginal_factor_queue_kernel" if marginal == "f16x2-factor" else
-              "marginal_split256_kernel" if Mp % 256 == 0 else "marginal_split_kernel") if msplit else "marginal_kernel<0>",
-             ("syrk_strip_kernel" if image_acc else "syrk_split_kernel")
-             if accumulate == "f16x2" else "syrk_kernel")
+    # kernel names as the library picks them: the plan's marginal pass runs resident workgroups on 16x16x32 MFMA serving per-XCD
+    # item queues (agpl_split.hip), its accumulation reads the point-major image (syrk_strip_kernel, agpl_syrk.hip); the
+    # float32-input pair is marginal_kernel<0> / syrk_kernel (agpl_mfma.hip)
+    names = ("marginal_factor_queue_kernel" if msplit else "marginal_kernel<0>",
+             "syrk_strip_kernel" if accumulate == "f16x2" else "syrk_kernel")
     mult = (3.0 if msplit else 1.0, 3.0 if accumulate == "f16x2" else 1.0)
     peaks = (PEAK_F16_MFMA_TFLOPS if msplit else PEAK_F32_MFMA_TFLOPS,
              PEAK_F16_MFMA_TFLOPS if accumulate == "f16x2" else PEAK_F32_MFMA_TFLOPS)
@@ -182,7 +180,7 @@ def roofline_of(kt, L, n_loc, M, Mp, marginal, accumulate, ms_per_step, world, N
 
 
 def sustained_f16(ctx, roofline):
-    """The float16 MFMA rate this device SUSTAINS (agpl_probe_mfma_f16: the accumulation kernel's own instruction mix, 12
+    """The float16 MFMA rate this device SUSTAINS (agpl_probe_mfma: the accumulation kernel's own instruction mix, 12
     MFMAs + 8 LDS fragment reads per step, nothing else, four waves per SIMD, ~40 ms of back-to-back launches): under
     matrix load the clock settles well below the boost clock the 2.5 PFLOP/s data-sheet peak assumes, so this -- not
     `peak` -- is what a perfect kernel of this shape could execute.  Added next to `peak`/`frac`, which stay the guide's."""
@@ -190,20 +188,20 @@ def sustained_f16(ctx, roofline):
     from agpl_amd import _ffi
 
     tf, ms = C.c_double(0), C.c_double(0)
-    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f16(ctx.bind(), C.c_int32(5000), C.c_int32(1), C.c_int32(4),
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma(ctx.bind(), C.c_int32(_ffi.F32), C.c_int32(5000), C.c_int32(1), C.c_int32(4),
                                                           C.byref(tf), C.byref(ms)))
     roofline["sustained_mfma_f16"] = {
         "tflops": round(tf.value, 1), "frac_of_peak": round(tf.value / PEAK_F16_MFMA_TFLOPS, 3),
-        "probe": "agpl_probe_mfma_f16(mode 1: 12 v_mfma_f32_32x32x16_f16 + 8 ds_read_b128 per step, 4 waves/SIMD), "
+        "probe": "agpl_probe_mfma(float16, mode 1: 12 v_mfma_f32_32x32x16_f16 + 8 ds_read_b128 per step, 4 waves/SIMD), "
                  "6 launches of %.1f ms timed as one region" % ms.value}
     # the shape the shipped kernels issue (16x16x32, one stage of the marginal kernel's wave, hashed operands): the ceiling the
     # executed fractions below are taken against
     tf2, ms2 = C.c_double(0), C.c_double(0)
-    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f16(ctx.bind(), C.c_int32(3000), C.c_int32(3), C.c_int32(2),
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma(ctx.bind(), C.c_int32(_ffi.F32), C.c_int32(3000), C.c_int32(3), C.c_int32(2),
                                                           C.byref(tf2), C.byref(ms2)))
     roofline["sustained_mfma_f16_16x16x32"] = {
         "tflops": round(tf2.value, 1), "frac_of_peak": round(tf2.value / PEAK_F16_MFMA_TFLOPS, 3),
-        "probe": "agpl_probe_mfma_f16(mode 3: 48 v_mfma_f32_16x16x32_f16 + 16 ds_read_b128 per step, hashed operands, "
+        "probe": "agpl_probe_mfma(float16, mode 3: 48 v_mfma_f32_16x16x32_f16 + 16 ds_read_b128 per step, hashed operands, "
                  "2 waves/SIMD), 6 launches of %.1f ms timed as one region" % ms2.value}
     ceiling = max(tf.value, tf2.value)
     for k in roofline["kernels"]:
@@ -296,7 +294,7 @@ def marginal_sample_indices(n, seed=11, ntiles=64, nrandom=4096):
 
 def full_size_marginal_check(cavi, Phi, mu=None, var=None):
     """The marginal kernel of the plan path at ANY N with the REAL posterior factor: after >= 1 update, q(v) = (U, v) is pulled from
-    the plan (agpl_plan_factor: U float64, column-major lower triangle), and mu_n = sum_a v_a T[a,n], var_n = d_n + sum_a T[a,n]^2,
+    the plan (agpl_plan_state: U float64, column-major lower triangle), and mu_n = sum_a v_a T[a,n], var_n = d_n + sum_a T[a,n]^2,
     T = U Phi (the `marginals(post_u(x))` of examples/bernoulli/script.jl:32-33 in factor form, include/agpl.h) is evaluated in
     float64 from the float32 feature rows of a sample of points (marginal_sample_indices) and compared with agpl_marginals_plan's
     float32 mu, var.  Then gamma, beta of those points (if the object exports them) against the float64 Bernoulli / NegBin / ...
@@ -442,7 +440,7 @@ def m1024_leg(A, ctx, args):
                       "float32_features": round(Phi.numel() * 4 / 1e9, 2)}}
     del cavi
     if not args.no_parity:
-        out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2")
+        out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2", ns=10_000)
     if not args.no_extra:
         # BASELINE configs[2] (C3: NegBin r = 15, N = 1e7, M = 1024) on ONE GPU, on the same features (x_i depends on (seed, i)
         # only): the numerator of c3r's projected 8-GPU scaling
@@ -492,7 +490,7 @@ def c5_leg(A, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     peak = C.c_double()
-    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma_f64(ctx.bind(), C.c_int32(4096), C.byref(peak)))
+    _ffi.check(ctx.bind(), _ffi.lib().agpl_probe_mfma(ctx.bind(), C.c_int32(_ffi.F64), C.c_int32(4096), C.c_int32(0), C.c_int32(1), C.byref(peak), None))
     tf = N ** 3 / 3 / dt / 1e12
     out = {"config": {"workload": f"StudentT(3.5, 2.0) full-rank Gibbs step, N={N}, SE kernel lengthscale 2.0, jitter 1e-6"},
            "value": round(1.0 / dt, 4), "unit": "sweeps/s", "ms_per_step": round(dt * 1e3, 1), "steps": steps, "dtype": "f64",
@@ -500,7 +498,7 @@ def c5_leg(A, args):
                       "trailing_update_kernel); 2048-wide diagonal blocks: own kernels (potrf64 + panel solve + the same update "
                       "kernel), overlapped with the update on a side stream; panel solves: rocBLAS dtrsm",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s (N^3/3 per sweep, float64)",
-                        "peak": round(peak.value, 1), "peak_source": "agpl_probe_mfma_f64: v_mfma_f64_16x16x4_f64 "
+                        "peak": round(peak.value, 1), "peak_source": "agpl_probe_mfma(float64): v_mfma_f64_16x16x4_f64 "
                         "back-to-back on every SIMD, measured on this device in this run",
                         "frac": round(tf / peak.value, 4) if peak.value > 0 else None},
            "f_finite": bool(torch.isfinite(dg.f).all().item()),
@@ -569,7 +567,7 @@ def main():
                     help="total observations (sharded over ranks)")
     ap.add_argument("--m", "--inducing", dest="m", type=int, default=512, help="inducing points")
     ap.add_argument("--lik", default="bernoulli")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="points of the CPU-baseline cross-check sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
@@ -585,9 +583,9 @@ def main():
     ap.add_argument("--c5-n", type=int, default=65_536)
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
-    ap.add_argument("--marginal", default="auto", choices=["auto", "f32", "f16x2", "f16x2-factor"],
-                    help="marginal pass: f32-input MFMA, split-float16 MFMA (3 f16 products per f32 product), or its "
-                         "one-pass factor form (needs padded M %% 256 == 0; auto picks it when it applies)")
+    ap.add_argument("--marginal", default="auto", choices=["auto", "f32", "f16x2-factor"],
+                    help="marginal pass: f32-input MFMA (with --accumulate f32), or the plan's split-float16 factor form "
+                         "(3 f16 products per f32 product; needs padded M %% 256 == 0; auto picks it when it applies)")
     args = ap.parse_args()
     default_config = (args.n, args.m, args.lik) == (10_000_000, 512, "bernoulli")
 
@@ -662,7 +660,9 @@ def main():
     Mp = Phi.shape[1]
 
     if args.marginal == "auto":
-        args.marginal = "f16x2-factor" if Mp % 256 == 0 else "f16x2"
+        args.marginal = "f16x2-factor" if (Mp % 256 == 0 and args.accumulate == "f16x2") else "f32"
+    if args.marginal == "f32":
+        args.accumulate = "f32"
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group, marginal_precision=args.marginal,
                         accumulate_precision=args.accumulate)
 
@@ -741,7 +741,7 @@ def main():
         for _ in range(2):
             gib.sweep()
         torch.cuda.synchronize()
-        _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+        _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-1), None, None)
         nsw = max(3, args.steps // 2)
         t0 = time.perf_counter()
         for _ in range(nsw):
@@ -801,7 +801,7 @@ def main():
             a, b = out["gibbs"]["sampler"].get("pg1_draws_per_s"), out["gibbs"]["sampler_negbin"].get("pg1_draws_per_s")
             out["gibbs"]["negbin_over_bernoulli_pg1_rate"] = round(b / a, 3) if a and b else None
             del yn
-        _ffi.lib().agpl_timing_enable(ctx.bind(), 0)
+        _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-2), None, None)
 
     # ---- parity leg: a slice of the same workload, GPU vs oracle, 10 sweeps ---------------------
     if not args.no_parity:
@@ -828,7 +828,7 @@ def main():
             mchk = full_size_marginal_check(cavi, Phi)
             out["full_size_check"]["marginals"] = {
                 **mchk, "reference": "float64 T = U Phi from the float32 feature rows of the sampled points, U, v from "
-                                     "agpl_plan_factor after the timed sweeps", "tolerance": 2e-5,
+                                     "agpl_plan_state after the timed sweeps", "tolerance": 2e-5,
                 "pass": bool(mchk["max_rel_d_mu"] < 2e-5 and mchk["max_rel_d_var"] < 2e-5 and mchk["max_abs_offdiag_U"] > 1e-3)}
             out["full_size_check"]["pass"] = bool(out["full_size_check"]["pass"] and out["full_size_check"]["marginals"]["pass"])
 
@@ -877,13 +877,14 @@ def main():
         full = None
         want_full = args.cpu_full if args.cpu_full is not None else (default_config and not args.no_extra)
         if want_full and L == 1 and extra.get("blas_twin_matches_oracle"):
-            # ONE sweep of the BLAS twin over ALL n_loc points, in chunks of the sample's size (the float32 features live on the
+            # ONE sweep of the BLAS twin over ALL n_loc points, in chunks of 1e6 points (the float32 features live on the
             # device: each chunk is copied to the host outside the timed regions; only the CPU work is timed) -- a measured
             # figure, the 1e6-point sample above stays as its cross-check
             Gf, gf = np.zeros((Mp, Mp)), np.zeros(Mp)
             t_full = 0.0
-            for c0 in range(0, n_loc, ns):
-                c1 = min(n_loc, c0 + ns)
+            chunk = 1_000_000
+            for c0 in range(0, n_loc, chunk):
+                c1 = min(n_loc, c0 + chunk)
                 Pc, kc, yc = Phi[c0:c1].cpu().numpy(), kd[c0:c1].cpu().numpy().astype(np.float64), y[c0:c1].cpu().numpy()
                 t0 = time.perf_counter()
                 P = Pc.astype(np.float64)
@@ -897,7 +898,7 @@ def main():
             t0 = time.perf_counter()
             O.gaussian_update(Gf[None], gf[None])
             t_full += time.perf_counter() - t0
-            full = {"value": 1.0 / t_full, "seconds": round(t_full, 2), "points": n_loc, "chunks": -(-n_loc // ns),
+            full = {"value": 1.0 / t_full, "seconds": round(t_full, 2), "points": n_loc, "chunks": -(-n_loc // chunk),
                     "extrapolated_from_sample": blas_value, "measured_over_extrapolated": round((1.0 / t_full) / blas_value, 3)}
             cpu_value = full["value"]
             note = (f"MEASURED: one full sweep over all {n_loc} points with the two contractions through numpy/OpenBLAS (float64) "
@@ -955,7 +956,7 @@ def main():
 
             # BASELINE configs[3] (C4): categorical K = 10, N = 1e6, M = 256 -- CAVI and Gibbs
             def c4():
-                o, _ = config_leg(A, ctx, "categorical", 1_000_000, 256, steps=5, gibbs=True, no_parity=args.no_parity, parity_points=20_000)
+                o, _ = config_leg(A, ctx, "categorical", 1_000_000, 256, steps=10, gibbs=True, no_parity=args.no_parity, parity_points=10_000)
                 return o
             leg("c4", c4)
         if not args.no_m1024:
@@ -970,13 +971,13 @@ def main():
             # one rank's share of the north-star configuration (Bernoulli, N = 1.25e6, M = 1024) and of C3 (NegBin r = 15, same
             # features): CAVI (+ Gibbs for C3), ten-sweep parity, projected 8-GPU scaling against the full-N single-GPU legs above
             def n8_m1024():
-                o, wl = config_leg(A, ctx, "bernoulli", N // 8, 1024, steps=6, no_parity=args.no_parity)
+                o, wl = config_leg(A, ctx, "bernoulli", N // 8, 1024, steps=6, no_parity=args.no_parity, parity_points=5_000)
                 full = out.get("m1024", {}).get("ms_per_step")
                 o["projected_scaling_8"] = round(full / o["ms_per_step"], 3) if full else None
                 out["n8_m1024"] = o
                 nlik = make_lik(A, "negbin")
                 _, yn = A.synth_xy(nlik, SEED, 0, N // 8, ctx=ctx, want_x=False)
-                o3, _ = config_leg(A, ctx, "negbin", N // 8, 1024, steps=6, gibbs=True, no_parity=args.no_parity,
+                o3, _ = config_leg(A, ctx, "negbin", N // 8, 1024, steps=6, gibbs=True, no_parity=args.no_parity, parity_points=5_000,
                                    workload=(yn, wl[1], wl[2]),
                                    label=f"one rank's share of C3: NegBin(r=15) SVGP CAVI sweep, N={N // 8}, M=1024, L=1")
                 full3 = out.get("m1024", {}).get("c3_full_one_gpu", {}).get("ms_per_step")

@@ -132,21 +132,15 @@ int main(int argc, char **argv) {
     AGPL(agpl_ctx_synchronize(ctx));
     HIP(hipFree(Kzx));
     HIP(hipFree(x));
-    // d_i = k_ii - |phi_i|^2 through agpl_marginals with W = I, alpha = 0 (sparse.py nystrom_residual)
+    // d_i = k_ii - |phi_i|^2 (agpl_feature_residual; sparse.py nystrom_residual), k_ii = 1 for the unit-variance kernel
     float *resid = dalloc<float>((size_t)N);
     {
-        std::vector<double> eye((size_t)M * M, 0.0);
-        for (int j = 0; j < M; ++j) eye[(size_t)j * M + j] = 1.0;
         std::vector<float> ones((size_t)N, 1.0f);
-        double *eyed = dalloc<double>((size_t)M * M);
-        float *Wp = dalloc<float>((size_t)M * M), *alpha0 = dalloc<float>((size_t)M, true);
-        float *kxx = dalloc<float>((size_t)N), *mu = dalloc<float>((size_t)N);
-        HIP(hipMemcpy(eyed, eye.data(), sizeof(double) * M * M, hipMemcpyHostToDevice));
+        float *kxx = dalloc<float>((size_t)N);
         HIP(hipMemcpy(kxx, ones.data(), sizeof(float) * N, hipMemcpyHostToDevice));
-        AGPL(agpl_pack_w(ctx, M, 1, eyed, 1.0, Wp));
-        AGPL(agpl_marginals(ctx, N, M, 1, Phi, kxx, nullptr, Wp, alpha0, mu, resid));
+        AGPL(agpl_feature_residual(ctx, N, M, Phi, kxx, resid));
         AGPL(agpl_ctx_synchronize(ctx));
-        HIP(hipFree(eyed)); HIP(hipFree(Wp)); HIP(hipFree(alpha0)); HIP(hipFree(kxx)); HIP(hipFree(mu));
+        HIP(hipFree(kxx));
     }
 
     // ---- state of the sweep -- SparseCAVI.__init__: ONE plan (both split-float16 images of Phi with one scale, the residual,

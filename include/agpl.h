@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGPL_VERSION 110
+#define AGPL_VERSION 120
 
 #if defined(__GNUC__)
 #define AGPL_API __attribute__((visibility("default")))
@@ -86,7 +86,7 @@ AGPL_API int32_t agpl_ctx_set_seed(agpl_ctx *ctx, uint64_t seed);
  * observations sets i0 here and, with the same seed on every rank, draws exactly what one process
  * holding all N points would (agpl_gibbs_draw_v is unaffected: every rank must draw the identical v).           */
 AGPL_API int32_t agpl_ctx_set_point_offset(agpl_ctx *ctx, int64_t i0);
-/* waits for the context's stream; also returns what an agpl_gaussian_factor_async still has to report */
+/* waits for the context's stream; also returns what an asynchronous factorisation (agpl_gaussian_factor, agpl_plan_update) still has to report */
 AGPL_API int32_t agpl_ctx_synchronize(agpl_ctx *ctx);
 AGPL_API const char *agpl_last_error(const agpl_ctx *ctx);
 AGPL_API int32_t agpl_version(void);
@@ -200,21 +200,15 @@ AGPL_API int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L,
  *   docs/src/index.md:154-163.  float64 Cholesky (rocSOLVER potrf/potri) on device.
  *   G [L,M,M], g [L,M], eta0 [L,M] or NULL.  Outputs (any may be NULL): S_out [L,M,M] f64,
  *   m_out [L,M] f64, Wpack_out [L,M,M] f32 (packed -S, so that var = kdiag + phi' S phi through
- *   agpl_marginals), alpha_out [L,M] f32 (= m).  Returns AGPL_ERR_NOT_POSDEF if I + G is not SPD.   */
+ *   agpl_marginals), alpha_out [L,M] f32 (= m).  Returns AGPL_ERR_NOT_POSDEF if I + G is not SPD.
+ *   kl_out (device double, may be NULL): sum over latents of KL(q(v_l) || N(0, I)) = (tr S + m'm - M + logdet(I + G)) / 2 of the
+ *   q(v) just formed -- the `kldivergence(u_post.approx.q, u_post.approx.fz)` term of aug_elbo (examples/bernoulli/script.jl:65-70)
+ *   in the whitened basis (agpl_gaussian_kl of v110 folded in).  G = 0, g = 0 gives S = I, m = 0 and the packed -I a sweep
+ *   starts from (script.jl:41-42; agpl_pack_w of v110).                                                                  */
 AGPL_API int32_t agpl_gaussian_update(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                              const double *eta0, double *S_out, double *m_out, float *Wpack_out,
-                             float *alpha_out);
+                             float *alpha_out, double *kl_out);
 
-/* agpl_gaussian_kl: sum over latents of KL(q(v_l) || p(v_l)) = (tr S + m'm - M + logdet(I + G)) / 2 for the
- *   q(v) that agpl_gaussian_update would produce from (G, g, eta0): the `kldivergence(u_post.approx.q,
- *   u_post.approx.fz)` term of aug_elbo (examples/bernoulli/script.jl:65-70) in the whitened basis, where the
- *   prior is N(0, I).  float64, synchronous, result to host.                                               */
-AGPL_API int32_t agpl_gaussian_kl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                  const double *eta0, double *kl_out_host);
-
-/* agpl_pack_w: Wpack (float32, packed as above) from a symmetric float64 W [L,M,M] scaled by `scale`. */
-AGPL_API int32_t agpl_pack_w(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
-                    float *Wpack_out);
 
 /* agpl_cavi_pass: one fused pass = agpl_marginals -> agpl_aux_posterior ->
  *   agpl_expected_potential_precision -> agpl_accumulate (the loop body of
@@ -257,159 +251,37 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
                                        const double *Lk, const double *mu0, const void *y, double *f_inout,
                                        double *B_work, uint32_t sweep, double *omega_out, int64_t *n_out);
 
-/* agpl_probe_mfma_f64: measured float64 MFMA rate of this device [TFLOP/s] (v_mfma_f64_16x16x4_f64 back to back on
- *   every SIMD for `iters` x 16 instructions per wave): the peak bench.py prices the C5 Cholesky against
- *   ("FP64 peak is not in the local guide -- measure, don't assume").  Synchronous.              */
-AGPL_API int32_t agpl_probe_mfma_f64(agpl_ctx *ctx, int32_t iters, double *tflops_host);
-
-/* agpl_debug_force_factor_rescue: test hook.  The one-launch M x M factorisation (agpl_gaussian_factor*, M <= 1024) runs as
- *   cooperating workgroups that assume each other resident; should other work hold their CUs, the launch reports it and a
- *   second launch queued behind it redoes the latent in one workgroup, without the host.  on != 0 makes every cooperative
- *   launch of this context take that path at once, so that it can be tested (it is otherwise never exercised on an idle
- *   device); the results are the cooperative launch's.  No reference counterpart (the reference calls LAPACK). */
-AGPL_API int32_t agpl_debug_force_factor_rescue(agpl_ctx *ctx, int32_t on);
-
-/* agpl_probe_mfma_f16: SUSTAINED float16 MFMA rate of this device [TFLOP/s]: v_mfma_f32_32x32x16_f16 in the instruction
- *   mix of one stage of the split accumulation's wave (12 per step into four 32 x 32 accumulators), six launches of
- *   `iters` steps per wave timed as one region after two that settle the clocks, `workgroups_per_cu` (1..4) 4-wave
- *   workgroups per CU.  mode 0: MFMA only; mode 1: with that stage's eight 16-byte LDS fragment reads; modes 2, 3: the
- *   same for v_mfma_f32_16x16x32_f16 in the mix of one stage of the shipped marginal kernel's wave (48 per step into
- *   sixteen 16 x 16 accumulators, hashed operands, at most 2 workgroups per CU; 3: with the stage's sixteen fragment reads)
- *   -- the shape the shipped
- *   contractions issue.  The ceiling bench.py reports next to the data-sheet peak (the clock under MFMA load is below the
- *   boost clock).  ms_host (may be NULL): average launch duration.  Synchronous.                                  */
-AGPL_API int32_t agpl_probe_mfma_f16(agpl_ctx *ctx, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
-                                     double *tflops_host, double *ms_host);
-
-/* Optional in-library timing of the two MFMA kernels (bench.py's roofline leg): when enabled, a hipEvent
- * pair is recorded on the context's stream around every launch of the marginal (which = 0), the
- * accumulation (which = 1), the Gibbs per-point (which = 2) and the aux_sample (which = 3) kernel.  agpl_timing_read synchronises the stream, returns the summed kernel
- * time [ms] and the number of launches since the last read, and resets the counters.                 */
-AGPL_API int32_t agpl_timing_enable(agpl_ctx *ctx, int32_t on);
-AGPL_API int32_t agpl_timing_read(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host);
-
-/* ---- split-float16 marginal pass (agpl_split.hip): the same a11 computation on the fast matrix cores ----------
- * Every float32 operand x is carried as hi = f16(x), lo = f16(x - hi); W' Phi ~= hi*hi + hi*lo + lo*hi runs as
- * three v_mfma_f32_32x32x16_f16 per sub-product with float32 accumulation (representation error
- * <= max(2^-22 |x|, 3e-8) per operand, |x| < 6e4).  Operands live in blocked images (4 KB blocks of
- * [2 planes][128 rows][8 halves], one per (row block, 16-wide k-slice)) that are both the HBM and the LDS layout.
- *   agpl_split_features_bytes: bytes of ONE image (hi or lo) for N points, M features.
- *   agpl_split_features: Phi (float32 [M,N] col-major) -> Phi_hi, Phi_lo images (once per data set).  This image is
- *                        UNSCALED: AGPL_ERR_DOMAIN (point and feature in agpl_last_error) if a feature is not finite
- *                        or |x| >= 65504, the float16 range.  Synchronises the stream once.
- *   agpl_pack_w_split:   scale * W' (W symmetric float64 [L,M,M]) -> W_hi, W_lo images, L*M*M halves each
- *                        (each sweep, after agpl_gaussian_update: W = S, scale = -1).
- *   agpl_marginals_split / agpl_cavi_pass_split: drop-in twins of agpl_marginals / agpl_cavi_pass taking the
- *                        images (the float32 Phi is still read by the Hadamard epilogue and the accumulation). */
-AGPL_API int64_t agpl_split_features_bytes(int64_t N, int32_t M);
-AGPL_API int32_t agpl_split_features(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *Phi_hi,
-                                     void *Phi_lo);
-AGPL_API int32_t agpl_pack_w_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *W, double scale,
-                                   void *W_hi, void *W_lo);
-AGPL_API int32_t agpl_marginals_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
-                                      const void *Phi_hi, const void *Phi_lo, const float *kdiag,
-                                      const float *mu0, const void *W_hi, const void *W_lo, const float *alpha,
-                                      float *mu_out, float *var_out);
-AGPL_API int32_t agpl_cavi_pass_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                      const float *Phi, const void *Phi_hi, const void *Phi_lo,
-                                      const float *kdiag, const float *mu0, const void *y, const void *W_hi,
-                                      const void *W_lo, const float *alpha, double *G_out, double *g_out,
-                                      float *c_out, float *gamma_out, float *beta_out);
-
-/* ---- factor (one-pass) form of the split-float16 marginal pass -------------------------------------------------
- * I + G = R R' (Cholesky), U = R^-1 (lower triangular), T = U Phi:
- *     var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2        mu_n = mu0_n + sum_a v_a T[a,n],   v = U (g + eta0)
- * which is the same q(f_n) as agpl_marginals (S = U'U, m = U'v; reference: the marginals of q(u) = N(m, S) pushed
- * through K_XZ K_ZZ^-1, examples/<lik>/script.jl `u_posterior` + the SVGP predictive of ApproximateGPs) but needs T only:
- * the launch reads the feature images once per 256-row block and never the float32 features.  M % 256 == 0.
- *
- * agpl_feature_residual : resid_n = k_nn - |phi_n|^2 (static; float64 accumulation).
- * agpl_gaussian_factor  : A_work [L,M,M] f64 scratch/out (on return its column-major lower triangle holds U);
- *                         v_out [L,M] f64 / v32_out [L,M] f32 / (U_hi, U_lo) images / logdet_out [L] f64 (device,
- *                         log det(I + G)) are optional.  AGPL_ERR_NOT_POSDEF as agpl_gaussian_update.
- * agpl_pack_factor_split: images of U from A_work (what agpl_gaussian_factor does when U_hi / U_lo are given).
- * agpl_marginals_factor_split / agpl_cavi_pass_factor_split: the factor-form twins of agpl_marginals_split /
- *                         agpl_cavi_pass_split (`resid` in place of kdiag, U images and v in place of W-pack and alpha).   */
+/* ---- the M x M update in factor form (agpl_factor.hip) -------------------------------------------------------------------
+ * I + G = R R' (Cholesky), U = R^-1 (lower triangular):  S = (I + G)^-1 = U'U,  m = S (g + eta0) = U'v,  v = U (g + eta0) --
+ * the update of examples/bernoulli/script.jl:35-36 kept as (U, v), which is all the marginals need:
+ *     var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2,   mu_n = mu0_n + sum_a v_a T[a,n],   T = U Phi
+ * (the same q(f_n) as agpl_marginals; reference: the marginals of q(u) = N(m, S) pushed through K_XZ K_ZZ^-1).
+ * agpl_gaussian_factor : A_work [L,M,M] f64 scratch/out (on return its column-major lower triangle holds U); v_out [L,M] f64 and
+ *                        logdet_out [L] f64 (device, log det(I + G)) are optional.  One hand-written launch for M <= 1024
+ *                        (rocSOLVER beyond).  ASYNCHRONOUS: a failed factorisation (AGPL_ERR_NOT_POSDEF with the pivot row, ...)
+ *                        is reported by the next agpl_gaussian_factor / agpl_plan_update / agpl_cavi_pass_plan on this context
+ *                        -- after that call has enqueued its own kernels, so the host never idles the GPU inside a sweep loop
+ *                        (script.jl:34-38) -- or by agpl_ctx_synchronize.  Work enqueued behind a failed factorisation computes
+ *                        on NaNs; only the moment of the report moves.
+ * agpl_feature_residual: resid_n = k_nn - |phi_n|^2 (static; float64 accumulation), the `resid` of agpl_plan_create.        */
+AGPL_API int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
+                                      const double *eta0, double *A_work, double *v_out, double *logdet_out);
 AGPL_API int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, const float *kdiag,
                                        float *resid_out);
-AGPL_API int32_t agpl_gaussian_factor(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                      const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
-                                      void *U_lo, double *logdet_out);
-/* The same without waiting for the outcome: a failed factorisation (AGPL_ERR_NOT_POSDEF, ...) is reported by the next
- * agpl_cavi_pass_factor_split -- after that call has enqueued its own kernels, so the host never idles the GPU between
- * the update and the next pass of a sweep loop (examples/bernoulli/script.jl:34-38) --, by the next
- * agpl_gaussian_factor[_async], or by agpl_ctx_synchronize on this context.  Work enqueued behind a failed
- * factorisation computes on NaNs; only the moment of the report moves. */
-AGPL_API int32_t agpl_gaussian_factor_async(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                      const double *eta0, double *A_work, double *v_out, float *v32_out, void *U_hi,
-                                      void *U_lo, double *logdet_out);
-AGPL_API int32_t agpl_pack_factor_split(agpl_ctx *ctx, int32_t M, int32_t L, const double *A, void *U_hi, void *U_lo);
-AGPL_API int32_t agpl_marginals_factor_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi,
-                                             const void *Phi_lo, const float *resid, const float *mu0,
-                                             const void *U_hi, const void *U_lo, const float *v, float *mu_out,
-                                             float *var_out);
-AGPL_API int32_t agpl_cavi_pass_factor_split(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                             const float *Phi, const void *Phi_hi, const void *Phi_lo,
-                                             const float *resid, const float *mu0, const void *y, const void *U_hi,
-                                             const void *U_lo, const float *v, double *G_out, double *g_out,
-                                             float *c_out, float *gamma_out, float *beta_out);
-
-/* ---- split-float16 accumulation from a static point-major image (agpl_syrk.hip) --------------------------------
- * G_l = Phi Diag(gamma_l) Phi', g_l = Phi beta_l (the accumulators of docs/src/index.md:154-163: S = (K_Z^-1 +
- * kappa Diag(r) kappa')^-1, m = S (kappa t + ...), in the whitened basis; script.jl:35-36 in sparse form).  The reduction
- * index of this product is the POINT, the strided index of the float32 features; the image stores, once per data set,
- * hi = f16(s phi), lo = f16(s phi - hi) (s = 2^e chosen from max |Phi|, -30 <= e <= 30: max |Phi| in 2^-24 .. 2^44, else
- * AGPL_ERR_DOMAIN; error <= 2^-22 |phi| down to 2^-17 max |Phi|) in 4 KB blocks [point slice of 16][feature block of 128][hi | lo] =
- * [2 planes of 8 points][128 features][8 halves], whose 16-byte granule (one feature, 8 consecutive points) is one MFMA
- * operand fragment.  The accumulation then reads ONLY the image: A = the image (HBM -> LDS by DMA), B = gamma_n x the
- * image (rebuilt, scaled and re-split in registers), three float16 MFMA products per float32 product, float32
- * accumulation over 4096-point slices, the fixed-order float64 slab reduction of agpl_accumulate.
- *   agpl_accumulate_image_bytes : bytes of the image (256-byte header + blocks) for N points, M features (M % 128 == 0).
- *   agpl_accumulate_image       : Phi (float32 [M,N] col-major) -> image.  AGPL_ERR_DOMAIN (with the offending point and
- *                                 feature in agpl_last_error) if a feature is not finite.  Synchronises the stream once.
- *   agpl_accumulate_split       : agpl_accumulate on the float16 matrix cores:
- *                                 from the image when acc_image != NULL and M % 256 == 0 (Phi may then be NULL), else from
- *                                 the float32 Phi (psi = sqrt(gamma) phi split while staging; |sqrt(gamma) phi| < 6e4).
- *                                 gamma >= 0 (TestUtils.jl:88): from the image, a negative or non-finite gamma is
- *                                 AGPL_ERR_DOMAIN with its index (the call then synchronises the stream once; inside a
- *                                 sweep the same report comes with the next update, without a synchronisation).        */
-AGPL_API int64_t agpl_accumulate_image_bytes(int64_t N, int32_t M);
-AGPL_API int32_t agpl_accumulate_image(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, void *image_out);
-AGPL_API int32_t agpl_accumulate_split(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi,
-                                       const void *acc_image, const float *beta, const float *gamma, double *G_out,
-                                       double *g_out);
-
-/* The sweep entry points on the image (the shipped path: bench.py, SparseCAVI / SparseGibbs defaults):
- *   agpl_cavi_pass_factor_image : agpl_cavi_pass_factor_split with the accumulation taken from Phi_acc (the image of
- *                                 agpl_accumulate_image) -- the float32 features are not an argument; M % 256 == 0.
- *   agpl_gibbs_pass_image       : agpl_gibbs_pass with the split-float16 accumulation, from Phi_acc when it is given
- *                                 and M % 256 == 0 (Phi is still read by the projection phi_i' v).
- * Every *_split / *_image entry point runs the split-float16 accumulation.
- * agpl_cavi_pass_factor_image is three launches up to the slabs (marginal partial sums; ONE per-point kernel: q(f_i),
- * aux_posterior!, expected potential / precision, written straight into the accumulation's gamma | beta records; the
- * accumulation) -- gamma_out / beta_out / c_out may be NULL and are then never materialised.  A gamma that is negative or not
- * finite (observations or marginals outside the likelihood's domain) is reported as AGPL_ERR_DOMAIN, with its flat index, by
- * the call that reports the outcome of the update enqueued behind this pass (agpl_gaussian_factor_async's rules).          */
-AGPL_API int32_t agpl_cavi_pass_factor_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                             const void *Phi_hi, const void *Phi_lo, const void *Phi_acc,
-                                             const float *resid, const float *mu0, const void *y, const void *U_hi,
-                                             const void *U_lo, const float *v, double *G_out, double *g_out,
-                                             float *c_out, float *gamma_out, float *beta_out);
-AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, int32_t M,
-                                       const float *Phi, const void *Phi_acc, const float *kdiag, const float *mu0,
-                                       const void *y, const double *v, uint32_t sweep, double *G_out, double *g_out,
-                                       double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
 
 /* ---- the plan: the shipped sweep path (agpl_plan.hip) -------------------------------------------------------------------
- * Everything static about one data set on one context, built once: the two split-float16 images of Phi (marginal image by
- * 128-point tile, accumulate image point-major), BOTH carrying 2^e Phi with one e chosen from max |Phi| (domain: any finite
- * features with max |Phi| in 2^-24 .. 2^44, else AGPL_ERR_DOMAIN; a non-finite feature is AGPL_ERR_DOMAIN with its (point,
- * feature)), a copy of the
- * Nystrom residual, and q(v) in factor form -- U = chol(I + G)^-1, v = U (g + eta0), log det(I + G) -- which the plan's update
- * writes and its passes read; kernels are chosen by shape.  After creation the float32 features are not read by any plan entry
- * point (C2: 41 GB of images resident instead of 61 GB with the features; 20.5 GB for a Gibbs-only plan).  These entry points supersede
- * agpl_split_features, agpl_accumulate_image, agpl_pack_factor_split, agpl_marginals_factor_split, agpl_cavi_pass_split,
- * agpl_cavi_pass_factor_split, agpl_cavi_pass_factor_image and agpl_gibbs_pass_image (kept below for existing callers).
+ * Split-float16 arithmetic: every float32 operand x is carried as hi = f16(s x), lo = f16(s x - hi) (s = 2^e chosen from
+ * max |Phi|: error <= 2^-22 |x| down to 2^-17 max |Phi|); a float32 product runs as three float16 MFMA products (hi*hi + hi*lo
+ * + lo*hi) with float32 accumulation over <= 8192 points and float64 reductions in a fixed order (bitwise reproducible, no
+ * atomics).  Everything static about one data set on one context is built once: the two images of Phi (marginal image by
+ * 128-point tile = the B operand of U Phi; accumulate image point-major = both operands of Phi Diag(gamma) Phi'), BOTH carrying
+ * 2^e Phi with one e (domain: any finite features with max |Phi| in 2^-24 .. 2^44, else AGPL_ERR_DOMAIN; a non-finite feature is
+ * AGPL_ERR_DOMAIN with its (point, feature)), a copy of the Nystrom residual, and q(v) in factor form -- U = chol(I + G)^-1,
+ * v = U (g + eta0), log det(I + G) -- which the plan's update writes and its passes read; kernels are chosen by shape.  After
+ * creation the float32 features are not read by any plan entry point (C2: 41 GB of images resident; 20.5 GB for a Gibbs-only plan).
+ * (v110's per-generation entry points -- agpl_split_features, agpl_pack_w_split, agpl_marginals_split, agpl_cavi_pass_split,
+ * agpl_pack_factor_split, agpl_marginals_factor_split, agpl_cavi_pass_factor_split, agpl_accumulate_image, agpl_accumulate_split,
+ * agpl_cavi_pass_factor_image, agpl_gibbs_pass_image -- are gone in v120 with the kernels only they reached.)
  *   agpl_plan_bytes     : device bytes a plan needs for (N, M, L, flags); 0 for sizes a plan does not take (M % 256 != 0, L > 64).
  *   agpl_plan_create    : Phi float32 [M, N] column-major; resid float32 [N] (agpl_feature_residual); flags: 0, or
  *                         AGPL_PLAN_NO_MARGINALS for a plan that serves Gibbs passes only (no marginal image: half the bytes);
@@ -422,23 +294,30 @@ AGPL_API int32_t agpl_gibbs_pass_image(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *   lifetime            : a plan enqueues on, and reports through, the context it was created on: agpl_plan_destroy it BEFORE
  *                         agpl_ctx_destroy (which returns AGPL_ERR_INVALID_ARGUMENT, and destroys nothing, while plans are alive).
  *   agpl_cavi_pass_plan : marginals of the plan's q(v) -> aux_posterior! -> expected potential / precision -> G, g
- *                         (script.jl:32-36 up to the M x M solve; agpl_cavi_pass's contract).  elbo_terms_out (device double, may be
- *                         NULL): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) the pass used, from
- *                         the same marginals in float64 -- the per-point part of aug_elbo (script.jl:65-70) rides the pass's one
- *                         per-point kernel (AGPL_ERR_UNSUPPORTED for the non-bijective categorical and the heteroscedastic
+ *                         (script.jl:32-36 up to the M x M solve; agpl_cavi_pass's contract) in three launches up to the slabs
+ *                         (marginal partial sums; ONE per-point kernel; the accumulation) -- gamma_out / beta_out / c_out may be
+ *                         NULL and are then never materialised.  A gamma that is negative or not finite (observations or marginals
+ *                         outside the likelihood's domain; TestUtils.jl:88) is AGPL_ERR_DOMAIN with its flat index, reported by the
+ *                         call that reports the outcome of the update enqueued behind this pass.  elbo_terms_out (device double,
+ *                         may be NULL): sum over the points of expected_logtilt_i - aux_kldivergence_i for the q(v) the pass used,
+ *                         from the same marginals in float64 -- the per-point part of aug_elbo (script.jl:65-70) rides the pass's
+ *                         one per-point kernel (AGPL_ERR_UNSUPPORTED for the non-bijective categorical and the heteroscedastic
  *                         likelihood, whose terms the reference does not define).
  *   agpl_plan_update    : q(v) <- N(S (g + eta0), S), S = (I + G)^-1 (script.jl:35-36), kept as (U, v); asynchronous, outcome
- *                         reported as by agpl_gaussian_factor_async.  kl_out (device double, may be NULL): KL(q(v) || N(0, I)) of
+ *                         reported as by agpl_gaussian_factor.  kl_out (device double, may be NULL): KL(q(v) || N(0, I)) of
  *                         the NEW q(v), from U and v (the kldivergence term of aug_elbo).  ELBO of a q(v) = the elbo_terms of the
  *                         pass that used it (summed over ranks) - the kl of the update that made it.
  *   agpl_marginals_plan : q(f_i) of the plan's q(v): mu, var float32 [L][N].
  *   agpl_gibbs_pass_plan: agpl_gibbs_pass with the plan's residual and accumulate image; the projection phi_i' v is formed from the
  *                         image too (x = (hi + lo) 2^-e: the features to 2^-22 relative, float64 accumulation in a fixed order),
  *                         so a Gibbs chain needs the float32 features at plan creation only.
- *   agpl_plan_factor    : device pointers to U (float64 [L, M, M], column-major lower triangle), v (float64 [L, M]) and the
- *                         residual, e.g. to form S = U'U, m = U'v.   agpl_plan_info: sizes, the images' scale exponent, bytes.
- *   agpl_plan_state     : device pointers to what an update rewrites besides U and v -- the images of 2^15 U (float16, L M M each),
- *                         v as float32 [L, M], log det(I + G) [L] -- for repeatability checks and checkpoints. */
+ *   agpl_plan_info      : sizes, the images' scale exponent, bytes.
+ *   agpl_plan_state     : device pointers to everything an update rewrites -- U (float64 [L, M, M], column-major lower triangle),
+ *                         v (float64 [L, M]), the float16 images of 2^15 U (L M M halves each), v as float32 [L, M],
+ *                         log det(I + G) [L] -- and to the plan's residual copy; any out pointer may be NULL.  To form S = U'U,
+ *                         m = U'v; for repeatability checks; and as the CHECKPOINT of a sweep loop: copy the five arrays out
+ *                         (with the context's seed and the host's sweep counter), and into the same pointers of a plan created
+ *                         on the same data to resume bit for bit (tests/test_gpu_checkpoint.py). */
 typedef struct agpl_plan agpl_plan;
 #define AGPL_PLAN_NO_MARGINALS 1u
 AGPL_API int64_t agpl_plan_bytes(int64_t N, int32_t M, int32_t L, uint32_t flags);
@@ -446,9 +325,8 @@ AGPL_API int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L
                                   uint32_t flags, void *storage, agpl_plan **plan_out);
 AGPL_API int32_t agpl_plan_destroy(agpl_plan *plan);
 AGPL_API int32_t agpl_plan_info(const agpl_plan *plan, int64_t *N, int32_t *M, int32_t *L, int32_t *scale_exp, int64_t *bytes);
-AGPL_API int32_t agpl_plan_factor(const agpl_plan *plan, const double **U_out, const double **v_out, const float **resid_out);
-AGPL_API int32_t agpl_plan_state(const agpl_plan *plan, const void **U_hi_out, const void **U_lo_out, const float **v32_out,
-                                 const double **logdet_out);
+AGPL_API int32_t agpl_plan_state(const agpl_plan *plan, double **U_out, double **v_out, void **U_hi_out, void **U_lo_out,
+                                 float **v32_out, double **logdet_out, const float **resid_out);
 AGPL_API int32_t agpl_cavi_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik, const float *mu0, const void *y, double *G_out,
                                      double *g_out, float *c_out, float *gamma_out, float *beta_out, double *elbo_terms_out);
 AGPL_API int32_t agpl_plan_update(agpl_plan *plan, const double *G, const double *g, const double *eta0, double *kl_out);
@@ -457,18 +335,33 @@ AGPL_API int32_t agpl_gibbs_pass_plan(agpl_plan *plan, const agpl_lik_desc *lik,
                                       const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out,
                                       double *omega_out, int64_t *n_out, uint32_t *nuni_out);
 
+/* ---- diagnostics (no reference counterpart) -----------------------------------------------------------------------------
+ * agpl_probe_mfma: measured matrix-core rate of this device [TFLOP/s]; synchronous; ms_host (may be NULL) = average launch time.
+ *   dtype AGPL_F64: v_mfma_f64_16x16x4_f64 back to back on every SIMD, `iters` x 16 instructions per wave (mode, workgroups_per_cu
+ *     ignored): the peak bench.py prices the C5 Cholesky against ("FP64 peak is not in the local guide").
+ *   dtype AGPL_F32 (float16 operands, float32 accumulate): the SUSTAINED rate of v_mfma_f32_32x32x16_f16 in the instruction mix
+ *     of one stage of the accumulation's wave (12 per step into four 32 x 32 accumulators), six launches of `iters` steps per wave
+ *     timed as one region after two that settle the clocks, `workgroups_per_cu` (1..4) 4-wave workgroups per CU.  mode 0: MFMA only;
+ *     1: with that stage's eight 16-byte LDS fragment reads; 2, 3: the same for v_mfma_f32_16x16x32_f16 in the mix of one stage of
+ *     the marginal kernel's wave (48 per step into sixteen 16 x 16 accumulators, hashed operands, <= 2 workgroups per CU; 3: with
+ *     the stage's sixteen fragment reads).  The ceiling bench.py reports next to the data-sheet peak.
+ * agpl_timing: in-library hipEvent timing of the hot kernels (bench.py's roofline leg).  which = -1 / -2: switch it on / off
+ *   (outputs ignored); which = 0 marginal, 1 accumulation, 2 Gibbs point pass, 3 aux_sample kernel: synchronises the stream, returns
+ *   the summed kernel time [ms] and the number of launches since the last read, and resets the counters.
+ * agpl_debug_force_factor_rescue: test hook.  The one-launch M x M factorisation runs as cooperating workgroups that assume each
+ *   other resident; should other work hold their CUs, the launch reports it and a second launch queued behind it redoes the latent
+ *   in one workgroup, without the host.  on != 0 makes every cooperative launch of this context take that path at once, so that
+ *   it can be tested; the results are the cooperative launch's. */
+AGPL_API int32_t agpl_probe_mfma(agpl_ctx *ctx, int32_t dtype, int32_t iters, int32_t mode, int32_t workgroups_per_cu,
+                                 double *tflops_host, double *ms_host);
+AGPL_API int32_t agpl_timing(agpl_ctx *ctx, int32_t which, double *total_ms_host, int64_t *launches_host);
+AGPL_API int32_t agpl_debug_force_factor_rescue(agpl_ctx *ctx, int32_t on);
+
 /* agpl_allreduce_nat: the exchange step of the N-sharded sweep: in-place float64 sum of the
  *   L (M^2 + M) natural-parameter accumulators over an RCCL communicator (ncclComm_t as void*), queued on the
  *   context's stream.  For hosts that own their communicator (the Julia / C++ callers of INTEGRATION.md); the
  *   Python host reaches the same RCCL through torch.distributed.  librccl is loaded at the first call.          */
 AGPL_API int32_t agpl_allreduce_nat(agpl_ctx *ctx, void *rccl_comm, double *buf, int64_t count);
-
-/* (agpl_set_accumulate_precision, v100: removed in v110.  The float32-named entry points -- agpl_accumulate, agpl_cavi_pass,
- * agpl_gibbs_pass -- always contract on the float32-input MFMA; the split-float16 arithmetic is the plan API's, and the
- * superseded *_split / *_image entry points'.  There is no per-context precision state any more.) */
-
-/* bytes of scratch the context will hold for a given problem (allocated lazily, reused) */
-AGPL_API int64_t agpl_workspace_bytes(int64_t N, int32_t M, int32_t L);
 
 /* ---- features and synthetic workloads (the step before the path) -----------
  * agpl_se_features: K_ZX[a,i] = exp(-(x_i - z_a)^2 / (2 ell^2)) (with_lengthscale(SqExponentialKernel(),

@@ -29,7 +29,7 @@ using AugmentedGPLikelihoods: AbstractLikelihood, BernoulliLikelihood, NegativeB
     InvScaledLogistic, nlatent
 import AugmentedGPLikelihoods: aux_sample!, aux_posterior!, auglik_potential, auglik_precision,
     auglik_potential_and_precision, expected_auglik_potential, expected_auglik_precision,
-    expected_auglik_potential_and_precision, logtilt, aug_loglik, expected_logtilt, aux_kldivergence
+    expected_auglik_potential_and_precision, logtilt, aug_loglik, expected_logtilt, expected_aug_loglik, aux_kldivergence
 
 const libagpl = get(ENV, "AGPL_LIB", "libagpl.so")
 
@@ -254,6 +254,20 @@ function aux_kldivergence(lik::AbstractLikelihood, qΩ, y::ROCArray)
     return out[]
 end
 
+# expected_aug_loglik(lik, qΩ, y, qf) generic.jl:52-54 (heteroscedasticgaussian.jl:130-145 its own method) -> agpl_expected_aug_loglik
+function expected_aug_loglik(lik::AbstractLikelihood, qΩ, y::ROCArray, qf::DeviceNormals)
+    c = ctx()
+    d, keep = desc(lik)
+    φ = only(qΩ.inds)
+    o2 = out2(φ)
+    out = Ref{Float64}(0.0)
+    GC.@preserve keep check(c.h, ccall((:agpl_expected_aug_loglik, libagpl), Int32,
+        (Ptr{Cvoid}, Ref{LikDesc}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}),
+        c.h, d, npoints(lik, qf.mean), dptr(y), dptr(flat(out1(lik, φ))), dptr(o2 === nothing ? nothing : flat(o2)),
+        dptr(qf.mean), dptr(qf.var), out))
+    return out[]
+end
+
 # ------------------------------------------------------------------------------------------------ sparse sweep
 """
     SparseSweep(lik, Φ, d, y; comm=C_NULL, track_elbo=false)
@@ -340,8 +354,9 @@ function moments(s::SparseSweep)
     synchronize()
     L, M = nlatent(s.lik), s.M
     U_p, v_p = Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL)
-    check(ctx().h, ccall((:agpl_plan_factor, libagpl), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ptr{Cvoid}),
-                         s.plan, U_p, v_p, C_NULL))
+    check(ctx().h, ccall((:agpl_plan_state, libagpl), Int32,
+                         (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                         s.plan, U_p, v_p, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
     A = Array(unsafe_wrap(ROCArray, U_p[], (M, M, L)))
     v = Array(unsafe_wrap(ROCArray, v_p[], (M, L)))
     U = [LowerTriangular(A[:, :, l]) for l in 1:L]
@@ -380,10 +395,10 @@ function aug_elbo(s::SparseSweep)
     qΩ = AugmentedGPLikelihoods.init_aux_posterior(s.lik, s.N)
     qΩdev = to_device(qΩ)
     aux_posterior!(qΩdev, s.lik, s.y, qf)
-    kl = Ref{Float64}(0.0)
-    check(c.h, ccall((:agpl_gaussian_kl, libagpl), Int32,
-        (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), c.h, M, L, Gptr(s), gptr(s), C_NULL, kl))
-    return expected_logtilt(s.lik, qΩdev, s.y, qf) - aux_kldivergence(s.lik, qΩdev, s.y) - kl[]
+    # KL(q(v) ‖ N(0, I)) = (tr S + mᵀm − M + log det(I + G)) / 2 from the plan's factor: S = UᵀU, m = Uᵀv, log det(S) = 2 Σ log U_aa
+    ms, Ss = moments(s)
+    kl = sum(0.5 * (tr(Ss[l]) + dot(ms[l], ms[l]) - M - logdet(Symmetric(Ss[l]))) for l in 1:L)
+    return expected_logtilt(s.lik, qΩdev, s.y, qf) - aux_kldivergence(s.lik, qΩdev, s.y) - kl
 end
 
 "A `For(TupleVector(...))` of host vectors -> the same container over device arrays (fields keep their names)."

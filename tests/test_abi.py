@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
     exported = sorted(set(re.findall(r" T (agpl_\w+)", out)))
     assert exported == _header_symbols()  # nothing else leaks out of the library
-    assert lib.agpl_version() == 110
+    assert lib.agpl_version() == 120
 
 
 def test_library_contains_gfx950_code_object(built):
@@ -83,8 +83,8 @@ def test_no_gpu_means_loud_failure(built):
 
     assert _ffi.lib().agpl_ctx_create(ctypes.byref(h), 0, ctypes.c_uint64(0)) != 0  # no device: error code, no crash
     tf = ctypes.c_double()
-    for probe in (lambda: _ffi.lib().agpl_probe_mfma_f64(None, 16, ctypes.byref(tf)),
-                  lambda: _ffi.lib().agpl_probe_mfma_f16(None, 16, 0, 1, ctypes.byref(tf), None)):
+    for probe in (lambda: _ffi.lib().agpl_probe_mfma(None, 1, 16, 0, 1, ctypes.byref(tf), None),
+                  lambda: _ffi.lib().agpl_probe_mfma(None, 0, 16, 0, 1, ctypes.byref(tf), None)):
         assert probe() == -1  # AGPL_ERR_INVALID_ARGUMENT on a null context, before anything touches a device
 
 

@@ -1,5 +1,5 @@
 """Checkpoint / resume of the sweep loops: after k sweeps the state -- q(v) in the plan's factor
-form (agpl_plan_factor + agpl_plan_state), the reduced (G, g), the context's Philox key and draw counter; for the Gibbs chain the
+form (agpl_plan_state), the reduced (G, g), the context's Philox key and draw counter; for the Gibbs chain the
 inducing draw v -- is written to disk by one process, restored by a FRESH process that rebuilds the static images from the same
 features, and the next CAVI sweep and the next Gibbs sweeps are bit for bit those of the uninterrupted run.
 (The reference keeps its state in user scope: (m, S, qΩ) examples/bernoulli/script.jl:41-43, (f, Ω) :89-90.)"""

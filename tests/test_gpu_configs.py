@@ -66,7 +66,7 @@ def shipped(A, lik, Phi, kd, y, ctx, **kw):
 
 def sampled_marginals_and_operators_match_float64(A, cavi, Phi, lik_name, r=None):
     """the marginal kernel at full size with a REAL posterior factor.  After >= 2 sweeps: U, v from
-    agpl_plan_factor, a sample of >= 1e4 points over every per-XCD item queue and the last (ragged) tile, mu / var of
+    agpl_plan_state, a sample of >= 1e4 points over every per-XCD item queue and the last (ragged) tile, mu / var of
     agpl_marginals_plan against float64 from the float32 feature rows (2e-5 of max, the bar of test_gpu_random_shapes),
     then gamma, beta of the next pass at those points against the float64 operators on the float64 marginals."""
     import bench

@@ -281,34 +281,38 @@ def _features(rng, N, M, scale=0.3):
 @pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (257, 384, 2), (20000, 128, 3), (1, 128, 1),
                                    (127, 128, 1), (129, 256, 1)])
 def test_marginals_against_float64(A, ctx, N, M, L):
-    rng = np.random.default_rng(N + M)
-    Phi = _features(rng, N, M)
-    W = rng.normal(size=(L, M, M)) / M
-    W = (W + W.transpose(0, 2, 1)) / 2
-    alpha = rng.normal(size=(L, M))
-    kd = rng.uniform(1, 2, size=N)
-    mu0 = rng.normal(size=(L, N))
-    Wp = torch.empty((L, M, M), dtype=torch.float32, device="cuda")
+    """agpl_marginals (float32-input MFMA) with the packed -S and alpha = m that agpl_gaussian_update writes, against float64."""
     import ctypes as C
 
-    dW = dev(W)  # keep every device tensor referenced until the stream has consumed it
-    ctx.call("agpl_pack_w", C.c_int32(M), C.c_int32(L), C.c_void_p(dW.data_ptr()), C.c_double(1.0),
-             C.c_void_p(Wp.data_ptr()))
+    rng = np.random.default_rng(N + M)
+    Phi = _features(rng, N, M)
+    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
+    G, g = np.einsum("lik,ljk->lij", B, B) * 3.0, rng.normal(size=(L, M))
+    kd = rng.uniform(1, 2, size=N)
+    mu0 = rng.normal(size=(L, N))
+    S = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    m = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    Wp = torch.empty((L, M, M), dtype=torch.float32, device="cuda")
+    dal = torch.empty((L, M), dtype=torch.float32, device="cuda")
+    dG, dg = dev(G), dev(g)  # keep every device tensor referenced until the stream has consumed it
+    pp = lambda t: C.c_void_p(t.data_ptr())
+    ctx.call("agpl_gaussian_update", C.c_int32(M), C.c_int32(L), pp(dG), pp(dg), C.c_void_p(0), pp(S), pp(m), pp(Wp), pp(dal),
+             C.c_void_p(0))
+    W = -host(S)
     # packed layout: Wp[b][a] = 2 W[a][b] (b > a), W[a][a] (b == a), 0 (b < a)
     Wph = host(Wp)[0]
     assert np.allclose(np.tril(Wph, -1), 2 * np.tril(W[0], -1), rtol=1e-6, atol=1e-8)
     assert np.allclose(np.diag(Wph), np.diag(W[0]), rtol=1e-6) and np.all(np.triu(Wph, 1) == 0)
     mu = torch.empty((L, N), dtype=torch.float32, device="cuda")
     var = torch.empty_like(mu)
-    dPhi, dkd, dmu0, dal = dev(Phi), dev(kd, torch.float32), dev(mu0, torch.float32), dev(alpha, torch.float32)
-    ctx.call("agpl_marginals", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
-             C.c_void_p(dkd.data_ptr()), C.c_void_p(dmu0.data_ptr()), C.c_void_p(Wp.data_ptr()),
-             C.c_void_p(dal.data_ptr()), C.c_void_p(mu.data_ptr()), C.c_void_p(var.data_ptr()))
+    dPhi, dkd, dmu0 = dev(Phi), dev(kd, torch.float32), dev(mu0, torch.float32)
+    ctx.call("agpl_marginals", C.c_int64(N), C.c_int32(M), C.c_int32(L), pp(dPhi), pp(dkd), pp(dmu0), pp(Wp), pp(dal), pp(mu),
+             pp(var))
     torch.cuda.synchronize()
     P = Phi.astype(np.float64)
     Wf = host(Wp).astype(np.float64)
     Wsym = np.stack([np.tril(w, -1) / 2 + np.tril(w, -1).T / 2 + np.diag(np.diag(w)) for w in Wf])
-    af = host(dev(alpha, torch.float32)).astype(np.float64)
+    af = host(dal).astype(np.float64)
     for l in range(L):
         ref_mu = mu0.astype(np.float32)[l] + P @ af[l]
         ref_var = kd.astype(np.float32) - np.einsum("ia,ab,ib->i", P, Wsym[l], P)
@@ -378,13 +382,17 @@ def test_gaussian_update_against_lapack(A, ctx, oracle, L, M):
     m = torch.empty((L, M), dtype=torch.float64, device="cuda")
     Wp = torch.empty((L, M, M), dtype=torch.float32, device="cuda")
     al = torch.empty((L, M), dtype=torch.float32, device="cuda")
+    kl = torch.zeros(1, dtype=torch.float64, device="cuda")
     import ctypes as C
 
     dG, dg = dev(G), dev(g)
     ctx.call("agpl_gaussian_update", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()),
              C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(S.data_ptr()), C.c_void_p(m.data_ptr()),
-             C.c_void_p(Wp.data_ptr()), C.c_void_p(al.data_ptr()))
+             C.c_void_p(Wp.data_ptr()), C.c_void_p(al.data_ptr()), C.c_void_p(kl.data_ptr()))
     Sr, mr = oracle.gaussian_update(G, g)
+    # kl_out: sum_l KL(N(m_l, S_l) || N(0, I)) = (tr S + m'm - M + logdet(I + G)) / 2  (aug_elbo's Gaussian term, script.jl:65-70)
+    klr = sum(0.5 * (np.trace(Sr[l]) + mr[l] @ mr[l] - M + np.linalg.slogdet(np.eye(M) + G[l])[1]) for l in range(L))
+    assert kl.item() == pytest.approx(klr, rel=1e-9)
     assert relmax(host(S), Sr) < 1e-9
     assert relmax(host(m), mr) < 1e-9
     assert np.array_equal(host(S), host(S).transpose(0, 2, 1))
@@ -394,7 +402,7 @@ def test_gaussian_update_against_lapack(A, ctx, oracle, L, M):
     with pytest.raises(A.PosDefException):
         ctx.call("agpl_gaussian_update", C.c_int32(M), C.c_int32(1), C.c_void_p(dbad.data_ptr()),
                  C.c_void_p(dg1.data_ptr()), C.c_void_p(0), C.c_void_p(S.data_ptr()),
-                 C.c_void_p(m.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+                 C.c_void_p(m.data_ptr()), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
 
 
 def _setup_svgp(A, ctx, O, lik, olik, N, M, ell_factor=1.5, pad=128):
@@ -669,242 +677,8 @@ def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
     assert vals[-1] == pytest.approx(ref, rel=2e-6)
 
 
-# ------------------------------------------------------------------------------------------ split-float16 marginals
-@pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (257, 384, 2), (129, 512, 1)])
-def test_split_f16_marginals_against_float64(A, ctx, N, M, L):
-    """agpl_marginals_split (3 float16 MFMA products per float32 product) against float64 numpy on the same
-    float32 inputs: the split representation keeps ~22 bits, so the bound is the float32 kernel's."""
-    import ctypes as C
-
-    rng = np.random.default_rng(N + 7 * M)
-    Phi = _features(rng, N, M)
-    Phi[::7] *= 1e-3  # small magnitudes exercise the float16 subnormal range of the lo parts
-    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
-    S = np.linalg.inv(np.eye(M) + B @ B.transpose(0, 2, 1) * 20.0)  # a posterior-like SPD matrix, entries <= 1
-    alpha = rng.normal(size=(L, M))
-    kd = rng.uniform(0.0, 0.5, size=N)
-    from agpl_amd import _ffi
-
-    nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(N), C.c_int32(M)) // 2
-    dPhi, dS, dal, dkd = dev(Phi), dev(S), dev(alpha, torch.float32), dev(kd, torch.float32)
-    Ph = torch.empty(nh, dtype=torch.float16, device="cuda")
-    Pl = torch.empty(nh, dtype=torch.float16, device="cuda")
-    Wh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
-    Wl = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
-    ctx.call("agpl_split_features", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()), C.c_void_p(Ph.data_ptr()),
-             C.c_void_p(Pl.data_ptr()))
-    ctx.call("agpl_pack_w_split", C.c_int32(M), C.c_int32(L), C.c_void_p(dS.data_ptr()), C.c_double(-1.0),
-             C.c_void_p(Wh.data_ptr()), C.c_void_p(Wl.data_ptr()))
-    mu = torch.empty((L, N), dtype=torch.float32, device="cuda")
-    var = torch.empty_like(mu)
-    ctx.call("agpl_marginals_split", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
-             C.c_void_p(Ph.data_ptr()), C.c_void_p(Pl.data_ptr()), C.c_void_p(dkd.data_ptr()), C.c_void_p(0),
-             C.c_void_p(Wh.data_ptr()), C.c_void_p(Wl.data_ptr()), C.c_void_p(dal.data_ptr()), C.c_void_p(mu.data_ptr()),
-             C.c_void_p(var.data_ptr()))
-    torch.cuda.synchronize()
-    # the split images reconstruct the float32 features to 2^-22 relative / 3e-8 absolute
-    rec = (Ph.float() + Pl.float()).cpu().numpy()
-    nks = M // 16
-    blk = rec[: (N // 128) * 128 * M].reshape(-1, nks, 2, 128, 8) if N >= 128 else None
-    if blk is not None:
-        full = blk.transpose(0, 3, 1, 2, 4).reshape(-1, M)  # [tile, row, ks, plane, 8] -> [n, b]
-        ref = Phi[: full.shape[0]]
-        assert np.abs(full - ref).max() <= np.maximum(2.0 ** -21 * np.abs(ref), 6e-8).max()
-    P = Phi.astype(np.float64)
-    af = host(dal).astype(np.float64)
-    for l in range(L):
-        ref_mu = P @ af[l]
-        ref_var = kd.astype(np.float32) + np.einsum("ia,ab,ib->i", P, S[l], P)
-        assert np.abs(host(mu)[l] - ref_mu).max() < 2e-6 * np.abs(P).sum(1).max() * np.abs(af[l]).max() + 1e-6
-        assert np.abs(host(var)[l] - ref_var).max() < 3e-6 * max(1.0, np.abs(ref_var).max())
-
-
-@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("cat", 4_000, 64)])
-def test_cavi_with_split_f16_marginals_matches_oracle(A, ctx, oracle, name, N, M):
-    """The same 10-sweep natural-parameter bar with the split-float16 marginal pass."""
-    O = oracle
-    lik, olik = lik_pairs(A, O)[name]
-    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2")
-    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
-    Mp, L = Phi_h.shape[1], olik.nlatent
-    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
-    for it in range(10):
-        cavi.sweep()
-        G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
-        S, m = O.gaussian_update(G, g)
-    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
-    assert relmax(host(cavi.g), g) < NAT_TOL
-
-
-# --------------------------------------------------------------------------------------- split-float16 accumulation
-@pytest.fixture()
-def split_accumulate(ctx):
-    """agpl_accumulate's arguments -> agpl_accumulate_split without an image: the float32-staged split-float16 kernel
-    (syrk_split_kernel), which serves feature counts that are not a multiple of 256."""
-    import ctypes as C
-
-    return lambda *a: ctx.call("agpl_accumulate_split", *a[:4], C.c_void_p(0), *a[4:])
-
-
-@pytest.mark.parametrize("N,M,L", [(1000, 128, 1), (4099, 256, 1), (70001, 128, 2), (31, 128, 1), (5000, 384, 1),
-                                   (300000, 128, 1), (4097, 128, 1), (16, 128, 1), (100003, 512, 1)])
-def test_split_accumulate_against_oracle(A, ctx, oracle, split_accumulate, N, M, L):
-    """agpl_accumulate_split without an image: sqrt(gamma) phi split into hi/lo float16 while
-    staging, 3 float16 MFMA products per float32 product; the same bound, symmetry and reproducibility as f32."""
-    import ctypes as C
-
-    rng = np.random.default_rng(N + 3 * M)
-    Phi = _features(rng, N, M)
-    gamma = rng.uniform(0.0, 0.25, size=(L, N)).astype(np.float32)
-    beta = rng.choice([-0.5, 0.5], size=(L, N)).astype(np.float32)
-    G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
-    g = torch.empty((L, M), dtype=torch.float64, device="cuda")
-    dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
-    args = (C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(dPhi.data_ptr()),
-            C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
-            C.c_void_p(g.data_ptr()))
-    split_accumulate(*args)
-    G1 = host(G).copy()
-    Gr, gr = oracle.accumulate(Phi, beta, gamma)
-    assert relmax(G1, Gr) < 5e-6
-    assert relmax(host(g), gr) < 5e-6
-    assert np.array_equal(G1, G1.transpose(0, 2, 1))
-    split_accumulate(*args)
-    assert np.array_equal(host(G), G1)
-
-
-@pytest.mark.parametrize("N,M", [(1_000_003, 512), (2_500_000, 256)])
-def test_split_accumulate_with_every_cu_shared(A, ctx, split_accumulate, N, M):
-    """Enough slices that four accumulation workgroups share every CU (the sizes above leave one per CU): a kernel
-    variant that passed all of them produced a wrong g here.  Reference: float64 torch reductions in chunks."""
-    import ctypes as C
-
-    gen = torch.Generator(device="cuda").manual_seed(N)
-    Phi = torch.randn((N, M), device="cuda", generator=gen) * 0.1
-    gamma = torch.rand((1, N), device="cuda", generator=gen) * 0.25
-    beta = torch.randn((1, N), device="cuda", generator=gen)
-    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
-    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
-    args = (C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(Phi.data_ptr()), C.c_void_p(beta.data_ptr()),
-            C.c_void_p(gamma.data_ptr()), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()))
-    split_accumulate(*args)
-    G1, g1 = G.clone(), g.clone()
-    Gr = torch.zeros((M, M), dtype=torch.float64, device="cuda")
-    gr = torch.zeros(M, dtype=torch.float64, device="cuda")
-    for i0 in range(0, N, 500_000):
-        P = Phi[i0:i0 + 500_000].double()
-        Gr += (P * gamma[0, i0:i0 + 500_000].double()[:, None]).T @ P
-        gr += P.T @ beta[0, i0:i0 + 500_000].double()
-    assert ((G1[0] - Gr).abs().max() / Gr.abs().max()).item() < 2e-6
-    assert ((g1[0] - gr).abs().max() / gr.abs().max()).item() < 2e-6
-    for _ in range(3):  # and bitwise reproducible under the same load
-        split_accumulate(*args)
-        assert torch.equal(G, G1) and torch.equal(g, g1)
-
-
-def test_split_accumulate_wide_dynamic_range(A, ctx, oracle, split_accumulate):
-    """gamma spanning 1e-6..1e2 and features spanning 1e-4..3: psi = 2^8 sqrt(gamma) phi stays inside the
-    float16 normal range for |sqrt(gamma) phi| in [2^-11, 2^8); smaller terms lose relative, not absolute, accuracy."""
-    import ctypes as C
-
-    N, M = 20000, 128
-    rng = np.random.default_rng(5)
-    Phi = (rng.normal(size=(N, M)) * 10.0 ** rng.uniform(-4, 0.5, size=(N, 1))).astype(np.float32)
-    gamma = (10.0 ** rng.uniform(-6, 2, size=(1, N))).astype(np.float32)
-    beta = rng.normal(size=(1, N)).astype(np.float32)
-    G = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
-    g = torch.empty((1, M), dtype=torch.float64, device="cuda")
-    dPhi, dbeta, dgamma = dev(Phi), dev(beta), dev(gamma)
-    split_accumulate(C.c_int64(N), C.c_int32(M), C.c_int32(1), C.c_void_p(dPhi.data_ptr()),
-                     C.c_void_p(dbeta.data_ptr()), C.c_void_p(dgamma.data_ptr()), C.c_void_p(G.data_ptr()),
-                     C.c_void_p(g.data_ptr()))
-    Gr, gr = oracle.accumulate(Phi, beta, gamma)
-    assert relmax(host(G), Gr) < 5e-6
-    assert relmax(host(g), gr) < 5e-6
-
-
-@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("negbin", 6_000, 128), ("cat", 4_000, 64),
-                                      ("studentt", 5_000, 128)])
-def test_cavi_with_split_f16_both_passes_matches_oracle(A, ctx, oracle, name, N, M):
-    """10-sweep natural-parameter bar with BOTH contractions on the float16 matrix cores (bench.py's default)."""
-    O = oracle
-    lik, olik = lik_pairs(A, O)[name]
-    x, y, Phi, kd = _setup_svgp(A, ctx, O, lik, olik, N, M)
-    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f16x2", accumulate_precision="f16x2")
-    Phi_h, kd_h, y_h = host(Phi), host(kd).astype(np.float64), host(y)
-    Mp, L = Phi_h.shape[1], olik.nlatent
-    S, m = np.tile(np.eye(Mp), (L, 1, 1)), np.zeros((L, Mp))
-    try:
-        for it in range(10):
-            cavi.sweep()
-            G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
-            S, m = O.gaussian_update(G, g)
-    finally:
-        pass
-    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
-    assert relmax(host(cavi.g), g) < NAT_TOL
-
-
-# ------------------------------------------------------------------------------- factor (one-pass) marginal form
-@pytest.mark.parametrize("N,M,L", [(1000, 256, 1), (4099, 512, 1), (257, 256, 2), (70001, 256, 1), (3001, 768, 1),
-                                   (2000, 1024, 1)])
-def test_factor_marginals_against_float64(A, ctx, N, M, L):
-    """agpl_gaussian_factor + agpl_marginals_factor_split against float64 numpy: with I + G = R R', U = R^-1,
-    var = (k - |phi|^2) + |U phi|^2 and mu = mu0 + (U g)'(U phi) must equal k - phi'(I - S)phi and mu0 + m'phi."""
-    import ctypes as C
-
-    from agpl_amd import _ffi
-
-    rng = np.random.default_rng(N + M)
-    Phi = _features(rng, N, M)
-    kd = (np.sum(Phi.astype(np.float64) ** 2, axis=1) + rng.uniform(0.01, 0.5, size=N)).astype(np.float32)
-    B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
-    G = np.einsum("lik,ljk->lij", B, B) * 3.0
-    g = rng.normal(size=(L, M))
-    mu0 = rng.normal(size=(L, N)).astype(np.float32)
-    dPhi, dkd, dG, dg, dmu0 = dev(Phi), dev(kd), dev(G), dev(g), dev(mu0)
-    nh = _ffi.lib().agpl_split_features_bytes(C.c_int64(N), C.c_int32(M)) // 2
-    Ph = torch.empty(nh, dtype=torch.float16, device="cuda")
-    Pl = torch.empty(nh, dtype=torch.float16, device="cuda")
-    ctx.call("agpl_split_features", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()), C.c_void_p(Ph.data_ptr()),
-             C.c_void_p(Pl.data_ptr()))
-    resid = torch.empty(N, dtype=torch.float32, device="cuda")
-    ctx.call("agpl_feature_residual", C.c_int64(N), C.c_int32(M), C.c_void_p(dPhi.data_ptr()),
-             C.c_void_p(dkd.data_ptr()), C.c_void_p(resid.data_ptr()))
-    ref_resid = kd.astype(np.float64) - np.sum(Phi.astype(np.float64) ** 2, axis=1)
-    assert np.abs(host(resid) - ref_resid).max() < 2e-7 * max(1.0, np.abs(kd).max())
-    Aw = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
-    v = torch.empty((L, M), dtype=torch.float64, device="cuda")
-    v32 = torch.empty((L, M), dtype=torch.float32, device="cuda")
-    Uh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
-    Ul = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
-    ld = torch.empty(L, dtype=torch.float64, device="cuda")
-    ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()),
-             C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(v32.data_ptr()),
-             C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(ld.data_ptr()))
-    mu = torch.empty((L, N), dtype=torch.float32, device="cuda")
-    var = torch.empty((L, N), dtype=torch.float32, device="cuda")
-    ctx.call("agpl_marginals_factor_split", C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_void_p(Ph.data_ptr()),
-             C.c_void_p(Pl.data_ptr()), C.c_void_p(resid.data_ptr()), C.c_void_p(dmu0.data_ptr()),
-             C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(v32.data_ptr()), C.c_void_p(mu.data_ptr()),
-             C.c_void_p(var.data_ptr()))
-    P = Phi.astype(np.float64)
-    for l in range(L):
-        S = np.linalg.inv(np.eye(M) + G[l])
-        m = S @ g[l]
-        # the factor itself: U'U = S, U'v = m, logdet
-        Ut = np.triu(host(Aw)[l])
-        assert relmax(Ut @ Ut.T, S) < 1e-10
-        assert relmax(Ut @ host(v)[l], m) < 1e-10
-        assert host(ld)[l] == pytest.approx(np.linalg.slogdet(np.eye(M) + G[l])[1], rel=1e-12)
-        ref_mu = mu0[l].astype(np.float64) + P @ m
-        ref_var = kd.astype(np.float64) - np.einsum("ia,ab,ib->i", P, np.eye(M) - S, P)
-        assert np.abs(host(mu)[l] - ref_mu).max() < 2e-6 * np.abs(P).sum(1).max() * np.abs(m).max() + 1e-6
-        assert np.abs(host(var)[l] - ref_var).max() < 3e-6 * max(1.0, np.abs(ref_var).max())
-
-
-def test_factor_form_rejects_unpadded_feature_count(A, ctx):
+# ------------------------------------------------------------------------------------------ the plan path (factor form)
+def test_plan_path_rejects_unpadded_feature_count(A, ctx):
     x = torch.zeros((64, 128), dtype=torch.float32, device="cuda")
     with pytest.raises(A.ArgumentError):
         A.SparseCAVI(A.BernoulliLikelihood(), x, torch.ones(64, device="cuda"),
@@ -941,8 +715,8 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
 @pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (352, 1), (512, 2), (544, 1), (640, 3), (1024, 1),
                                  (1024, 2), (1536, 1), (256, 30)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
-    """agpl_gaussian_factor with eta0: v = U (g + eta0); the fused kernel (M <= 512), the two-block form around it
-    (512 < M <= 1024) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
+    """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernel (M <= 1024, every block count and both
+    latent-per-XCD packings) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
     U'v = (I+G)^-1 (g + eta0), log det."""
     import ctypes as C
 
@@ -955,8 +729,8 @@ def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
     v = torch.empty((L, M), dtype=torch.float64, device="cuda")
     ld = torch.empty(L, dtype=torch.float64, device="cuda")
     ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()),
-             C.c_void_p(de.data_ptr()), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(0),
-             C.c_void_p(0), C.c_void_p(0), C.c_void_p(ld.data_ptr()))
+             C.c_void_p(de.data_ptr()), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(ld.data_ptr()))
+    ctx.synchronize()  # (asynchronous: the outcome is reported here)
     for l in range(L):
         S = np.linalg.inv(np.eye(M) + G[l])
         Ut = np.triu(host(Aw)[l])
@@ -969,33 +743,39 @@ def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
 def test_gaussian_factor_rescue_launch_reproduces_the_cooperative_result(A, M, L):
     """The one-launch factorisation runs as cooperating workgroups that assume each other resident; when other work holds their
     CUs the launch reports info = -1 and a second launch queued behind it redoes the latent in one workgroup.  On an idle device
-    that path never runs: agpl_debug_force_factor_rescue makes every cooperative launch take it.  U, v and log det
-    must be the cooperative launch's -- bitwise: both run the same elimination order -- and a sweep driven through it the same."""
+    that path never runs: agpl_debug_force_factor_rescue makes every cooperative launch take it.  U, v, log det and
+    the float16 images of a plan's update must be the cooperative launch's -- bitwise: both run the same elimination order."""
     import ctypes as C
 
     rctx = A.Context(0, seed=3)
     rng = np.random.default_rng(M + L)
     B = rng.normal(size=(L, M, 2 * M)) / np.sqrt(2 * M)
     G, g = dev(np.einsum("lik,ljk->lij", B, B) * 2.0), dev(rng.normal(size=(L, M)))
+    Phi = dev(_features(rng, 300, M))
+    plan = A.sparse.Plan(Phi, torch.ones(300, device="cuda"), L, rctx)
     outs = []
     for force in (0, 1):
         rctx.call("agpl_debug_force_factor_rescue", C.c_int32(force))
+        plan.U_colmajor.zero_()
+        plan.call("agpl_plan_update", C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+        rctx.synchronize()
+        outs.append((torch.triu(plan.U_colmajor).clone(), plan.v.clone(), plan.logdet.clone(), plan.U_hi.clone(),
+                     plan.U_lo.clone(), plan.v32.clone()))
+        # ... and the stand-alone entry point
         Aw = torch.zeros((L, M, M), dtype=torch.float64, device="cuda")
         v = torch.empty((L, M), dtype=torch.float64, device="cuda")
-        v32 = torch.empty((L, M), dtype=torch.float32, device="cuda")
-        Uh = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
-        Ul = torch.empty(L * M * M, dtype=torch.float16, device="cuda")
         ld = torch.empty(L, dtype=torch.float64, device="cuda")
         rctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()),
-                  C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(v32.data_ptr()),
-                  C.c_void_p(Uh.data_ptr()), C.c_void_p(Ul.data_ptr()), C.c_void_p(ld.data_ptr()))
-        outs.append((torch.triu(Aw).clone(), v.clone(), ld.clone(), Uh.clone(), Ul.clone()))
+                  C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(ld.data_ptr()))
+        rctx.synchronize()
+        assert torch.equal(torch.triu(Aw), outs[-1][0]) and torch.equal(v, outs[-1][1]) and torch.equal(ld, outs[-1][2])
     rctx.call("agpl_debug_force_factor_rescue", C.c_int32(0))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     for l in range(L):  # and it is the factor: U'U = (I + G)^-1
         Ut = host(outs[1][0])[l]
         assert relmax(Ut @ Ut.T, np.linalg.inv(np.eye(M) + host(G)[l])) < 1e-10
+    del plan
 
 
 @pytest.mark.parametrize("M,first_bad", [(256, 0), (1024, 0), (1024, 700)])
@@ -1009,12 +789,12 @@ def test_gaussian_factor_reports_indefinite_matrix(A, ctx, M, first_bad):
     Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
     with pytest.raises(A.PosDefException):
         ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()),
-                 C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
-                 C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+                 C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+        ctx.synchronize()
 
 
-def test_gaussian_factor_async_defers_the_report(A, ctx):
-    """agpl_gaussian_factor_async returns before the outcome is known; a failed factorisation is reported by the next
+def test_gaussian_factor_defers_the_report(A, ctx):
+    """agpl_gaussian_factor returns before the outcome is known; a failed factorisation is reported by the next
     synchronisation point of the context (here agpl_ctx_synchronize), once, and the context is usable afterwards."""
     import ctypes as C
 
@@ -1024,23 +804,22 @@ def test_gaussian_factor_async_defers_the_report(A, ctx):
     dG, dg = dev(np.diag(d)[None]), dev(np.zeros((1, M)))
     Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")
     args = (C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(0),
-            C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
-    ctx.call("agpl_gaussian_factor_async", *args)  # no exception yet
-    with pytest.raises(A.PosDefException):
+            C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+    ctx.call("agpl_gaussian_factor", *args)  # no exception yet
+    with pytest.raises(A.PosDefException, match="pivot at row 100"):
         ctx.synchronize()
     ctx.synchronize()  # reported once
     good = dev(np.zeros((1, M, M)))
-    ctx.call("agpl_gaussian_factor_async", C.c_int32(M), C.c_int32(1), C.c_void_p(good.data_ptr()),
-             C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
-             C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+    gargs = (C.c_int32(M), C.c_int32(1), C.c_void_p(good.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(0),
+             C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+    ctx.call("agpl_gaussian_factor", *gargs)
     ctx.synchronize()
     assert np.allclose(np.triu(host(Aw)[0]), np.eye(M))
     # a pending failure is also reported by the next factorisation on the context, before it starts
-    ctx.call("agpl_gaussian_factor_async", *args)
+    ctx.call("agpl_gaussian_factor", *args)
     with pytest.raises(A.PosDefException):
-        ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(1), C.c_void_p(good.data_ptr()),
-                 C.c_void_p(dg.data_ptr()), C.c_void_p(0), C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0),
-                 C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+        ctx.call("agpl_gaussian_factor", *gargs)
+    ctx.synchronize()
 
 
 def test_cavi_factor_form_reports_a_failed_update(A, ctx):
@@ -1150,7 +929,7 @@ def test_c2_full_size_properties_of_the_shipped_path(A, ctx):
         assert chk["max_rel_d_vGv"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6 and chk["max_rel_dg"] < 2e-6, chk
         cavi.accumulate()  # same state: bitwise identical
         assert torch.equal(cavi.G, G1) and torch.equal(cavi.g, g1)
-        # the marginal kernel at this size with a REAL factor: two sweeps, then U, v from agpl_plan_factor and
+        # the marginal kernel at this size with a REAL factor: two sweeps, then U, v from agpl_plan_state and
         # a sampled float64 evaluation over every per-XCD queue and the last tile; then gamma, beta from those marginals
         cavi.sweep()
         cavi.sweep()

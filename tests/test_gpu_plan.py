@@ -229,7 +229,10 @@ def test_plan_argument_and_domain_errors(A):
     y = torch.zeros((N, 4), dtype=torch.uint8, device="cuda")
     rc = lib.agpl_cavi_pass_plan(h, C.byref(lik), C.c_void_p(0), p(y), p(G), p(g), None, None, None, None)
     assert rc == A._ffi.ERR_INVALID_ARGUMENT  # 4 latents against a plan for 1
+    # lifetime rule: the context refuses to go while a plan created on it is alive, and destroys nothing
+    assert lib.agpl_ctx_destroy(ctx._h) == A._ffi.ERR_INVALID_ARGUMENT and b"still alive" in lib.agpl_last_error(ctx._h)
     assert lib.agpl_plan_destroy(h) == 0
+    ctx.synchronize()  # the context is intact
 
 
 def image_features(Phi):

@@ -22,7 +22,7 @@ def child():
         _ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), os.environ["AGPL_LIB_AB"])
     ctx = A.Context(0, seed=5)
     out = {"lib": os.path.basename(_ffi.LIB_PATH)}
-    _ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+    _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-1), None, None)
     import numpy as np
 
     for name, lik, n in (("bernoulli", A.BernoulliLikelihood(), 10_000_000), ("negbin", A.NegativeBinomialLikelihood(15.0), 4_000_000),
@@ -33,11 +33,11 @@ def child():
         f = torch.randn((n,) if L == 1 else (n, L), dtype=torch.float64, device="cuda", generator=g) * 1.5
         Om = A.aux_sample(lik, y, f, ctx=ctx, sweep=1)
         ms, cnt = C.c_double(), C.c_int64()
-        _ffi.lib().agpl_timing_read(ctx.bind(), 3, C.byref(ms), C.byref(cnt))
+        _ffi.lib().agpl_timing(ctx.bind(), 3, C.byref(ms), C.byref(cnt))
         best = 1e9
         for _ in range(4):
             A.aux_sample_(Om, lik, y, f, ctx=ctx, sweep=1)
-            _ffi.lib().agpl_timing_read(ctx.bind(), 3, C.byref(ms), C.byref(cnt))
+            _ffi.lib().agpl_timing(ctx.bind(), 3, C.byref(ms), C.byref(cnt))
             best = min(best, ms.value / max(cnt.value, 1))
         if hasattr(_ffi.lib(), "agpl_debug_pgtrace"):
             tr = (C.c_ulonglong * 8)()

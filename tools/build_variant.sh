@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development aid: a variant build of libagpl.so for same-box A/B runs (tools/ab_syrk_image.py, AGPL_LIB_AB=<name>):
+# Development aid: a variant build of libagpl.so for same-box A/B runs (tools/kbench.py, tools/time_update.py, tools/bench_with_lib.py: AGPL_LIB_AB=<name>):
 #   tools/build_variant.sh <suffix> <file.hip> "<extra -D flags>"   ->  augmentedgplikelihoods.jl_amd/libagpl_<suffix>.so
 # The other objects are the regular build's (run make first).
 set -e

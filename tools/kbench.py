@@ -21,15 +21,14 @@ g = torch.Generator(device="cuda").manual_seed(0)
 Phi = torch.randn((N, M), device="cuda", generator=g) * 0.1
 kd = torch.ones(N, device="cuda")
 y = (torch.rand(N, device="cuda", generator=g) < 0.5).to(torch.uint8)
-cavi = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision=os.environ.get("AGPL_PREC", "f32"), accumulate_precision=os.environ.get("AGPL_APREC", "f32"))
+cavi = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision=os.environ.get("AGPL_PREC", "auto"))  # AGPL_PREC=f32: the float32-input pair
 cavi.sweep()
-if os.environ.get('AGPL_ASPLIT'): cavi.acc_split = int(os.environ['AGPL_ASPLIT'])
 torch.cuda.synchronize()
-_ffi.lib().agpl_timing_enable(ctx.bind(), 1)
+_ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-1), None, None)
 for _ in range(reps):
     cavi.accumulate()
 torch.cuda.synchronize()
 for which, nm in ((0, "marginal"), (1, "syrk")):
     ms, cnt = C.c_double(), C.c_int64()
-    _ffi.lib().agpl_timing_read(ctx.bind(), which, C.byref(ms), C.byref(cnt))
-    print(f"{nm:9s} N={N} M={M} avg {ms.value / cnt.value:8.3f} ms  prec={os.environ.get('AGPL_PREC', 'f32')}/{os.environ.get('AGPL_APREC', 'f32')}")
+    _ffi.lib().agpl_timing(ctx.bind(), which, C.byref(ms), C.byref(cnt))
+    print(f"{nm:9s} N={N} M={M} avg {ms.value / cnt.value:8.3f} ms  prec={cavi.marginal_precision}")
