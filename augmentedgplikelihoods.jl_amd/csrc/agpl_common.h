@@ -36,6 +36,7 @@ struct agpl_ctx {
     int ncu = 0;              // compute units of `device` (queried once, by the first queue-served launch)
     int strip_attr = 0;       // the accumulation kernels' dynamic-LDS attributes are set (once)
     int queue_attr = 0;       // marginal_factor_queue_kernel's dynamic-LDS attribute is set (once)
+    int pipe_attr = 0;        // factor_pipe_kernel's dynamic-LDS attribute is set (once)
     const void *checked_image = nullptr; // the accumulate image whose header agpl_syrk_image_launch has validated last, and for which (N, M)
     int64_t checked_image_N = 0;
     int32_t checked_image_M = 0;

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
     if (NW == 1 && rescue) { // ... and leaves the hand-off flags of its latent zero for the next factorisation (no memset)
-        if (threadIdx.x < 4) sync_all[4 * blockIdx.x + threadIdx.x] = 0u;
-        if (info[blockIdx.x] != -1) return;
+        if (threadIdx.x < 8) sync_all[8 * blockIdx.x + threadIdx.x] = 0u; // (8 words per latent: PipeFlags / ready, done, crit)
+        if (info[blockIdx.x] != -1 || M > 512) return; // (beyond 512 one workgroup cannot hold the panel: the loss is reported)
     }
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
     double *PXg0 = PXg_all + (size_t)l * 2 * M * FB;       // NW > 1: P | X_k' of a block step (LA: two buffers)
-    unsigned *ready = sync_all + 4 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
+    unsigned *ready = sync_all + 8 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -551,49 +551,633 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     }
 }
 
+// =====================================================================================================================
+// factor_pipe_kernel (round 5): the same factorisation as factor_kernel, M % 128 == 0, M <= 1024, ONE launch, with the serial
+// chain cut down to the diagonal blocks.  Per latent the workgroups take fixed roles:
+//
+//   F  (1 workgroup)   the diagonal chain: D_k -> R_kk = chol(D_k), W_k = R_kk^-1 (the 16 column-pair steps of factor_kernel),
+//                      publishes W_k, then P0 = T[k+1,k] W_k' and D_{k+1} = T[k+1,k+1] - P0 P0' from two 32 x 32 blocks that a P
+//                      workgroup handed over a whole step earlier.  Nothing else is on its path: ~10 us per block step instead of
+//                      the ~21 us of factor_kernel's spine (factor 7.8 + panel 3.7 + publish 2.4 + own update 5.4 + waits).
+//   P  (ceil(M / 512)) the block column: each owns 512 rows of the LDS image PX (row c < 32 (k + 1): X_k'[c], column c of U; row
+//                      g >= 32 (k + 1): the raw panel T[g, k]); per step: load W_k, every row times W_k' in place (the panel of
+//                      R and the final rows of U), publish the rows, update the diagonal tiles T[j,j] of its rows (it owns all
+//                      of them, for ever), and apply this step's update to the NEXT block column and the next 32 rows of the
+//                      eliminated identity in LDS (factor_kernel's look-ahead).  The wave whose rows are block k + 2 hands
+//                      T[k+2,k+1] and T[k+2,k+2] to F by itself.
+//   T  (10 or 20)      the trailing update: region (a, b), a >= b, of a 4 x 4 partition of the rows into ranges of M / 4: the
+//                      strictly-lower 32 x 32 tiles of T and the tiles of the eliminated identity with rows in a and columns in b;
+//                      stages only the 2 M / 4 rows of P | X' it needs (<= 135 KB of LDS at M = 1024).  Two passes per step as
+//                      before: first what the P workgroups take over at the next step (counted in `crit`), then the rest.
+//
+// Hand-offs inside the launch follow the local guide's recipe (cdna_hip_programming.md Guideline 16):
+//   * W_k, P0, the two blocks for F, and P | X' are stored write-through (sc1: relaxed agent-scope atomic stores of the 8-byte
+//     words), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane stores / adds the flag;
+//     every load of those bytes in the consumer is an sc1 load (relaxed agent-scope atomic load) behind ONE relaxed poll: no fence;
+//   * the tiles of T and U travel from the T workgroups to P by plain stores + an agent-scope release add (crit / done) and an
+//     agent-scope acquire in P after its poll, as in factor_kernel.
+// Nothing is reused inside a launch (W, P0, P | X' have a slot per step: M x M doubles of scratch), so there is no
+// write-after-read hazard to reason about; the flag words are zeroed by the clean-up launch queued behind every launch.
+// Arithmetic: every element sees exactly factor_kernel's sequence of float64 MFMA accumulations and subtractions, in the same
+// order -- the results are bit for bit those of factor_kernel<1, false> (the rescue path and tests rely on it).
+// =====================================================================================================================
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ double ld_sc1(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, RLX_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double *p, double x) {
+    __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(x), RLX_AGENT);
+}
+// ONE lane polls ONE word, relaxed, bounded (a lost partner must not hang the device)
+__device__ __forceinline__ bool poll_ge(unsigned *p, unsigned target) {
+    for (int it = 0; it < (1 << 22); ++it) {
+        if (__hip_atomic_load(p, RLX_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+#define AGPL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+struct PipeFlags { // one 32-byte record per latent, zero between launches
+    unsigned wready;  // F: W_k published            (value k + 1)
+    unsigned p0ready; // F: P0 of step k published   (value k + 1)
+    unsigned ready;   // P: rows of step k published (+1 per P workgroup and step)
+    unsigned crit;    // T: first pass of a step finished (+1 per T workgroup and step; release)
+    unsigned done;    // T: step finished             (+1 per T workgroup and step; release)
+    unsigned hand;    // P: T[k+2,k+1], T[k+2,k+2] of step k stored (value k + 1)
+    unsigned alldone; // every workgroup: U complete  (+1 each; release)
+    unsigned lost;    // any workgroup: a partner never arrived
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int TS, const double *__restrict__ Gall,
+                                                              const double *__restrict__ gall,
+                                                              const double *__restrict__ eta0all, double *__restrict__ Tall,
+                                                              double *__restrict__ Aall, double *__restrict__ vall,
+                                                              float *__restrict__ v32all, double *__restrict__ logdet,
+                                                              int *__restrict__ info, double *__restrict__ scratch_all,
+                                                              PipeFlags *__restrict__ flags_all, int rescue) {
+    if ((blockIdx.x & 7) != (blockIdx.y & 7)) return; // latent l works on XCD l % 8 (as factor_kernel)
+    const int l = (int)blockIdx.y;
+    const int wg = (int)(blockIdx.x >> 3);
+    if (rescue == 2) { // fault injection (agpl_debug_force_factor_rescue): behave as if a partner never arrived
+        if (wg == 0 && threadIdx.x == 0) info[l] = -1;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int bad, lostf;
+    __shared__ double ldsum;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = M / FB;
+    const int NT = 10 * TS, NWG = 1 + NP + NT;
+    const double *G = Gall + (size_t)l * M * M;
+    double *T = Tall + (size_t)l * M * M;
+    double *A = Aall + (size_t)l * M * M;
+    // scratch of this latent: W [nb][32][32] | P0 [nb][32][32] | PXg [nb][M][32] | pivots [M]
+    double *Wg = scratch_all + (size_t)l * ((size_t)2 * nb * FB * FB + (size_t)M * M + M);
+    double *P0g = Wg + (size_t)nb * FB * FB;
+    double *PXg = P0g + (size_t)nb * FB * FB;
+    PipeFlags *fl = flags_all + l;
+    if (tid == 0) {
+        bad = 0;
+        lostf = 0;
+        ldsum = 0.0;
+    }
+    __syncthreads();
+
+    if (wg == 0) {
+        // =================================================================================== F: the diagonal chain
+        double *Ds = sm;              // [32][FP] the diagonal block being eliminated
+        double *Ys = Ds + FB * FP;    // [32][FP] the identity being eliminated alongside
+        double *Wf = Ys + FB * FP;    // [32][FP] W = R_kk^-1
+        double *T1 = Wf + FB * FP;    // [32][FP] T[k+1, k]   (raw rows of the next block, column block k)
+        double *T2 = T1 + FB * FP;    // [32][FP] T[k+1, k+1] (the next diagonal block before this step's update)
+        double *Ps = T2 + FB * FP;    // [32][FP] P0 = T1 W'
+        double *piv = Ps + FB * FP;   // [M] pivots (log det at the end)
+        {   // D_0 = (I + G)[0:32, 0:32], lower triangle
+            const int r = tid >> 5, c = tid & 31;
+            const double dval = G[(size_t)r * M + c];
+            Ds[r * FP + c] = c < r ? dval : (c == r ? dval + 1.0 : 0.0);
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            int tk = tid, ln = lane;
+            asm volatile("" : "+v"(tk), "+v"(ln));
+            const int kb = k * FB;
+            // ---- R_kk = chol(D), W = R_kk^-1: factor_kernel's sixteen column-pair steps, verbatim
+            {
+                const bool act = tk < 512;
+                const int cc = tk & 31, rq = (tk >> 5) & 15;
+                double *Y = Ys;
+                double d0 = Ds[rq * FP + cc], d1 = Ds[(rq + 16) * FP + cc];
+                double y0r = rq == cc ? 1.0 : 0.0, y1r = rq + 16 == cc ? 1.0 : 0.0;
+                Y[(tk >> 5) * FP + cc] = (tk >> 5) == cc ? 1.0 : 0.0;
+#pragma unroll
+                for (int c = 0; c < FB; c += 2) {
+                    __syncthreads();
+                    if (act) {
+                        double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
+                        double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];
+                        double ya = Y[c * FP + cc], yb = Y[(c + 1) * FP + cc];
+                        double a0 = Ds[rq * FP + c], a1 = Ds[rq * FP + c + 1];
+                        double e0 = Ds[(rq + 16) * FP + c], e1 = Ds[(rq + 16) * FP + c + 1];
+                        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(ya), "+v"(yb), "+v"(a0), "+v"(a1), "+v"(e0), "+v"(e1));
+                        const double det = __builtin_fma(d11, p0, -(b10 * b10));
+                        double r0 = __builtin_amdgcn_rsq(p0), rd = __builtin_amdgcn_rsq(det);
+                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
+                        rd = rd * (1.5 - 0.5 * det * rd * rd);
+                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
+                        rd = rd * (1.5 - 0.5 * det * rd * rd);
+                        const double l10 = b10 * r0;
+                        const double r1 = rd * (p0 * r0);
+                        const double p1 = det * (r0 * r0);
+                        const double lc0 = x0 * r0;
+                        const double lc1 = (x1 - lc0 * l10) * r1;
+                        const double w0 = ya * r0;
+                        const double w1 = (yb - l10 * w0) * r1;
+                        const double la0 = a0 * r0, la1 = (a1 - la0 * l10) * r1;
+                        const double le0 = e0 * r0, le1 = (e1 - le0 * l10) * r1;
+                        const double md0 = (cc > c + 1 && rq >= cc) ? 1.0 : 0.0, md1 = (cc > c + 1 && rq + 16 >= cc) ? 1.0 : 0.0;
+                        const double my0 = rq > c + 1 ? 1.0 : 0.0, my1 = rq + 16 > c + 1 ? 1.0 : 0.0;
+                        d0 -= md0 * (la0 * lc0 + la1 * lc1);
+                        d1 -= md1 * (le0 * lc0 + le1 * lc1);
+                        y0r -= my0 * (la0 * w0 + la1 * w1);
+                        y1r -= my1 * (le0 * w0 + le1 * w1);
+                        if (rq == c) Wf[c * FP + cc] = w0;
+                        if (rq == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                        if (rq + 16 == c) Wf[c * FP + cc] = w0;
+                        if (rq + 16 == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                        if (c + 2 < FB) {
+                            if (cc == c + 2 || cc == c + 3) {
+                                Ds[rq * FP + cc] = d0;
+                                Ds[(rq + 16) * FP + cc] = d1;
+                            }
+                            if (rq == c + 2 || rq == c + 3) Y[rq * FP + cc] = y0r;
+                            if (rq + 16 == c + 2 || rq + 16 == c + 3) Y[(rq + 16) * FP + cc] = y1r;
+                        }
+                        if (tk == 0) {
+                            piv[kb + c] = p0;
+                            piv[kb + c + 1] = p1;
+                            if (!(p0 > 0.0)) bad = bad ? bad : kb + c + 1;
+                            else if (!(p1 > 0.0)) bad = bad ? bad : kb + c + 2;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- publish W_k (write-through); fetch what the next diagonal block needs
+            st_sc1(Wg + (size_t)k * FB * FB + tk, Wf[(tk >> 5) * FP + (tk & 31)]);
+            const bool more = k + 1 < nb;
+            double t1 = 0.0, t2 = 0.0;
+            if (more && k == 0) { // nothing has been updated before step 0: straight from G (+ I)
+                const int r = tk >> 5, c = tk & 31;
+                t1 = G[(size_t)(FB + r) * M + c];
+                t2 = G[(size_t)(FB + r) * M + FB + c] + (r == c ? 1.0 : 0.0);
+            }
+            AGPL_DRAIN(); // W stores (and the k == 0 loads) have completed
+            __syncthreads();
+            if (tk == 0) __hip_atomic_store(&fl->wready, (unsigned)(k + 1), RLX_AGENT);
+            if (!more) break;
+            if (k > 0) {
+                // T[k+1, k] and T[k+1, k+1] as P's step k - 1 left them (a whole step ago: normally long there)
+                if (tk == 0 && !poll_ge(&fl->hand, (unsigned)k)) lostf = 1;
+                __syncthreads();
+                if (lostf) break;
+                const int r = tk >> 5, c = tk & 31;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the loads stay below the poll; every one is sc1)
+                t1 = ld_sc1(T + (size_t)(kb + FB + r) * M + kb + c);
+                t2 = ld_sc1(T + (size_t)(kb + FB + r) * M + kb + FB + c);
+            }
+            {
+                const int r = tk >> 5, c = tk & 31;
+                T1[r * FP + c] = t1;
+                T2[r * FP + c] = t2;
+            }
+            __syncthreads();
+            // P0 = T1 W' (waves 0..3: one 16 x 16 tile each; W lower triangular: the tj = 0 tiles stop at column 15)
+            if (wave < 4) {
+                const int ti = wave >> 1, tj = wave & 1;
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                const double *u = T1 + (16 * ti + (ln & 15)) * FP + (ln >> 4), *v = Wf + (16 * tj + (ln & 15)) * FP + (ln >> 4);
+#pragma unroll
+                for (int kk = 0; kk < FB / 4; ++kk)
+                    if (tj == 1 || kk < FB / 8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u[4 * kk], v[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + 4 * r + (ln >> 4), m = 16 * tj + (ln & 15);
+                    Ps[i * FP + m] = acc[r];
+                    st_sc1(P0g + (size_t)k * FB * FB + i * FB + m, acc[r]);
+                }
+            }
+            AGPL_DRAIN();
+            __syncthreads();
+            if (tk == 0) __hip_atomic_store(&fl->p0ready, (unsigned)(k + 1), RLX_AGENT);
+            // D_{k+1} = T2 - P0 P0' (lower triangle; upper zero)
+            if (wave < 4) {
+                const int ti = wave >> 1, tj = wave & 1;
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                const double *u = Ps + (16 * ti + (ln & 15)) * FP + (ln >> 4), *v = Ps + (16 * tj + (ln & 15)) * FP + (ln >> 4);
+#pragma unroll
+                for (int kk = 0; kk < FB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u[4 * kk], v[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + 4 * r + (ln >> 4), j = 16 * tj + (ln & 15);
+                    const double val = T2[i * FP + j] - acc[r];
+                    Ds[i * FP + j] = j <= i ? val : 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        // log det(I + G) = sum of the log pivots (fixed order), the outcome word
+        if (wave == 0 && !lostf) {
+            double acc = 0.0;
+            for (int i = lane; i < M; i += 64) acc += log(piv[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) ldsum = acc;
+        }
+        __syncthreads();
+    } else if (wg <= NP) {
+        // =================================================================================== P: the block column
+        const int j = wg - 1, R0 = 512 * j;           // this workgroup's rows: global R0 .. R0 + 511 (< M)
+        const int nrow = min(512, M - R0);
+        double *PX = sm;                // [512][FP]
+        double *Wf = PX + (size_t)512 * FP; // [32][FP]
+        double *Rs = Wf + FB * FP;      // [32][FP] P0
+        // ---- stage step 0: rows R >= 32: G[R][0:32] (T = I + G, off the diagonal block); rows R < 32: the identity block
+        for (int idx = tid; idx < nrow * FB; idx += 1024) {
+            const int r = idx >> 5, c = idx & 31, R = R0 + r;
+            PX[(size_t)r * FP + c] = R >= FB ? G[(size_t)R * M + c] : (R == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        const int myR = R0 + 32 * wave; // first global row of this wave's 32 rows
+        const bool have = 32 * wave < nrow;
+        for (int k = 0; k < nb; ++k) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int kb = k * FB, ncx = kb + FB, Mp = M - ncx;
+            const int Rb = myR >> 5; // global 32-row block of this wave's rows
+            // ---- W_k
+            if (tid == 0 && !poll_ge(&fl->wready, (unsigned)(k + 1))) lostf = 1;
+            __syncthreads();
+            if (lostf) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            Wf[(tid >> 5) * FP + (tid & 31)] = ld_sc1(Wg + (size_t)k * FB * FB + tid);
+            __syncthreads();
+            // ---- every row times W': P (panel of R below the block) and X_k' (rows kb .. kb + 31 of U, final)
+            const bool xrows = myR < ncx;
+            if (have) {
+                d4 acc[2][2];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+                double *rows = PX + (size_t)wave * 32 * FP;
+                macro_mac<true>(rows, Wf, ln, acc);
+                double *pub = PXg + ((size_t)k * M + myR) * FB;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + 4 * r + (ln >> 4), m = 16 * tj + (ln & 15);
+                            const double val = acc[ti][tj][r];
+                            rows[i * FP + m] = val;
+                            if (Mp >= 2 * FB) st_sc1(pub + i * FB + m, val); // (no T workgroup reads the last two steps)
+                            if (xrows) {
+                                const int c = myR + i;
+                                if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // final rows of U
+                            }
+                        }
+                // ---- the diagonal tile of this wave's rows: T[Rb,Rb] -= P_k[Rb] P_k[Rb]' (P owns every diagonal tile;
+                //      Rb == k + 1 is F's).  Old values by sc1 loads (written sc1 by whichever wave had these rows last step)
+                if (!xrows && Rb >= k + 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes above
+                    d4 dg[2][2], old[2][2];
+                    const size_t to = (size_t)myR * M + myR;
+                    const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj) {
+                            dg[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const size_t o = to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_;
+                                old[ti][tj][r] = k == 0 ? G[o] : ld_sc1(T + o);
+                            }
+                        }
+                    macro_mac<false>(rows, rows, ln, dg);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
+                                if (jj <= i)
+                                    st_sc1(T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_,
+                                           old[ti][tj][r] - dg[ti][tj][r] + (k == 0 && jj == i ? 1.0 : 0.0));
+                            }
+                }
+            }
+            AGPL_DRAIN(); // this wave's published rows have left the CU
+            __syncthreads();
+            if (tid == 0 && Mp >= 2 * FB) __hip_atomic_fetch_add(&fl->ready, 1u, RLX_AGENT);
+            if (Mp <= 0) break; // last step: the final rows of U are written
+            // ---- look-ahead: this step's update of the NEXT block column of T and of the next 32 rows of the eliminated
+            //      identity, in LDS, straight into the layout of step k + 1
+            if (tid == 0) {
+                if (!poll_ge(&fl->p0ready, (unsigned)(k + 1))) lostf = 1;
+                // the T workgroups' first pass of step k - 1 wrote (plain stores) the old values read below
+                else if (k > 0 && !poll_ge(&fl->crit, (unsigned)(NT * k))) lostf = 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                AGPL_DRAIN();
+            }
+            __syncthreads();
+            if (lostf) break;
+            Rs[(tid >> 5) * FP + (tid & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + tid);
+            __syncthreads();
+            if (have && Rb != k + 1) {
+                const bool ta = !xrows; // P rows: against T; X rows: against U (column-major: A)
+                const double *oldp = ta ? (k == 0 ? G : T) + (size_t)myR * M + ncx : A + (size_t)myR * M + ncx;
+                const bool zero_old = !ta && myR >= kb; // column block k of U: nothing eliminated into it yet
+                double *rowsU = PX + (size_t)wave * 32 * FP;
+                const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+                d4 acc[2][2], old[2][2];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            old[ti][tj][r] = zero_old ? 0.0 : oldp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
+                    }
+                macro_mac<false>(rowsU, Rs, ln, acc);
+                const bool crit_wave = ta && Rb == k + 2; // F needs these rows (T[k+2, k+1]) at the end of ITS next step
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
+                            const double val = old[ti][tj][r] - acc[ti][tj][r];
+                            rowsU[i * FP + jj] = val;
+                            if (crit_wave) st_sc1(T + (size_t)(myR + i) * M + ncx + jj, val);
+                        }
+                if (crit_wave) { // this wave signals for its own stores only (the diagonal tile above included)
+                    AGPL_DRAIN();
+                    if (ln == 0) __hip_atomic_store(&fl->hand, (unsigned)(k + 1), RLX_AGENT);
+                }
+            } else if (have) {
+                // rows ncx .. ncx + 31 held the first 32 rows of P: block (k + 1, k + 1) of the eliminated identity is the identity
+                double *rowsU = PX + (size_t)wave * 32 * FP;
+                for (int e = ln; e < FB * FB; e += 64) rowsU[(e >> 5) * FP + (e & 31)] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+        }
+    } else {
+        // =================================================================================== T: the trailing update
+        const int tw = wg - 1 - NP;            // 0 .. 10 TS - 1
+        const int reg = tw / TS, part = tw - reg * TS;
+        int ra = 0;
+        while ((ra + 1) * (ra + 2) / 2 <= reg) ++ra;
+        const int rbq = reg - ra * (ra + 1) / 2; // region (ra, rbq), ra >= rbq, over four ranges of Rg rows
+        const int Rg = M / 4, nbr = Rg / FB;   // rows / 32-row blocks per range
+        double *PXa = sm;                      // [Rg][FP] rows of range ra of P | X'
+        double *PXb = ra == rbq ? PXa : PXa + (size_t)Rg * FP;
+        const int a0 = ra * Rg, b0 = rbq * Rg;
+        for (int k = 0; k + 2 < nb; ++k) { // (the last two steps leave no tile: block column k + 1 is P's)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int kb = k * FB, ncx = kb + FB;
+            const bool active = a0 + Rg > ncx + FB; // some row of the range is still below the block column P holds
+            if (active) {
+                if (tid == 0 && !poll_ge(&fl->ready, (unsigned)(NP * (k + 1)))) lostf = 1;
+                __syncthreads();
+                if (lostf) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double *src = PXg + (size_t)k * M * FB;
+#pragma unroll 1
+                for (int i0 = tid; i0 < Rg * FB; i0 += 8 * 1024) { // 8 loads in flight per thread and range
+                    double ta_[8], tb_[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = min(i0 + u * 1024, Rg * FB - 1);
+                        ta_[u] = ld_sc1(src + (size_t)a0 * FB + idx);
+                        tb_[u] = ra == rbq ? 0.0 : ld_sc1(src + (size_t)b0 * FB + idx);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = i0 + u * 1024;
+                        if (idx < Rg * FB) {
+                            PXa[(size_t)(idx >> 5) * FP + (idx & 31)] = ta_[u];
+                            if (ra != rbq) PXb[(size_t)(idx >> 5) * FP + (idx & 31)] = tb_[u];
+                        }
+                    }
+                }
+                __syncthreads();
+                const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+                for (int pass = 0; pass < 2; ++pass) {
+                    int cnt = 0;
+                    // (a) T[i][j] -= P_i . P_j: tiles of 32 rows (block ib of range a) x 16 columns (block jb of range b),
+                    //     strictly below the diagonal 32 x 32 tiles (those are P's) and right of block column k + 1 (P's too)
+                    for (int ib = 0; ib < nbr; ++ib) {
+                        const int gi = a0 + 32 * ib;
+                        if (gi < ncx + FB) continue; // (row block k + 1: P0's rows; above: finished)
+                        for (int jb = 0; jb < 2 * nbr; ++jb) {
+                            const int gj = b0 + 16 * jb;
+                            if (gj < ncx + FB || (gj >> 5) >= (gi >> 5)) continue;
+                            // first pass: block column k + 2 -- what the P workgroups take over at their next step
+                            if ((gj < ncx + 2 * FB) != (pass == 0)) continue;
+                            if ((cnt++ % (16 * TS)) != part * 16 + wave) continue;
+                            d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
+                            const size_t to = (size_t)gi * M + gj;
+                            const double *tsrc = (k == 0 ? G : T) + to;
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                            mac_2x1(PXa + (size_t)(32 * ib) * FP, PXb + (size_t)(16 * jb) * FP, ln, acc);
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    T[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                        }
+                    }
+                    // (b) RHS[i][c] -= X_k'[c] . P_i: tiles of 32 columns c (block cb of range b, c < ncx) x 16 rows i (block
+                    //     ib16 of range a, below block row k + 1); U is column-major: the lanes of a result run along i
+                    for (int cb = 0; cb < nbr; ++cb) {
+                        const int gc = b0 + 32 * cb;
+                        if (gc >= ncx) break;
+                        for (int ib16 = 0; ib16 < 2 * nbr; ++ib16) {
+                            const int gi = a0 + 16 * ib16;
+                            if (gi < ncx + FB) continue;
+                            // first pass: rows of block k + 2 of the eliminated identity
+                            if ((gi < ncx + 2 * FB) != (pass == 0)) continue;
+                            if ((cnt++ % (16 * TS)) != part * 16 + wave) continue;
+                            d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
+                            double *ap = A + (size_t)gc * M + gi;
+                            const bool fresh = gc >= kb; // column block k: nothing eliminated into it yet
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                            mac_2x1(PXb + (size_t)(32 * cb) * FP, PXa + (size_t)(16 * ib16) * FP, ln, acc);
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                        }
+                    }
+                    if (pass == 0) {
+                        AGPL_DRAIN();
+                        __syncthreads();
+                        if (tid == 0) __hip_atomic_fetch_add(&fl->crit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                AGPL_DRAIN();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(&fl->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (tid == 0) { // nothing left in this region: keep the counters' arithmetic uniform
+                __hip_atomic_fetch_add(&fl->crit, 1u, RLX_AGENT);
+                __hip_atomic_fetch_add(&fl->done, 1u, RLX_AGENT);
+            }
+        }
+    }
+
+    // ======================================================================================= all: U complete -> v = U (g + eta0)
+    AGPL_DRAIN();
+    __syncthreads();
+    if (tid == 0) {
+        if (lostf) __hip_atomic_store(&fl->lost, 1u, RLX_AGENT);
+        __hip_atomic_fetch_add(&fl->alldone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!poll_ge(&fl->alldone, (unsigned)NWG)) lostf = 1;
+        if (__hip_atomic_load(&fl->lost, RLX_AGENT)) lostf = 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        AGPL_DRAIN();
+    }
+    __syncthreads();
+    if (lostf) {
+        if (wg == 0 && tid == 0) info[l] = -1; // a partner workgroup never arrived: the clean-up launch redoes M <= 512 alone
+        return;
+    }
+    {
+        // v[a] = sum_{b <= a} A[b * M + a] r[b]: workgroup w takes the 64-wide blocks of a with index = w (mod NWG); wave w' the
+        // b = w', w' + 16, ...; the 16 partial sums of an a are combined in wave order (fixed: reproducible, and the same
+        // for every NWG)
+        double *rs = sm;           // [M]
+        double *part = sm + M;     // [16][64]
+        const double *g = gall + (size_t)l * M;
+        for (int b = tid; b < M; b += 1024) rs[b] = g[b] + (eta0all ? eta0all[(size_t)l * M + b] : 0.0);
+        __syncthreads();
+        for (int ab = wg; ab < M / 64; ab += NWG) {
+            const int a = ab * 64 + lane;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int b = wave; b <= ab * 64 + 63; b += 16) {
+                const double u = A[(size_t)b * M + a]; // (rows b > a of this column block hold the other triangle: unused)
+                if (b <= a) acc += u * rs[b];
+            }
+            part[wave * 64 + lane] = acc;
+            __syncthreads();
+            if (tid < 64) {
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) s += part[w * 64 + tid];
+                if (vall) vall[(size_t)l * M + ab * 64 + tid] = s;
+                if (v32all) v32all[(size_t)l * M + ab * 64 + tid] = (float)s;
+            }
+            __syncthreads();
+        }
+    }
+    if (wg == 0 && tid == 0) {
+        if (logdet) logdet[l] = ldsum;
+        info[l] = bad;
+    }
+}
+
 } // namespace
 
-// internal: fused factorisation (M % 32 == 0, M <= 512); T_work / A_work [L][M][M] float64, info [L] int (device),
-// coop_work: L * (2 * M * 32 doubles) + 4 L unsigned for the multi-workgroup forms (may be null: single workgroup)
+// bytes of `coop_work` for the cooperative forms of agpl_factor_fused
+size_t agpl_factor_coop_bytes(int32_t M, int32_t L) {
+    const size_t nb = (size_t)M / FB;
+    const size_t pipe = sizeof(double) * (size_t)L * (2 * nb * FB * FB + (size_t)M * M + M); // W | P0 | P|X' per step | pivots
+    const size_t la = sizeof(double) * (size_t)L * 2 * M * FB;                               // factor_kernel's two P|X' buffers
+    return (pipe > la ? pipe : la) + 1024;
+}
+
+// internal: fused factorisation (M % 32 == 0; M <= 512, or M <= 1024 with M % 128 == 0); T_work / A_work [L][M][M] float64,
+// info [L] int (device), coop_work: agpl_factor_coop_bytes(M, L) for the multi-workgroup forms (may be null: single workgroup,
+// M <= 512 only)
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work) {
-    const size_t lds = sizeof(double) * ((size_t)M * FP + 3 * FB * FP);
-    // workgroups per latent: 5 = look-ahead, one spine workgroup + 4 tile workgroups (2, 3 = narrower look-ahead forms used when
-    // several latents share an XCD; the forms that shared the tiles of every step without look-ahead, 4 and 8, measured slower
-    // at M = 512 -- DESIGN.md 4.5 -- and are no longer instantiated)
-    constexpr int nw_env = 5;
-    // the multi-workgroup forms spin on their partners: every working workgroup must be resident at once (one per CU,
-    // the 150 KB of LDS see to that).  Latent l runs on XCD l % 8 (32 CUs each), so ceil(L / 8) latents share an XCD:
-    // the widest look-ahead form that keeps their workgroups within 24 CUs is used, else one workgroup per latent
-    int nw = 1;
-    if (coop_work) {
-        const int per_xcd = (L + 7) / 8;
-        if (per_xcd * nw_env <= 24) nw = nw_env;
-        else if (nw_env == 5 && per_xcd * 3 <= 24) nw = 3;
-        else if ((nw_env == 5 || nw_env == 3) && per_xcd * 2 <= 24) nw = 2;
-    }
-    double *PXg = (double *)coop_work;
-    // hand-off flags: fixed words of the small workspace that are zero between launches (agpl_ws2_reserve; the rescue launch
-    // behind every cooperative launch zeroes them again)
+    const size_t lds = sizeof(double) * ((size_t)(M < 512 ? M : 512) * FP + 3 * FB * FP);
+    // hand-off flags: fixed words of the small workspace (8 per latent) that are zero between launches (agpl_ws2_reserve; the
+    // clean-up launch behind every cooperative launch zeroes them again)
     unsigned *sync = coop_work ? (unsigned *)((char *)ctx->ws2 + 8448) : nullptr;
+    const int per_xcd = (L + 7) / 8; // latent l runs on XCD l % 8 (32 CUs each)
+    const int coop_mode = ctx->debug_force_rescue ? 2 : 0;
 #define AGPL_LAUNCH_FACTOR(NW_, LA_, GRID_, RESCUE_)                                                                         \
     do {                                                                                                             \
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<NW_, LA_>),                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
         factor_kernel<NW_, LA_><<<GRID_, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,    \
-                                                                   logdet_out, info_dev, PXg, sync, RESCUE_);        \
+                                                                   logdet_out, info_dev, (double *)coop_work, sync, RESCUE_); \
     } while (0)
-    const int coop_mode = ctx->debug_force_rescue ? 2 : 0;
+    // ---- the pipeline form (round 5): roles F | P x NP | T x 10 TS.  All of a latent's workgroups must be resident at once (one
+    //      per CU: the 150 KB of LDS see to that) within the 32 CUs of its XCD
+    if (coop_work && M % 128 == 0 && M <= 1024) {
+        const int NP = (M + 511) / 512;
+        int TS = M > 512 ? 2 : 1;
+        if (per_xcd * (1 + NP + 10 * TS) > 28) TS = 1;
+        const int nwg = 1 + NP + 10 * TS;
+        if (per_xcd * nwg <= 28) {
+            const size_t ldsp = sizeof(double) * ((size_t)(512 + 2 * FB) * FP);
+            if (!ctx->pipe_attr) {
+                AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_pipe_kernel<0>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+                ctx->pipe_attr = 1;
+            }
+            factor_pipe_kernel<0><<<dim3(8 * nwg, (unsigned)L), 1024, ldsp, ctx->stream>>>(
+                M, NP, TS, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, (double *)coop_work,
+                (PipeFlags *)sync, coop_mode);
+            AGPL_LAUNCH_CHECK(ctx);
+            // the clean-up launch: zeroes the flag words; redoes a latent whose partners never arrived in ONE workgroup (M <= 512)
+            AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 1);
+            AGPL_LAUNCH_CHECK(ctx);
+            return AGPL_OK;
+        }
+    }
+    if (M > 512) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "agpl_factor_fused: M = %d, L = %d has no one-launch form", M, L);
+    // workgroups per latent: 5 = look-ahead, one spine workgroup + 4 tile workgroups (2, 3 = narrower look-ahead forms used when
+    // several latents share an XCD): the round 1-4 form, kept for feature counts that are not a multiple of 128
+    constexpr int nw_env = 5;
+    int nw = 1;
+    if (coop_work) {
+        if (per_xcd * nw_env <= 24) nw = nw_env;
+        else if (nw_env == 5 && per_xcd * 3 <= 24) nw = 3;
+        else if ((nw_env == 5 || nw_env == 3) && per_xcd * 2 <= 24) nw = 2;
+    }
     if (nw == 2) AGPL_LAUNCH_FACTOR(2, true, dim3(16, (unsigned)L), coop_mode);
     else if (nw == 3) AGPL_LAUNCH_FACTOR(3, true, dim3(24, (unsigned)L), coop_mode);
     else if (nw == 5) AGPL_LAUNCH_FACTOR(5, true, dim3(40, (unsigned)L), coop_mode);
     else AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 0);
     AGPL_LAUNCH_CHECK(ctx);
     // The multi-workgroup forms are plain launches that assume their partners co-resident (true when this process has
-    // the device to itself: per_xcd * nw <= 24 CUs of an XCD's 32).  Should other work hold those CUs for longer than
-    // the bounded spin, the spine reports info = -1 and the rescue launch behind it redoes that latent in one workgroup,
-    // in stream order and without the host; otherwise it exits at once (~2 us per update).
+    // the device to itself).  Should other work hold those CUs for longer than the bounded spin, the spine reports info = -1 and
+    // the rescue launch behind it redoes that latent in one workgroup, in stream order and without the host; otherwise it exits
+    // at once (~2 us per update).
     if (nw > 1) AGPL_LAUNCH_FACTOR(1, false, dim3((unsigned)L), 1);
 #undef AGPL_LAUNCH_FACTOR
     AGPL_LAUNCH_CHECK(ctx);

@@ -181,6 +181,13 @@ __global__ void sum_latents_kernel(int L, const double *__restrict__ per, double
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work);
+size_t agpl_factor_coop_bytes(int32_t M, int32_t L); // agpl_factor.hip
+// the one-launch factorisation takes this shape (else: the two-block form for 512 < M <= 1024, rocSOLVER beyond)
+static inline bool factor_one_launch(int32_t M, int32_t L) {
+    if (M % 32 || L > 64) return false;
+    if (M <= 512) return true;
+    return M <= 1024 && M % 128 == 0 && ((L + 7) / 8) * (1 + 2 + 10) <= 28; // the pipeline form's workgroups fit an XCD
+}
 
 namespace {
 // Uz = the factor with its foreign triangle zeroed: Uz[i][j] = A[i][j] for i <= j (row-major; = U[j][i]), else 0
@@ -210,21 +217,24 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     if (rc) return rc;
     const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
     const size_t info_off = 16384; // ws2 head is used by the reductions
-    const bool two = M > 512;
-    if ((M <= 512 || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64) {
-        // one-launch factorisation (agpl_factor.hip; two block rows of it for 512 < M <= 1024): U = chol(I + G)^-1,
-        // then S = U'U as one float64 GEMM -- 1.1 ms at M = 512 against 3.4 ms for the ~300 launches of potrf + potri
+    const bool one = factor_one_launch(M, L);
+    const bool two = !one && M > 512;
+    if ((one || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64) {
+        // one-launch factorisation (agpl_factor.hip; two block rows of it for feature counts in (512, 1024] that are not a multiple
+        // of 128): U = chol(I + G)^-1, then S = U'U as one float64 GEMM -- against 3.4 ms for the ~300 launches of potrf + potri
+        const size_t coop_bytes = one ? ((agpl_factor_coop_bytes(M, L) + 255) & ~(size_t)255) : 0;
         const size_t own = two ? ((two_block_ws2_bytes(L) + 255) & ~(size_t)255) : info_off + 1024;
-        rc = agpl_ws2_reserve(ctx, own + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + 1024);
+        rc = agpl_ws2_reserve(ctx, own + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + coop_bytes + 1024);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         char *p = (char *)ctx->ws2 + own;
         double *T = (double *)p, *Aw = (double *)(p + mat_bytes), *Uz = (double *)(p + 2 * mat_bytes);
         double *S = S_out ? S_out : (double *)(p + 3 * mat_bytes);
+        void *coop = one ? (void *)(p + 3 * mat_bytes + (S_out ? 0 : mat_bytes)) : nullptr;
         if (two)
             rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, Aw, nullptr, nullptr, logdet_dev, &info);
         else
-            rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, nullptr);
+            rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, coop);
         if (rc) return rc;
         dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
         factor_clean_kernel<<<grid, 128, 0, ctx->stream>>>(M, Aw, Uz);
@@ -374,7 +384,7 @@ __global__ void two_block_assemble_kernel(int M, int m1, const double *__restric
 // the sum first, so that the reservation inside cannot move the buffer
 size_t two_block_ws2_bytes(int32_t L) {
     const size_t blk = sizeof(double) * (size_t)L * 512 * 512;
-    const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * 512 * 32 + 1024;
+    const size_t coop_bytes = (agpl_factor_coop_bytes(512, L) + 255) & ~(size_t)255;
     const size_t vec = (sizeof(double) * (size_t)L * 512 + 255) & ~(size_t)255;
     return 16384 + 1024 + 9 * blk + coop_bytes + 6 * vec;
 }
@@ -387,7 +397,7 @@ int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const dou
     if (rc) return rc;
     const int m1 = 512, m2 = M - m1;
     const size_t info_off = 16384, blk = sizeof(double) * (size_t)L * m1 * m1;
-    const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * m1 * 32 + 1024;
+    const size_t coop_bytes = (agpl_factor_coop_bytes(512, L) + 255) & ~(size_t)255;
     const size_t vec = (sizeof(double) * (size_t)L * m1 + 255) & ~(size_t)255;
     rc = agpl_ws2_reserve(ctx, two_block_ws2_bytes(L));
     if (rc) return rc;
@@ -528,10 +538,10 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         const int32_t rp = agpl_pending_resolve(ctx); // the previous factorisation's outcome, before its slot is reused
         if (rp) return rp;
     }
-    if (M <= 512 && M % 32 == 0) {
+    if (factor_one_launch(M, L)) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
         const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
-        const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * M * 32 + 1024;
+        const size_t coop_bytes = agpl_factor_coop_bytes(M, L);
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
@@ -550,7 +560,7 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
         *armed = true;
         return AGPL_OK;
     }
-    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) {
+    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) { // (feature counts in (512, 1024] that are not a multiple of 128)
         int *info2 = nullptr;
         int32_t rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, logdet_out, &info2);
         if (rc) return rc;
@@ -742,12 +752,12 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
-    if (M <= 512 && M % 32 == 0 && L <= 64) {
+    if (factor_one_launch(M, L)) {
         // I + G = C C', U = C^-1:  m = U'(U r),  v = m + C^-T z = U'(U r + z)   (one fused factor launch + one matvec)
         const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
         const size_t info_off = 16384;
-        const size_t coop_bytes = sizeof(double) * (size_t)L * 2 * M * 32 + 1024;
+        const size_t coop_bytes = agpl_factor_coop_bytes(M, L);
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);

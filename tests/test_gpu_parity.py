@@ -148,9 +148,9 @@ def test_aux_sample_matches_oracle(A, ctx, oracle, name):
         assert al == pytest.approx(ral, rel=1e-9)  # (the 101-term PG density series through the device's libm: 1.1e-10 seen at b = n + 1/2)
         # the full-conditional-Omega identity of TestUtils.jl:107-116 with the DEVICE's aug_loglik on both draws
         Om2 = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(f), ctx=ctx, sweep=8)
-        ref2 = O.aux_sample(olik, y, f, seed=SEED, sweep=8)
-        c1 = al - O.full_conditional_logpdf(olik, y, f, ref["omega"], ref.get("n"))
-        c2 = A.aug_loglik(lik, Om2, dev(y), dev(f), ctx=ctx) - O.full_conditional_logpdf(olik, y, f, ref2["omega"], ref2.get("n"))
+        hn = lambda o: host(o.n) if "n" in ref else None  # (each constant from the DEVICE's own draw: the identity holds for any Omega)
+        c1 = al - O.full_conditional_logpdf(olik, y, f, host(Om.ω), hn(Om))
+        c2 = A.aug_loglik(lik, Om2, dev(y), dev(f), ctx=ctx) - O.full_conditional_logpdf(olik, y, f, host(Om2.ω), hn(Om2))
         assert c1 == pytest.approx(c2, abs=1e-6)  # (1e-5 for n = 10 in the reference; measured ~1e-11 at n = 3000)
     if name in ("bernoulli", "negbin", "negbin_real", "studentt", "poisson", "laplace"):
         pl = A.aux_prior_logpdf(lik, Om, dev(y), ctx=ctx)
@@ -712,8 +712,8 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
     assert relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
 
 
-@pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (352, 1), (512, 2), (544, 1), (640, 3), (1024, 1),
-                                 (1024, 2), (1536, 1), (256, 30)])
+@pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (256, 1), (352, 1), (384, 3), (512, 2), (544, 1), (640, 3),
+                                 (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 9), (1536, 1), (256, 30), (512, 17)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
     """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernel (M <= 1024, every block count and both
     latent-per-XCD packings) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
@@ -806,7 +806,7 @@ def test_gaussian_factor_defers_the_report(A, ctx):
     args = (C.c_int32(M), C.c_int32(1), C.c_void_p(dG.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(0),
             C.c_void_p(Aw.data_ptr()), C.c_void_p(0), C.c_void_p(0))
     ctx.call("agpl_gaussian_factor", *args)  # no exception yet
-    with pytest.raises(A.PosDefException, match="pivot at row 100"):
+    with pytest.raises(A.PosDefException, match=r"row 100\)"):
         ctx.synchronize()
     ctx.synchronize()  # reported once
     good = dev(np.zeros((1, M, M)))
