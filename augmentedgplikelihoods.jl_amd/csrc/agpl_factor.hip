@@ -28,10 +28,10 @@
 
 #ifdef AGPL_FTRACE
 // debug build only (tools/scratch/ftrace.py): wall-clock stamps of the phases of every block step, per workgroup
-__device__ unsigned long long g_ftrace[8 * 16 * 8];
+__device__ unsigned long long g_ftrace[16 * 32 * 8];
 #define AGPL_TS(id_)                                                                                                  \
     do {                                                                                                              \
-        if (tid == 0 && blockIdx.y == 0) g_ftrace[(wg * 16 + k) * 8 + (id_)] = wall_clock64();                         \
+        if (tid == 0 && blockIdx.y == 0 && wg < 16 && k < 32) g_ftrace[(wg * 32 + k) * 8 + (id_)] = wall_clock64();    \
     } while (0)
 extern "C" __attribute__((visibility("default"))) int agpl_debug_ftrace(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ftrace), sizeof(g_ftrace));
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
     if (NW == 1 && rescue) { // ... and leaves the hand-off flags of its latent zero for the next factorisation (no memset)
-        if (threadIdx.x < 8) sync_all[8 * blockIdx.x + threadIdx.x] = 0u; // (8 words per latent: PipeFlags / ready, done, crit)
+        if (threadIdx.x < 24) sync_all[24 * blockIdx.x + threadIdx.x] = 0u; // (24 words per latent: PipeFlags / ready, done, crit)
         if (info[blockIdx.x] != -1 || M > 512) return; // (beyond 512 one workgroup cannot hold the panel: the loss is reported)
     }
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
     double *PXg0 = PXg_all + (size_t)l * 2 * M * FB;       // NW > 1: P | X_k' of a block step (LA: two buffers)
-    unsigned *ready = sync_all + 8 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
+    unsigned *ready = sync_all + 24 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -600,19 +600,36 @@ __device__ __forceinline__ bool poll_ge(unsigned *p, unsigned target) {
 }
 #define AGPL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-struct PipeFlags { // one 32-byte record per latent, zero between launches
-    unsigned wready;  // F: W_k published            (value k + 1)
-    unsigned p0ready; // F: P0 of step k published   (value k + 1)
-    unsigned ready;   // P: rows of step k published (+1 per P workgroup and step)
-    unsigned crit;    // T: first pass of a step finished (+1 per T workgroup and step; release)
-    unsigned done;    // T: step finished             (+1 per T workgroup and step; release)
-    unsigned hand;    // P: T[k+2,k+1], T[k+2,k+2] of step k stored (value k + 1)
-    unsigned alldone; // every workgroup: U complete  (+1 each; release)
-    unsigned lost;    // any workgroup: a partner never arrived
+struct PipeFlags { // one 96-byte record per latent, zero between launches.  Every word has ONE writer (or is a final count):
+                   // a sum over producers could be reached by a fast one running a step ahead of a slow one
+    unsigned wready;   // F: W_k published                                 (value k + 1)
+    unsigned p0ready;  // F: P0 of step k published                        (value k + 1)
+    unsigned hand;     // P: T[k+2,k+1], T[k+2,k+2] of step k stored        (value k + 1)
+    unsigned alldone;  // every workgroup: U complete                       (+1 each; release)
+    unsigned lost;     // any workgroup: a partner never arrived (which wait: diagnostic)
+    unsigned ready[2]; // P workgroup j: its rows of step k published       (value k + 1)
+    unsigned pad;
+    unsigned crit[16]; // T workgroup w: first pass of step k finished      (value k + 1; release)
 };
 
+// 16-byte write-through store (global_store_dwordx4 ... sc1): the 8-byte form costs 2.7 x per byte on the fabric
+// (MI355X_MICROARCH.md, visibility table) -- publishing a block column by 8-byte sc1 stores took 12 us of P's 20 us step
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
+#ifdef AGPL_PIPE_PUB8
+    st_sc1(p, a);
+    st_sc1(p + 1, b);
+#else
+    d2v v = {a, b};
+    // (s_nop 1: a VMEM store of more than 8 bytes still reads its data registers for two cycles after issue, and the compiler's
+    //  hazard recogniser does not look inside inline asm: without it the next VALU write of those registers corrupted the low
+    //  words of the stored doubles -- 2e-7 relative errors in U; cdna_hip_programming.md 5.7)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 template <int DUMMY>
-__global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int TS, const double *__restrict__ Gall,
+__global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int CY, const double *__restrict__ Gall,
                                                               const double *__restrict__ gall,
                                                               const double *__restrict__ eta0all, double *__restrict__ Tall,
                                                               double *__restrict__ Aall, double *__restrict__ vall,
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = M / FB;
-    const int NT = 10 * TS, NWG = 1 + NP + NT;
+    const int NT = CY * CY, NWG = 1 + NP + NT; // T workgroups: a CY x CY (4 x 4, or 2 x 2) block-cyclic grid over the 32 x 32 tiles
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             int tk = tid, ln = lane;
             asm volatile("" : "+v"(tk), "+v"(ln));
             const int kb = k * FB;
+            AGPL_TS(0);
             // ---- R_kk = chol(D), W = R_kk^-1: factor_kernel's sixteen column-pair steps, verbatim
             {
                 const bool act = tk < 512;
@@ -728,6 +746,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                 }
             }
             __syncthreads();
+            AGPL_TS(1);
             // ---- publish W_k (write-through); fetch what the next diagonal block needs
             st_sc1(Wg + (size_t)k * FB * FB + tk, Wf[(tk >> 5) * FP + (tk & 31)]);
             const bool more = k + 1 < nb;
@@ -735,16 +754,18 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             if (more && k == 0) { // nothing has been updated before step 0: straight from G (+ I)
                 const int r = tk >> 5, c = tk & 31;
                 t1 = G[(size_t)(FB + r) * M + c];
-                t2 = G[(size_t)(FB + r) * M + FB + c] + (r == c ? 1.0 : 0.0);
+                t2 = G[(size_t)(FB + r) * M + FB + c]; // (T = I + G: the 1 is added behind the subtraction, as factor_kernel does)
             }
             AGPL_DRAIN(); // W stores (and the k == 0 loads) have completed
             __syncthreads();
             if (tk == 0) __hip_atomic_store(&fl->wready, (unsigned)(k + 1), RLX_AGENT);
+            AGPL_TS(2);
             if (!more) break;
             if (k > 0) {
                 // T[k+1, k] and T[k+1, k+1] as P's step k - 1 left them (a whole step ago: normally long there)
                 if (tk == 0 && !poll_ge(&fl->hand, (unsigned)k)) lostf = 1;
                 __syncthreads();
+                AGPL_TS(3);
                 if (lostf) break;
                 const int r = tk >> 5, c = tk & 31;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the loads stay below the poll; every one is sc1)
@@ -757,6 +778,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                 T2[r * FP + c] = t2;
             }
             __syncthreads();
+            AGPL_TS(4);
             // P0 = T1 W' (waves 0..3: one 16 x 16 tile each; W lower triangular: the tj = 0 tiles stop at column 15)
             if (wave < 4) {
                 const int ti = wave >> 1, tj = wave & 1;
@@ -775,6 +797,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             AGPL_DRAIN();
             __syncthreads();
             if (tk == 0) __hip_atomic_store(&fl->p0ready, (unsigned)(k + 1), RLX_AGENT);
+            AGPL_TS(5);
             // D_{k+1} = T2 - P0 P0' (lower triangle; upper zero)
             if (wave < 4) {
                 const int ti = wave >> 1, tj = wave & 1;
@@ -786,7 +809,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * ti + 4 * r + (ln >> 4), j = 16 * tj + (ln & 15);
                     const double val = T2[i * FP + j] - acc[r];
-                    Ds[i * FP + j] = j <= i ? val : 0.0;
+                    Ds[i * FP + j] = j < i ? val : (j == i ? val + (k == 0 ? 1.0 : 0.0) : 0.0);
                 }
             }
             __syncthreads();
@@ -821,12 +844,15 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             const int kb = k * FB, ncx = kb + FB, Mp = M - ncx;
             const int Rb = myR >> 5; // global 32-row block of this wave's rows
             // ---- W_k
-            if (tid == 0 && !poll_ge(&fl->wready, (unsigned)(k + 1))) lostf = 1;
+            AGPL_TS(0);
+            if (tid == 0 && !poll_ge(&fl->wready, (unsigned)(k + 1))) lostf = 3;
             __syncthreads();
+            AGPL_TS(1);
             if (lostf) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             Wf[(tid >> 5) * FP + (tid & 31)] = ld_sc1(Wg + (size_t)k * FB * FB + tid);
             __syncthreads();
+            AGPL_TS(2);
             // ---- every row times W': P (panel of R below the block) and X_k' (rows kb .. kb + 31 of U, final)
             const bool xrows = myR < ncx;
             if (have) {
@@ -837,7 +863,6 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                     for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
                 double *rows = PX + (size_t)wave * 32 * FP;
                 macro_mac<true>(rows, Wf, ln, acc);
-                double *pub = PXg + ((size_t)k * M + myR) * FB;
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -847,31 +872,48 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                             const int i = 16 * ti + 4 * r + (ln >> 4), m = 16 * tj + (ln & 15);
                             const double val = acc[ti][tj][r];
                             rows[i * FP + m] = val;
-                            if (Mp >= 2 * FB) st_sc1(pub + i * FB + m, val); // (no T workgroup reads the last two steps)
                             if (xrows) {
                                 const int c = myR + i;
                                 if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // final rows of U
                             }
                         }
-                // ---- the diagonal tile of this wave's rows: T[Rb,Rb] -= P_k[Rb] P_k[Rb]' (P owns every diagonal tile;
-                //      Rb == k + 1 is F's).  Old values by sc1 loads (written sc1 by whichever wave had these rows last step)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes above (only this wave touches these rows)
+                if (Mp >= 2 * FB) { // publish (no T workgroup reads the last two steps): 8 x (64 lanes x 16 bytes), write-through
+                    double *pub = PXg + ((size_t)k * M + myR) * FB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = 2 * (64 * q + ln); // element pair (row e >> 5, columns e & 31, + 1)
+                        st_sc1_x2(pub + e, rows[(e >> 5) * FP + (e & 31)], rows[(e >> 5) * FP + (e & 31) + 1]);
+                    }
+                }
+                // ---- the diagonal tile of this wave's rows: T[Rb,Rb] -= P_k[Rb] P_k[Rb]' (P owns every diagonal tile; Rb == k + 1
+                //      is F's).  P's own data: plain loads / stores (the same CU wrote them last step) -- except the tile of block
+                //      k + 2, which F reads next step: that one is stored write-through by the wave that signals `hand`
                 if (!xrows && Rb >= k + 2) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes above
                     d4 dg[2][2], old[2][2];
                     const size_t to = (size_t)myR * M + myR;
                     const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+                    [[maybe_unused]] const double *tsrc = k == 0 ? G : T;
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                         for (int tj = 0; tj < 2; ++tj) {
                             dg[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const size_t o = to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_;
-                                old[ti][tj][r] = k == 0 ? G[o] : ld_sc1(T + o);
-                            }
+                            for (int r = 0; r < 4; ++r)
+#ifdef AGPL_PIPE_DIAGSC1
+                                old[ti][tj][r] = k == 0 ? G[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_]
+                                                        : ld_sc1(T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_);
+#else
+                                old[ti][tj][r] = tsrc[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
+#endif
                         }
                     macro_mac<false>(rows, rows, ln, dg);
+#ifdef AGPL_PIPE_DIAGSC1
+                    const bool toF = true;
+#else
+                    const bool toF = Rb == k + 2;
+#endif
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -879,29 +921,37 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
-                                if (jj <= i)
-                                    st_sc1(T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_,
-                                           old[ti][tj][r] - dg[ti][tj][r] + (k == 0 && jj == i ? 1.0 : 0.0));
+                                if (jj <= i) {
+                                    double *dst = T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_;
+                                    const double val = old[ti][tj][r] - dg[ti][tj][r] + (k == 0 && jj == i ? 1.0 : 0.0);
+                                    if (toF) st_sc1(dst, val);
+                                    else *dst = val;
+                                }
                             }
                 }
             }
             AGPL_DRAIN(); // this wave's published rows have left the CU
             __syncthreads();
-            if (tid == 0 && Mp >= 2 * FB) __hip_atomic_fetch_add(&fl->ready, 1u, RLX_AGENT);
+            if (tid == 0 && Mp >= 2 * FB) __hip_atomic_store(&fl->ready[j], (unsigned)(k + 1), RLX_AGENT);
             if (Mp <= 0) break; // last step: the final rows of U are written
+            AGPL_TS(3);
             // ---- look-ahead: this step's update of the NEXT block column of T and of the next 32 rows of the eliminated
             //      identity, in LDS, straight into the layout of step k + 1
-            if (tid == 0) {
-                if (!poll_ge(&fl->p0ready, (unsigned)(k + 1))) lostf = 1;
-                // the T workgroups' first pass of step k - 1 wrote (plain stores) the old values read below
-                else if (k > 0 && !poll_ge(&fl->crit, (unsigned)(NT * k))) lostf = 1;
+            if (wave == 0) { // lane 0: P0 of this step; lanes 16..31: the T workgroups' first passes of step k - 1 (plain stores
+                             // behind a release: the old values read below), one word each
+                bool ok = true;
+                if (lane == 0) ok = poll_ge(&fl->p0ready, (unsigned)(k + 1));
+                else if (lane >= 16 && lane < 16 + NT && k > 0) ok = poll_ge(&fl->crit[lane - 16], (unsigned)k);
+                if (!__all(ok) && lane == 0) lostf = 4;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 AGPL_DRAIN();
             }
             __syncthreads();
+            AGPL_TS(4);
             if (lostf) break;
             Rs[(tid >> 5) * FP + (tid & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + tid);
             __syncthreads();
+            AGPL_TS(5);
             if (have && Rb != k + 1) {
                 const bool ta = !xrows; // P rows: against T; X rows: against U (column-major: A)
                 const double *oldp = ta ? (k == 0 ? G : T) + (size_t)myR * M + ncx : A + (size_t)myR * M + ncx;
@@ -941,117 +991,125 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                 for (int e = ln; e < FB * FB; e += 64) rowsU[(e >> 5) * FP + (e & 31)] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
             }
             __syncthreads();
+            AGPL_TS(6);
         }
     } else {
         // =================================================================================== T: the trailing update
-        const int tw = wg - 1 - NP;            // 0 .. 10 TS - 1
-        const int reg = tw / TS, part = tw - reg * TS;
-        int ra = 0;
-        while ((ra + 1) * (ra + 2) / 2 <= reg) ++ra;
-        const int rbq = reg - ra * (ra + 1) / 2; // region (ra, rbq), ra >= rbq, over four ranges of Rg rows
-        const int Rg = M / 4, nbr = Rg / FB;   // rows / 32-row blocks per range
-        double *PXa = sm;                      // [Rg][FP] rows of range ra of P | X'
-        double *PXb = ra == rbq ? PXa : PXa + (size_t)Rg * FP;
-        const int a0 = ra * Rg, b0 = rbq * Rg;
+        // Workgroup (tr, tc) of a CY x CY block-cyclic grid over the 32 x 32 tiles: the strictly-lower tiles (ib, jb) of T with
+        // ib = tr, jb = tc (mod CY) (the diagonal tiles and block column k + 1 are P's), and the tiles of the eliminated identity
+        // with row block ib = tr and column block cb = tc (mod CY).  Cyclic: every workgroup keeps its share of the work to the
+        // last steps (contiguous regions left most of them idle half-way, and the bottom ones with 25 us per step at M = 1024).
+        // It stages the 2 x nb / CY row blocks of P | X' it needs: <= 2 x 256 rows (CY = 2 only for M <= 512).
+        const int tw = wg - 1 - NP;            // 0 .. CY^2 - 1
+        const int tr = tw / CY, tc = tw - tr * CY;
+        const int nq = nb / CY;                // row blocks per residue class (ib = CY q + tr); nb % 4 == 0
+        double *PXa = sm;                      // [nq][32][FP] row blocks ib = tr (mod 4)
+        double *PXb = tr == tc ? PXa : PXa + (size_t)nq * FB * FP; // [nq][32][FP] row blocks = tc (mod 4)
         for (int k = 0; k + 2 < nb; ++k) { // (the last two steps leave no tile: block column k + 1 is P's)
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const int kb = k * FB, ncx = kb + FB;
-            const bool active = a0 + Rg > ncx + FB; // some row of the range is still below the block column P holds
-            if (active) {
-                if (tid == 0 && !poll_ge(&fl->ready, (unsigned)(NP * (k + 1)))) lostf = 1;
-                __syncthreads();
-                if (lostf) break;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const double *src = PXg + (size_t)k * M * FB;
-#pragma unroll 1
-                for (int i0 = tid; i0 < Rg * FB; i0 += 8 * 1024) { // 8 loads in flight per thread and range
-                    double ta_[8], tb_[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int idx = min(i0 + u * 1024, Rg * FB - 1);
-                        ta_[u] = ld_sc1(src + (size_t)a0 * FB + idx);
-                        tb_[u] = ra == rbq ? 0.0 : ld_sc1(src + (size_t)b0 * FB + idx);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int idx = i0 + u * 1024;
-                        if (idx < Rg * FB) {
-                            PXa[(size_t)(idx >> 5) * FP + (idx & 31)] = ta_[u];
-                            if (ra != rbq) PXb[(size_t)(idx >> 5) * FP + (idx & 31)] = tb_[u];
-                        }
-                    }
-                }
-                __syncthreads();
-                const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
-                for (int pass = 0; pass < 2; ++pass) {
-                    int cnt = 0;
-                    // (a) T[i][j] -= P_i . P_j: tiles of 32 rows (block ib of range a) x 16 columns (block jb of range b),
-                    //     strictly below the diagonal 32 x 32 tiles (those are P's) and right of block column k + 1 (P's too)
-                    for (int ib = 0; ib < nbr; ++ib) {
-                        const int gi = a0 + 32 * ib;
-                        if (gi < ncx + FB) continue; // (row block k + 1: P0's rows; above: finished)
-                        for (int jb = 0; jb < 2 * nbr; ++jb) {
-                            const int gj = b0 + 16 * jb;
-                            if (gj < ncx + FB || (gj >> 5) >= (gi >> 5)) continue;
-                            // first pass: block column k + 2 -- what the P workgroups take over at their next step
-                            if ((gj < ncx + 2 * FB) != (pass == 0)) continue;
-                            if ((cnt++ % (16 * TS)) != part * 16 + wave) continue;
-                            d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
-                            const size_t to = (size_t)gi * M + gj;
-                            const double *tsrc = (k == 0 ? G : T) + to;
-#pragma unroll
-                            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
-                            mac_2x1(PXa + (size_t)(32 * ib) * FP, PXb + (size_t)(16 * jb) * FP, ln, acc);
-#pragma unroll
-                            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    T[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
-                        }
-                    }
-                    // (b) RHS[i][c] -= X_k'[c] . P_i: tiles of 32 columns c (block cb of range b, c < ncx) x 16 rows i (block
-                    //     ib16 of range a, below block row k + 1); U is column-major: the lanes of a result run along i
-                    for (int cb = 0; cb < nbr; ++cb) {
-                        const int gc = b0 + 32 * cb;
-                        if (gc >= ncx) break;
-                        for (int ib16 = 0; ib16 < 2 * nbr; ++ib16) {
-                            const int gi = a0 + 16 * ib16;
-                            if (gi < ncx + FB) continue;
-                            // first pass: rows of block k + 2 of the eliminated identity
-                            if ((gi < ncx + 2 * FB) != (pass == 0)) continue;
-                            if ((cnt++ % (16 * TS)) != part * 16 + wave) continue;
-                            d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
-                            double *ap = A + (size_t)gc * M + gi;
-                            const bool fresh = gc >= kb; // column block k: nothing eliminated into it yet
-#pragma unroll
-                            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
-                            mac_2x1(PXb + (size_t)(32 * cb) * FP, PXa + (size_t)(16 * ib16) * FP, ln, acc);
-#pragma unroll
-                            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
-                        }
-                    }
-                    if (pass == 0) {
-                        AGPL_DRAIN();
-                        __syncthreads();
-                        if (tid == 0) __hip_atomic_fetch_add(&fl->crit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                AGPL_DRAIN();
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(&fl->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (tid == 0) { // nothing left in this region: keep the counters' arithmetic uniform
-                __hip_atomic_fetch_add(&fl->crit, 1u, RLX_AGENT);
-                __hip_atomic_fetch_add(&fl->done, 1u, RLX_AGENT);
+            AGPL_TS(0);
+            if (wave == 0) {
+                bool ok = true;
+                if (lane < NP) ok = poll_ge(&fl->ready[lane], (unsigned)(k + 1));
+                if (!__all(ok) && lane == 0) lostf = 5;
             }
+            __syncthreads();
+            AGPL_TS(1);
+            if (lostf) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {   // stage: thread t takes 16-byte pairs; 8 loads in flight per thread and class
+                const double *src = PXg + (size_t)k * M * FB;
+                const int npair = nq * FB * FB / 2;
+#pragma unroll 1
+                for (int i0 = tid; i0 < npair; i0 += 4 * 1024) {
+                    double ta_[4][2], tb_[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = 2 * min(i0 + u * 1024, npair - 1); // element (q, row, col) of the class image
+                        const int q = e >> 10, rc = e & 1023;
+                        const int ba = min(CY * q + tr, nb - 1), bb = min(CY * q + tc, nb - 1);
+                        ta_[u][0] = ld_sc1(src + (size_t)ba * FB * FB + rc);
+                        ta_[u][1] = ld_sc1(src + (size_t)ba * FB * FB + rc + 1);
+                        tb_[u][0] = tr == tc ? 0.0 : ld_sc1(src + (size_t)bb * FB * FB + rc);
+                        tb_[u][1] = tr == tc ? 0.0 : ld_sc1(src + (size_t)bb * FB * FB + rc + 1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = i0 + u * 1024;
+                        if (idx < npair) {
+                            const int e = 2 * idx, row = e >> 5, col = e & 31;
+                            PXa[(size_t)row * FP + col] = ta_[u][0];
+                            PXa[(size_t)row * FP + col + 1] = ta_[u][1];
+                            if (tr != tc) {
+                                PXb[(size_t)row * FP + col] = tb_[u][0];
+                                PXb[(size_t)row * FP + col + 1] = tb_[u][1];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            AGPL_TS(2);
+            const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
+            // A wave walks the rectangle (row blocks q of class tr) x (16-wide halves of the blocks of class tc) in steps of 16
+            // and keeps what is a tile of this step and pass: a handful of iterations each
+            const int ncol = 2 * nq, nrect = nq * ncol;
+            for (int pass = 0; pass < 2; ++pass) {
+                // (a) T[i][j] -= P_i . P_j: 32 rows (block ib) x 16 columns (half h of block jb), jb < ib, jb >= k + 2
+                for (int t = wave; t < nrect; t += 16) {
+                    const int qa = t / ncol, hb = t - qa * ncol, qb = hb >> 1, h = hb & 1;
+                    const int ib = CY * qa + tr, jb = CY * qb + tc;
+                    if (ib >= nb || jb >= ib || jb < k + 2) continue;
+                    // first pass: block column k + 2 -- what the P workgroups take over at their next step
+                    if ((jb == k + 2) != (pass == 0)) continue;
+                    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
+                    const size_t to = (size_t)(32 * ib) * M + 32 * jb + 16 * h;
+                    const double *tsrc = (k == 0 ? G : T) + to;
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                    mac_2x1(PXa + (size_t)(32 * qa) * FP, PXb + (size_t)(32 * qb + 16 * h) * FP, ln, acc);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            T[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                }
+                // (b) RHS[i][c] -= X_k'[c] . P_i: 32 columns c (block cb <= k) x 16 rows i (half h of block ib >= k + 2); U is
+                //     column-major: the lanes of a result run along i
+                for (int t = wave; t < nrect; t += 16) {
+                    const int qb = t / ncol, ha = t - qb * ncol, qa = ha >> 1, h = ha & 1;
+                    const int ib = CY * qa + tr, cb = CY * qb + tc;
+                    if (ib >= nb || ib < k + 2 || cb > k) continue;
+                    // first pass: the rows of block k + 2 of the eliminated identity
+                    if ((ib == k + 2) != (pass == 0)) continue;
+                    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
+                    double *ap = A + (size_t)(32 * cb) * M + 32 * ib + 16 * h;
+                    const bool fresh = cb == k; // column block k: nothing eliminated into it yet
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
+                    mac_2x1(PXb + (size_t)(32 * qb) * FP, PXa + (size_t)(32 * qa + 16 * h) * FP, ln, acc);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                }
+                if (pass == 0) {
+                    AGPL_DRAIN();
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(&fl->crit[tw], (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    AGPL_TS(3);
+                }
+            }
+            AGPL_DRAIN();
+            __syncthreads();
+            AGPL_TS(4);
         }
     }
 
@@ -1059,7 +1117,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
     AGPL_DRAIN();
     __syncthreads();
     if (tid == 0) {
-        if (lostf) __hip_atomic_store(&fl->lost, 1u, RLX_AGENT);
+        if (lostf) __hip_atomic_store(&fl->lost, (unsigned)(100 * wg + lostf), RLX_AGENT); // (which wait gave up: diagnostic)
         __hip_atomic_fetch_add(&fl->alldone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (!poll_ge(&fl->alldone, (unsigned)NWG)) lostf = 1;
         if (__hip_atomic_load(&fl->lost, RLX_AGENT)) lostf = 1;
@@ -1135,13 +1193,14 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
         factor_kernel<NW_, LA_><<<GRID_, 1024, lds, ctx->stream>>>(M, G, g, eta0, T_work, A_work, v_out, v32_out,    \
                                                                    logdet_out, info_dev, (double *)coop_work, sync, RESCUE_); \
     } while (0)
-    // ---- the pipeline form (round 5): roles F | P x NP | T x 10 TS.  All of a latent's workgroups must be resident at once (one
+    // ---- the pipeline form (round 5): roles F | P x NP | T x 16.  All of a latent's workgroups must be resident at once (one
     //      per CU: the 150 KB of LDS see to that) within the 32 CUs of its XCD
     if (coop_work && M % 128 == 0 && M <= 1024) {
         const int NP = (M + 511) / 512;
-        int TS = M > 512 ? 2 : 1;
-        if (per_xcd * (1 + NP + 10 * TS) > 28) TS = 1;
-        const int nwg = 1 + NP + 10 * TS;
+        // T workgroups: 4 x 4 block-cyclic; 2 x 2 where several latents share an XCD and a class still fits the LDS (M <= 512)
+        int CY = 4;
+        if (per_xcd * (1 + NP + 16) > 28 && M <= 512) CY = 2;
+        const int nwg = 1 + NP + CY * CY;
         if (per_xcd * nwg <= 28) {
             const size_t ldsp = sizeof(double) * ((size_t)(512 + 2 * FB) * FP);
             if (!ctx->pipe_attr) {
@@ -1150,7 +1209,7 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
                 ctx->pipe_attr = 1;
             }
             factor_pipe_kernel<0><<<dim3(8 * nwg, (unsigned)L), 1024, ldsp, ctx->stream>>>(
-                M, NP, TS, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, (double *)coop_work,
+                M, NP, CY, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, (double *)coop_work,
                 (PipeFlags *)sync, coop_mode);
             AGPL_LAUNCH_CHECK(ctx);
             // the clean-up launch: zeroes the flag words; redoes a latent whose partners never arrived in ONE workgroup (M <= 512)

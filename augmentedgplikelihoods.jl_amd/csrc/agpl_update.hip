@@ -186,7 +186,7 @@ size_t agpl_factor_coop_bytes(int32_t M, int32_t L); // agpl_factor.hip
 static inline bool factor_one_launch(int32_t M, int32_t L) {
     if (M % 32 || L > 64) return false;
     if (M <= 512) return true;
-    return M <= 1024 && M % 128 == 0 && ((L + 7) / 8) * (1 + 2 + 10) <= 28; // the pipeline form's workgroups fit an XCD
+    return M <= 1024 && M % 128 == 0 && L <= 8; // the pipeline form's 19 workgroups (F, 2 P, 4 x 4 T) need an XCD to themselves
 }
 
 namespace {

@@ -142,15 +142,25 @@ def test_aux_sample_matches_oracle(A, ctx, oracle, name):
     if name in ("bernoulli", "negbin", "negbin_real", "studentt", "poisson", "laplace", "hetero"):
         # aug_loglik = logtilt + log-density of the aux prior at the draw (generic.jl:48-50; PG series polyagamma.jl:37-91;
         # priors poisson.jl:67-76 / polyagammapoisson.jl:29-33, laplace.jl:90-96); heteroscedasticgaussian.jl:106-128 its own
-        al = A.aug_loglik(lik, Om, dev(y), dev(f), ctx=ctx)
-        ral = O.aug_loglik(olik, y, ref["omega"], f, ref.get("n"))
+        fd, Omd, refd = f, Om, ref
+        if name == "hetero":
+            # The reference's 101-term series for logpdf(PG(b, 0), x) cancels catastrophically at large x (condition number 5e13 at
+            # b = 106.5, x = 27 -- the draws (f - y)^2 ~ 50 above produce): there host and device libm differ in the third digit
+            # and neither is right (docs/src/index.md:190-191 says to avoid it).  The density checks use residuals |f - y| ~ 0.8.
+            fd = f.copy()
+            fd[:, 0] = y + 0.8 * rng.normal(size=n)
+            Omd = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(fd), ctx=ctx, sweep=9)
+            refd = O.aux_sample(olik, y, fd, seed=SEED, sweep=9)
+            assert np.array_equal(host(Omd.n), refd["n"])
+        al = A.aug_loglik(lik, Omd, dev(y), dev(fd), ctx=ctx)
+        ral = O.aug_loglik(olik, y, refd["omega"], fd, refd.get("n"))
         assert np.isfinite(ral)
-        assert al == pytest.approx(ral, rel=1e-9)  # (the 101-term PG density series through the device's libm: 1.1e-10 seen at b = n + 1/2)
-        # the full-conditional-Omega identity of TestUtils.jl:107-116 with the DEVICE's aug_loglik on both draws
-        Om2 = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(f), ctx=ctx, sweep=8)
-        hn = lambda o: host(o.n) if "n" in ref else None  # (each constant from the DEVICE's own draw: the identity holds for any Omega)
-        c1 = al - O.full_conditional_logpdf(olik, y, f, host(Om.ω), hn(Om))
-        c2 = A.aug_loglik(lik, Om2, dev(y), dev(f), ctx=ctx) - O.full_conditional_logpdf(olik, y, f, host(Om2.ω), hn(Om2))
+        assert al == pytest.approx(ral, rel=1e-9)  # (the 101-term PG density series through the device's libm)
+        # the full-conditional-Omega identity of TestUtils.jl:107-116 with the DEVICE's aug_loglik on two of its own draws
+        Om2 = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(fd), ctx=ctx, sweep=8)
+        hn = lambda o: host(o.n) if "n" in ref else None
+        c1 = al - O.full_conditional_logpdf(olik, y, fd, host(Omd.ω), hn(Omd))
+        c2 = A.aug_loglik(lik, Om2, dev(y), dev(fd), ctx=ctx) - O.full_conditional_logpdf(olik, y, fd, host(Om2.ω), hn(Om2))
         assert c1 == pytest.approx(c2, abs=1e-6)  # (1e-5 for n = 10 in the reference; measured ~1e-11 at n = 3000)
     if name in ("bernoulli", "negbin", "negbin_real", "studentt", "poisson", "laplace"):
         pl = A.aux_prior_logpdf(lik, Om, dev(y), ctx=ctx)
@@ -713,7 +723,7 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
 
 
 @pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (256, 1), (352, 1), (384, 3), (512, 2), (544, 1), (640, 3),
-                                 (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 9), (1536, 1), (256, 30), (512, 17)])
+                                 (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 8), (1024, 9), (1536, 1), (256, 30), (512, 9), (256, 20), (512, 40)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
     """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernel (M <= 1024, every block count and both
     latent-per-XCD packings) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
@@ -758,6 +768,17 @@ def test_gaussian_factor_rescue_launch_reproduces_the_cooperative_result(A, M, L
         rctx.call("agpl_debug_force_factor_rescue", C.c_int32(force))
         plan.U_colmajor.zero_()
         plan.call("agpl_plan_update", C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+        if force and M > 512:
+            # beyond 512 rows one workgroup cannot hold a block column: a lost partner is REPORTED (the clean-up launch still
+            # zeroes the hand-off flags, so the context stays usable)
+            with pytest.raises(A.AGPLError, match="never arrived"):
+                rctx.synchronize()
+            rctx.call("agpl_debug_force_factor_rescue", C.c_int32(0))
+            plan.call("agpl_plan_update", C.c_void_p(G.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(0), C.c_void_p(0))
+            rctx.synchronize()
+            assert torch.equal(torch.triu(plan.U_colmajor), outs[0][0]) and torch.equal(plan.v, outs[0][1])
+            outs.append(outs[0])
+            continue
         rctx.synchronize()
         outs.append((torch.triu(plan.U_colmajor).clone(), plan.v.clone(), plan.logdet.clone(), plan.U_hi.clone(),
                      plan.U_lo.clone(), plan.v32.clone()))
