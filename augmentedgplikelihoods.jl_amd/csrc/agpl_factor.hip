@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
     if (NW == 1 && rescue) { // ... and leaves the hand-off flags of its latent zero for the next factorisation (no memset)
-        if (threadIdx.x < 24) sync_all[24 * blockIdx.x + threadIdx.x] = 0u; // (24 words per latent: PipeFlags / ready, done, crit)
+        if (threadIdx.x < 28) sync_all[28 * blockIdx.x + threadIdx.x] = 0u; // (28 words per latent: PipeFlags / ready, done, crit)
         if (info[blockIdx.x] != -1 || M > 512) return; // (beyond 512 one workgroup cannot hold the panel: the loss is reported)
     }
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
     double *PXg0 = PXg_all + (size_t)l * 2 * M * FB;       // NW > 1: P | X_k' of a block step (LA: two buffers)
-    unsigned *ready = sync_all + 24 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
+    unsigned *ready = sync_all + 28 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -600,15 +600,15 @@ __device__ __forceinline__ bool poll_ge(unsigned *p, unsigned target) {
 }
 #define AGPL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-struct PipeFlags { // one 96-byte record per latent, zero between launches.  Every word has ONE writer (or is a final count):
+struct PipeFlags { // one 112-byte record per latent, zero between launches.  Every word has ONE writer (or is a final count):
                    // a sum over producers could be reached by a fast one running a step ahead of a slow one
     unsigned wready;   // F: W_k published                                 (value k + 1)
     unsigned p0ready;  // F: P0 of step k published                        (value k + 1)
     unsigned hand;     // P: T[k+2,k+1], T[k+2,k+2] of step k stored        (value k + 1)
     unsigned alldone;  // every workgroup: U complete                       (+1 each; release)
     unsigned lost;     // any workgroup: a partner never arrived (which wait: diagnostic)
-    unsigned ready[2]; // P workgroup j: its rows of step k published       (value k + 1)
-    unsigned pad;
+    unsigned ready[4]; // P workgroup j: its rows of step k published       (value k + 1)
+    unsigned pad[3];
     unsigned crit[16]; // T workgroup w: first pass of step k finished      (value k + 1; release)
 };
 
@@ -825,24 +825,39 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
         __syncthreads();
     } else if (wg <= NP) {
         // =================================================================================== P: the block column
-        const int j = wg - 1, R0 = 512 * j;           // this workgroup's rows: global R0 .. R0 + 511 (< M)
-        const int nrow = min(512, M - R0);
-        double *PX = sm;                // [512][FP]
-        double *Wf = PX + (size_t)512 * FP; // [32][FP]
-        double *Rs = Wf + FB * FP;      // [32][FP] P0
+        // 256 rows per workgroup: waves 0..7 OWN 32 rows each (panel, look-ahead), waves 8..15 HELP (wave w + 8 publishes the rows
+        // of wave w, updates their diagonal tile, waits for the write-through and signals) -- so the ~4 us a block column takes to
+        // reach the fabric, and the diagonal tiles, run beside the look-ahead instead of in front of it.  The rows live in two LDS
+        // images: the panel of step k is formed in place in image k & 1 (read by the helpers), the look-ahead writes the raw rows
+        // of step k + 1 into the other one.
+        const int j = wg - 1, R0 = 256 * j;           // this workgroup's rows: global R0 .. R0 + 255 (< M)
+        const int nrow = min(256, M - R0);
+        double *PXbuf = sm;                        // [2][256][FP]
+        double *Wf = PXbuf + (size_t)2 * 256 * FP; // [32][FP]
+        double *Rs = Wf + FB * FP;                 // [32][FP] P0
+        __shared__ unsigned pubcnt;                // helpers whose published rows have reached the fabric (monotonic)
+        if (tid == 0) pubcnt = 0u;
         // ---- stage step 0: rows R >= 32: G[R][0:32] (T = I + G, off the diagonal block); rows R < 32: the identity block
         for (int idx = tid; idx < nrow * FB; idx += 1024) {
             const int r = idx >> 5, c = idx & 31, R = R0 + r;
-            PX[(size_t)r * FP + c] = R >= FB ? G[(size_t)R * M + c] : (R == c ? 1.0 : 0.0);
+            PXbuf[(size_t)r * FP + c] = R >= FB ? G[(size_t)R * M + c] : (R == c ? 1.0 : 0.0);
         }
         __syncthreads();
-        const int myR = R0 + 32 * wave; // first global row of this wave's 32 rows
-        const bool have = 32 * wave < nrow;
+        const bool owner = wave < 8;
+        const int ow = wave & 7;                 // the owner wave this wave is or helps
+        const int myR = R0 + 32 * ow;            // first global row of its 32 rows
+        const bool have = 32 * ow < nrow;
+        const int nhelp = (nrow + 31) / 32;      // helpers with rows
         for (int k = 0; k < nb; ++k) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int kb = k * FB, ncx = kb + FB, Mp = M - ncx;
-            const int Rb = myR >> 5; // global 32-row block of this wave's rows
+            const int Rb = myR >> 5; // global 32-row block of the rows
+            double *rows = PXbuf + (size_t)(k & 1) * 256 * FP + (size_t)ow * 32 * FP;        // this step's rows (panel in place)
+            double *rowsN = PXbuf + (size_t)((k + 1) & 1) * 256 * FP + (size_t)ow * 32 * FP; // the raw rows of step k + 1
+            const bool xrows = myR < ncx;
+            const bool pub = Mp >= 2 * FB;       // (no T workgroup reads the last two steps)
+            const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
             // ---- W_k
             AGPL_TS(0);
             if (tid == 0 && !poll_ge(&fl->wready, (unsigned)(k + 1))) lostf = 3;
@@ -851,17 +866,33 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             if (lostf) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             Wf[(tid >> 5) * FP + (tid & 31)] = ld_sc1(Wg + (size_t)k * FB * FB + tid);
+            // helpers: the old values of the diagonal tile, on their way while the panel is formed (the owners' come behind the panel:
+            // they wait for the T workgroups)
+            const bool upd = owner && have && Mp > 0 && Rb != k + 1;
+            const bool dgt = !owner && have && !xrows && Rb >= k + 2; // (P owns every diagonal tile; Rb == k + 1 is F's)
+            d4 uold[2][2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) uold[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (dgt) { // P's own data (this wave wrote it last step): plain loads
+                const double *oldp = (k == 0 ? G : T) + (size_t)myR * M + myR;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) uold[ti][tj][r] = oldp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
+            }
             __syncthreads();
             AGPL_TS(2);
-            // ---- every row times W': P (panel of R below the block) and X_k' (rows kb .. kb + 31 of U, final)
-            const bool xrows = myR < ncx;
-            if (have) {
+            // ---- owners: every row times W': P (panel of R below the block) and X_k' (rows kb .. kb + 31 of U, final)
+            if (owner && have) {
                 d4 acc[2][2];
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
-                double *rows = PX + (size_t)wave * 32 * FP;
                 macro_mac<true>(rows, Wf, ln, acc);
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
@@ -877,43 +908,86 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                                 if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // final rows of U
                             }
                         }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own LDS writes above (only this wave touches these rows)
-                if (Mp >= 2 * FB) { // publish (no T workgroup reads the last two steps): 8 x (64 lanes x 16 bytes), write-through
-                    double *pub = PXg + ((size_t)k * M + myR) * FB;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = 2 * (64 * q + ln); // element pair (row e >> 5, columns e & 31, + 1)
-                        st_sc1_x2(pub + e, rows[(e >> 5) * FP + (e & 31)], rows[(e >> 5) * FP + (e & 31) + 1]);
-                    }
-                }
-                // ---- the diagonal tile of this wave's rows: T[Rb,Rb] -= P_k[Rb] P_k[Rb]' (P owns every diagonal tile; Rb == k + 1
-                //      is F's).  P's own data: plain loads / stores (the same CU wrote them last step) -- except the tile of block
-                //      k + 2, which F reads next step: that one is stored write-through by the wave that signals `hand`
-                if (!xrows && Rb >= k + 2) {
-                    d4 dg[2][2], old[2][2];
-                    const size_t to = (size_t)myR * M + myR;
-                    const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
-                    [[maybe_unused]] const double *tsrc = k == 0 ? G : T;
+            }
+            if (wave == 8 && Mp > 0) { // beside the panel: P0 of this step (F: ~2 us behind W_k) and the T workgroups' first passes of
+                                       // step k - 1 (the look-ahead's old values: stored write-through there, read by sc1 loads
+                                       // here -- no fence on either side)
+                bool ok = true;
+                if (lane == 0) ok = poll_ge(&fl->p0ready, (unsigned)(k + 1));
+                else if (lane >= 16 && lane < 16 + NT && k > 0) ok = poll_ge(&fl->crit[lane - 16], (unsigned)k);
+                if (!__all(ok) && lane == 0) lostf = 4;
+            }
+            __syncthreads(); // the panel rows are in LDS for the helpers
+            AGPL_TS(3);
+            if (Mp <= 0) break; // last step: the final rows of U are written (drained behind the loop)
+            if (lostf) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            Rs[(tid >> 5) * FP + (tid & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + tid);
+            if (upd && !(xrows && myR >= kb)) { // (column block k of U: nothing eliminated into it yet -> zeros)
+                const double *oldp = !xrows ? (k == 0 ? G : T) + (size_t)myR * M + ncx : A + (size_t)myR * M + ncx;
+                if (k == 0) {
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                        for (int tj = 0; tj < 2; ++tj) {
-                            dg[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+                        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) uold[ti][tj][r] = oldp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
+                } else {
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-#ifdef AGPL_PIPE_DIAGSC1
-                                old[ti][tj][r] = k == 0 ? G[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_]
-                                                        : ld_sc1(T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_);
-#else
-                                old[ti][tj][r] = tsrc[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
-#endif
+                                uold[ti][tj][r] = ld_sc1(oldp + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_);
+                }
+            }
+            __syncthreads();
+            AGPL_TS(4);
+            if (upd) {
+                // ---- owners, look-ahead: this step's update of the NEXT block column of T and of the next 32 rows of the
+                //      eliminated identity, into the other LDS image = the layout of step k + 1
+                d4 acc[2][2];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+                macro_mac<false>(rows, Rs, ln, acc);
+                const bool crit_wave = !xrows && Rb == k + 2; // F needs these rows (T[k+2, k+1]) at the end of ITS next step
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
+                            const double val = uold[ti][tj][r] - acc[ti][tj][r];
+                            rowsN[i * FP + jj] = val;
+                            if (crit_wave) st_sc1(T + (size_t)(myR + i) * M + ncx + jj, val);
                         }
+                if (crit_wave) AGPL_DRAIN(); // (its half of the hand-over; the flag goes behind the end-of-step barrier)
+            } else if (owner && have) {
+                // rows ncx .. ncx + 31 held the first 32 rows of P: block (k + 1, k + 1) of the eliminated identity is the identity
+                for (int e = ln; e < FB * FB; e += 64) rowsN[(e >> 5) * FP + (e & 31)] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
+            } else if (!owner && have) {
+                // ---- helpers: publish the rows (8 x (64 lanes x 16 bytes), write-through), the diagonal tile, the signal
+                if (pub) {
+                    double *pubp = PXg + ((size_t)k * M + myR) * FB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = 2 * (64 * q + ln); // element pair (row e >> 5, columns e & 31, + 1)
+                        st_sc1_x2(pubp + e, rows[(e >> 5) * FP + (e & 31)], rows[(e >> 5) * FP + (e & 31) + 1]);
+                    }
+                }
+                if (dgt) { // T[Rb,Rb] -= P_k[Rb] P_k[Rb]'; the tile of block k + 2 goes to F next step: write-through
+                    d4 dg[2][2];
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj) dg[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
                     macro_mac<false>(rows, rows, ln, dg);
-#ifdef AGPL_PIPE_DIAGSC1
-                    const bool toF = true;
-#else
+                    const size_t to = (size_t)myR * M + myR;
                     const bool toF = Rb == k + 2;
-#endif
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -923,74 +997,20 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                                 const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
                                 if (jj <= i) {
                                     double *dst = T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_;
-                                    const double val = old[ti][tj][r] - dg[ti][tj][r] + (k == 0 && jj == i ? 1.0 : 0.0);
+                                    const double val = uold[ti][tj][r] - dg[ti][tj][r] + (k == 0 && jj == i ? 1.0 : 0.0);
                                     if (toF) st_sc1(dst, val);
                                     else *dst = val;
                                 }
                             }
                 }
-            }
-            AGPL_DRAIN(); // this wave's published rows have left the CU
-            __syncthreads();
-            if (tid == 0 && Mp >= 2 * FB) __hip_atomic_store(&fl->ready[j], (unsigned)(k + 1), RLX_AGENT);
-            if (Mp <= 0) break; // last step: the final rows of U are written
-            AGPL_TS(3);
-            // ---- look-ahead: this step's update of the NEXT block column of T and of the next 32 rows of the eliminated
-            //      identity, in LDS, straight into the layout of step k + 1
-            if (wave == 0) { // lane 0: P0 of this step; lanes 16..31: the T workgroups' first passes of step k - 1 (plain stores
-                             // behind a release: the old values read below), one word each
-                bool ok = true;
-                if (lane == 0) ok = poll_ge(&fl->p0ready, (unsigned)(k + 1));
-                else if (lane >= 16 && lane < 16 + NT && k > 0) ok = poll_ge(&fl->crit[lane - 16], (unsigned)k);
-                if (!__all(ok) && lane == 0) lostf = 4;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                AGPL_DRAIN();
-            }
-            __syncthreads();
-            AGPL_TS(4);
-            if (lostf) break;
-            Rs[(tid >> 5) * FP + (tid & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + tid);
-            __syncthreads();
-            AGPL_TS(5);
-            if (have && Rb != k + 1) {
-                const bool ta = !xrows; // P rows: against T; X rows: against U (column-major: A)
-                const double *oldp = ta ? (k == 0 ? G : T) + (size_t)myR * M + ncx : A + (size_t)myR * M + ncx;
-                const bool zero_old = !ta && myR >= kb; // column block k of U: nothing eliminated into it yet
-                double *rowsU = PX + (size_t)wave * 32 * FP;
-                const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
-                d4 acc[2][2], old[2][2];
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < 2; ++tj) {
-                        acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            old[ti][tj][r] = zero_old ? 0.0 : oldp[(unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_];
-                    }
-                macro_mac<false>(rowsU, Rs, ln, acc);
-                const bool crit_wave = ta && Rb == k + 2; // F needs these rows (T[k+2, k+1]) at the end of ITS next step
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = 16 * ti + 4 * r + (ln >> 4), jj = 16 * tj + (ln & 15);
-                            const double val = old[ti][tj][r] - acc[ti][tj][r];
-                            rowsU[i * FP + jj] = val;
-                            if (crit_wave) st_sc1(T + (size_t)(myR + i) * M + ncx + jj, val);
-                        }
-                if (crit_wave) { // this wave signals for its own stores only (the diagonal tile above included)
-                    AGPL_DRAIN();
-                    if (ln == 0) __hip_atomic_store(&fl->hand, (unsigned)(k + 1), RLX_AGENT);
+                AGPL_DRAIN(); // this helper's rows (and its diagonal tile) have reached the fabric
+                if (pub && ln == 0) { // the helper whose rows arrive last signals for the workgroup (no barrier on the owners' path)
+                    const unsigned n = __hip_atomic_fetch_add(&pubcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+                    if (n == (unsigned)(nhelp * (k + 1))) __hip_atomic_store(&fl->ready[j], (unsigned)(k + 1), RLX_AGENT);
                 }
-            } else if (have) {
-                // rows ncx .. ncx + 31 held the first 32 rows of P: block (k + 1, k + 1) of the eliminated identity is the identity
-                double *rowsU = PX + (size_t)wave * 32 * FP;
-                for (int e = ln; e < FB * FB; e += 64) rowsU[(e >> 5) * FP + (e & 31)] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
             }
-            __syncthreads();
+            __syncthreads(); // (Wf, Rs and image k & 1 are free again; both halves of the hand-over have drained)
+            if (tid == 0 && Mp >= 2 * FB && ((ncx + FB) >> 8) == j) __hip_atomic_store(&fl->hand, (unsigned)(k + 1), RLX_AGENT);
             AGPL_TS(6);
         }
     } else {
@@ -1052,17 +1072,29 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             __syncthreads();
             AGPL_TS(2);
             const unsigned lo_ = (unsigned)(ln >> 4) * (unsigned)M + (unsigned)(ln & 15);
-            // A wave walks the rectangle (row blocks q of class tr) x (16-wide halves of the blocks of class tc) in steps of 16
-            // and keeps what is a tile of this step and pass: a handful of iterations each
-            const int ncol = 2 * nq, nrect = nq * ncol;
+            // Tiles per wave.  (a) 32 rows (block ib = CY qa + tr) x 16 columns (half h of block jb = CY qb + tc), jb < ib, jb >= k + 2;
+            // (b) 32 columns of U (block cb = CY qb + tc <= k) x 16 rows (half h of block ib = CY qa + tr >= k + 2).  First pass:
+            // (a) with jb == k + 2 and (b) with ib == k + 2 -- what the P workgroups take over at their next step: ONE block
+            // column / row, its <= 2 nq tiles dealt one per wave, stored write-through (P reads them by sc1 loads: no fence on
+            // either side).  Second pass: wave w takes, for every q, the half-column hb = (w - 3 q) mod 16 -- each wave a mix of
+            // long and short columns of the triangle, no division in the walk.  (Walking t = w, w + 16, ... over the rectangle gave a
+            // wave one fixed half-column: the first pass ran on 2 waves, 6-10 us.)
+            const int ncol = 2 * nq;
             for (int pass = 0; pass < 2; ++pass) {
-                // (a) T[i][j] -= P_i . P_j: 32 rows (block ib) x 16 columns (half h of block jb), jb < ib, jb >= k + 2
-                for (int t = wave; t < nrect; t += 16) {
-                    const int qa = t / ncol, hb = t - qa * ncol, qb = hb >> 1, h = hb & 1;
+                for (int it = 0; it < (pass == 0 ? 1 : nq); ++it) {
+                    int qa, qb, h;
+                    if (pass == 0) { // jb == k + 2 fixes qb: tiles (qa, h), wave = 2 qa + h
+                        if ((k + 2) % CY != tc) break;
+                        qb = (k + 2) / CY, qa = wave >> 1, h = wave & 1;
+                        if (qa >= nq) break;
+                    } else {
+                        qa = it;
+                        const int hb = (wave + 16 - ((3 * qa) & 15)) & 15;
+                        if (hb >= ncol) continue;
+                        qb = hb >> 1, h = hb & 1;
+                    }
                     const int ib = CY * qa + tr, jb = CY * qb + tc;
-                    if (ib >= nb || jb >= ib || jb < k + 2) continue;
-                    // first pass: block column k + 2 -- what the P workgroups take over at their next step
-                    if ((jb == k + 2) != (pass == 0)) continue;
+                    if (jb >= ib || jb < k + 2 || (pass == 1 && jb == k + 2)) continue;
                     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
                     const size_t to = (size_t)(32 * ib) * M + 32 * jb + 16 * h;
                     const double *tsrc = (k == 0 ? G : T) + to;
@@ -1071,20 +1103,34 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
 #pragma unroll
                         for (int r = 0; r < 4; ++r) old[ti][r] = tsrc[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
                     mac_2x1(PXa + (size_t)(32 * qa) * FP, PXb + (size_t)(32 * qb + 16 * h) * FP, ln, acc);
+                    if (pass == 0) {
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
+                        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            T[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                            for (int r = 0; r < 4; ++r)
+                                st_sc1(T + to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_, old[ti][r] - acc[ti][r]);
+                    } else {
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                T[to + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                    }
                 }
-                // (b) RHS[i][c] -= X_k'[c] . P_i: 32 columns c (block cb <= k) x 16 rows i (half h of block ib >= k + 2); U is
-                //     column-major: the lanes of a result run along i
-                for (int t = wave; t < nrect; t += 16) {
-                    const int qb = t / ncol, ha = t - qb * ncol, qa = ha >> 1, h = ha & 1;
+                for (int it = 0; it < (pass == 0 ? 1 : nq); ++it) {
+                    int qa, qb, h;
+                    if (pass == 0) { // ib == k + 2 fixes qa: tiles (qb, h), wave = 2 qb + h
+                        if ((k + 2) % CY != tr) break;
+                        qa = (k + 2) / CY, qb = wave >> 1, h = wave & 1;
+                        if (qb >= nq) break;
+                    } else {
+                        qb = it;
+                        const int ha = (wave + 16 - ((3 * qb) & 15)) & 15;
+                        if (ha >= ncol) continue;
+                        qa = ha >> 1, h = ha & 1;
+                    }
                     const int ib = CY * qa + tr, cb = CY * qb + tc;
-                    if (ib >= nb || ib < k + 2 || cb > k) continue;
-                    // first pass: the rows of block k + 2 of the eliminated identity
-                    if ((ib == k + 2) != (pass == 0)) continue;
+                    if (ib < k + 2 || cb > k || (pass == 1 && ib == k + 2)) continue;
                     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}}, old[2];
                     double *ap = A + (size_t)(32 * cb) * M + 32 * ib + 16 * h;
                     const bool fresh = cb == k; // column block k: nothing eliminated into it yet
@@ -1094,16 +1140,24 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                         for (int r = 0; r < 4; ++r)
                             old[ti][r] = fresh ? 0.0 : ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_];
                     mac_2x1(PXb + (size_t)(32 * qb) * FP, PXa + (size_t)(32 * qa + 16 * h) * FP, ln, acc);
+                    if (pass == 0) {
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
+                        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                            for (int r = 0; r < 4; ++r)
+                                st_sc1(ap + (unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_, old[ti][r] - acc[ti][r]);
+                    } else {
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                ap[(unsigned)(16 * ti + 4 * r) * (unsigned)M + lo_] = old[ti][r] - acc[ti][r];
+                    }
                 }
                 if (pass == 0) {
-                    AGPL_DRAIN();
+                    AGPL_DRAIN(); // (every wave: its write-through stores have completed)
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_store(&fl->crit[tw], (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(&fl->crit[tw], (unsigned)(k + 1), RLX_AGENT);
                     AGPL_TS(3);
                 }
             }
@@ -1196,13 +1250,13 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     // ---- the pipeline form (round 5): roles F | P x NP | T x 16.  All of a latent's workgroups must be resident at once (one
     //      per CU: the 150 KB of LDS see to that) within the 32 CUs of its XCD
     if (coop_work && M % 128 == 0 && M <= 1024) {
-        const int NP = (M + 511) / 512;
+        const int NP = (M + 255) / 256; // P workgroups of 256 rows
         // T workgroups: 4 x 4 block-cyclic; 2 x 2 where several latents share an XCD and a class still fits the LDS (M <= 512)
         int CY = 4;
         if (per_xcd * (1 + NP + 16) > 28 && M <= 512) CY = 2;
         const int nwg = 1 + NP + CY * CY;
         if (per_xcd * nwg <= 28) {
-            const size_t ldsp = sizeof(double) * ((size_t)(512 + 2 * FB) * FP);
+            const size_t ldsp = sizeof(double) * ((size_t)(512 + 2 * FB) * FP); // P: two images of 256 rows + W + P0; T: two classes of <= 256 rows
             if (!ctx->pipe_attr) {
                 AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_pipe_kernel<0>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
