@@ -138,7 +138,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     // launch gave up on a partner that was not resident (info = -1: the device is shared with other work); G, g are
     // untouched inputs, so the result is the one the cooperative launch would have produced
     if (NW == 1 && rescue) { // ... and leaves the hand-off flags of its latent zero for the next factorisation (no memset)
-        if (threadIdx.x < 28) sync_all[28 * blockIdx.x + threadIdx.x] = 0u; // (28 words per latent: PipeFlags / ready, done, crit)
+        if (blockIdx.x == 0) // the whole flag area of the small workspace (bytes 8448 .. 16383: PipeFlags records, or 4 words per latent)
+            for (int i = threadIdx.x; i < 1984; i += 1024) sync_all[i] = 0u;
         if (info[blockIdx.x] != -1 || M > 512) return; // (beyond 512 one workgroup cannot hold the panel: the loss is reported)
     }
     const int wg = NW > 1 ? (int)(blockIdx.x >> 3) : 0;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = NW > 1 ? (int)blockIdx.y : (int)blockIdx.x;
     double *PXg0 = PXg_all + (size_t)l * 2 * M * FB;       // NW > 1: P | X_k' of a block step (LA: two buffers)
-    unsigned *ready = sync_all + 28 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
+    unsigned *ready = sync_all + 4 * l, *done = ready + 1, *crit = ready + 2; // steps published / tiles finished
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -600,7 +601,7 @@ __device__ __forceinline__ bool poll_ge(unsigned *p, unsigned target) {
 }
 #define AGPL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-struct PipeFlags { // one 112-byte record per latent, zero between launches.  Every word has ONE writer (or is a final count):
+struct PipeFlags { // one 192-byte record per latent (at most 32 latents take this form), zero between launches.  Every word has ONE writer (or is a final count):
                    // a sum over producers could be reached by a fast one running a step ahead of a slow one
     unsigned wready;   // F: W_k published                                 (value k + 1)
     unsigned p0ready;  // F: P0 of step k published                        (value k + 1)
@@ -609,7 +610,7 @@ struct PipeFlags { // one 112-byte record per latent, zero between launches.  Ev
     unsigned lost;     // any workgroup: a partner never arrived (which wait: diagnostic)
     unsigned ready[4]; // P workgroup j: its rows of step k published       (value k + 1)
     unsigned pad[3];
-    unsigned crit[16]; // T workgroup w: first pass of step k finished      (value k + 1; release)
+    unsigned crit[36]; // T workgroup w (<= 32): first pass of step k finished (value k + 1)
 };
 
 // 16-byte write-through store (global_store_dwordx4 ... sc1): the 8-byte form costs 2.7 x per byte on the fabric
@@ -629,16 +630,18 @@ __device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
 }
 
 template <int DUMMY>
-__global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int CY, const double *__restrict__ Gall,
+__global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int CY, int TS, int spread, const double *__restrict__ Gall,
                                                               const double *__restrict__ gall,
                                                               const double *__restrict__ eta0all, double *__restrict__ Tall,
                                                               double *__restrict__ Aall, double *__restrict__ vall,
                                                               float *__restrict__ v32all, double *__restrict__ logdet,
                                                               int *__restrict__ info, double *__restrict__ scratch_all,
                                                               PipeFlags *__restrict__ flags_all, int rescue) {
-    if ((blockIdx.x & 7) != (blockIdx.y & 7)) return; // latent l works on XCD l % 8 (as factor_kernel)
+    // spread == 0: latent l works on XCD l % 8 (as factor_kernel: the launch is 8 x wide and 7 of 8 workgroups leave at once);
+    // spread == 1 (M > 512: up to 37 workgroups a latent): wherever the dispatcher puts them -- every hand-off is agent-scope
+    if (!spread && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
     const int l = (int)blockIdx.y;
-    const int wg = (int)(blockIdx.x >> 3);
+    const int wg = spread ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
     if (rescue == 2) { // fault injection (agpl_debug_force_factor_rescue): behave as if a partner never arrived
         if (wg == 0 && threadIdx.x == 0) info[l] = -1;
         return;
@@ -649,7 +652,8 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = M / FB;
-    const int NT = CY * CY, NWG = 1 + NP + NT; // T workgroups: a CY x CY (4 x 4, or 2 x 2) block-cyclic grid over the 32 x 32 tiles
+    const int NT = CY * CY * TS, NWG = 1 + NP + NT; // T workgroups: a CY x CY (4 x 4, or 2 x 2) block-cyclic grid over the 32 x 32
+                                                    // tiles, TS (1, 2) workgroups per cell
     const double *G = Gall + (size_t)l * M * M;
     double *T = Tall + (size_t)l * M * M;
     double *A = Aall + (size_t)l * M * M;
@@ -909,20 +913,26 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                             }
                         }
             }
-            if (wave == 8 && Mp > 0) { // beside the panel: P0 of this step (F: ~2 us behind W_k) and the T workgroups' first passes of
-                                       // step k - 1 (the look-ahead's old values: stored write-through there, read by sc1 loads
-                                       // here -- no fence on either side)
+            if (!owner && Mp > 0) {
+                // helpers, beside the panel: P0 of this step (F publishes it ~2 us behind W_k) into LDS -- every helper wave polls
+                // for itself and loads its eighth; wave 8 also waits for the T workgroups' first passes of step k - 1 (the
+                // look-ahead's old values: stored write-through there, read by sc1 loads here -- no fence on either side)
                 bool ok = true;
                 if (lane == 0) ok = poll_ge(&fl->p0ready, (unsigned)(k + 1));
-                else if (lane >= 16 && lane < 16 + NT && k > 0) ok = poll_ge(&fl->crit[lane - 16], (unsigned)k);
+                else if (wave == 8 && lane >= 16 && lane < 16 + NT && k > 0) ok = poll_ge(&fl->crit[lane - 16], (unsigned)k);
                 if (!__all(ok) && lane == 0) lostf = 4;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = (wave - 8) * 128 + 64 * u + lane; // 1024 elements over 8 waves
+                    Rs[(e >> 5) * FP + (e & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + e);
+                }
             }
-            __syncthreads(); // the panel rows are in LDS for the helpers
+            __syncthreads(); // the panel rows and P0 are in LDS
             AGPL_TS(3);
             if (Mp <= 0) break; // last step: the final rows of U are written (drained behind the loop)
             if (lostf) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            Rs[(tid >> 5) * FP + (tid & 31)] = ld_sc1(P0g + (size_t)k * FB * FB + tid);
             if (upd && !(xrows && myR >= kb)) { // (column block k of U: nothing eliminated into it yet -> zeros)
                 const double *oldp = !xrows ? (k == 0 ? G : T) + (size_t)myR * M + ncx : A + (size_t)myR * M + ncx;
                 if (k == 0) {
@@ -942,7 +952,6 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                                 uold[ti][tj][r] = ld_sc1(oldp + (unsigned)(16 * ti + 4 * r) * (unsigned)M + 16 * tj + lo_);
                 }
             }
-            __syncthreads();
             AGPL_TS(4);
             if (upd) {
                 // ---- owners, look-ahead: this step's update of the NEXT block column of T and of the next 32 rows of the
@@ -1020,8 +1029,9 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
         // with row block ib = tr and column block cb = tc (mod CY).  Cyclic: every workgroup keeps its share of the work to the
         // last steps (contiguous regions left most of them idle half-way, and the bottom ones with 25 us per step at M = 1024).
         // It stages the 2 x nb / CY row blocks of P | X' it needs: <= 2 x 256 rows (CY = 2 only for M <= 512).
-        const int tw = wg - 1 - NP;            // 0 .. CY^2 - 1
-        const int tr = tw / CY, tc = tw - tr * CY;
+        const int tw = wg - 1 - NP;            // 0 .. CY^2 TS - 1
+        const int cell = tw / TS, part = tw - cell * TS; // TS workgroups share a cell: they split its tiles
+        const int tr = cell / CY, tc = cell - tr * CY;
         const int nq = nb / CY;                // row blocks per residue class (ib = CY q + tr); nb % 4 == 0
         double *PXa = sm;                      // [nq][32][FP] row blocks ib = tr (mod 4)
         double *PXb = tr == tc ? PXa : PXa + (size_t)nq * FB * FP; // [nq][32][FP] row blocks = tc (mod 4)
@@ -1085,10 +1095,13 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                     int qa, qb, h;
                     if (pass == 0) { // jb == k + 2 fixes qb: tiles (qa, h), wave = 2 qa + h
                         if ((k + 2) % CY != tc) break;
-                        qb = (k + 2) / CY, qa = wave >> 1, h = wave & 1;
+                        // one tile per wave; a part keeps the row blocks it owns in the second pass (qa % TS == part): its
+                        // earlier plain stores to the tile sit in ITS XCD's L2
+                        qb = (k + 2) / CY, qa = (wave >> 1) * TS + part, h = wave & 1;
                         if (qa >= nq) break;
                     } else {
                         qa = it;
+                        if (qa % TS != part) continue;
                         const int hb = (wave + 16 - ((3 * qa) & 15)) & 15;
                         if (hb >= ncol) continue;
                         qb = hb >> 1, h = hb & 1;
@@ -1121,10 +1134,11 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                     int qa, qb, h;
                     if (pass == 0) { // ib == k + 2 fixes qa: tiles (qb, h), wave = 2 qb + h
                         if ((k + 2) % CY != tr) break;
-                        qa = (k + 2) / CY, qb = wave >> 1, h = wave & 1;
+                        qa = (k + 2) / CY, qb = (wave >> 1) * TS + part, h = wave & 1;
                         if (qb >= nq) break;
                     } else {
                         qb = it;
+                        if (qb % TS != part) continue;
                         const int ha = (wave + 16 - ((3 * qb) & 15)) & 15;
                         if (ha >= ncol) continue;
                         qa = ha >> 1, h = ha & 1;
@@ -1251,19 +1265,25 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
     //      per CU: the 150 KB of LDS see to that) within the 32 CUs of its XCD
     if (coop_work && M % 128 == 0 && M <= 1024) {
         const int NP = (M + 255) / 256; // P workgroups of 256 rows
-        // T workgroups: 4 x 4 block-cyclic; 2 x 2 where several latents share an XCD and a class still fits the LDS (M <= 512)
-        int CY = 4;
-        if (per_xcd * (1 + NP + 16) > 28 && M <= 512) CY = 2;
-        const int nwg = 1 + NP + CY * CY;
-        if (per_xcd * nwg <= 28) {
+        // T workgroups: 4 x 4 block-cyclic cells; 2 x 2 where several latents share an XCD and a class still fits the LDS (M <= 512);
+        // beyond 512 two workgroups per cell (the trailing update of the first steps is float64-MFMA-bound on 16 CUs), and the
+        // workgroups go wherever the dispatcher puts them (37 per latent do not fit the 32 CUs of one XCD)
+        int CY = 4, TS = 1, spread = 0;
+        if (M > 512) {
+            spread = 1;
+            TS = L * (1 + NP + 32) <= 200 ? 2 : 1;
+        } else if (per_xcd * (1 + NP + 16) > 28)
+            CY = 2;
+        const int nwg = 1 + NP + CY * CY * TS;
+        if (L <= 32 && (spread ? L * nwg <= 200 : per_xcd * nwg <= 28)) {
             const size_t ldsp = sizeof(double) * ((size_t)(512 + 2 * FB) * FP); // P: two images of 256 rows + W + P0; T: two classes of <= 256 rows
             if (!ctx->pipe_attr) {
                 AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_pipe_kernel<0>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
                 ctx->pipe_attr = 1;
             }
-            factor_pipe_kernel<0><<<dim3(8 * nwg, (unsigned)L), 1024, ldsp, ctx->stream>>>(
-                M, NP, CY, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, (double *)coop_work,
+            factor_pipe_kernel<0><<<dim3(spread ? nwg : 8 * nwg, (unsigned)L), 1024, ldsp, ctx->stream>>>(
+                M, NP, CY, TS, spread, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, (double *)coop_work,
                 (PipeFlags *)sync, coop_mode);
             AGPL_LAUNCH_CHECK(ctx);
             // the clean-up launch: zeroes the flag words; redoes a latent whose partners never arrived in ONE workgroup (M <= 512)
