@@ -239,7 +239,7 @@ constexpr int kRecBytes = 256;                     // one gamma | beta record
 constexpr int kStripLds = kRing * kStepBytes + 8 * kRing * kRecBytes;
 
 template <bool DIAG>
-__device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int l,
+__device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int chunk, int l,
                                                 int s, int I, int J, const unsigned char *__restrict__ image,
                                                 const float *__restrict__ gb_all, const unsigned *__restrict__ scal,
                                                 float *__restrict__ slabG, float *__restrict__ slabg) {
@@ -256,8 +256,9 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     const int eB = acc_scale_exp(scal[0]);
     const float sB = __uint_as_float((unsigned)(127 + eB) << 23); // gamma is scaled as it is used (exact)
 
-    const int64_t nbeg = (int64_t)s * agpl_chunk_points(M);
-    int64_t nend = nbeg + agpl_chunk_points(M);
+    const int64_t nbeg = (int64_t)s * chunk;
+    int64_t nend = nbeg + chunk;
+
     if (nend > N) nend = N;
     const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
     const int64_t ps0 = nbeg / 16;
@@ -544,7 +545,7 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     }
 }
 
-__global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit,
+__global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
                                                             const unsigned char *__restrict__ image,
                                                             const float *__restrict__ gb_all,
                                                             const unsigned *__restrict__ scal,
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t N
     } else {
         I = J = p2 - noff;
     }
-    if (I == J) syrk_strip_body<true>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
-    else syrk_strip_body<false>(smem_raw, N, Npad, M, nsplit, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    if (I == J) syrk_strip_body<true>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    else syrk_strip_body<false>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
 }
 
 } // namespace
@@ -660,7 +661,7 @@ int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const f
 // of a gamma that is negative or not finite).  records_ready: both are filled already; gamma / beta are not read.
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
-                               float *slabg, int ns, bool records_ready) {
+                               float *slabg, int ns, int chunk, bool records_ready) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
     if (ctx->checked_image != image || ctx->checked_image_N != N || ctx->checked_image_M != M) {
         // the header, once per (image, N, M): an image of another (N, M), or a buffer that never was one, would otherwise give
@@ -693,7 +694,7 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
         ctx->strip_attr = 1;
     }
-    syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, (const unsigned char *)image, gb,
+    syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
                                                                      scal, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;

@@ -97,6 +97,11 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
     the last factorisation is read inside the timed region.  Returns (seconds, per-kernel hipEvent timings)."""
     from agpl_amd import _ffi
 
+    # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
+    # used to land in one random sweep of the timed loop: collect now (before the warm-up: 75 ms of idle device between the warm-up
+    # and the timed sweeps would let the clocks drop again), keep the collector off while timing
+    gc.collect()
+    gc.disable()
     for _ in range(warmup):
         cavi.sweep()
     barrier()
@@ -104,10 +109,6 @@ def timed_sweeps(ctx, cavi, steps, warmup, barrier):
     _ffi.lib().agpl_timing(ctx.bind(), C.c_int32(-1), None, None)
     read_timing(ctx, 0)  # discard what earlier legs left in the kernel timers (the sampler legs call cavi.marginals() with the
     read_timing(ctx, 1)  # timers on: two C2-size launches used to be averaged into the m1024 leg's marginal kernel: 16.8 for 20.1 ms)
-    # a full (generation-2) pass of Python's cyclic collector over the ~1e6 objects torch imports takes ~75 ms and
-    # used to land in one random sweep of the timed loop: collect now, keep the collector off while timing
-    gc.collect()
-    gc.disable()
     trace = os.environ.get("AGPL_BENCH_TRACE")  # debug: per-step wall times
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -334,7 +335,7 @@ def f32_contract_leg(A, ctx, lik, likname, Phi, kd, y, N, M, Mp, L, args):
 
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
     steps = 3
-    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
+    dt, kt = timed_sweeps(ctx, cavi, steps, warmup, torch.cuda.synchronize)
     ms = dt / steps * 1e3
     roof = roofline_of(kt, L, N, M, Mp, "f32", "f32", ms, 1, N)
     # SURVEY 8(d) counts the variance projection as a dense product (2 N M^2); marginal_kernel<0> uses the symmetry of W (packed
@@ -380,9 +381,11 @@ def elbo_leg(A, ctx, lik, Phi, kd, y, base_ms, args, plain=None):
             "non_decreasing": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(vals, vals[1:])))}
 
 
-def config_leg(A, ctx, likname, N, M, steps=5, gibbs=False, parity_points=10_000, no_parity=False, workload=None, label=None):
-    """One more BASELINE configuration on this GPU with the headline's timed-loop discipline: `steps` plan sweeps after one
-    warm-up, the two contraction kernels from the in-library events (roofline.kernels), a ten-sweep parity slice against the
+def config_leg(A, ctx, likname, N, M, steps=5, gibbs=False, parity_points=10_000, no_parity=False, workload=None, label=None,
+               warmup=1):
+    """One more BASELINE configuration on this GPU with the headline's timed-loop discipline: `steps` plan sweeps after `warmup`
+    untimed ones (the N/8 legs take 8: their sweeps are 2-6 ms and the first five after the set-up run up to 14 % slower --
+    kernel trace of round 5: 6.84, 6.44, 6.22, 6.06, 6.02, 6.00, 6.00 ms -- while the device clocks come up), the two contraction kernels from the in-library events (roofline.kernels), a ten-sweep parity slice against the
     oracle, optionally the sparse Gibbs sweep on the same plan.  `workload`: (y, Phi, kd) to reuse instead of building one."""
     import torch
 
@@ -393,10 +396,10 @@ def config_leg(A, ctx, likname, N, M, steps=5, gibbs=False, parity_points=10_000
     Mp = Phi.shape[1]
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
     t_setup = time.time() - t0
-    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
+    dt, kt = timed_sweeps(ctx, cavi, steps, warmup, torch.cuda.synchronize)
     ms = dt / steps * 1e3
     out = {"config": {"workload": label or f"{likname} SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, 1 GPU", "N": N, "M": M, "L": L},
-           "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": 1,
+           "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
            "roofline": roofline_of(kt, L, N, M, Mp, "f16x2-factor", "f16x2", ms, 1, N), "setup_s": round(t_setup, 2)}
     if gibbs:
         yg = y.to(torch.float64) if lik.ykind == "real" else y
@@ -948,7 +951,7 @@ def main():
         if not args.no_extra:
             # one rank's share of C2 at 8 GPUs (N / 8 points, everything but the all-reduce): the per-rank fixed cost decides scaling
             def n8():
-                o, _ = config_leg(A, ctx, "bernoulli", N // 8, 512, steps=10, no_parity=args.no_parity)
+                o, _ = config_leg(A, ctx, "bernoulli", N // 8, 512, steps=10, warmup=8, no_parity=args.no_parity)
                 o["projected_scaling_8"] = round(ms_per_step / o["ms_per_step"], 3)
                 o["projected_scaling_8_note"] = "ms_per_step of the full-N headline / ms_per_step of one rank's N/8 share, before the all-reduce (2 MB of float64)"
                 return o
@@ -971,13 +974,13 @@ def main():
             # one rank's share of the north-star configuration (Bernoulli, N = 1.25e6, M = 1024) and of C3 (NegBin r = 15, same
             # features): CAVI (+ Gibbs for C3), ten-sweep parity, projected 8-GPU scaling against the full-N single-GPU legs above
             def n8_m1024():
-                o, wl = config_leg(A, ctx, "bernoulli", N // 8, 1024, steps=6, no_parity=args.no_parity, parity_points=5_000)
+                o, wl = config_leg(A, ctx, "bernoulli", N // 8, 1024, steps=10, warmup=8, no_parity=args.no_parity, parity_points=5_000)
                 full = out.get("m1024", {}).get("ms_per_step")
                 o["projected_scaling_8"] = round(full / o["ms_per_step"], 3) if full else None
                 out["n8_m1024"] = o
                 nlik = make_lik(A, "negbin")
                 _, yn = A.synth_xy(nlik, SEED, 0, N // 8, ctx=ctx, want_x=False)
-                o3, _ = config_leg(A, ctx, "negbin", N // 8, 1024, steps=6, gibbs=True, no_parity=args.no_parity, parity_points=5_000,
+                o3, _ = config_leg(A, ctx, "negbin", N // 8, 1024, steps=10, warmup=8, gibbs=True, no_parity=args.no_parity, parity_points=5_000,
                                    workload=(yn, wl[1], wl[2]),
                                    label=f"one rank's share of C3: NegBin(r=15) SVGP CAVI sweep, N={N // 8}, M=1024, L=1")
                 full3 = out.get("m1024", {}).get("c3_full_one_gpu", {}).get("ms_per_step")
