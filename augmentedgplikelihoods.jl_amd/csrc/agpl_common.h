@@ -27,6 +27,8 @@ struct agpl_ctx {
     size_t ws_bytes = 0;
     void *ws2 = nullptr; // small persistent scratch (reductions, info flags)
     size_t ws2_bytes = 0;
+    unsigned *pg_retry = nullptr; // PG(1) kernels: [0] entries, [1] workgroups done (both zero between launches), [2 ..] the point list
+    size_t pg_retry_entries = 0;
     double *logtheta_dev = nullptr; // categorical link parameters mirrored on device
     int logtheta_cap = 0;
     double logtheta_host[128];      // last uploaded values (skip the copy when unchanged)
@@ -104,6 +106,7 @@ int32_t agpl_timing_end(agpl_ctx *ctx, int which);
 // grow-only scratch
 int32_t agpl_ws_reserve(agpl_ctx *ctx, size_t bytes);
 int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes);
+int32_t agpl_pg_retry_reserve(agpl_ctx *ctx, int64_t n); // the retry list of the PG(1) kernels for n points (agpl_core.hip)
 
 // device-side view of a likelihood descriptor (logtheta mirrored to device memory)
 struct agpl_lik_dev {

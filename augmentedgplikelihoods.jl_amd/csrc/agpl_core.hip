@@ -43,6 +43,7 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->pg_retry) (void)hipFree(ctx->pg_retry);
     if (ctx->elbo_part) (void)hipFree(ctx->elbo_part);
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
     if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
@@ -119,6 +120,23 @@ int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes) {
     }
     ctx->ws2 = grown;
     ctx->ws2_bytes = bytes;
+    return AGPL_OK;
+}
+
+// The list of points a PG(1) kernel hands to its retry kernel (aux_sample_pg1_retry_kernel, agpl_ops.hip): two counter words that
+// are zero between launches, then one 32-bit point index per entry -- every point can end up there (|f| >= 16 has no fitted
+// branch mass), so the list holds n.
+int32_t agpl_pg_retry_reserve(agpl_ctx *ctx, int64_t n) {
+    if ((size_t)n <= ctx->pg_retry_entries) return AGPL_OK;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pg_retry) AGPL_HIP(ctx, hipFree(ctx->pg_retry));
+    ctx->pg_retry = nullptr;
+    ctx->pg_retry_entries = 0;
+    const size_t bytes = sizeof(unsigned) * ((size_t)n + 2);
+    if (hipMalloc((void **)&ctx->pg_retry, bytes) != hipSuccess)
+        AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the PG retry list failed", bytes);
+    AGPL_HIP(ctx, hipMemsetAsync(ctx->pg_retry, 0, 2 * sizeof(unsigned), ctx->stream));
+    ctx->pg_retry_entries = (size_t)n;
     return AGPL_OK;
 }
 

@@ -249,7 +249,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                     K = scr->par[wave][4 * lo + 1], rlo = scr->par[wave][4 * lo + 2], rhi = scr->par[wave][4 * lo + 3];
                 } else { // (no fit for z >= 8: an empty bracket around u sends the draw to the sequential sampler)
                     K = kPi2_8 + z * z / 2.0;
-                    const double rf = pg_mass_fit(z < 8.0 ? z : 0.0);
+                    const double rf = pg_mass_fit<true>(z < 8.0 ? z : 0.0);
                     rlo = z < 8.0 ? rf - kPgMassSlack : u, rhi = z < 8.0 ? rf + kPgMassSlack : u;
                 }
                 if (!(u < rlo) && !(u > rhi)) // inside the bracket of r: decided exactly
@@ -309,8 +309,9 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                     w = e >> 8, slot = e & 255;
                     const int lo = scr->owner[w][slot];
                     s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
-                    (void)s.u01(); // the branch uniform, drawn in phase A
-                    (void)s.u01(); // `while (alpha < rand())` with alpha = 0: always entered (u is in the open interval)
+                    // the branch uniform (drawn in phase A) and the first `while (alpha < rand())` (alpha = 0: always entered, u is in the
+                    // open interval) are block 0 of the sub-stream: passed over without its ten rounds
+                    s.skip_first_block();
                     z = PG_OWNER_Z(w, lo);
                 }
             };
@@ -623,35 +624,40 @@ __global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(a
 // and the dealing machinery above has nothing to deal -- but the trial queue wants to be long (a lane that finds the queue
 // empty idles until the unluckiest lane of its wave is done).  A workgroup therefore takes kPg1Pts points per thread through
 // the same phases: A (branch uniform; truncated-exponential proposals finished), B1 (trials of the truncated inverse-Gaussian
-// proposals with refill from the workgroup's queue), B2 (their series test), C (sequential redo of the 8e-4 rejected).  Same
-// sub-streams (draw 0 of latent 0 = id 1), same values, uniforms consumed and series indices as sample_point_wave's case.
+// proposals with refill from the workgroup's queue), B2 (their series test).  The 8e-4 whose proposal the series rejects (and the
+// points without a fitted branch mass, |f| >= 16) are redone from the start of their sub-stream by the sequential sampler -- in a
+// launch of their own (aux_sample_pg1_retry_kernel, round 5): the point goes on a list in global memory.  With that loop inside
+// this kernel its live state cost the trial loops 300 bytes of scratch per lane, and every workgroup iteration waited at two more
+// barriers for the one wave that had a redo.  Same sub-streams (draw 0 of latent 0 = id 1), same values, uniforms consumed and
+// series indices as sample_point_wave's case.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPg1Pts = 8;                   // points per thread and workgroup iteration
 constexpr int kPg1Slots = kPg1Pts * kBlock;  // 2048 draws per iteration
 struct Pg1BlockScratch {
     double x[kPg1Slots];                     // parked proposals
     unsigned st[kPg1Slots];                  // their stream positions
-    unsigned short queue[kPg1Slots], queue2[kPg1Slots], retry[kPg1Slots];
-    int qn, q2n, qhead, rn;
+    unsigned short queue[kPg1Slots], queue2[kPg1Slots];
+    int qn, q2n, qhead;
 };
 
 // GIBBS: the Bernoulli point pass of a sparse Gibbs sweep in the same kernel -- f_i = projection_i + sqrt(d_i) eps_i (+ mu0_i) on the
 // point's main stream (two uniforms) is formed in phase A and written over the projection (fbuf, read back by the later phases),
 // and a finished draw also leaves gamma_i = omega_i, beta_i = +-1/2 (auglik_precision / auglik_potential, bernoulli.jl:27-33).
 template <bool GIBBS>
-__global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, const double *__restrict__ f,
+__global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigned n, const double *__restrict__ f,
                                                                    double *__restrict__ omega, uint64_t seed, uint64_t i0,
                                                                    uint32_t sweep, uint32_t *__restrict__ nuni_out,
                                                                    uint32_t *__restrict__ nterms_out, double *fbuf,
                                                                    const float *__restrict__ kdiag, const float *__restrict__ mu0,
                                                                    const uint8_t *__restrict__ y, float *__restrict__ gamma,
-                                                                   float *__restrict__ beta, double *__restrict__ f_out) {
+                                                                   float *__restrict__ beta, double *__restrict__ f_out,
+                                                                   unsigned *__restrict__ retry) {
     if (GIBBS) f = fbuf;
     constexpr uint32_t kMain = GIBBS ? 2u : 0u; // uniforms the point's main stream has consumed (the normal of f)
     __shared__ Pg1BlockScratch scr;
     const int lane = threadIdx.x & 63;
-    const int64_t nblocks = (n + kPg1Slots - 1) / kPg1Slots;
-    if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = scr.rn = 0;
+    const unsigned nblocks = (n + kPg1Slots - 1u) / kPg1Slots; // (n <= 2^30 per launch: 32-bit point indices, launch_pg1)
+    if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = 0;
     __syncthreads();
     auto push = [&](bool flag, unsigned short *q, int *cnt, int slot) { // compacted append of the wave's flagged lanes
         const unsigned long long m = __ballot(flag);
@@ -662,7 +668,16 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
             if (flag) q[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)slot;
         }
     };
-    auto finish = [&](int64_t i, double w, const Philox &s, uint32_t nt) {
+    auto push_retry = [&](bool flag, unsigned i) { // the same onto the launch's retry list: [0] entries, [2 ..] point indices
+        const unsigned long long m = __ballot(flag);
+        if (m) {
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&retry[0], (unsigned)__popcll(m));
+            at = __shfl(at, 0);
+            if (flag) retry[2u + at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+    };
+    auto finish = [&](unsigned i, double w, const Philox &s, uint32_t nt) {
         if (!GIBBS || omega) omega[i] = w;
         if (nuni_out) nuni_out[i] = kMain + s.nuni;
         if (nterms_out) nterms_out[i] = nt;
@@ -671,27 +686,32 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
             beta[i] = y[i] ? 0.5f : -0.5f;
         }
     };
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int64_t base = blk * kPg1Slots;
+    for (unsigned blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const unsigned base = blk * kPg1Slots;
         Philox g0; // key and sweep of every stream of this launch; point and sub-stream set by pg_substream
         g0.init(seed, 0, sweep);
         // ---- phase A
-        for (int p = 0; p < kPg1Pts; ++p) {
-            const int slot = p * kBlock + (int)threadIdx.x;
-            const int64_t i = base + slot;
-            bool to_b = false, to_b2 = false, to_c = false;
-            if (i < n) {
-                double fi;
-                if (GIBBS) { // (the point half of gibbs_sample_points for this likelihood)
+        if (GIBBS) { // (the point half of gibbs_sample_points for this likelihood; a loop of its own: the normal's registers -- log,
+                     //  sqrt, cos -- are free again when the branch test below starts, which left 8 bytes of scratch otherwise)
+            for (int p = 0; p < kPg1Pts; ++p) {
+                const unsigned i = base + (unsigned)(p * kBlock) + threadIdx.x;
+                if (i < n) {
                     Philox g;
                     g.init(seed, i0 + (uint64_t)i, sweep);
                     const double kd = (double)kdiag[i];
-                    fi = fbuf[i] + sqrt(kd > 0.0 ? kd : 0.0) * g.normal();
+                    double fi = fbuf[i] + sqrt(kd > 0.0 ? kd : 0.0) * g.normal();
                     if (mu0) fi += (double)mu0[i];
                     fbuf[i] = fi;
                     if (f_out) f_out[i] = fi;
-                } else
-                    fi = f[i];
+                }
+            }
+        }
+        for (int p = 0; p < kPg1Pts; ++p) {
+            const int slot = p * kBlock + (int)threadIdx.x;
+            const unsigned i = base + (unsigned)slot;
+            bool to_b = false, to_b2 = false, to_c = false;
+            if (i < n) {
+                const double fi = GIBBS ? fbuf[i] : f[i];
                 const double c = fabs(fi);
                 if (!(c < __builtin_inf())) { // NaN / Inf in, NaN out (rand_pg_int)
                     finish(i, __builtin_nan(""), g0, 0u);
@@ -716,7 +736,7 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
             }
             push(to_b, scr.queue, &scr.qn, slot);
             push(to_b2, scr.queue2, &scr.q2n, slot);
-            push(to_c, scr.retry, &scr.rn, slot);
+            push_retry(to_c, i);
         }
         __syncthreads();
         // ---- phase B1: trials with refill (see pg_int_sum_block)
@@ -730,10 +750,9 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
                 e = -1;
                 if (idx < qn) {
                     e = scr.queue[idx];
-                    const int64_t i = base + e;
+                    const unsigned i = base + (unsigned)e;
                     s = pg_substream(g0, i0 + (uint64_t)i, 1u);
-                    (void)s.u01();
-                    (void)s.u01();
+                    s.skip_first_block(); // (the branch uniform and the always-entered first `alpha < rand()`: see pg_int_sum_block)
                     z = fabs(f[i]) / 2.0; // (Pg1Params::set)
                 }
             };
@@ -758,7 +777,7 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
         if (q2n) {
             for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
                 const int e = scr.queue2[q];
-                const int64_t i = base + e;
+                const unsigned i = base + (unsigned)e;
                 Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
                 (void)s.u01();
                 scr.x[e] = rand_tig(s, fabs(f[i]) / 2.0);
@@ -772,7 +791,7 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
             int e = 0;
             if (q < qn + q2n) {
                 e = q < qn ? scr.queue[q] : scr.queue2[q - qn];
-                const int64_t i = base + e;
+                const unsigned i = base + (unsigned)e;
                 Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
                 const uint32_t st = scr.st[e], c0 = st >> 3, pos = st & 7u;
                 if (pos < 4u) {
@@ -787,23 +806,75 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(int64_t n, co
                 if (pg_series_accept<false>(s, x, nt)) finish(i, x / 4.0, s, nt);
                 else to_c = true;
             }
-            push(to_c, scr.retry, &scr.rn, e);
+            push_retry(to_c, base + e);
         }
         __syncthreads();
-        // ---- phase C: rejected proposals, redone from the start of their sub-stream by the sequential sampler
-        const int rn = scr.rn;
-        for (int q = (int)threadIdx.x; q < rn; q += kBlock) {
-            const int64_t i = base + scr.retry[q];
-            Pg1Params prm;
-            prm.set(fabs(f[i]));
-            Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
-            uint32_t nt = 0;
-            const double w = sample_pg1(s, prm, nt);
-            finish(i, w, s, nt);
+        if (threadIdx.x == 0) {
+            int zero = 0; // (formed here: as a loop invariant the compiler kept three zeroed registers alive over the whole iteration --
+            asm volatile("" : "+v"(zero)); // and spilled them, the kernel's last 12 bytes of scratch)
+            scr.qn = zero, scr.q2n = zero, scr.qhead = zero;
         }
         __syncthreads();
-        if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = scr.rn = 0;
-        __syncthreads();
+    }
+}
+
+// The points aux_sample_pg1_kernel left on its list: the sequential sampler from the start of the draw's sub-stream
+// (polyagamma.jl:223-257 as sample_pg1 restates it).  The last workgroup to finish leaves the two counter words zero for the next launch.
+template <bool GIBBS>
+__global__ __launch_bounds__(kBlock) void aux_sample_pg1_retry_kernel(unsigned *__restrict__ retry, const double *__restrict__ f,
+                                                                      double *__restrict__ omega, uint64_t seed, uint64_t i0,
+                                                                      uint32_t sweep, uint32_t *__restrict__ nuni_out,
+                                                                      uint32_t *__restrict__ nterms_out,
+                                                                      const uint8_t *__restrict__ y, float *__restrict__ gamma,
+                                                                      float *__restrict__ beta) {
+    constexpr uint32_t kMain = GIBBS ? 2u : 0u;
+    const unsigned cnt = retry[0];
+    Philox g0;
+    g0.init(seed, 0, sweep);
+    for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < cnt; q += gridDim.x * kBlock) {
+        const int64_t i = (int64_t)retry[2u + q];
+        Pg1Params prm;
+        prm.set(fabs(f[i]));
+        Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+        uint32_t nt = 0;
+        const double w = sample_pg1(s, prm, nt);
+        if (!GIBBS || omega) omega[i] = w;
+        if (nuni_out) nuni_out[i] = kMain + s.nuni;
+        if (nterms_out) nterms_out[i] = nt;
+        if (GIBBS) {
+            gamma[i] = (float)w;
+            beta[i] = y[i] ? 0.5f : -0.5f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&retry[1], 1u) == gridDim.x - 1u) { // (every other workgroup has read retry[0] before its add)
+        retry[0] = 0u;
+        retry[1] = 0u;
+    }
+}
+
+// host side of the pair: kernel, then the retry kernel over its list.  Point indices on the list are 32-bit: launches of at most
+// 2^30 points (pointers and the stream offset advanced per launch).
+constexpr int64_t kPg1MaxLaunch = (int64_t)1 << 30;
+template <bool GIBBS>
+static void launch_pg1(agpl_ctx *ctx, int64_t n, const double *f, double *omega, uint32_t sweep, uint32_t *nuni_out,
+                          uint32_t *nterms_out, double *fbuf, const float *kdiag, const float *mu0, const uint8_t *y, float *gamma,
+                          float *beta, double *f_out) {
+    constexpr int64_t kMaxLaunch = kPg1MaxLaunch; // (the caller has reserved the list: agpl_pg_retry_reserve(ctx, min(n, this)))
+    for (int64_t o = 0; o < n; o += kMaxLaunch) {
+        const int64_t m = n - o < kMaxLaunch ? n - o : kMaxLaunch;
+        int64_t nb = agpl_cdiv(m, kPg1Slots);
+        if (nb > 256 * 4 * 8) nb = 256 * 4 * 8;
+        int64_t nr = agpl_cdiv(m, 16 * kBlock);
+        if (nr > 1024) nr = 1024;
+#define AGPL_O(p_) ((p_) ? (p_) + o : nullptr)
+        aux_sample_pg1_kernel<GIBBS><<<(unsigned)nb, kBlock, 0, ctx->stream>>>(
+            (unsigned)m, AGPL_O(f), AGPL_O(omega), ctx->seed, (uint64_t)ctx->point_offset + (uint64_t)o, sweep, AGPL_O(nuni_out), AGPL_O(nterms_out),
+            AGPL_O(fbuf), AGPL_O(kdiag), AGPL_O(mu0), AGPL_O(y), AGPL_O(gamma), AGPL_O(beta), AGPL_O(f_out), ctx->pg_retry);
+        aux_sample_pg1_retry_kernel<GIBBS><<<(unsigned)nr, kBlock, 0, ctx->stream>>>(
+            ctx->pg_retry, GIBBS ? AGPL_O(fbuf) : AGPL_O(f), AGPL_O(omega), ctx->seed, (uint64_t)ctx->point_offset + (uint64_t)o, sweep,
+            AGPL_O(nuni_out), AGPL_O(nterms_out), AGPL_O(y), AGPL_O(gamma), AGPL_O(beta));
+#undef AGPL_O
     }
 }
 
@@ -1451,6 +1522,10 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
     if (rc) return rc;
     int *bad = (int *)ctx->ws2;
     AGPL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    if (ld.kind == AGPL_LIK_BERNOULLI_LOGISTIC) {
+        rc = agpl_pg_retry_reserve(ctx, n < kPg1MaxLaunch ? n : kPg1MaxLaunch);
+        if (rc) return rc;
+    }
     rc = agpl_timing_begin(ctx, 3);
     if (rc) return rc;
 #define AGPL_LAUNCH_AUX(K)                                                                                     \
@@ -1461,11 +1536,8 @@ extern "C" int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int6
         break;
     switch (ld.kind) {
     case AGPL_LIK_BERNOULLI_LOGISTIC: { // one draw per point: the kernel with the long trial queue
-        int64_t nb = agpl_cdiv(n, kPg1Slots);
-        if (nb > 256 * 4 * 8) nb = 256 * 4 * 8;
-        aux_sample_pg1_kernel<false><<<(unsigned)nb, kBlock, 0, ctx->stream>>>(
-            n, f, omega_out, ctx->seed, (uint64_t)ctx->point_offset, sweep, nuni_out, nterms_out, nullptr, nullptr, nullptr, nullptr,
-            nullptr, nullptr, nullptr);
+        launch_pg1<false>(ctx, n, f, omega_out, sweep, nuni_out, nterms_out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr);
     } break;
         AGPL_LAUNCH_AUX(AGPL_LIK_NEGBINOMIAL)
         AGPL_LAUNCH_AUX(AGPL_LIK_STUDENTT)
@@ -2234,9 +2306,12 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "Gibbs pass: L * M = %d x %d does not fit the LDS working set", Lf, M);
     int64_t nb = agpl_cdiv(agpl_cdiv(N, 64), 4);
     if (nb > 256 * 8) nb = 256 * 8;
-    int32_t rc = agpl_timing_begin(ctx, 2);
-    if (rc) return rc;
     if (!proj_work) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "Gibbs point pass: no projection scratch");
+    int32_t rc = AGPL_OK;
+    if (ld.kind == AGPL_LIK_BERNOULLI_LOGISTIC) rc = agpl_pg_retry_reserve(ctx, N < kPg1MaxLaunch ? N : kPg1MaxLaunch);
+    if (rc) return rc;
+    rc = agpl_timing_begin(ctx, 2);
+    if (rc) return rc;
     {
         const size_t lds_p = sizeof(double) * (size_t)Lf * M, lds_s = sizeof(double) * 4 * (size_t)(64 * (Lf + Lo) + 32 * Lo);
         int64_t nbp = agpl_cdiv(agpl_cdiv(N, 64), 4);
@@ -2270,11 +2345,8 @@ int32_t agpl_launch_gibbs_project_sample(agpl_ctx *ctx, const agpl_lik_dev &ld, 
         break;
         switch (ld.kind) {
         case AGPL_LIK_BERNOULLI_LOGISTIC: { // one PG(1, |f_i|) draw per point: the kernel with the long trial queue (f over proj_work)
-            int64_t nb1 = agpl_cdiv(N, kPg1Slots);
-            if (nb1 > 256 * 4 * 8) nb1 = 256 * 4 * 8;
-            aux_sample_pg1_kernel<true><<<(unsigned)nb1, kBlock, 0, ctx->stream>>>(
-                N, nullptr, omega_out, ctx->seed, (uint64_t)ctx->point_offset, sweep, nuni_out, nullptr, proj_work, kdiag, mu0,
-                (const uint8_t *)y, gamma, beta, f_out);
+            launch_pg1<true>(ctx, N, nullptr, omega_out, sweep, nuni_out, nullptr, proj_work, kdiag, mu0, (const uint8_t *)y,
+                             gamma, beta, f_out);
         } break;
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_NEGBINOMIAL)
             AGPL_LAUNCH_GIBBS_S(AGPL_LIK_STUDENTT)

@@ -72,12 +72,25 @@ struct Philox {
         c0 += 1u;
         pos = 0;
     }
+    // a fresh (sub-)stream whose first two uniforms -- all four words of block 0 -- are not needed: the state after them, without
+    // the ten rounds of the block
+    __device__ __forceinline__ void skip_first_block() {
+        c0 = 1u;
+        pos = 4;
+        nuni = 2u;
+    }
     // uniform in the open interval (0,1): (k + 1/2) 2^-52 for a 52-bit k -- every value is exact in float64
     // (k + 1/2 needs 53 bits), so neither 0 nor 1 can come out of the rounding of the conversion
     __device__ __forceinline__ double u01() {
         if (pos >= 4) refill();
         uint32_t w0, w1;
-        if (pos == 0) { w0 = b0; w1 = b1; } else { w0 = b2; w1 = b3; }
+        // (all four words read unconditionally: loads in the two arms of a branch are merged into ONE load through a selected
+        //  address, which pins the whole stream in scratch memory -- 40 bytes stored per refill and two scratch loads per
+        //  uniform inside the trial loops of the PG sampler, round 5)
+        const uint32_t a0 = b0, a1 = b1, a2 = b2, a3 = b3;
+        const bool first = pos == 0;
+        w0 = first ? a0 : a2;
+        w1 = first ? a1 : a3;
         pos += 2;
         nuni += 1u;
         uint64_t k = ((uint64_t)(w0 >> 6) << 26) | (uint64_t)(w1 >> 6);
@@ -146,31 +159,35 @@ __device__ __forceinline__ double pg_mass_texpon(double z, double K) {
 // u below the bracket takes the truncated-exponential branch, u above it the inverse-Gaussian branch, and a draw whose u falls
 // INSIDE it (2e-8 of the draws) is handed to the sequential sampler with the exact formula (phase C of the kernels): the decisions
 // are those of the exact formula, at a twentieth of its ~900 instructions (two erfc, three exp, a division) per point.
-constexpr double kPgMassCheb[25] = {
-    0.17891350136487277, -0.29110615717444843, 0.14413720467193056,
-    -0.019096796213082485, -0.030408673533667163, 0.02413478068743331,
-    -0.005763120734068512, -0.0025295518306110215, 0.0022193291620839425,
-    -0.00036720422556672745, -0.0002554337564001494, 0.0001344480400196417,
-    2.6363411059142603e-06, -1.989863672582531e-05, 3.945796121778492e-06,
-    1.8751767350099586e-06, -8.57276875529128e-07, -9.114466427503223e-08,
-    1.221518168946105e-07, -8.29437512251279e-09, -1.3409793302941801e-08,
-    3.0516811956701023e-09, 1.0826812382200682e-09, -5.089763581593449e-10,
-    -3.546254472440936e-11,
-};
+#define AGPL_PG_MASS_CHEB                                                                                           \
+    0.17891350136487277, -0.29110615717444843, 0.14413720467193056, -0.019096796213082485, -0.030408673533667163,  \
+        0.02413478068743331, -0.005763120734068512, -0.0025295518306110215, 0.0022193291620839425,                 \
+        -0.00036720422556672745, -0.0002554337564001494, 0.0001344480400196417, 2.6363411059142603e-06,            \
+        -1.989863672582531e-05, 3.945796121778492e-06, 1.8751767350099586e-06, -8.57276875529128e-07,              \
+        -9.114466427503223e-08, 1.221518168946105e-07, -8.29437512251279e-09, -1.3409793302941801e-08,             \
+        3.0516811956701023e-09, 1.0826812382200682e-09, -5.089763581593449e-10, -3.546254472440936e-11
+constexpr double kPgMassChebLit[25] = {AGPL_PG_MASS_CHEB};
+// The same table in constant memory (weak: one definition per code object that includes this header), read through scalar loads.  As
+// compile-time literals the 25 coefficients are hoisted out of a kernel's point loop into 50 VGPRs: fine where the fit runs per
+// DRAW (the multi-latent engine: literals measured 3-7 % faster there), the largest block of register pressure where it runs once
+// per point (the PG(1) kernels and the one-latent engine, which spilled because of it) -- round 5.
+__attribute__((weak)) __constant__ double kPgMassChebMem[25] = {AGPL_PG_MASS_CHEB};
+#undef AGPL_PG_MASS_CHEB
 constexpr double kPgMassSlack = 1e-8;
+template <bool LITERAL = false>
 __device__ __forceinline__ double pg_mass_fit(double z) { // z in [0, 8)
     const double x = z * 0.25 - 1.0;
     const double x2 = 2.0 * x;
     double b1 = 0.0, b2 = 0.0;
 #pragma unroll
     for (int j = 24; j > 0; --j) {
-        const double t = __builtin_fma(x2, b1, kPgMassCheb[j] - b2);
+        const double t = __builtin_fma(x2, b1, (LITERAL ? kPgMassChebLit[j] : kPgMassChebMem[j]) - b2);
         b2 = b1;
         b1 = t;
     }
-    return __builtin_fma(x, b1, kPgMassCheb[0] - b2);
+    return __builtin_fma(x, b1, (LITERAL ? kPgMassChebLit[0] : kPgMassChebMem[0]) - b2);
 }
-// the bracket [rlo, rhi] of r for tilt c (rlo == rhi == the exact r where the fit does not apply)
+// the bracket [rlo, rhi] of r for tilt c ([0, 1] where the fit does not apply: decided by the exact formula, phase C)
 __device__ __forceinline__ void pg_mass_bracket(double c, double &z, double &K, double &rlo, double &rhi);
 
 // rand_truncated_inverse_gaussian(rng,z) polyagamma.jl:195-221
@@ -225,10 +242,8 @@ __device__ __forceinline__ void pg_mass_bracket(double c, double &z, double &K, 
         const double r = pg_mass_fit(z);
         rlo = r - kPgMassSlack;
         rhi = r + kPgMassSlack;
-    } else {
-        Pg1Params p;
-        p.set(c);
-        rlo = rhi = p.r;
+    } else { // no fit: the bracket is all of (0, 1), i.e. every draw of this owner goes to the sequential sampler, which forms the exact
+        rlo = 0.0, rhi = 1.0; // r (the ~900 instructions of mass_texpon inline here cost every point's prologue their registers)
     }
 }
 // sample_pg1(rng,c) polyagamma.jl:237-257.  The alternating-series accept loop runs with the wave's

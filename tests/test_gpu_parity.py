@@ -218,6 +218,27 @@ def test_aux_sample_edge_cases(A, ctx, oracle):
         A.rand_polyagamma(65535.0, 1.0, torch.empty(4, dtype=torch.float64, device="cuda"), ctx=ctx)
 
 
+@pytest.mark.parametrize("name", ["bernoulli", "negbin"])
+def test_aux_sample_without_a_fitted_branch_mass(A, ctx, oracle, name):
+    """|f| >= 16 (z >= 8) has no Chebyshev fit of the branch mass: every such draw is decided by the exact formula in the sequential
+    sampler -- for Bernoulli on the retry list of the PG(1) kernel pair (here the list is FULL: every point is on it, at a ragged
+    point count and with a second launch straight behind on the same list), for the one-latent engine in its phase C.  Values,
+    uniforms consumed and series indices must be the oracle's (polyagamma.jl:223-257)."""
+    O = oracle
+    lik, olik = lik_pairs(A, O)[name]
+    rng = np.random.default_rng(31)
+    n = 5003
+    f = rng.uniform(16.0, 30.0, size=n) * rng.choice([-1.0, 1.0], size=n)
+    f[::7] = rng.normal(size=f[::7].shape)  # (and some ordinary points between them)
+    y = gen_y(O, olik, n, rng)
+    for sweep in (2, 3):
+        Om, nuni, nterms = A.aux_sample_(A.init_aux_variables(lik, n, ctx=ctx), lik, dev(y), dev(f), ctx=ctx, sweep=sweep, stats=True)
+        ref = O.aux_sample(olik, y, f, seed=SEED, sweep=sweep, stats=True)
+        assert np.array_equal(host(nuni).astype(np.uint32), ref["nuni"])
+        assert np.array_equal(host(nterms).astype(np.uint32), ref["nterms"])
+        assert np.allclose(host(Om.ω), ref["omega"], rtol=1e-10, atol=0)
+
+
 # ------------------------------------------------------------------------------------------ CAVI operators
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

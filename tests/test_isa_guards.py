@@ -127,18 +127,56 @@ def test_the_step_loops_wait_with_a_counted_vmcnt(syrk_isa, kernel):
         assert "s_waitcnt vmcnt(5)" in waits  # the step's five DMA pieces stay in flight
 
 
-def test_sampler_kernels_contain_no_function_call(tmp_path):
-    """The PG sampler engine (pg_int_sum_block and its callers) must be inlined into its kernels: left to its heuristics the
-    inliner once turned it into a real call (`s_swappc_b64`), and the negative-binomial aux_sample_kernel went from 8.6 to 18.0 ms
-    per 4e6 points without a single source line of it changing.  Checked on the generated code of agpl_ops.hip."""
+@pytest.fixture(scope="module")
+def ops_asm(tmp_path_factory):
+    """agpl_ops.hip compiled to gfx950 assembly with the flags the Makefile gives that file (COMMON, NOFMA and its own EXTRA +=)."""
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
+    d = tmp_path_factory.mktemp("ops_isa")
     mk = open(os.path.join(CSRC, "Makefile")).read()
     flags = re.search(r"^COMMON\s*:=\s*(.*)$", mk, flags=re.M).group(1).replace("$(ARCH)", "gfx950").split()
     flags += re.search(r"^NOFMA\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    for extra in re.findall(r"^agpl_ops\.o:\s*EXTRA\s*\+=\s*(.*)$", mk, flags=re.M):
+        if "AGPL_PG_TRACE" not in extra:  # (the diagnostic build's flag sits behind an ifdef)
+            flags += extra.split()
+    assert "-disable-machine-licm" in flags  # (the flag the scratch guard below depends on)
     subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, "agpl_ops.hip"), "-o", "ops.s"],
-                          cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    asm = open(os.path.join(tmp_path, "ops.s")).read()
+                          cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(os.path.join(d, "ops.s")).read()
+
+
+def test_pg_sampler_kernels_keep_scratch_out_of_their_phases(ops_asm):
+    """Round 5.  The PG(1) kernels (Bernoulli `aux_sample!` and the Bernoulli point pass of a Gibbs sweep) use
+    no scratch memory at all; the general engine's negative-binomial kernels have no scratch instruction between the barriers that
+    delimit phases A, B1 and B2 (what remains: saves around the engine call and the sequential phase C, whose `cos` carries the
+    math library's 24-byte argument-reduction array).  Three things made the difference and each can silently come back: the Philox
+    word selection through a selected address (the whole stream lived in scratch), phase C inside the PG(1) kernels, and machine
+    LICM hoisting ~100 registers of float64 polynomial coefficients out of the point loops only to spill them."""
+    meta = dict(re.findall(r"\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", ops_asm, flags=re.S))
+    pg1 = [k for k in meta if "aux_sample_pg1_kernel" in k]
+    assert len(pg1) == 2
+    for k in pg1:
+        assert int(meta[k]) == 0, (k, meta[k])
+    checked = 0
+    for name, body in re.findall(r"^(_Z\w*(?:aux_sample_kernelILi1E|gibbs_sample_kernelILi1E)\w*):.*?\n(.*?)s_endpgm", ops_asm,
+                                 flags=re.S | re.M):
+        lines = body.splitlines()
+        bars = [i for i, ln in enumerate(lines) if "s_barrier" in ln]
+        # barriers: [scratch init, engine set-up, tmax, end of A, end of B1, end of B2, end of C, end of the chunk]
+        assert len(bars) == 8, (name, bars)
+        phases = lines[bars[2]:bars[5]]
+        stray = [ln.strip() for ln in phases if re.search(r"\b(scratch_|buffer_(load|store))", ln)]
+        assert not stray, (name, stray[:5])
+        assert len(phases) > 2000  # (the three phases really are between those barriers)
+        checked += 1
+    assert checked == 2
+
+
+def test_sampler_kernels_contain_no_function_call(ops_asm):
+    """The PG sampler engine (pg_int_sum_block and its callers) must be inlined into its kernels: left to its heuristics the
+    inliner once turned it into a real call (`s_swappc_b64`), and the negative-binomial aux_sample_kernel went from 8.6 to 18.0 ms
+    per 4e6 points without a single source line of it changing.  Checked on the generated code of agpl_ops.hip."""
+    asm = ops_asm
     kernels = re.findall(r"^(_Z\w*(?:aux_sample_kernel|gibbs_sample_kernel|aux_sample_pg1_kernel)\w*):.*?\n(.*?)s_endpgm", asm,
                          flags=re.S | re.M)
     assert len(kernels) >= 16  # 8 + 7 likelihood instantiations + the two PG(1) kernels

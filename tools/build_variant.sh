@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../augmentedgplikelihoods.jl_amd/csrc"
 SUF=$1; SRC=$2; FLAGS=$3
 COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden -Wall -Wno-unused-function -fno-slp-vectorize"
 EXTRA=""
-case $SRC in agpl_ops.hip|agpl_synth.hip) EXTRA="-ffp-contract=off";; esac
+case $SRC in agpl_synth.hip) EXTRA="-ffp-contract=off";; agpl_ops.hip) EXTRA="-ffp-contract=off -mllvm -disable-machine-licm";; esac  # (as the Makefile)
 /opt/rocm/bin/hipcc $COMMON $EXTRA $FLAGS -c $SRC -o /tmp/variant_$SUF.o
 OBJS=""
 for f in agpl_syrk agpl_core agpl_ops agpl_mfma agpl_update agpl_synth agpl_dense agpl_split agpl_factor agpl_plan; do
