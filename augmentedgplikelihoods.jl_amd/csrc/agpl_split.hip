@@ -214,6 +214,21 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..15
     const unsigned lane_v = (unsigned)lane;
     const int wr = wave >> 2, wc = wave & 3;
+    // Issue priority by row group (round 5).  The hardware issues oldest wave first: waves 12..15 (row group 3, whose rows carry work to
+    // the last stage of an item's diagonal block and which therefore end every such stage) got the leftover slots (round-4 stamps: they
+    // arrive last at every barrier whatever their share).  With priority = row group the wave that ends the stage goes first:
+    // 7.66 -> 7.49 ms at N = 1e7, M = 512 and 13.28 -> 13.07 ms at N = 5e6, M = 1024 (random features, tools/kbench.py,
+    // profiles/r05_ab_marginal_priority.txt).  Measured beside it (-DAGPL_MPRIO=k): 0 none, 2 reversed (no gain), 3 only row
+    // group 3 raised (7.50 / 13.12), 4 graded with the item sums dropped to priority 0 (7.58 / 13.06).
+#ifndef AGPL_MPRIO
+#define AGPL_MPRIO 1
+#endif
+    {
+        const int pr = AGPL_MPRIO == 0 ? 0 : AGPL_MPRIO == 2 ? 3 - wr : AGPL_MPRIO == 3 ? (wr == 3 ? 3 : 0) : wr;
+        if (pr == 3) __builtin_amdgcn_s_setprio(3);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    }
     const int nb = M / BS, nks = M / KS, nb2 = M / NT2;
     const int qn = (int)(blockIdx.x & 7); // (the launch has >= 8 workgroups: every queue is served)
     const int ntq = qn < ntiles2 ? (ntiles2 - qn + 7) / 8 : 0;
@@ -524,7 +539,17 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             const float *vrow = alpha_s + (ck & 1) * M + rb * NT2 + wr * 64 + 4 * kg;
             float *qr = qred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64, *mr = mred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64;
             constexpr bool kNoSums = AGPL_MPROBE == 4;
-            if (wr < 3 ? s_idle == 0 : ks + KU == 16 * (rb + 1)) item_sums_rows<0, 4, kNoSums>(acc, vrow, qr, mr);
+            if (wr < 3 ? s_idle == 0 : ks + KU == 16 * (rb + 1)) {
+#if AGPL_MPRIO == 4
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                item_sums_rows<0, 4, kNoSums>(acc, vrow, qr, mr);
+#if AGPL_MPRIO == 4
+                if (wr == 3) __builtin_amdgcn_s_setprio(3);
+                else if (wr == 2) __builtin_amdgcn_s_setprio(2);
+                else if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
+            }
         }
         ks += KU;
         if (ks == 16 * (rb + 1)) {
