@@ -558,25 +558,38 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 //
 //   F  (1 workgroup)   the diagonal chain: D_k -> R_kk = chol(D_k), W_k = R_kk^-1 (the 16 column-pair steps of factor_kernel),
 //                      publishes W_k, then P0 = T[k+1,k] W_k' and D_{k+1} = T[k+1,k+1] - P0 P0' from two 32 x 32 blocks that a P
-//                      workgroup handed over a whole step earlier.  Nothing else is on its path: ~10 us per block step instead of
-//                      the ~21 us of factor_kernel's spine (factor 7.8 + panel 3.7 + publish 2.4 + own update 5.4 + waits).
-//   P  (ceil(M / 512)) the block column: each owns 512 rows of the LDS image PX (row c < 32 (k + 1): X_k'[c], column c of U; row
-//                      g >= 32 (k + 1): the raw panel T[g, k]); per step: load W_k, every row times W_k' in place (the panel of
-//                      R and the final rows of U), publish the rows, update the diagonal tiles T[j,j] of its rows (it owns all
-//                      of them, for ever), and apply this step's update to the NEXT block column and the next 32 rows of the
-//                      eliminated identity in LDS (factor_kernel's look-ahead).  The wave whose rows are block k + 2 hands
-//                      T[k+2,k+1] and T[k+2,k+2] to F by itself.
-//   T  (10 or 20)      the trailing update: region (a, b), a >= b, of a 4 x 4 partition of the rows into ranges of M / 4: the
-//                      strictly-lower 32 x 32 tiles of T and the tiles of the eliminated identity with rows in a and columns in b;
-//                      stages only the 2 M / 4 rows of P | X' it needs (<= 135 KB of LDS at M = 1024).  Two passes per step as
-//                      before: first what the P workgroups take over at the next step (counted in `crit`), then the rest.
+//                      workgroup handed over a whole step earlier.  Nothing else is on its path: 12-13 us per block step (factor
+//                      8.2, publish 0.45, wait for the hand-over 1-3, the two blocks 0.65, P0 and D 0.8, 0.55 to the next step:
+//                      -DAGPL_FTRACE stamps) instead of the ~21 us of factor_kernel's spine.
+//   P  (ceil(M / 256)) the block column: each owns 256 rows of the LDS image PX (row c < 32 (k + 1): X_k'[c], column c of U; row
+//                      g >= 32 (k + 1): the raw panel T[g, k]), two images by step parity.  Waves 0-7 (owners): load W_k, every row
+//                      times W_k' in place (the panel of R and the final rows of U, which go to A), then this step's update of the
+//                      NEXT block column and of the next 32 rows of the eliminated identity into the other image (factor_kernel's
+//                      look-ahead; the old values by write-through loads).  The owner whose rows are block k + 2 stores
+//                      T[k+2,k+1] for F.  Waves 8-15 (helpers), beside the owners' look-ahead: fetch P0, publish the
+//                      workgroup's rows (LDS-staged 16-byte write-through stores), update the diagonal tiles T[j,j] of its
+//                      rows (the one for F write-through), drain; the last helper to finish stores `ready[j]`.
+//   T  (CY^2 x TS)     the trailing update: cell (tr, tc) of a CY x CY block-cyclic grid over the 32 x 32 tiles (CY = 4; 2 where
+//                      several latents share an XCD at M <= 512), TS = 2 workgroups per cell beyond M = 512 (they split a cell's
+//                      row blocks by parity).  A cell holds the strictly-lower tiles (ib, jb) of T with ib = tr, jb = tc (mod CY)
+//                      and the tiles of the eliminated identity with row block = tr, column block = tc; it stages the two
+//                      residue classes of P | X' it needs (<= 2 x 256 rows).  Two passes per step: first the block column / row
+//                      P takes over at its next step (one tile per wave, stored write-through, then `crit[w]`), then the rest on
+//                      a skewed walk that gives every wave a mix of long and short columns.  Cyclic, not contiguous regions:
+//                      every workgroup keeps its share of the work to the last steps.
 //
 // Hand-offs inside the launch follow the local guide's recipe (cdna_hip_programming.md Guideline 16):
-//   * W_k, P0, the two blocks for F, and P | X' are stored write-through (sc1: relaxed agent-scope atomic stores of the 8-byte
-//     words), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane stores / adds the flag;
-//     every load of those bytes in the consumer is an sc1 load (relaxed agent-scope atomic load) behind ONE relaxed poll: no fence;
-//   * the tiles of T and U travel from the T workgroups to P by plain stores + an agent-scope release add (crit / done) and an
-//     agent-scope acquire in P after its poll, as in factor_kernel.
+//   * everything another workgroup reads inside the launch -- W_k, P0, the blocks for F, P | X', the first-pass tiles of T and U -- is
+//     stored write-through (sc1: relaxed agent-scope atomic stores; 16-byte inline-asm stores where a wave has pairs), every
+//     storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier (or counts its helper waves in LDS), ONE lane
+//     stores the flag; every load of those bytes in the consumer is an sc1 load behind ONE relaxed poll: no fence on either side
+//     (an acquire fence in a wave with publish stores in flight waits for its own drain: measured, 4 us per step);
+//   * second-pass tiles stay with the workgroup that wrote them (plain stores and loads through its own L2; a cell's parts keep the
+//     row blocks they own in BOTH passes -- with chip-wide placement another part's plain stores sit in another XCD's L2);
+//   * the end of the factorisation is one agent-scope release add per workgroup (`alldone`) and an acquire behind its poll; then
+//     every workgroup takes its 64-wide blocks of v = U (g + eta0).
+// Placement: M <= 512: the <= 19 workgroups of a latent on the XCD l % 8 (8 x wide launch, 7 of 8 leave at once), so that the
+// hand-offs stay in one L2; beyond, up to 37 workgroups a latent do not fit 32 CUs: chip-wide (`spread`), every hand-off agent-scope.
 // Nothing is reused inside a launch (W, P0, P | X' have a slot per step: M x M doubles of scratch), so there is no
 // write-after-read hazard to reason about; the flag words are zeroed by the clean-up launch queued behind every launch.
 // Arithmetic: every element sees exactly factor_kernel's sequence of float64 MFMA accumulations and subtractions, in the same

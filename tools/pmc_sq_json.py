@@ -11,7 +11,7 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 KEEP = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "marginal_factor16_kernel", "syrk_strip_kernel",
-        "syrk_split_kernel", "factor_kernel", "reduce_slab_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel", "gibbs_project_image_kernel", "gibbs_project_kernel",
+        "syrk_split_kernel", "factor_pipe_kernel", "factor_kernel", "aux_sample_pg1_retry_kernel", "reduce_slab_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel", "gibbs_project_image_kernel", "gibbs_project_kernel",
         "gibbs_sample_kernel", "agpl_fused_point_kernel")
 
 

@@ -12,7 +12,7 @@ def means(root, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 KNOWN = ("marginal_factor_queue_kernel", "marginal_factor_persist_kernel", "marginal_split256_kernel", "syrk_gang_kernel", "syrk_strip_kernel", "syrk_split_kernel",
-         "agpl_fused_point_kernel", "reduce_slab_kernel", "reduce_G_kernel", "gibbs_project_image_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_kernel",
+         "agpl_fused_point_kernel", "reduce_slab_kernel", "reduce_G_kernel", "gibbs_project_image_kernel", "gibbs_project_kernel", "gibbs_sample_kernel", "factor_pipe_kernel", "factor_kernel", "aux_sample_pg1_retry_kernel",
          "split_prep_kernel", "acc_prep_kernel", "aux_sample_pg1_kernel", "aux_sample_kernel")
 
 

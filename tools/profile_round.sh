@@ -9,7 +9,7 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 O=$ROOT/$1; shift
 mkdir -p "$O"
-COMMON="--steps 2 --warmup 1 --no-cpu --no-parity --no-m1024 --no-c5 --no-f32 --no-elbo"
+COMMON="--steps 2 --warmup 1 --no-cpu --no-parity --no-m1024 --no-c5 --no-f32 --no-elbo --no-extra"
 for cfg in "$@"; do
   case $cfg in
     c2) ARGS="$COMMON";;
