@@ -16,8 +16,11 @@ HDR = os.path.join(ROOT, "augmentedgplikelihoods.jl_amd", "csrc", "agpl_random.h
 
 def header_constants():
     src = open(HDR).read()
-    body = re.search(r"constexpr double kPgMassCheb\[25\] = \{(.*?)\};", src, flags=re.S).group(1)
+    # the coefficients are ONE macro (AGPL_PG_MASS_CHEB) that initialises both tables: the literal one and the constant-memory one
+    body = re.search(r"#define AGPL_PG_MASS_CHEB(.*?)\nconstexpr double kPgMassChebLit\[25\] = \{AGPL_PG_MASS_CHEB\};", src, flags=re.S).group(1)
+    assert "__constant__ double kPgMassChebMem[25] = {AGPL_PG_MASS_CHEB};" in src
     coef = np.array([float(v) for v in re.findall(r"[-+]?\d\.\d+(?:e[-+]?\d+)?", body)])
+    assert coef.size == 25
     slack = float(re.search(r"constexpr double kPgMassSlack = ([0-9.e-]+);", src).group(1))
     return coef, slack
 

@@ -1,7 +1,7 @@
 """Chebyshev fit of r(z) = mass_texpon(z, pi^2/8 + z^2/2) (polyagamma.jl:179-192, 226-236) on z in [0, 8], used by the device
 sampler ONLY to bracket r: a draw whose branch uniform u is within +-1e-8 of the fit is decided by the exact formula
 (Pg1Params::set), every other draw by the fit -- the decisions are those of the exact formula as long as the fit's error is
-below the bracket.  This script prints the coefficients pasted into agpl_random.h (kPgMassCheb) and the error of the fit against
+below the bracket.  This script prints the coefficients pasted into agpl_random.h (the AGPL_PG_MASS_CHEB macro behind kPgMassChebLit / kPgMassChebMem) and the error of the fit against
 a 60-digit mpmath evaluation on a dense grid."""
 import mpmath as mp
 import numpy as np
