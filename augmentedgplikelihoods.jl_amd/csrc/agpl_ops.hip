@@ -578,7 +578,13 @@ __device__ __forceinline__ void sample_point_wave(const agpl_lik_dev &lik, PgBlo
 // negative binomial r = 15 16.9 / 10.4 / 8.9 / 8.5 ms per 4e6 points (profiles/r03_ab_sampler.txt).  The kinds without PG draws
 // have no barriers and keep their registers.
 constexpr int sampler_wps(int kind) {
-    return (kind == AGPL_LIK_STUDENTT || kind == AGPL_LIK_LAPLACE) ? 1 : 4;
+    // (round 5, after the scratch was gone: 3 / 4 / 5 waves -- Bernoulli PG(1) kernel 0.540 / 0.533 / 0.532 ms, negative binomial
+    //  7.26 / 6.30 / 7.23 ms, categorical K = 10 0.525 / 0.665 / 0.646 ms: the categorical kinds take 3)
+#ifdef AGPL_SAMPLER_WPS // measurement builds
+    return (kind == AGPL_LIK_STUDENTT || kind == AGPL_LIK_LAPLACE) ? 1 : AGPL_SAMPLER_WPS;
+#else
+    return (kind == AGPL_LIK_STUDENTT || kind == AGPL_LIK_LAPLACE) ? 1 : (kind == AGPL_LIK_CATEGORICAL || kind == AGPL_LIK_CATEGORICAL_BIJ) ? 3 : 4;
+#endif
 }
 
 template <int KIND>
@@ -2180,8 +2186,16 @@ __global__ __launch_bounds__(256) void gibbs_project_kernel(int64_t N, int M, in
     }
 }
 
+// the Gibbs point pass: the categorical kinds at two waves (C4 Gibbs sweep 4.19 / 3.90 / 3.84 ms at 4 / 3 / 2, round 5; its per-wave
+// LDS scratch sets the occupancy at K = 10 anyway), the other PG kinds at four
+constexpr int gibbs_wps(int kind) {
+#ifdef AGPL_GIBBS_WPS_CAT // measurement builds
+    if (kind == AGPL_LIK_CATEGORICAL || kind == AGPL_LIK_CATEGORICAL_BIJ) return AGPL_GIBBS_WPS_CAT;
+#endif
+    return (kind == AGPL_LIK_STUDENTT || kind == AGPL_LIK_LAPLACE) ? 1 : (kind == AGPL_LIK_CATEGORICAL || kind == AGPL_LIK_CATEGORICAL_BIJ) ? 2 : 4;
+}
 template <int KIND>
-__global__ __launch_bounds__(256, sampler_wps(KIND)) void gibbs_sample_kernel(
+__global__ __launch_bounds__(256, gibbs_wps(KIND)) void gibbs_sample_kernel(
     agpl_lik_dev lik, int64_t N, const double *__restrict__ proj, const float *__restrict__ kdiag,
     const float *__restrict__ mu0, const void *yv, uint64_t seed, uint64_t i0, uint32_t sweep,
     float *__restrict__ gamma, float *__restrict__ beta, double *__restrict__ f_out, double *__restrict__ omega_out, int64_t *__restrict__ n_out,

@@ -335,7 +335,7 @@ def f32_contract_leg(A, ctx, lik, likname, Phi, kd, y, N, M, Mp, L, args):
 
     cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
     steps = 3
-    dt, kt = timed_sweeps(ctx, cavi, steps, warmup, torch.cuda.synchronize)
+    dt, kt = timed_sweeps(ctx, cavi, steps, 1, torch.cuda.synchronize)
     ms = dt / steps * 1e3
     roof = roofline_of(kt, L, N, M, Mp, "f32", "f32", ms, 1, N)
     # SURVEY 8(d) counts the variance projection as a dense product (2 N M^2); marginal_kernel<0> uses the symmetry of W (packed
