@@ -65,12 +65,13 @@ struct agpl_ctx {
 // 2.92 against 3.27 ms on one box); at M >= 512 the longer slice measured slower (round 3).
 __host__ __device__ constexpr int agpl_chunk_points(int M) { return M <= 256 ? 8192 : 4096; }
 // Points per accumulation slice (float32 sums within a slice, float64 across slices): the figure above, doubled while the launch
-// would still have >= 64 workgroups per CU -- N = 1e7 at M = 1024: 2442 slices of 36 x 64 KB are 5.8 GB of slabs written and read
-// again per sweep (the reduction alone 0.98 ms); 1221 slices halve that.  A function of (N, M, L) only: results repeat.
+// would still have >= 32 workgroups per CU -- N = 1e7 at M = 1024: 2442 slices of 36 x 64 KB are 5.8 GB of slabs written and read
+// again per sweep (the reduction alone 0.98-1.05 ms); 1221 slices (47 workgroups per CU) halve that.  A function of (N, M, L) only:
+// results repeat.
 inline int agpl_slice_points(int64_t N, int M, int L) {
     int chunk = agpl_chunk_points(M);
     const int64_t nb2 = (M + 255) / 256, pairs = nb2 * (nb2 + 1) / 2;
-    while (chunk < 32768 && (int64_t)L * pairs * ((N + 2 * chunk - 1) / (2 * chunk)) >= 64 * 256) chunk *= 2;
+    while (chunk < 16384 && (int64_t)L * pairs * ((N + 2 * chunk - 1) / (2 * chunk)) >= 32 * 256) chunk *= 2;
     return chunk;
 }
 
