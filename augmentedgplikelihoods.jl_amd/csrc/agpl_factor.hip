@@ -1197,6 +1197,10 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
     // ======================================================================================= all: U complete -> v = U (g + eta0)
     AGPL_DRAIN();
     __syncthreads();
+#ifdef AGPL_FTRACE
+    const int k = 31; // (the tail's stamps go to the free slots 5, 6, 7 of the last step's row)
+#endif
+    AGPL_TS(5);
     if (tid == 0) {
         if (lostf) __hip_atomic_store(&fl->lost, (unsigned)(100 * wg + lostf), RLX_AGENT); // (which wait gave up: diagnostic)
         __hip_atomic_fetch_add(&fl->alldone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1206,6 +1210,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
         AGPL_DRAIN();
     }
     __syncthreads();
+    AGPL_TS(6);
     if (lostf) {
         if (wg == 0 && tid == 0) info[l] = -1; // a partner workgroup never arrived: the clean-up launch redoes M <= 512 alone
         return;
@@ -1222,9 +1227,29 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
         for (int ab = wg; ab < M / 64; ab += NWG) {
             const int a = ab * 64 + lane;
             double acc = 0.0;
+            // sixteen loads in flight per lane, the sums in the order of the plain loop (the last column block is 64 dependent L2
+            // round trips per wave otherwise: ~25 us behind the last block step at M = 1024 with four in flight)
+            const int bend = ab * 64 + 63;
+            int b = wave;
+            for (; b + 16 * 31 <= bend; b += 16 * 32) { // (the long column blocks: thirty-two in flight)
+                double u[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) u[j] = A[(size_t)(b + 16 * j) * M + a];
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (b + 16 * j <= a) acc += u[j] * rs[b + 16 * j];
+            }
+            for (; b + 16 * 15 <= bend; b += 16 * 16) {
+                double u[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) u[j] = A[(size_t)(b + 16 * j) * M + a]; // (rows b > a hold the other triangle: unused)
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (b + 16 * j <= a) acc += u[j] * rs[b + 16 * j];
+            }
 #pragma unroll 4
-            for (int b = wave; b <= ab * 64 + 63; b += 16) {
-                const double u = A[(size_t)b * M + a]; // (rows b > a of this column block hold the other triangle: unused)
+            for (; b <= bend; b += 16) {
+                const double u = A[(size_t)b * M + a];
                 if (b <= a) acc += u * rs[b];
             }
             part[wave * 64 + lane] = acc;
@@ -1239,6 +1264,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             __syncthreads();
         }
     }
+    AGPL_TS(7);
     if (wg == 0 && tid == 0) {
         if (logdet) logdet[l] = ldsum;
         info[l] = bad;
