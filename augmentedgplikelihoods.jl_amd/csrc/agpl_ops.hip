@@ -70,6 +70,7 @@ struct PgBlockScratch {
     unsigned char owner[kPgWaves][256];  // owner lane of each dealt draw
     double etheta[64];                   // categorical kinds: exp(log theta_k), filled once per kernel (pg_scratch_init)
     int qn, q2n, qhead, rn, tmax;
+    int wqn[kPgWaves], wq2n[kPgWaves], wqhead[kPgWaves], wrn[kPgWaves]; // the same counters per wave (kPgWaveLocal)
 #ifdef AGPL_PG_TRACE
     unsigned long long trace[8];
 #endif
@@ -179,6 +180,24 @@ __device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, 
 // sum of tb PG(1, c) draws on the sub-streams sub_base + 0 .. tb - 1 of the calling lane's point (tb = 0: the lane only helps).
 // sub_base is uniform over the workgroup.  __forceinline__ (and its callers): left to its heuristics the inliner turned this into a
 // real call in some builds -- the negative-binomial kernel then ran 18.0 instead of 8.6 ms per 4e6 points.
+// kPgWaveLocal (round 5): every wave runs the phases on its OWN draws, queues and counters -- no workgroup barrier anywhere in the
+// engine (a wave's LDS operations execute in order: a fence for the compiler is all a phase boundary needs).  The workgroup-wide
+// queue balanced the trial loop between the four waves, but a lane gets the same ~1.7 entries per chunk either way, and the six
+// barriers per 256-draw chunk were 29 % of a negative-binomial wave's cycles (PGTRACE, profiles/r05_ab_sampler.txt).
+#ifndef AGPL_PG_WAVE_LOCAL
+#define AGPL_PG_WAVE_LOCAL 1
+#endif
+constexpr bool kPgWaveLocal = AGPL_PG_WAVE_LOCAL != 0;
+#define PG_SYNC()                                                                                                     \
+    do {                                                                                                              \
+        if (kPgWaveLocal) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                      \
+        else __syncthreads();                                                                                         \
+    } while (0)
+#define PG_CNT(name_) (kPgWaveLocal ? scr->w##name_[wave] : scr->name_)
+#define PG_Q(name_) (kPgWaveLocal ? scr->name_ + wave * 256 : scr->name_)
+#define PG_QSTRIDE (kPgWaveLocal ? 64 : kBlock)
+#define PG_QFIRST (kPgWaveLocal ? lane : (int)threadIdx.x)
+#define PG_LEADER (kPgWaveLocal ? lane == 0 : threadIdx.x == 0)
 template <int NB>
 __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, int lane, const Philox &g, int latent0,
                                                  const int (&tb)[NB], const double (&c)[NB], double (&acc)[NB], uint32_t &nuni,
@@ -216,19 +235,29 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
     }
     if (lane == 63) scr->off[wave][kOwners] = T;
     if (lane == 0) scr->index0[wave] = (uint64_t)g.c2 | ((uint64_t)(g.c3 & 0xFFu) << 32); // lanes = consecutive points
-    if (threadIdx.x == 0) scr->tmax = scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
-    PGT_MARK(0);
-    __syncthreads();
-    if (lane == 0 && T > 0) atomicMax(&scr->tmax, T);
-    __syncthreads();
-    const int tmax = scr->tmax;
+    int tmax;
+    if (kPgWaveLocal) {
+        if (lane == 0) PG_CNT(qn) = PG_CNT(q2n) = PG_CNT(qhead) = PG_CNT(rn) = 0;
+        PGT_MARK(0);
+        PG_SYNC();
+        tmax = T; // (wave-uniform: every wave walks its own chunks)
+    } else {
+        if (threadIdx.x == 0) scr->tmax = scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
+        PGT_MARK(0);
+        __syncthreads();
+        if (lane == 0 && T > 0) atomicMax(&scr->tmax, T);
+        __syncthreads();
+        tmax = scr->tmax;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[j] = 0.0;
     PGT_MARK(1);
     // the parameters of owner o_ of wave w_ (z always; K, the bracket of r: stored for NB == 1, formed per draw otherwise)
 #define PG_OWNER_Z(w_, o_) (NB == 1 ? scr->par[w_][4 * (o_)] : scr->par[w_][o_])
+#define PG_ST(e_) scr->st[e_] /* (e = (wave << 8) | slot: every wave's own 256 words in either form) */
 #define PG_OWNER_SUB(o_) (1u + ((uint32_t)(latent0 + ((o_) >> 6)) << 16))
     for (int cb = 0; cb < tmax; cb += 256) {
+        asm volatile("; agpl-pg-phases-begin"); // (markers in the generated code: tests/test_isa_guards.py looks between them)
         // ---- phase A
         for (int r = 0; r < 4; ++r) {
             const int t = cb + 64 * r + lane;
@@ -271,41 +300,41 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             const unsigned long long mb = __ballot(to_b), mc = __ballot(to_c), mb2 = __ballot(to_b2);
             if (mb2) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scr->q2n, __popcll(mb2));
+                if (lane == 0) base = atomicAdd(&PG_CNT(q2n), __popcll(mb2));
                 base = __shfl(base, 0);
-                if (to_b2) scr->queue2[base + __popcll(mb2 & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_b2) PG_Q(queue2)[base + __popcll(mb2 & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
             }
             if (mb) { // (wave-uniform)
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scr->qn, __popcll(mb));
+                if (lane == 0) base = atomicAdd(&PG_CNT(qn), __popcll(mb));
                 base = __shfl(base, 0);
-                if (to_b) scr->queue[base + __popcll(mb & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_b) PG_Q(queue)[base + __popcll(mb & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
             }
             if (mc) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scr->rn, __popcll(mc));
+                if (lane == 0) base = atomicAdd(&PG_CNT(rn), __popcll(mc));
                 base = __shfl(base, 0);
-                if (to_c) scr->retry[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_c) PG_Q(retry)[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
             }
         }
         PGT_MARK(2);
-        __syncthreads();
+        PG_SYNC();
         PGT_MARK(3);
         // ---- phase B: truncated inverse-Gaussian proposals, polyagamma.jl:241-242 (rand_truncated_inverse_gaussian :195-221)
         // B1: the mu > t branch as a stream of TRIALS (E, E' -> test -> x, alpha -> test).  A wave running the two nested
         // rejection loops waits for its unluckiest lane (measured: 4.9 inner iterations per pass against a mean of 1.6 per lane);
         // here a lane whose proposal is accepted parks it (x in the draw's slot, the stream position beside it) and takes the next
         // entry of the queue, so every iteration of the loop is a trial for (nearly) all 64 lanes of all four waves.
-        const int qn = scr->qn, q2n = scr->q2n;
+        const int qn = PG_CNT(qn), q2n = PG_CNT(q2n);
         {
             int e = -1, w = 0, slot = 0;
             double z = 0.0;
             Philox s = g;
             auto fetch = [&]() {
-                const int idx = atomicAdd(&scr->qhead, 1);
+                const int idx = atomicAdd(&PG_CNT(qhead), 1);
                 e = -1;
                 if (idx < qn) {
-                    e = scr->queue[idx];
+                    e = PG_Q(queue)[idx];
                     w = e >> 8, slot = e & 255;
                     const int lo = scr->owner[w][slot];
                     s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
@@ -325,7 +354,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                         const double ua = s.u01();
                         if (!pg_alpha_below(z * z * x / 2.0, ua)) { // `alpha < u` with alpha = exp(-z^2 x / 2) is false: accepted
                             scr->draws[w][slot] = x;
-                            scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+                            PG_ST(e) = (s.c0 << 3) | (uint32_t)s.pos;
                             fetch();
                         }
                     }
@@ -334,27 +363,27 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         }
         // the mu <= t branch (|c| >= 3.125: Michael-Schucany-Haas proposals until x <= t) is rare: whole passes of the loop as is
         if (q2n) {
-            for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
-                const int e = scr->queue2[q];
+            for (int q = PG_QFIRST; q < q2n; q += PG_QSTRIDE) {
+                const int e = PG_Q(queue2)[q];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
                 Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
                 (void)s.u01();
                 scr->draws[w][slot] = rand_tig(s, PG_OWNER_Z(w, lo));
-                scr->st[e] = (s.c0 << 3) | (uint32_t)s.pos;
+                PG_ST(e) = (s.c0 << 3) | (uint32_t)s.pos;
             }
         }
         PGT_MARK(4);
-        __syncthreads();
+        PG_SYNC();
         PGT_MARK(5);
         // B2: the series test of the parked proposals (x <= t: a(n, x) in its logarithmic form), whole waves
-        for (int q = (int)threadIdx.x; q < ((qn + q2n + 63) & ~63); q += kBlock) {
+        for (int q = PG_QFIRST; q < ((qn + q2n + 63) & ~63); q += PG_QSTRIDE) {
             bool to_c = false;
             int e = 0;
             if (q < qn + q2n) {
-                e = q < qn ? scr->queue[q] : scr->queue2[q - qn];
+                e = q < qn ? PG_Q(queue)[q] : PG_Q(queue2)[q - qn];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
                 Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
-                const uint32_t st = scr->st[e], c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it
+                const uint32_t st = PG_ST(e), c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it
                 if (pos < 4u) {
                     s.c0 = c0 - 1u;
                     s.refill();
@@ -374,18 +403,19 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             const unsigned long long mc = __ballot(to_c);
             if (mc) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scr->rn, __popcll(mc));
+                if (lane == 0) base = atomicAdd(&PG_CNT(rn), __popcll(mc));
                 base = __shfl(base, 0);
-                if (to_c) scr->retry[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                if (to_c) PG_Q(retry)[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)e;
             }
         }
         PGT_MARK(4);
-        __syncthreads();
+        PG_SYNC();
+        asm volatile("; agpl-pg-phases-end");
         PGT_MARK(5);
         // ---- phase C: the draws whose first proposal was rejected, from the start of their sub-stream
-        const int rn = scr->rn;
-        for (int q = (int)threadIdx.x; q < rn; q += kBlock) {
-            const int e = scr->retry[q];
+        const int rn = PG_CNT(rn);
+        for (int q = PG_QFIRST; q < rn; q += PG_QSTRIDE) {
+            const int e = PG_Q(retry)[q];
             const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
             Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
             Pg1Params p;
@@ -395,21 +425,22 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
             atomicAdd(&scr->nterms[w][lo & 63], nt);
         }
-        __syncthreads();
+        PG_SYNC();
         PGT_MARK(6);
-        if (threadIdx.x == 0) scr->qn = scr->q2n = scr->qhead = scr->rn = 0;
+        if (PG_LEADER) PG_CNT(qn) = PG_CNT(q2n) = PG_CNT(qhead) = PG_CNT(rn) = 0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int a0 = off[j] > cb ? off[j] : cb, a1 = (off[j] + tb[j]) < (cb + 256) ? (off[j] + tb[j]) : (cb + 256);
             for (int t = a0; t < a1; ++t) acc[j] += scr->draws[wave][t - cb];
         }
-        __syncthreads();
+        PG_SYNC();
         PGT_MARK(1);
     }
     nuni += scr->nuni[wave][lane];
     nterms += scr->nterms[wave][lane];
 #undef PG_OWNER_Z
 #undef PG_OWNER_SUB
+#undef PG_ST
 }
 
 // rand(PolyaGamma(b_j, c_j)) for latents latent0 .. latent0 + nk - 1 of the lane's point (nk <= NB), integer parts dealt across
@@ -642,9 +673,17 @@ constexpr int kPg1Slots = kPg1Pts * kBlock;  // 2048 draws per iteration
 struct Pg1BlockScratch {
     double x[kPg1Slots];                     // parked proposals
     unsigned st[kPg1Slots];                  // their stream positions
-    unsigned short queue[kPg1Slots], queue2[kPg1Slots];
+    unsigned short queue[kPg1Slots], queue2[kPg1Slots]; // (kPg1WaveLocal: wave w's entries at [512 w ..])
     int qn, q2n, qhead;
+    int wqn[kBlock / 64], wq2n[kBlock / 64], wqhead[kBlock / 64];
 };
+#ifndef AGPL_PG1_WAVE_LOCAL
+#define AGPL_PG1_WAVE_LOCAL 0
+#endif
+// as kPgWaveLocal (every wave its own 512 points, queues and counters, no workgroup barrier) -- measured and NOT shipped for this kernel:
+// 0.554-0.560 against 0.534-0.536 ms per 1e7 points (its 2048-entry workgroup queue keeps the trial loop fuller than four 512-entry ones,
+// and it has four barriers per 2048 points, not six per 256 draws)
+constexpr bool kPg1WaveLocal = AGPL_PG1_WAVE_LOCAL != 0;
 
 // GIBBS: the Bernoulli point pass of a sparse Gibbs sweep in the same kernel -- f_i = projection_i + sqrt(d_i) eps_i (+ mu0_i) on the
 // point's main stream (two uniforms) is formed in phase A and written over the projection (fbuf, read back by the later phases),
@@ -661,10 +700,21 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
     if (GIBBS) f = fbuf;
     constexpr uint32_t kMain = GIBBS ? 2u : 0u; // uniforms the point's main stream has consumed (the normal of f)
     __shared__ Pg1BlockScratch scr;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
+    int &qn_c = kPg1WaveLocal ? scr.wqn[wave] : scr.qn, &q2n_c = kPg1WaveLocal ? scr.wq2n[wave] : scr.q2n,
+        &qhead_c = kPg1WaveLocal ? scr.wqhead[wave] : scr.qhead;
+    unsigned short *const queue_w = kPg1WaveLocal ? scr.queue + wave * (kPg1Slots / (kBlock / 64)) : scr.queue;
+    unsigned short *const queue2_w = kPg1WaveLocal ? scr.queue2 + wave * (kPg1Slots / (kBlock / 64)) : scr.queue2;
+    const bool leader = kPg1WaveLocal ? lane == 0 : threadIdx.x == 0;
+    const int qfirst = kPg1WaveLocal ? lane : (int)threadIdx.x, qstride = kPg1WaveLocal ? 64 : kBlock;
+#define PG1_SYNC()                                                                                                    \
+    do {                                                                                                              \
+        if (kPg1WaveLocal) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                     \
+        else __syncthreads();                                                                                         \
+    } while (0)
     const unsigned nblocks = (n + kPg1Slots - 1u) / kPg1Slots; // (n <= 2^30 per launch: 32-bit point indices, launch_pg1)
-    if (threadIdx.x == 0) scr.qn = scr.q2n = scr.qhead = 0;
-    __syncthreads();
+    if (leader) qn_c = q2n_c = qhead_c = 0;
+    PG1_SYNC();
     auto push = [&](bool flag, unsigned short *q, int *cnt, int slot) { // compacted append of the wave's flagged lanes
         const unsigned long long m = __ballot(flag);
         if (m) {
@@ -740,22 +790,22 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
                         to_b2 = true;
                 }
             }
-            push(to_b, scr.queue, &scr.qn, slot);
-            push(to_b2, scr.queue2, &scr.q2n, slot);
+            push(to_b, queue_w, &qn_c, slot);
+            push(to_b2, queue2_w, &q2n_c, slot);
             push_retry(to_c, i);
         }
-        __syncthreads();
+        PG1_SYNC();
         // ---- phase B1: trials with refill (see pg_int_sum_block)
-        const int qn = scr.qn, q2n = scr.q2n;
+        const int qn = qn_c, q2n = q2n_c;
         {
             int e = -1;
             double z = 0.0;
             Philox s = g0;
             auto fetch = [&]() {
-                const int idx = atomicAdd(&scr.qhead, 1);
+                const int idx = atomicAdd(&qhead_c, 1);
                 e = -1;
                 if (idx < qn) {
-                    e = scr.queue[idx];
+                    e = queue_w[idx];
                     const unsigned i = base + (unsigned)e;
                     s = pg_substream(g0, i0 + (uint64_t)i, 1u);
                     s.skip_first_block(); // (the branch uniform and the always-entered first `alpha < rand()`: see pg_int_sum_block)
@@ -781,8 +831,8 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
             }
         }
         if (q2n) {
-            for (int q = (int)threadIdx.x; q < q2n; q += kBlock) {
-                const int e = scr.queue2[q];
+            for (int q = qfirst; q < q2n; q += qstride) {
+                const int e = queue2_w[q];
                 const unsigned i = base + (unsigned)e;
                 Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
                 (void)s.u01();
@@ -790,13 +840,13 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
                 scr.st[e] = (s.c0 << 3) | (uint32_t)s.pos;
             }
         }
-        __syncthreads();
+        PG1_SYNC();
         // ---- phase B2: series test of the parked proposals
-        for (int q = (int)threadIdx.x; q < ((qn + q2n + 63) & ~63); q += kBlock) {
+        for (int q = qfirst; q < ((qn + q2n + 63) & ~63); q += qstride) {
             bool to_c = false;
             int e = 0;
             if (q < qn + q2n) {
-                e = q < qn ? scr.queue[q] : scr.queue2[q - qn];
+                e = q < qn ? queue_w[q] : queue2_w[q - qn];
                 const unsigned i = base + (unsigned)e;
                 Philox s = pg_substream(g0, i0 + (uint64_t)i, 1u);
                 const uint32_t st = scr.st[e], c0 = st >> 3, pos = st & 7u;
@@ -814,14 +864,15 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
             }
             push_retry(to_c, base + e);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        PG1_SYNC();
+        if (leader) {
             int zero = 0; // (formed here: as a loop invariant the compiler kept three zeroed registers alive over the whole iteration --
             asm volatile("" : "+v"(zero)); // and spilled them, the kernel's last 12 bytes of scratch)
-            scr.qn = zero, scr.q2n = zero, scr.qhead = zero;
+            qn_c = zero, q2n_c = zero, qhead_c = zero;
         }
-        __syncthreads();
+        PG1_SYNC();
     }
+#undef PG1_SYNC
 }
 
 // The points aux_sample_pg1_kernel left on its list: the sequential sampler from the start of the draw's sub-stream
