@@ -852,7 +852,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
         double *PXbuf = sm;                        // [2][256][FP]
         double *Wf = PXbuf + (size_t)2 * 256 * FP; // [32][FP]
         double *Rs = Wf + FB * FP;                 // [32][FP] P0
-        __shared__ unsigned pubcnt;                // helpers whose published rows have reached the fabric (monotonic)
+        __shared__ unsigned pubcnt;                // owner waves whose published rows have reached the fabric (monotonic)
         if (tid == 0) pubcnt = 0u;
         // ---- stage step 0: rows R >= 32: G[R][0:32] (T = I + G, off the diagonal block); rows R < 32: the identity block
         for (int idx = tid; idx < nrow * FB; idx += 1024) {
@@ -925,6 +925,20 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                                 if (c <= kb + m) A[(size_t)c * M + kb + m] = val; // final rows of U
                             }
                         }
+                if (pub) {
+                    // publish its own 32 rows at once (8 x (64 lanes x 16 bytes), write-through, re-read from LDS as pairs: the wave's
+                    // own LDS writes, in order).  Not waited for here: the stores drain beside the wait for P0 / the T workgroups and
+                    // the look-ahead; the signal goes out behind the look-ahead.  (Until round 5's last pass the HELPERS published,
+                    // behind the barrier below: `ready` then came 6.3 us behind it instead of 3, and through the T workgroups' first
+                    // pass that wait closed a 13.4 us cycle around this barrier; now F's 10.7 us chain is the longest.)
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    double *pubp = PXg + ((size_t)k * M + myR) * FB;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = 2 * (64 * q + ln); // element pair (row e >> 5, columns e & 31, + 1)
+                        st_sc1_x2(pubp + e, rows[(e >> 5) * FP + (e & 31)], rows[(e >> 5) * FP + (e & 31) + 1]);
+                    }
+                }
             }
             if (!owner && Mp > 0) {
                 // helpers, beside the panel: P0 of this step (F publishes it ~2 us behind W_k) into LDS -- every helper wave polls
@@ -987,20 +1001,20 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                             rowsN[i * FP + jj] = val;
                             if (crit_wave) st_sc1(T + (size_t)(myR + i) * M + ncx + jj, val);
                         }
-                if (crit_wave) AGPL_DRAIN(); // (its half of the hand-over; the flag goes behind the end-of-step barrier)
             } else if (owner && have) {
                 // rows ncx .. ncx + 31 held the first 32 rows of P: block (k + 1, k + 1) of the eliminated identity is the identity
                 for (int e = ln; e < FB * FB; e += 64) rowsN[(e >> 5) * FP + (e & 31)] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
-            } else if (!owner && have) {
-                // ---- helpers: publish the rows (8 x (64 lanes x 16 bytes), write-through), the diagonal tile, the signal
-                if (pub) {
-                    double *pubp = PXg + ((size_t)k * M + myR) * FB;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = 2 * (64 * q + ln); // element pair (row e >> 5, columns e & 31, + 1)
-                        st_sc1_x2(pubp + e, rows[(e >> 5) * FP + (e & 31)], rows[(e >> 5) * FP + (e & 31) + 1]);
-                    }
+            }
+            if (owner && have) {
+                // its published rows (and, for the wave of block k + 2, its half of the hand-over to F) have reached the fabric; the
+                // owner whose rows arrive last signals for the workgroup
+                AGPL_DRAIN();
+                if (pub && ln == 0) {
+                    const unsigned n = __hip_atomic_fetch_add(&pubcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+                    if (n == (unsigned)(nhelp * (k + 1))) __hip_atomic_store(&fl->ready[j], (unsigned)(k + 1), RLX_AGENT);
                 }
+            } else if (!owner && have) {
+                // ---- helpers: the diagonal tile of their rows
                 if (dgt) { // T[Rb,Rb] -= P_k[Rb] P_k[Rb]'; the tile of block k + 2 goes to F next step: write-through
                     d4 dg[2][2];
 #pragma unroll
@@ -1025,11 +1039,7 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
                                 }
                             }
                 }
-                AGPL_DRAIN(); // this helper's rows (and its diagonal tile) have reached the fabric
-                if (pub && ln == 0) { // the helper whose rows arrive last signals for the workgroup (no barrier on the owners' path)
-                    const unsigned n = __hip_atomic_fetch_add(&pubcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
-                    if (n == (unsigned)(nhelp * (k + 1))) __hip_atomic_store(&fl->ready[j], (unsigned)(k + 1), RLX_AGENT);
-                }
+                AGPL_DRAIN(); // its diagonal tile (the one of block k + 2: F's) has reached the fabric
             }
             __syncthreads(); // (Wf, Rs and image k & 1 are free again; both halves of the hand-over have drained)
             if (tid == 0 && Mp >= 2 * FB && ((ncx + FB) >> 8) == j) __hip_atomic_store(&fl->hand, (unsigned)(k + 1), RLX_AGENT);
