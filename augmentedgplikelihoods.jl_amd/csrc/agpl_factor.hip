@@ -595,6 +595,12 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 // Arithmetic: every element sees exactly factor_kernel's sequence of float64 MFMA accumulations and subtractions, in the same
 // order -- the results are bit for bit those of factor_kernel<1, false> (the rescue path and tests rely on it).
 // =====================================================================================================================
+// Measured as builds in round 5 and not shipped: (1) the T workgroups' second pass in batches of 2 / 4 tiles whose old values are in
+// flight together (to hide the ~1 us round trip per tile): at the 128-VGPR cap the compiler spills the loaded values (172 / 660
+// bytes of scratch) and reloads them one by one; (2) every owner wave of P polling the T workgroups' first passes itself and issuing
+// the look-ahead's old-value loads BEFORE the barrier behind the panel (its poll first waits for its own publish stores to drain):
+// same box, 100 updates each, 0.206-0.215 / 0.426-0.428 ms as shipped against 0.207-0.221 / 0.424-0.428 at M = 512 / 1024; (3) the same
+// with the loads in front of the publish stores (`ready` comes later: 0.226 / 0.437).
 typedef unsigned long long u64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
