@@ -441,6 +441,21 @@ def m1024_leg(A, ctx, args):
            "setup_s": round(t_setup, 2),
            "hbm_gb": {"plan": round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None,
                       "float32_features": round(Phi.numel() * 4 / 1e9, 2)}}
+    if not args.no_parity:
+        # the same full-size self-check as the headline's, at the north-star size (the accumulation runs 8192-point slices here:
+        # agpl_slice_points): g, tr G and four quadratic forms against float64 reductions over the exported gamma, beta, and the
+        # sampled marginals with the real q(v) of the timed sweeps
+        cavi.gamma = torch.empty((1, N), dtype=torch.float32, device="cuda")
+        cavi.beta = torch.empty((1, N), dtype=torch.float32, device="cuda")
+        cavi.c = torch.empty((N,), dtype=torch.float32, device="cuda")
+        cavi.accumulate()
+        torch.cuda.synchronize()
+        chk = full_size_quadratic_check(Phi, cavi.gamma, cavi.beta, cavi.G, cavi.g)
+        cavi.gamma = cavi.beta = cavi.c = None
+        mchk = full_size_marginal_check(cavi, Phi)
+        out["full_size_check"] = {"points": N, **chk, "marginals": mchk, "tolerance": {"G_g": 2e-6, "marginals": 2e-5},
+                                  "pass": bool(chk["max_rel_dg"] < 2e-6 and chk["rel_d_trace_G"] < 2e-6 and chk["max_rel_d_vGv"] < 2e-6
+                                               and chk["G_symmetric"] and mchk["max_rel_d_mu"] < 2e-5 and mchk["max_rel_d_var"] < 2e-5)}
     del cavi
     if not args.no_parity:
         out["parity"] = parity_slice(A, ctx, lik, "bernoulli", Phi, kd, y, "f16x2-factor", "f16x2", ns=10_000)
