@@ -53,6 +53,85 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// R_kk = chol(D) and W = R_kk^-1 of one 32 x 32 diagonal block, by the whole workgroup (1024 threads; called under uniform control
+// flow): sixteen steps over column PAIRS (c, c + 1), one barrier each.  Ds: the block (lower triangle + diagonal, pitch FP), Y: 32 x FP
+// of LDS for the identity being eliminated, Wf: W on return (row c final behind step c / 2).  Behind the previous step columns c, c + 1
+// of D and rows c, c + 1 of Y are final; every working thread rebuilds the two pivots and its own entries of R from D:
+//     R[r][c] = D[r][c] / sqrt(D[c][c]),  R[r][c+1] = (D[r][c+1] - R[r][c] R[c+1][c]) / R[c+1][c+1]
+//     D[r][cc] -= R[r][c] R[cc][c] + R[r][c+1] R[cc][c+1]                              (cc > c + 1)
+//     W[c][:] = Y[c][:] / R[c][c],  W[c+1][:] = (Y[c+1][:] - R[c+1][c] W[c][:]) / R[c+1][c+1]
+//     Y[r][:] -= R[r][c] W[c][:] + R[r][c+1] W[c+1][:]                                 (r > c + 1)
+// The reciprocal pivots are v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle sqrt + divide sequences, the
+// two of a step from independent chains (det = D[c][c] D[c+1][c+1] - D[c+1][c]^2: the second pivot is det / D[c][c]).  Four waves work
+// (one per SIMD): thread (rq, cc) keeps D and Y of rows rq, rq + 8, rq + 16, rq + 24 at column cc in registers.  Rounds 1-4 ran it on
+// eight waves (rows rq, rq + 16) on the reading that a step was bound by instruction issue -- most of a wave's instructions are the
+// two chains every wave repeats; with four waves a SIMD issues them once instead of twice and a block takes the SAME 8.2-8.3 us
+// (0.52 us per step, round-5 stamps): the step is bound by its dependent chain (barrier, LDS round trip, ~20 dependent float64
+// operations behind v_rsq_f64, LDS write), not by issue.  Every element sees the same formula in either form: results unchanged to the
+// bit.  Written branch-free (masks: a read inside a branch exposes its latency behind the chains); LDS only carries what other
+// threads need next (columns c + 2, c + 3 of D, rows c + 2, c + 3 of Y).  sink(c, p0, p1): thread 0, the two pivots of the step (log
+// det, first-bad-pivot bookkeeping of the caller).  One routine for factor_kernel and factor_pipe_kernel's F.
+template <class SINK>
+__device__ __forceinline__ void block_factor_32(int tk, double *__restrict__ Ds, double *__restrict__ Y, double *__restrict__ Wf,
+                                                SINK sink) {
+    const bool act = tk < 256;
+    const int cc = tk & 31, rq = (tk >> 5) & 7;
+    double d[4], y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        d[j] = Ds[(rq + 8 * j) * FP + cc];
+        y[j] = rq + 8 * j == cc ? 1.0 : 0.0;
+    }
+    Y[(tk >> 5) * FP + cc] = (tk >> 5) == cc ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < FB; c += 2) {
+        __syncthreads();
+        if (act) {
+            double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
+            double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1]; // D[cc][c], D[cc][c+1]
+            double ya = Y[c * FP + cc], yb = Y[(c + 1) * FP + cc];
+            double a0[4], a1[4]; // D[row][c], D[row][c+1] of the thread's four rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = Ds[(rq + 8 * j) * FP + c];
+                a1[j] = Ds[(rq + 8 * j) * FP + c + 1];
+            }
+            // (every read above is issued before the first use: the asm keeps them out of later branches)
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(ya), "+v"(yb), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(a0[2]),
+                         "+v"(a1[2]), "+v"(a0[3]), "+v"(a1[3]));
+            const double det = __builtin_fma(d11, p0, -(b10 * b10));
+            double r0 = __builtin_amdgcn_rsq(p0), rd = __builtin_amdgcn_rsq(det);
+            r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
+            rd = rd * (1.5 - 0.5 * det * rd * rd);
+            r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
+            rd = rd * (1.5 - 0.5 * det * rd * rd);
+            const double l10 = b10 * r0;          // R[c+1][c]
+            const double r1 = rd * (p0 * r0);     // 1 / R[c+1][c+1]
+            const double p1 = det * (r0 * r0);    // the second pivot
+            const double lc0 = x0 * r0;                   // R[cc][c]
+            const double lc1 = (x1 - lc0 * l10) * r1;     // R[cc][c+1]
+            const double w0 = ya * r0;                    // W[c][cc]
+            const double w1 = (yb - l10 * w0) * r1;       // W[c+1][cc]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = rq + 8 * j;
+                const double la0 = a0[j] * r0, la1 = (a1[j] - la0 * l10) * r1; // R[row][c], R[row][c+1]
+                // masks instead of branches (rows above the block being eliminated hold finite leftovers)
+                const double md = (cc > c + 1 && row >= cc) ? 1.0 : 0.0, my = row > c + 1 ? 1.0 : 0.0;
+                d[j] -= md * (la0 * lc0 + la1 * lc1);
+                y[j] -= my * (la0 * w0 + la1 * w1);
+                if (row == c) Wf[c * FP + cc] = w0;
+                if (row == c + 1) Wf[(c + 1) * FP + cc] = w1;
+                if (c + 2 < FB) {
+                    if (cc == c + 2 || cc == c + 3) Ds[row * FP + cc] = d[j];
+                    if (row == c + 2 || row == c + 3) Y[row * FP + cc] = y[j];
+                }
+            }
+            if (tk == 0) sink(c, p0, p1);
+        }
+    }
+}
+
 // 32 x 32 macro tile on the float64 matrix cores:  acc[ti][tj] += Uop[16 ti + i][:] . Vop[16 tj + j][:]  over the 32
 // columns of both LDS operands (row pitch FP).  v_mfma_f64_16x16x4_f64 (layout probed on gfx950, tools/scratch):
 // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
@@ -223,86 +302,14 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
             __syncthreads();
             }
             AGPL_TS(2);
-            // ---- R_kk = chol(D) and W = R_kk^-1 together, all 1024 threads as a 32 x 32 grid (r, cc), ONE barrier per
-            //      PAIR of columns (c, c + 1): columns c, c + 1 of the working block D and rows c, c + 1 of the
-            //      eliminated identity Y are final since the previous step, and this step only writes columns > c + 1
-            //      of D and rows > c + 1 of Y.  Every thread rebuilds the two pivots and its own entries of R from D:
-            //         R[r][c] = D[r][c] / sqrt(D[c][c]),  R[r][c+1] = (D[r][c+1] - R[r][c] R[c+1][c]) / R[c+1][c+1]
-            //         D[r][cc] -= R[r][c] R[cc][c] + R[r][c+1] R[cc][c+1]                              (cc > c + 1)
-            //         W[c][:] = Y[c][:] / R[c][c],  W[c+1][:] = (Y[c+1][:] - R[c+1][c] W[c][:]) / R[c+1][c+1]
-            //         Y[r][:] -= R[r][c] W[c][:] + R[r][c+1] W[c+1][:]                                 (r > c + 1)
-            //      The reciprocal pivots are v_rsq_f64 + two Newton steps (rounding-limited) instead of the ~400-cycle
-            //      sqrt + divide sequences, the two of a step from independent chains: these 16 dependent steps per
-            //      block are the serial spine of the factorisation.
-            //      A step is bound by instruction issue (about 120 instructions per wave, most of them the two
-            //      reciprocal-pivot chains every wave repeats; 4 waves per SIMD), so only waves 0..7 work here: thread
-            //      (rq, cc) keeps D and Y of rows rq and rq + 16 at column cc in registers, written branch-free (masks,
-            //      not branches: a read inside a branch exposes its latency after the chains).  LDS only carries what
-            //      other threads need next: columns c + 2, c + 3 of D and rows c + 2, c + 3 of Y.
-            {
-                const bool act = tk < 512;
-                const int cc = tk & 31, rq = (tk >> 5) & 15;
-                double *Y = Rs; // the identity being eliminated (R itself is only needed column by column, from D)
-                double d0 = Ds[rq * FP + cc], d1 = Ds[(rq + 16) * FP + cc];
-                double y0r = rq == cc ? 1.0 : 0.0, y1r = rq + 16 == cc ? 1.0 : 0.0;
-                Y[(tk >> 5) * FP + cc] = (tk >> 5) == cc ? 1.0 : 0.0;
-#pragma unroll
-                for (int c = 0; c < FB; c += 2) {
-                    __syncthreads();
-                    if (act) {
-                        double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
-                        double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];       // D[cc][c], D[cc][c+1]
-                        double ya = Y[c * FP + cc], yb = Y[(c + 1) * FP + cc];
-                        double a0 = Ds[rq * FP + c], a1 = Ds[rq * FP + c + 1];       // D[rq][c], D[rq][c+1]
-                        double e0 = Ds[(rq + 16) * FP + c], e1 = Ds[(rq + 16) * FP + c + 1];
-                        // (every read above is issued before the first use: the asm keeps them out of later branches)
-                        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(ya), "+v"(yb), "+v"(a0), "+v"(a1), "+v"(e0), "+v"(e1));
-                        // both reciprocal pivots from independent chains: with det = D[c][c] D[c+1][c+1] - D[c+1][c]^2,
-                        // the second pivot is det / D[c][c] and 1 / R[c+1][c+1] = rsqrt(det) sqrt(D[c][c])
-                        const double det = __builtin_fma(d11, p0, -(b10 * b10));
-                        double r0 = __builtin_amdgcn_rsq(p0), rd = __builtin_amdgcn_rsq(det);
-                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
-                        rd = rd * (1.5 - 0.5 * det * rd * rd);
-                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0); // 1 / R[c][c]
-                        rd = rd * (1.5 - 0.5 * det * rd * rd);
-                        const double l10 = b10 * r0;          // R[c+1][c]
-                        const double r1 = rd * (p0 * r0);     // 1 / R[c+1][c+1]
-                        const double p1 = det * (r0 * r0);    // the second pivot
-                        const double lc0 = x0 * r0;                   // R[cc][c]
-                        const double lc1 = (x1 - lc0 * l10) * r1;     // R[cc][c+1]
-                        const double w0 = ya * r0;                    // W[c][cc]
-                        const double w1 = (yb - l10 * w0) * r1;       // W[c+1][cc]
-                        const double la0 = a0 * r0, la1 = (a1 - la0 * l10) * r1; // R[rq][c], R[rq][c+1]
-                        const double le0 = e0 * r0, le1 = (e1 - le0 * l10) * r1; // R[rq+16][c], R[rq+16][c+1]
-                        // masks instead of branches (rows above the block being eliminated hold finite leftovers)
-                        const double md0 = (cc > c + 1 && rq >= cc) ? 1.0 : 0.0, md1 = (cc > c + 1 && rq + 16 >= cc) ? 1.0 : 0.0;
-                        const double my0 = rq > c + 1 ? 1.0 : 0.0, my1 = rq + 16 > c + 1 ? 1.0 : 0.0;
-                        d0 -= md0 * (la0 * lc0 + la1 * lc1);
-                        d1 -= md1 * (le0 * lc0 + le1 * lc1);
-                        y0r -= my0 * (la0 * w0 + la1 * w1);
-                        y1r -= my1 * (le0 * w0 + le1 * w1);
-                        if (rq == c) Wf[c * FP + cc] = w0;
-                        if (rq == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                        if (rq + 16 == c) Wf[c * FP + cc] = w0;
-                        if (rq + 16 == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                        if (c + 2 < FB) {
-                            if (cc == c + 2 || cc == c + 3) {
-                                Ds[rq * FP + cc] = d0;
-                                Ds[(rq + 16) * FP + cc] = d1;
-                            }
-                            if (rq == c + 2 || rq == c + 3) Y[rq * FP + cc] = y0r;
-                            if (rq + 16 == c + 2 || rq + 16 == c + 3) Y[(rq + 16) * FP + cc] = y1r;
-                        }
-                        if (tk == 0) {
-                            // the pivots go to the padding column of PX (log det at the end, off the serial path)
-                            PX[(size_t)(kb + c) * FP + FB] = p0;
-                            PX[(size_t)(kb + c + 1) * FP + FB] = p1;
-                            if (!(p0 > 0.0)) bad = kb + c + 1;
-                            else if (!(p1 > 0.0)) bad = kb + c + 2;
-                        }
-                    }
-                }
-            }
+            // ---- R_kk = chol(D) and W = R_kk^-1 together (block_factor_32: sixteen column-pair steps, the serial spine of the
+            //      factorisation).  The pivots go to the padding column of PX (log det at the end, off the serial path)
+            block_factor_32(tk, Ds, Rs, Wf, [&](int c, double p0, double p1) {
+                PX[(size_t)(kb + c) * FP + FB] = p0;
+                PX[(size_t)(kb + c + 1) * FP + FB] = p1;
+                if (!(p0 > 0.0)) bad = kb + c + 1;
+                else if (!(p1 > 0.0)) bad = kb + c + 2;
+            });
             __syncthreads();
             AGPL_TS(3);
             // ---- every row of PX times W':  P[i'][c] = sum_m Araw[i'][m] W[c][m]  (panel of R below the block) and
@@ -708,66 +715,13 @@ __global__ __launch_bounds__(1024, 1) void factor_pipe_kernel(int M, int NP, int
             asm volatile("" : "+v"(tk), "+v"(ln));
             const int kb = k * FB;
             AGPL_TS(0);
-            // ---- R_kk = chol(D), W = R_kk^-1: factor_kernel's sixteen column-pair steps, verbatim
-            {
-                const bool act = tk < 512;
-                const int cc = tk & 31, rq = (tk >> 5) & 15;
-                double *Y = Ys;
-                double d0 = Ds[rq * FP + cc], d1 = Ds[(rq + 16) * FP + cc];
-                double y0r = rq == cc ? 1.0 : 0.0, y1r = rq + 16 == cc ? 1.0 : 0.0;
-                Y[(tk >> 5) * FP + cc] = (tk >> 5) == cc ? 1.0 : 0.0;
-#pragma unroll
-                for (int c = 0; c < FB; c += 2) {
-                    __syncthreads();
-                    if (act) {
-                        double p0 = Ds[c * FP + c], b10 = Ds[(c + 1) * FP + c], d11 = Ds[(c + 1) * FP + c + 1];
-                        double x0 = Ds[cc * FP + c], x1 = Ds[cc * FP + c + 1];
-                        double ya = Y[c * FP + cc], yb = Y[(c + 1) * FP + cc];
-                        double a0 = Ds[rq * FP + c], a1 = Ds[rq * FP + c + 1];
-                        double e0 = Ds[(rq + 16) * FP + c], e1 = Ds[(rq + 16) * FP + c + 1];
-                        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(ya), "+v"(yb), "+v"(a0), "+v"(a1), "+v"(e0), "+v"(e1));
-                        const double det = __builtin_fma(d11, p0, -(b10 * b10));
-                        double r0 = __builtin_amdgcn_rsq(p0), rd = __builtin_amdgcn_rsq(det);
-                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
-                        rd = rd * (1.5 - 0.5 * det * rd * rd);
-                        r0 = r0 * (1.5 - 0.5 * p0 * r0 * r0);
-                        rd = rd * (1.5 - 0.5 * det * rd * rd);
-                        const double l10 = b10 * r0;
-                        const double r1 = rd * (p0 * r0);
-                        const double p1 = det * (r0 * r0);
-                        const double lc0 = x0 * r0;
-                        const double lc1 = (x1 - lc0 * l10) * r1;
-                        const double w0 = ya * r0;
-                        const double w1 = (yb - l10 * w0) * r1;
-                        const double la0 = a0 * r0, la1 = (a1 - la0 * l10) * r1;
-                        const double le0 = e0 * r0, le1 = (e1 - le0 * l10) * r1;
-                        const double md0 = (cc > c + 1 && rq >= cc) ? 1.0 : 0.0, md1 = (cc > c + 1 && rq + 16 >= cc) ? 1.0 : 0.0;
-                        const double my0 = rq > c + 1 ? 1.0 : 0.0, my1 = rq + 16 > c + 1 ? 1.0 : 0.0;
-                        d0 -= md0 * (la0 * lc0 + la1 * lc1);
-                        d1 -= md1 * (le0 * lc0 + le1 * lc1);
-                        y0r -= my0 * (la0 * w0 + la1 * w1);
-                        y1r -= my1 * (le0 * w0 + le1 * w1);
-                        if (rq == c) Wf[c * FP + cc] = w0;
-                        if (rq == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                        if (rq + 16 == c) Wf[c * FP + cc] = w0;
-                        if (rq + 16 == c + 1) Wf[(c + 1) * FP + cc] = w1;
-                        if (c + 2 < FB) {
-                            if (cc == c + 2 || cc == c + 3) {
-                                Ds[rq * FP + cc] = d0;
-                                Ds[(rq + 16) * FP + cc] = d1;
-                            }
-                            if (rq == c + 2 || rq == c + 3) Y[rq * FP + cc] = y0r;
-                            if (rq + 16 == c + 2 || rq + 16 == c + 3) Y[(rq + 16) * FP + cc] = y1r;
-                        }
-                        if (tk == 0) {
-                            piv[kb + c] = p0;
-                            piv[kb + c + 1] = p1;
-                            if (!(p0 > 0.0)) bad = bad ? bad : kb + c + 1;
-                            else if (!(p1 > 0.0)) bad = bad ? bad : kb + c + 2;
-                        }
-                    }
-                }
-            }
+            // ---- R_kk = chol(D), W = R_kk^-1: factor_kernel's sixteen column-pair steps (the same routine)
+            block_factor_32(tk, Ds, Ys, Wf, [&](int c, double p0, double p1) {
+                piv[kb + c] = p0;
+                piv[kb + c + 1] = p1;
+                if (!(p0 > 0.0)) bad = bad ? bad : kb + c + 1;
+                else if (!(p1 > 0.0)) bad = bad ? bad : kb + c + 2;
+            });
             __syncthreads();
             AGPL_TS(1);
             // ---- publish W_k (write-through); fetch what the next diagonal block needs
