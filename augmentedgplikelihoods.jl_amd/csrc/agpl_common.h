@@ -68,10 +68,14 @@ __host__ __device__ constexpr int agpl_chunk_points(int M) { return M <= 256 ? 8
 // would still have >= 32 workgroups per CU -- N = 1e7 at M = 1024: 2442 slices of 36 x 64 KB are 5.8 GB of slabs written and read
 // again per sweep (the reduction alone 0.98-1.05 ms); 1221 slices (47 workgroups per CU) halve that.  A function of (N, M, L) only:
 // results repeat.
+#ifndef AGPL_SLICE_MIN_WG
+#define AGPL_SLICE_MIN_WG 32 // workgroups per CU the launch must keep after a doubling.  (Measured with 8: C2 then runs 8192-point slices at 14
+                             // workgroups per CU -- the accumulation kernel loses 0.24-0.34 ms to its coarser tail, the reduction gains 0.14.)
+#endif
 inline int agpl_slice_points(int64_t N, int M, int L) {
     int chunk = agpl_chunk_points(M);
     const int64_t nb2 = (M + 255) / 256, pairs = nb2 * (nb2 + 1) / 2;
-    while (chunk < 16384 && (int64_t)L * pairs * ((N + 2 * chunk - 1) / (2 * chunk)) >= 32 * 256) chunk *= 2;
+    while (chunk < 16384 && (int64_t)L * pairs * ((N + 2 * chunk - 1) / (2 * chunk)) >= AGPL_SLICE_MIN_WG * 256) chunk *= 2;
     return chunk;
 }
 
