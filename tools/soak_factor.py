@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Soak of the one-launch factorisation (factor_pipe_kernel's inter-workgroup hand-offs): for every (M, L) a random G, the first result
+checked against its definition (U'U (I + G) = I, v = U (g + eta0), log det), then REPEATS more launches on the same input that must
+reproduce it bit for bit -- a lost or early hand-off shows as different bits long before it shows as a wrong answer.
+python3 tools/soak_factor.py [repeats]  -> one JSON line"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import agpl_amd as A  # noqa: E402
+
+REPEATS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+ctx = A.Context(0, seed=3)
+p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+out = {"repeats": REPEATS, "cases": {}}
+gen = torch.Generator(device="cuda").manual_seed(5)
+for M, L in ((128, 1), (256, 1), (256, 9), (384, 2), (512, 1), (512, 3), (512, 12), (640, 1), (768, 2), (896, 1), (1024, 1), (1024, 2), (1024, 5),
+             (1024, 8)):
+    B = torch.randn((L, M, 2 * M), dtype=torch.float64, device="cuda", generator=gen) / (2 * M) ** 0.5
+    G = (B @ B.transpose(1, 2) * 5.0).contiguous()
+    g = torch.randn((L, M), dtype=torch.float64, device="cuda", generator=gen)
+    Aw = torch.zeros((L, M, M), dtype=torch.float64, device="cuda")
+    v = torch.zeros((L, M), dtype=torch.float64, device="cuda")
+    ld = torch.zeros((L,), dtype=torch.float64, device="cuda")
+
+    def run():
+        ctx.call("agpl_gaussian_factor", C.c_int32(M), C.c_int32(L), p(G), p(g), C.c_void_p(0), p(Aw), p(v), p(ld))
+
+    run()
+    ctx.synchronize()
+    U = torch.tril(Aw.transpose(1, 2))  # U[a][b] = A[b * M + a], b <= a
+    eye = torch.eye(M, dtype=torch.float64, device="cuda")
+    res = float(((U.transpose(1, 2) @ U) @ (eye + G) - eye).abs().max().item())
+    dv = float((v - (U @ g.unsqueeze(2)).squeeze(2)).abs().max().item())
+    dl = float((ld - torch.linalg.slogdet(eye + G)[1]).abs().max().item())
+    ref = (Aw.clone(), v.clone(), ld.clone())
+    bad = 0
+    for i in range(REPEATS):
+        if i % 50 == 0:  # (dirty outputs: a launch that skipped work cannot hide behind the previous result)
+            Aw.zero_()
+            v.zero_()
+        run()
+        if i % 10 == 9 or i == REPEATS - 1:
+            ctx.synchronize()
+            if not (torch.equal(torch.tril(Aw.transpose(1, 2)), torch.tril(ref[0].transpose(1, 2))) and torch.equal(v, ref[1]) and torch.equal(ld, ref[2])):
+                bad += 1
+    out["cases"][f"M={M},L={L}"] = {"residual": res, "d_v": dv, "d_logdet": dl, "checks_differing": bad}
+out["pass"] = all(c["checks_differing"] == 0 and c["residual"] < 1e-9 and c["d_v"] < 1e-9 and c["d_logdet"] < 1e-8 for c in out["cases"].values())
+print(json.dumps(out))
