@@ -607,7 +607,8 @@ __global__ __launch_bounds__(1024, 1) void factor_kernel(int M, const double *__
 // bytes of scratch) and reloads them one by one; (2) every owner wave of P polling the T workgroups' first passes itself and issuing
 // the look-ahead's old-value loads BEFORE the barrier behind the panel (its poll first waits for its own publish stores to drain):
 // same box, 100 updates each, 0.206-0.215 / 0.426-0.428 ms as shipped against 0.207-0.221 / 0.424-0.428 at M = 512 / 1024; (3) the same
-// with the loads in front of the publish stores (`ready` comes later: 0.226 / 0.437).
+// with the loads in front of the publish stores (`ready` comes later: 0.226 / 0.437); (4) the hand-over flag stored by whichever of its
+// two waves drains last (a pair through one LDS word) instead of behind the workgroup's end-of-step barrier: 0.210 / 0.421, no change.
 typedef unsigned long long u64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
