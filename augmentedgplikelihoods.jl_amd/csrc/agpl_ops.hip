@@ -912,7 +912,10 @@ __global__ __launch_bounds__(kBlock) void aux_sample_pg1_retry_kernel(unsigned *
 
 // host side of the pair: kernel, then the retry kernel over its list.  Point indices on the list are 32-bit: launches of at most
 // 2^30 points (pointers and the stream offset advanced per launch).
-constexpr int64_t kPg1MaxLaunch = (int64_t)1 << 30;
+#ifndef AGPL_PG1_MAX_LAUNCH
+#define AGPL_PG1_MAX_LAUNCH ((int64_t)1 << 30)
+#endif
+constexpr int64_t kPg1MaxLaunch = AGPL_PG1_MAX_LAUNCH; // (a test build sets 5000: tests/test_gpu_regressions_r5.py)
 template <bool GIBBS>
 static void launch_pg1(agpl_ctx *ctx, int64_t n, const double *f, double *omega, uint32_t sweep, uint32_t *nuni_out,
                           uint32_t *nterms_out, double *fbuf, const float *kdiag, const float *mu0, const uint8_t *y, float *gamma,
