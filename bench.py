@@ -20,6 +20,11 @@ At N = 1 the same JSON line also carries (each skippable by a --no-... flag):
            BASELINE configs[3] (categorical K = 10, N = 1e6, M = 256): ms_per_step, roofline.kernels, ten-sweep parity, Gibbs
            sweep, projected_scaling_8 = full-N ms / per-rank ms (--no-extra skips them and the full-N CPU sweep).
 
+At N > 1 (default configuration, or --sharded-legs on) the ranks go on, after the sharded C2 headline, to BASELINE configs[2] itself
+("c3": NegBin r = 15, N sharded, M = 1024, ten CAVI sweeps + five sparse Gibbs sweeps, all-reduce time, per-rank min / max, ten-sweep
+parity on a slice) and to the Bernoulli M = 1024 north-star target ("m1024"), same timed-loop discipline.
+The LAST key of the line is "summary": every configuration's ms per step / sweeps/s / dominant-kernel frac / parity in <= 1.5 KB.
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 10000000] [--m 512] [--lik bernoulli]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -526,6 +531,141 @@ def c5_leg(A, args):
     return out
 
 
+def gather_over_ranks(mine, dt, group, device):
+    """What a multi-rank leg reports: every rank's record (all_gather_object) and the MAX over ranks of the timed region.
+    `device`: where the reduced scalar lives ("cuda" under RCCL, "cpu" under gloo).  Plain torch.distributed, no GPU needed
+    (tests/test_bench_launcher_cpu.py runs it with 2 and 8 gloo ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine, group=group)
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+    return per_rank, float(tt.item())
+
+
+def sharded_leg(A, ctx, likname, N, M, rank, world, group, barrier, steps=10, warmup=2, gibbs_steps=5, parity_points=5_000,
+                workload=None, label=None, red_device="cuda"):
+    """One more BASELINE configuration on the ranks of an N > 1 run: N points sharded with shard_range, one
+    all-reduce of L (M^2 + M) float64 per sweep -- CAVI `steps` sweeps after `warmup`, then `gibbs_steps` sparse Gibbs sweeps on the
+    same plan (global point index = this rank's offset), timed with the headline's barrier + MAX-over-ranks discipline; rank 0
+    adds a ten-sweep oracle parity slice of its own shard.  Every rank calls this; rank 0 gets the object, the others None.
+    `workload`: this rank's (Phi, kd) to reuse (the features depend on (seed, point index) only)."""
+    import torch
+
+    lik = make_lik(A, likname)
+    L = A.nlatent(lik)
+    i0, i1 = A.shard_range(N, rank, world)
+    n_loc = i1 - i0
+    t0 = time.time()
+    if workload is None:
+        y, Phi, kd = build_workload(A, ctx, lik, i0, n_loc, M)
+    else:
+        Phi, kd = workload
+        _, y = A.synth_xy(lik, SEED, i0, n_loc, ctx=ctx, want_x=False)
+    Mp = Phi.shape[1]
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx, group=group)
+    t_setup = time.time() - t0
+    dt, kt = timed_sweeps(ctx, cavi, steps, warmup, barrier)
+    xms = getattr(cavi, "exchange_ms", (0.0, 0.0))
+    mine = {"rank": rank, "points": n_loc, "ms_per_step": round(dt / steps * 1e3, 3), "allreduce_ms_avg": round(xms[0], 4),
+            "allreduce_ms_max": round(xms[1], 4), "marginal_kernel_ms": round(kt[0][0] / max(kt[0][1], 1), 4),
+            "accumulate_kernel_ms": round(kt[1][0] / max(kt[1][1], 1), 4), "setup_s": round(t_setup, 2)}
+    per_rank, dt = gather_over_ranks(mine, dt, group, red_device)
+    gibbs_ms = None
+    if gibbs_steps > 0:
+        yg = y.to(torch.float64) if lik.ykind == "real" else y
+        gib = A.SparseGibbs(lik, Phi, kd, yg, ctx=ctx, group=group, plan=cavi.plan, point_offset=i0)
+        gib.sweep()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(gibbs_steps):
+            gib.sweep()
+        barrier()
+        _, tg = gather_over_ranks(None, time.perf_counter() - tg, group, red_device)
+        gibbs_ms = round(tg / gibbs_steps * 1e3, 3)
+        del gib
+    del cavi
+    parity = None
+    if rank == 0 and parity_points > 0:
+        parity = parity_slice(A, ctx, lik, likname, Phi, kd, y, "f16x2-factor", "f16x2", ns=parity_points)
+    barrier()
+    if rank != 0:
+        return None, (Phi, kd)
+    ms = dt / steps * 1e3
+    steps_ms = [r["ms_per_step"] for r in per_rank]
+    out = {"config": {"workload": label or f"{likname} SVGP CAVI sweep, N={N}, M={M} (padded {Mp}), L={L}, N sharded over {world} ranks, "
+                                           f"1 all-reduce of L*(M^2+M) f64 per sweep", "N": N, "M": M, "L": L,
+                      "parallelism": f"N-shard x{world}"},
+           "value": round(steps / dt, 4), "unit": "sweeps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "world": world, "n_gpus": world,
+           "allreduce_ms": round(sum(r["allreduce_ms_avg"] for r in per_rank) / world, 4), "allreduce_bytes": 8 * L * (Mp * Mp + Mp),
+           "ms_per_step_min_rank": min(steps_ms), "ms_per_step_max_rank": max(steps_ms), "per_rank": per_rank,
+           "roofline": roofline_of(kt, L, n_loc, M, Mp, "f16x2-factor", "f16x2", ms, world, N)}
+    if gibbs_ms is not None:
+        out["gibbs_ms_per_sweep"] = gibbs_ms
+        out["gibbs_steps"] = gibbs_steps
+    if parity is not None:
+        out["parity"] = parity
+    return out, (Phi, kd)
+
+
+def summarize(out):
+    """The LAST key of the line, <= 1.5 KB: every configuration's driver-timed number in one compact object (the driver's record
+    keeps the headline object and only the last ~2 KB of the line -- VERDICT r5 item 2).  Per leg: ms = ms per step (sweep),
+    sps = sweeps/s, frac = the dominant kernel's algorithmic fraction of the guide's peak, k = [marginal, accumulation] kernel ms,
+    par = max relative error of (G, g) after ten sweeps against the oracle, gibbs_ms = ms per sparse Gibbs sweep,
+    proj8 = projected 8-GPU scaling (full-N ms / per-rank ms, before the all-reduce), ar_ms = all-reduce ms per sweep (N > 1)."""
+    def r3(x):
+        return None if x is None else float(f"{x:.3g}")
+
+    def leg(o):
+        if not isinstance(o, dict):
+            return None
+        if "error" in o:
+            return {"error": str(o["error"])[:60]}
+        if "ms_per_step" not in o:
+            return None
+        rf = o.get("roofline") or {}
+        s = {"ms": o["ms_per_step"], "sps": r3(o.get("value")), "frac": rf.get("frac")}
+        ks = rf.get("kernels")
+        if ks:
+            s["k"] = [round(k["avg_ms"], 2) for k in ks]
+        p = o.get("parity")
+        if p:
+            s["par"] = r3(max(p["max_rel_dG"], p["max_rel_dg"]))
+        if "gibbs_ms_per_sweep" in o:
+            s["gibbs_ms"] = o["gibbs_ms_per_sweep"]
+        if o.get("projected_scaling_8") is not None:
+            s["proj8"] = o["projected_scaling_8"]
+        if "allreduce_ms" in o:
+            s["ar_ms"] = o["allreduce_ms"]
+            s["ranks"] = o.get("world", o.get("n_gpus"))
+        return s
+
+    sm = {"c2": leg(out)}
+    for name in ("m1024", "n8", "n8_m1024", "c3r", "c3", "c4", "c5", "f32_contract"):
+        if name in out:
+            sm[name] = leg(out[name])
+    c3f = out.get("m1024", {}).get("c3_full_one_gpu") if isinstance(out.get("m1024"), dict) else None
+    if c3f is not None:
+        sm["c3_full_one_gpu"] = leg(c3f)
+    g = out.get("gibbs")
+    if isinstance(g, dict):
+        sm["gibbs"] = {"ms": g.get("ms_per_sweep"), "pg1_per_s": r3((g.get("sampler") or {}).get("pg1_draws_per_s")),
+                       "pg1_per_s_negbin": r3((g.get("sampler_negbin") or {}).get("pg1_draws_per_s"))}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        sm["cpu"] = {"sps": r3(cb.get("value")), "cores": cb.get("cores"), "gpu_over_cpu": cb.get("gpu_over_cpu")}
+    fs = out.get("full_size_check")
+    if isinstance(fs, dict):
+        sm["full_size_pass"] = fs.get("pass")
+    sm["n_gpus"] = out.get("n_gpus")
+    return {k: v for k, v in sm.items() if v is not None}
+
+
 def visible_gpu_count():
     """GPUs visible to a rank, counted WITHOUT loading a HIP runtime into this process: the launching parent goes on to
     start torch.distributed.run, and a process that has initialised the GPU must not start (exec) other programs on this
@@ -599,6 +739,10 @@ def main():
     ap.add_argument("--cpu-full", dest="cpu_full", action="store_true", default=None,
                     help="time ONE full-N sweep of the CPU twin (default: on for the default configuration)")
     ap.add_argument("--c5-n", type=int, default=65_536)
+    ap.add_argument("--sharded-legs", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1 runs: BASELINE C3 (NegBin r=15, M=1024, CAVI + Gibbs) and the Bernoulli M=1024 north-star target on the "
+                         "same ranks after the headline (auto: on for the default configuration)")
+    ap.add_argument("--sharded-m", type=int, default=1024, help="inducing points of the sharded legs")
     ap.add_argument("--accumulate", default="f16x2", choices=["f32", "f16x2"],
                     help="K_ZX diag(gamma) K_XZ accumulation: f32-input MFMA, or split-float16 MFMA")
     ap.add_argument("--marginal", default="auto", choices=["auto", "f32", "f16x2-factor"],
@@ -694,6 +838,8 @@ def main():
     torch.cuda.reset_peak_memory_stats()
     dt, kt = timed_sweeps(ctx, cavi, args.steps, args.warmup, barrier)
     hbm_sweep_gb = round(torch.cuda.max_memory_allocated() / 1e9, 1)
+    plan_gb = round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None
+    feat_gb = round(Phi.numel() * 4 / 1e9, 2)
     if world > 1:
         import torch.distributed as dist
 
@@ -704,16 +850,35 @@ def main():
                 "allreduce_ms_avg": round(cavi.exchange_ms[0], 4), "allreduce_ms_max": round(cavi.exchange_ms[1], 4),
                 "marginal_kernel_ms": round(kt[0][0] / max(kt[0][1], 1), 4),
                 "accumulate_kernel_ms": round(kt[1][0] / max(kt[1][1], 1), 4)}
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        per_rank, dt = gather_over_ranks(mine, dt, group, "cuda")
+        dist.barrier()
+        # BASELINE configs[2] itself (C3: NegBin r = 15, N sharded, M = 1024, CAVI + Gibbs) and the north-star target (Bernoulli,
+        # M = 1024) on the same ranks, so that a scaling run speaks to the configuration north_star shards -- every rank takes part,
+        # rank 0 keeps the objects.  Budget at 8 ranks (N = 1e7): two workload builds of 1.25e6 x 1024 (~1 s each), 2 x 12 CAVI
+        # sweeps of ~6 ms, 6 Gibbs sweeps, two 5000-point parity slices on rank 0 (~10-20 s each): well under 120 s.
+        sharded = {}
+        want_sharded = args.sharded_legs == "on" or (args.sharded_legs == "auto" and default_config and not args.no_extra)
+        if want_sharded:
+            del cavi, y, Phi, kd
+            gc.collect()
+            torch.cuda.empty_cache()
+            Ms = args.sharded_m
+            pp = 0 if args.no_parity else min(5_000, max(1, N // world))
+            c3o, wl = sharded_leg(A, ctx, "negbin", N, Ms, rank, world, group, barrier, steps=10, warmup=2, gibbs_steps=5,
+                                  parity_points=pp,
+                                  label=f"C3: NegBin(r=15) SVGP CAVI sweep, N={N}, M={Ms}, L=1, N sharded over {world} ranks, "
+                                        f"1 all-reduce of L*(M^2+M) f64 per sweep (+ 5 sparse Gibbs sweeps on the same plan)")
+            m1o, _ = sharded_leg(A, ctx, "bernoulli", N, Ms, rank, world, group, barrier, steps=10, warmup=2, gibbs_steps=0,
+                                 parity_points=pp, workload=wl,
+                                 label=f"north-star target: bernoulli-logistic SVGP CAVI sweep, N={N}, M={Ms}, L=1, N sharded over "
+                                       f"{world} ranks, 1 all-reduce of L*(M^2+M) f64 per sweep")
+            del wl
+            sharded = {"c3": c3o, "m1024": m1o}
         dist.barrier()
         dist.destroy_process_group()
         if rank != 0:
             return
-        # the single-GPU extra legs (Gibbs, parity slice, CPU baseline, M = 1024, C5) are reported at N = 1 only
+        # the single-GPU extra legs (Gibbs, parity slice, CPU baseline, C5) are reported at N = 1 only
         args.no_gibbs = args.no_cpu = args.no_parity = args.no_m1024 = args.no_c5 = args.no_f32 = args.no_elbo = args.no_extra = True
 
     ms_per_step = dt / args.steps * 1e3
@@ -737,8 +902,8 @@ def main():
                    "N": N, "M": M, "L": L, "parallelism": f"N-shard x{world}", "marginal_pass": args.marginal, "accumulate_pass": args.accumulate},
         "roofline": roofline, "setup_s": round(t_setup, 2),
         "hbm_gb": {"timed_sweeps_high_water": hbm_sweep_gb,
-                   "plan": round(cavi.plan.nbytes / 1e9, 2) if getattr(cavi, "plan", None) is not None else None,
-                   "float32_features": round(Phi.numel() * 4 / 1e9, 2),
+                   "plan": plan_gb,
+                   "float32_features": feat_gb,
                    "note": "the plan (both split-float16 images + q(v)) is all that CAVI and Gibbs sweeps read; the float32 features "
                            "stay resident here only because the parity, float32-contract and CPU-baseline legs of this run use them"},
     }
@@ -750,6 +915,11 @@ def main():
         out["per_rank"] = per_rank
         out["per_rank_kernels"] = [{"rank": r["rank"], "marginal_kernel_ms": r["marginal_kernel_ms"],
                                     "accumulate_kernel_ms": r["accumulate_kernel_ms"]} for r in per_rank]
+        for k_, v_ in sharded.items():
+            if v_ is not None:
+                out[k_] = v_
+        out["scaling_curve_note"] = ("this line is ONE point of a scaling curve; efficiency is the driver's to compute from its own "
+                                     "N = 1, 2, 4, 8 runs")
 
     # ---- Gibbs half on the same resident workload (extra legs, not the headline value) ------------------------
     if not args.no_gibbs:
@@ -1010,6 +1180,7 @@ def main():
             except Exception as e:
                 out["c5"] = {"error": f"{type(e).__name__}: {e}"}
         out["extra_legs_s"] = round(time.time() - t_legs, 1)
+    out["summary"] = summarize(out)  # LAST key: the driver's record keeps the tail of the line
     print(json.dumps(out), flush=True)
 
 

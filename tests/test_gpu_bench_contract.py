@@ -58,6 +58,12 @@ def test_bench_line_single_gpu_small_workload():
     # aug_elbo riding the sweep: the last values do not decrease
     assert d["elbo"]["non_decreasing"] and len(d["elbo"]["elbo_entering_last_sweeps"]) == 3
     assert d["hbm_gb"]["plan"] > 0
+    # the compact summary is the LAST key of the line (the driver's record keeps the tail) and repeats the headline
+    assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) <= 1536
+    sm = d["summary"]
+    assert sm["c2"]["ms"] == d["ms_per_step"] and sm["c2"]["frac"] == rf["frac"] and sm["c2"]["par"] < 1e-5
+    assert sm["f32_contract"]["ms"] == f32["ms_per_step"] and sm["gibbs"]["ms"] == d["gibbs"]["ms_per_sweep"]
+    assert sm["cpu"]["cores"] == cb["cores"] and sm["full_size_pass"] is True
 
 
 @pytest.mark.timeout(600)
@@ -67,12 +73,25 @@ def test_bench_line_two_ranks_through_the_driver_launcher():
     env = dict(os.environ, AGPL_BENCH_SINGLE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29617", "bench.py", "--gpus", "2",
-                        "--points", "300000", "--inducing", "256", "--steps", "3", "--warmup", "1"],
+                        "--points", "300000", "--inducing", "256", "--steps", "3", "--warmup", "1", "--sharded-legs", "on"],
                        cwd=ROOT, capture_output=True, text=True, timeout=550, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # BASELINE C3 itself (NegBin r = 15, M = 1024, CAVI + Gibbs) and the Bernoulli M = 1024 north-star target on the same two ranks
+    for name, lik in (("c3", "NegBin"), ("m1024", "bernoulli")):
+        o = d[name]
+        assert o["world"] == 2 and o["config"]["M"] == 1024 and o["config"]["N"] == 300000 and lik in o["config"]["workload"]
+        assert o["ms_per_step"] > 0 and o["allreduce_ms"] > 0 and o["allreduce_bytes"] == 8 * (1024 * 1024 + 1024)
+        assert len(o["per_rank"]) == 2 and all(r["points"] == 150000 for r in o["per_rank"])
+        assert o["ms_per_step_min_rank"] <= o["ms_per_step_max_rank"] <= o["ms_per_step"] * 1.001
+        assert o["parity"]["pass"] and o["parity"]["sweeps"] == 10
+    assert d["c3"]["gibbs_ms_per_sweep"] > 0 and "gibbs_ms_per_sweep" not in d["m1024"]
+    assert list(d)[-1] == "summary"
+    sm = d["summary"]
+    assert sm["n_gpus"] == 2 and sm["c3"]["ranks"] == 2 and sm["c3"]["ms"] == d["c3"]["ms_per_step"]
+    assert sm["m1024"]["ar_ms"] == d["m1024"]["allreduce_ms"] and sm["c3"]["gibbs_ms"] == d["c3"]["gibbs_ms_per_sweep"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
     # the diagnosis a scaling run needs: the exchange step as the stream saw it, and every rank's own numbers
     assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] == 8 * (256 * 256 + 256)
