@@ -1258,6 +1258,20 @@ size_t agpl_factor_coop_bytes(int32_t M, int32_t L) {
 int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work) {
+    if (M > 512 && L > 8) {
+        // Beyond M = 512 a latent's pipeline is 21-37 workgroups spread over the chip: eight latents at a time (round 6; rounds 4-5
+        // sent L > 8 to two block rows around four library GEMMs).  Every array is indexed by the latent inside the launch, the flag
+        // words are zero again behind each clean-up launch, and the launches are in stream order: the batches share coop_work.
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            const int lb = L - l0 < 8 ? L - l0 : 8;
+            const size_t mm = (size_t)l0 * M * M, mv = (size_t)l0 * M;
+            const int32_t rc = agpl_factor_fused(ctx, M, lb, G + mm, g + mv, eta0 ? eta0 + mv : nullptr, T_work + mm, A_work + mm,
+                                                 v_out ? v_out + mv : nullptr, v32_out ? v32_out + mv : nullptr,
+                                                 logdet_out ? logdet_out + l0 : nullptr, info_dev + l0, coop_work);
+            if (rc) return rc;
+        }
+        return AGPL_OK;
+    }
     const size_t lds = sizeof(double) * ((size_t)(M < 512 ? M : 512) * FP + 3 * FB * FP);
     // hand-off flags: fixed words of the small workspace (8 per latent) that are zero between launches (agpl_ws2_reserve; the
     // clean-up launch behind every cooperative launch zeroes them again)

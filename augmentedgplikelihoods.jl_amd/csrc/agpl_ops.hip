@@ -166,12 +166,12 @@ __device__ __forceinline__ bool pg_trial_passes(Philox &s, double &E) {
     return !(E * E > (2.0 * Ep / kPgT));
 }
 
-// sub-stream of draw `sub` of point `index`
-__device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, uint32_t sub) {
+// sub-stream of PG(1, c) draw j of point `index`, sub_base = 1 + (latent << 16) (agpl_random.h: pg_draw_id / pg_draw_block0)
+__device__ __forceinline__ Philox pg_substream(const Philox &g, uint64_t index, uint32_t sub_base, uint32_t j = 0u) {
     Philox s = g;
-    s.c0 = 0;
+    s.c0 = pg_draw_block0(j);
     s.c2 = (uint32_t)index;
-    s.c3 = (uint32_t)(index >> 32) + (sub << 8);
+    s.c3 = (uint32_t)(index >> 32) + ((sub_base + pg_draw_id(j)) << 8);
     s.pos = 4;
     s.nuni = 0;
     return s;
@@ -270,7 +270,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                     else hi = mid - 1;
                 }
                 scr->owner[wave][t - cb] = (unsigned char)lo;
-                Philox s = pg_substream(g, scr->index0[wave] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(t - scr->off[wave][lo]));
+                Philox s = pg_substream(g, scr->index0[wave] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(t - scr->off[wave][lo]));
                 const double u = s.u01();
                 const double z = PG_OWNER_Z(wave, lo);
                 double K, rlo, rhi;
@@ -329,23 +329,38 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         {
             int e = -1, w = 0, slot = 0;
             double z = 0.0;
+            uint32_t c0first = 0u;
             Philox s = g;
-            auto fetch = [&]() {
-                const int idx = atomicAdd(&PG_CNT(qhead), 1);
-                e = -1;
-                if (idx < qn) {
-                    e = PG_Q(queue)[idx];
-                    w = e >> 8, slot = e & 255;
-                    const int lo = scr->owner[w][slot];
-                    s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
-                    // the branch uniform (drawn in phase A) and the first `while (alpha < rand())` (alpha = 0: always entered, u is in the
-                    // open interval) are block 0 of the sub-stream: passed over without its ten rounds
-                    s.skip_first_block();
-                    z = PG_OWNER_Z(w, lo);
+            // the lanes that need a new entry take them with ONE returning LDS atomic per wave and iteration (round 6: every lane adding
+            // 1 to the same word was a 64-way serialised atomic at the start of the loop and a several-way one in every iteration --
+            // SQ_LDS_BANK_CONFLICT ~ 50 % of the LDS-active cycles of the sampler kernels, profiles/r05_pmc_sq2_c2.json); which lane
+            // runs which entry does not matter (a draw's value is a function of its own sub-stream).  Called by the whole wave.
+            auto fetch = [&](bool need) {
+                const unsigned long long mneed = __ballot(need);
+                if (mneed) { // (wave-uniform)
+                    const int first = __ffsll((long long)mneed) - 1;
+                    int idx = 0;
+                    if (lane == first) idx = atomicAdd(&PG_CNT(qhead), __popcll(mneed));
+                    idx = __shfl(idx, first) + __popcll(mneed & ((1ull << lane) - 1ull));
+                    if (need) {
+                        e = -1;
+                        if (idx < qn) {
+                            e = PG_Q(queue)[idx];
+                            w = e >> 8, slot = e & 255;
+                            const int lo = scr->owner[w][slot];
+                            s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
+                            // the branch uniform (drawn in phase A) and the first `while (alpha < rand())` (alpha = 0: always entered, u is
+                            // in the open interval) are block 0 of the sub-stream: passed over without its ten rounds
+                            c0first = s.c0;
+                            s.skip_first_block();
+                            z = PG_OWNER_Z(w, lo);
+                        }
+                    }
                 }
             };
-            fetch();
+            fetch(true);
             while (__ballot(e >= 0)) {
+                bool need = false;
                 if (e >= 0) {
                     double E;
                     if (pg_trial_passes(s, E)) { // E, E' ~ Exp(1) with E^2 <= 2 E' / t (polyagamma.jl:200-204)
@@ -354,11 +369,12 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                         const double ua = s.u01();
                         if (!pg_alpha_below(z * z * x / 2.0, ua)) { // `alpha < u` with alpha = exp(-z^2 x / 2) is false: accepted
                             scr->draws[w][slot] = x;
-                            PG_ST(e) = (s.c0 << 3) | (uint32_t)s.pos;
-                            fetch();
+                            PG_ST(e) = ((s.c0 - c0first) << 3) | (uint32_t)s.pos; // (blocks since the draw's first one)
+                            need = true;
                         }
                     }
                 }
+                fetch(need);
             }
         }
         // the mu <= t branch (|c| >= 3.125: Michael-Schucany-Haas proposals until x <= t) is rare: whole passes of the loop as is
@@ -366,10 +382,11 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             for (int q = PG_QFIRST; q < q2n; q += PG_QSTRIDE) {
                 const int e = PG_Q(queue2)[q];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
+                const uint32_t c0first = s.c0;
                 (void)s.u01();
                 scr->draws[w][slot] = rand_tig(s, PG_OWNER_Z(w, lo));
-                PG_ST(e) = (s.c0 << 3) | (uint32_t)s.pos;
+                PG_ST(e) = ((s.c0 - c0first) << 3) | (uint32_t)s.pos;
             }
         }
         PGT_MARK(4);
@@ -382,13 +399,13 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             if (q < qn + q2n) {
                 e = q < qn ? PG_Q(queue)[q] : PG_Q(queue2)[q - qn];
                 const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
-                const uint32_t st = PG_ST(e), c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it
+                Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
+                const uint32_t st = PG_ST(e), c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it (blocks since its first)
                 if (pos < 4u) {
-                    s.c0 = c0 - 1u;
+                    s.c0 += c0 - 1u;
                     s.refill();
                 } else
-                    s.c0 = c0;
+                    s.c0 += c0;
                 s.pos = (int)pos;
                 s.nuni = 2u * c0 - (4u - pos) / 2u; // (every uniform takes two of the four words of a block)
                 const double x = scr->draws[w][slot];
@@ -417,7 +434,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         for (int q = PG_QFIRST; q < rn; q += PG_QSTRIDE) {
             const int e = PG_Q(retry)[q];
             const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
-            Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo) + (uint32_t)(cb + slot - scr->off[w][lo]));
+            Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
             Pg1Params p;
             p.set(2.0 * PG_OWNER_Z(w, lo)); // (z = |c| / 2 exactly)
             uint32_t nt = 0;
@@ -458,10 +475,10 @@ __device__ __forceinline__ void pg_points_wave(PgBlockScratch *scr, int lane, bo
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const bool on = valid && j < nk;
-        // b >= 65535 would leave the sub-stream id space (agpl_random.h: 16-bit draw index): flagged (bit 1), reported by the
+        // b >= kPgMaxB = 2^22 is outside the numbering of a point's draws (agpl_random.h): flagged (bit 1), reported by the
         // host as AGPL_ERR_UNSUPPORTED instead of a silent NaN
-        if (on && b[j] >= 65535.0) atomicOr(bad, 2);
-        ok[j] = on && (b[j] >= 0.0) && (fabs(c[j]) < __builtin_inf()) && (b[j] < 65535.0);
+        if (on && b[j] >= kPgMaxB) atomicOr(bad, 2);
+        ok[j] = on && (b[j] >= 0.0) && (fabs(c[j]) < __builtin_inf()) && (b[j] < kPgMaxB);
         tb[j] = ok[j] ? (int)floor(b[j]) : 0;
     }
     pg_int_sum_block<NB>(scr, wave, lane, g, latent0, tb, c, w, g.nuni, nterms);
@@ -801,19 +818,28 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
             int e = -1;
             double z = 0.0;
             Philox s = g0;
-            auto fetch = [&]() {
-                const int idx = atomicAdd(&qhead_c, 1);
-                e = -1;
-                if (idx < qn) {
-                    e = queue_w[idx];
-                    const unsigned i = base + (unsigned)e;
-                    s = pg_substream(g0, i0 + (uint64_t)i, 1u);
-                    s.skip_first_block(); // (the branch uniform and the always-entered first `alpha < rand()`: see pg_int_sum_block)
-                    z = fabs(f[i]) / 2.0; // (Pg1Params::set)
+            auto fetch = [&](bool need) { // ONE returning LDS atomic per wave and iteration (see pg_int_sum_block); whole wave calls
+                const unsigned long long mneed = __ballot(need);
+                if (mneed) {
+                    const int first = __ffsll((long long)mneed) - 1;
+                    int idx = 0;
+                    if (lane == first) idx = atomicAdd(&qhead_c, __popcll(mneed));
+                    idx = __shfl(idx, first) + __popcll(mneed & ((1ull << lane) - 1ull));
+                    if (need) {
+                        e = -1;
+                        if (idx < qn) {
+                            e = queue_w[idx];
+                            const unsigned i = base + (unsigned)e;
+                            s = pg_substream(g0, i0 + (uint64_t)i, 1u);
+                            s.skip_first_block(); // (the branch uniform and the always-entered first `alpha < rand()`: see pg_int_sum_block)
+                            z = fabs(f[i]) / 2.0; // (Pg1Params::set)
+                        }
+                    }
                 }
             };
-            fetch();
+            fetch(true);
             while (__ballot(e >= 0)) {
+                bool need = false;
                 if (e >= 0) {
                     const double E = s.exp1();
                     const double Ep = s.exp1();
@@ -824,10 +850,11 @@ __global__ __launch_bounds__(kBlock, 4) void aux_sample_pg1_kernel(const unsigne
                         if (!pg_alpha_below(z * z * x / 2.0, ua)) { // `alpha < u` with alpha = exp(-z^2 x / 2) is false: accepted
                             scr.x[e] = x;
                             scr.st[e] = (s.c0 << 3) | (uint32_t)s.pos;
-                            fetch();
+                            need = true;
                         }
                     }
                 }
+                fetch(need);
             }
         }
         if (q2n) {
@@ -1545,7 +1572,7 @@ int32_t run_reduction(agpl_ctx *ctx, int mode, const agpl_lik_desc *lik, int64_t
 // C ABI
 // ================================================================================================
 // the sampler kernels' flag word: bit 0 = invalid NegativeMultinomial parameters, bit 1 = a PolyaGamma(b, c) draw with
-// b >= 65535 (outside the sub-stream id space).  Read (one stream synchronisation) for the likelihoods that can set it.
+// b >= 2^22 (agpl_random.h kPgMaxB: outside the numbering of a point's draws).  Read (one stream synchronisation) for the likelihoods that can set it.
 int32_t agpl_sampler_outcome(agpl_ctx *ctx, int32_t kind, const int *bad) {
     if (kind != AGPL_LIK_CATEGORICAL && kind != AGPL_LIK_CATEGORICAL_BIJ && kind != AGPL_LIK_NEGBINOMIAL &&
         kind != AGPL_LIK_POISSON && kind != AGPL_LIK_HETEROGAUSS)
@@ -1559,8 +1586,8 @@ int32_t agpl_sampler_outcome(agpl_ctx *ctx, int32_t kind, const int *bad) {
                   "(negativemultinomial.jl:17-22)");
     if (hbad & 2)
         AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED,
-                  "PolyaGamma(b, c) with b >= 65535 (y + r, or y + n): this build numbers the PG(1, c) draws of a point "
-                  "with 16 bits; the outputs of that point are NaN");
+                  "PolyaGamma(b, c) with b >= 4194304 = 2^22 (y + r, or y + n): outside this build's numbering of the PG(1, c) "
+                  "draws of a point; the outputs of that point are NaN");
     return AGPL_OK;
 }
 
@@ -1620,9 +1647,9 @@ extern "C" int32_t agpl_rand_polyagamma(agpl_ctx *ctx, double b, double c, int64
                                         double *out, uint32_t *nuni_out, uint32_t *nterms_out) {
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (n < 0 || !(b >= 0.0)) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "need n >= 0 and b >= 0");
-    if (b >= 65535.0)
-        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "PolyaGamma(b, c) with b >= 65535: this build numbers the PG(1, c) draws of a "
-                                            "point with 16 bits (b = %g)", b);
+    if (b >= kPgMaxB)
+        AGPL_FAIL(ctx, AGPL_ERR_UNSUPPORTED, "PolyaGamma(b, c) with b >= 4194304 = 2^22: outside this build's numbering of the "
+                                            "PG(1, c) draws of a point (b = %g)", b);
     if (n == 0) return AGPL_OK;
     if (!out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null out");
     rand_pg_kernel<<<grid_for(n), kBlock, 0, ctx->stream>>>(b, c, n, ctx->seed, sweep, out, nuni_out, nterms_out);

@@ -21,9 +21,9 @@
 int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float limit, const char *what,
                                  unsigned *max_bits_out);                                                       // agpl_syrk.hip
 int32_t agpl_image_scale_exp(agpl_ctx *ctx, unsigned hmx, int *eA_out);                                         // agpl_syrk.hip
-int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, int eA, unsigned hmx,
+int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, int32_t Msrc, const float *Phi, int eA, unsigned hmx,
                                     void *image_out);                                                           // agpl_syrk.hip
-int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float scale, void *Phi_hi,
+int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, int32_t Msrc, const float *Phi, float scale, void *Phi_hi,
                                   void *Phi_lo);                                                                // agpl_split.hip
 int32_t agpl_marginals_factor_internal(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const void *Phi_hi, const void *Phi_lo,
                                        const float *resid, const float *mu0, const void *U_hi, const void *U_lo, const float *v,
@@ -43,10 +43,20 @@ int32_t agpl_gibbs_pass_internal(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_
                                  const double *v, uint32_t sweep, double *G_out, double *g_out, double *f_out, double *omega_out,
                                  int64_t *n_out, uint32_t *nuni_out);                                           // agpl_update.hip
 
+// Feature counts (round 6): the caller's M is ANY positive count; the plan works on Mp = M rounded up to a multiple of 256 -- the images
+// carry zero features M .. Mp - 1, so G and g have zero rows / columns there, I + G is the identity there and U = chol(I + G)^-1,
+// v are the caller's in their leading M x M / M block (the rest: identity / zero).  The caller's arrays (G, g, eta0, the Gibbs
+// draw v) are M-sized; for M != Mp they pass through the plan's Mp-sized staging copies (two small kernels per call).
+int32_t agpl_pad_natural(agpl_ctx *ctx, int L, int Mc, int Mp, const double *G, const double *g, const double *e, const double *v,
+                         double *Gp, double *gp, double *ep, double *vp);                                       // agpl_update.hip
+int32_t agpl_unpad_natural(agpl_ctx *ctx, int L, int Mc, int Mp, const double *Gp, const double *gp, double *G, double *g); // agpl_update.hip
+
 struct agpl_plan {
     agpl_ctx *ctx = nullptr;
     int64_t N = 0;
-    int32_t M = 0, L = 0;
+    int32_t M = 0, L = 0;  // M: the padded count Mp every kernel works on
+    int32_t Mc = 0;        // the caller's feature count (<= M)
+    double *Gp = nullptr, *gp = nullptr, *eta0p = nullptr, *vp = nullptr; // staging at Mp (Mc != M only)
     uint32_t flags = 0;
     int scale_exp = 0;     // both images hold 2^scale_exp Phi
     char *base = nullptr;  // the plan's device memory
@@ -69,9 +79,11 @@ constexpr int kKlBlocks = 16, kKlWaves = kKlBlocks * 4;
 constexpr int kUExp = 15; // the plan's U images carry 2^15 U: |U[a][b]| <= 1 always (I + G >= I), so this never overflows float16
 
 struct PlanLayout {
-    size_t hi, lo, acc, resid, uhi, ulo, awork, v, v32, logdet, klpart, total;
+    size_t hi, lo, acc, resid, uhi, ulo, awork, v, v32, logdet, klpart, stage, total;
 };
-PlanLayout plan_layout(int64_t N, int32_t M, int32_t L, uint32_t flags) {
+inline int32_t plan_padded(int32_t M) { return (M + 255) / 256 * 256; }
+// M: the padded count; Mc: the caller's
+PlanLayout plan_layout(int64_t N, int32_t M, int32_t Mc, int32_t L, uint32_t flags) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     PlanLayout o;
     // one of hi / lo; a plan without the marginal image (AGPL_PLAN_NO_MARGINALS: Gibbs sweeps only) keeps none
@@ -87,7 +99,9 @@ PlanLayout plan_layout(int64_t N, int32_t M, int32_t L, uint32_t flags) {
     o.v32 = al(o.v + sizeof(double) * (size_t)L * M);
     o.logdet = al(o.v32 + sizeof(float) * (size_t)L * M);
     o.klpart = al(o.logdet + sizeof(double) * (size_t)L);
-    o.total = al(o.klpart + sizeof(double) * (size_t)L * kKlWaves * 2);
+    o.stage = al(o.klpart + sizeof(double) * (size_t)L * kKlWaves * 2);
+    // staging of the caller's M-sized natural parameters at the padded size: G [L, M, M], g, eta0, v [L, M] each
+    o.total = Mc == M ? o.stage : al(o.stage + sizeof(double) * (size_t)L * ((size_t)M * M + 3 * (size_t)M));
     return o;
 }
 
@@ -117,11 +131,16 @@ __global__ __launch_bounds__(256) void plan_residual_kernel(int64_t N, int M, co
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t i = wave; i < N; i += nwaves) {
-        const float4 *row = (const float4 *)(Phi + i * M);
         float s = 0.f;
-        for (int q = lane; q < M / 4; q += 64) {
-            const float4 x = row[q];
-            s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        if (!(M & 3)) {
+            const float4 *row = (const float4 *)(Phi + i * M);
+            for (int q = lane; q < M / 4; q += 64) {
+                const float4 x = row[q];
+                s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            }
+        } else { // (a feature count that is not a multiple of 4: the rows are not 16-byte aligned)
+            const float *row = Phi + i * M;
+            for (int q = lane; q < M; q += 64) s += row[q] * row[q];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -188,8 +207,8 @@ int32_t plan_check(const agpl_plan *p, bool needs_marginals = false) {
 } // namespace
 
 extern "C" int64_t agpl_plan_bytes(int64_t N, int32_t M, int32_t L, uint32_t flags) {
-    if (N <= 0 || M <= 0 || M % 256 || L <= 0 || L > 64 || (flags & ~(uint32_t)AGPL_PLAN_NO_MARGINALS)) return 0;
-    return (int64_t)plan_layout(N, M, L, flags).total;
+    if (N <= 0 || M <= 0 || M > (1 << 20) || L <= 0 || L > 64 || (flags & ~(uint32_t)AGPL_PLAN_NO_MARGINALS)) return 0;
+    return (int64_t)plan_layout(N, plan_padded(M), M, L, flags).total;
 }
 
 extern "C" int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, const float *Phi, const float *resid,
@@ -197,25 +216,26 @@ extern "C" int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (!plan_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null plan_out");
     *plan_out = nullptr;
-    if (N <= 0 || M <= 0 || L <= 0 || L > 64) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
-    if (M % 256)
-        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT,
-                  "M = %d must be a multiple of 256 for a plan (zero-pad the features: zero columns change nothing)", M);
+    if (N <= 0 || M <= 0 || M > (1 << 20) || L <= 0 || L > 64)
+        AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad sizes N=%lld M=%d L=%d", (long long)N, M, L);
+    const int32_t Mc = M; // the caller's feature count; every kernel below works on the padded one
+    M = plan_padded(Mc);
     if (!Phi || !resid) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
     if (flags & ~(uint32_t)AGPL_PLAN_NO_MARGINALS) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "unknown plan flags 0x%x", flags);
     // one range check and ONE scale for both images (a non-finite feature is AGPL_ERR_DOMAIN with its position)
     unsigned hmx = 0;
-    int32_t rc = agpl_feature_range_check(ctx, N, M, Phi, __builtin_inff(), "the split-float16 images", &hmx);
+    int32_t rc = agpl_feature_range_check(ctx, N, Mc, Phi, __builtin_inff(), "the split-float16 images", &hmx);
     if (rc) return rc;
     int e = 0;
     rc = agpl_image_scale_exp(ctx, hmx, &e);
     if (rc) return rc;
-    const PlanLayout lo = plan_layout(N, M, L, flags);
+    const PlanLayout lo = plan_layout(N, M, Mc, L, flags);
     agpl_plan *p = new agpl_plan;
     p->flags = flags;
     p->ctx = ctx;
     p->N = N;
     p->M = M;
+    p->Mc = Mc;
     p->L = L;
     p->scale_exp = e;
     p->bytes = lo.total;
@@ -239,22 +259,28 @@ extern "C" int32_t agpl_plan_create(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     p->v32 = (float *)(p->base + lo.v32);
     p->logdet = (double *)(p->base + lo.logdet);
     p->klpart = (double *)(p->base + lo.klpart);
+    if (Mc != M) {
+        p->Gp = (double *)(p->base + lo.stage);
+        p->gp = p->Gp + (size_t)L * M * M;
+        p->eta0p = p->gp + (size_t)L * M;
+        p->vp = p->eta0p + (size_t)L * M;
+    }
     auto fail = [&](int32_t code) {
         if (p->own) (void)hipFree(p->base);
         delete p;
         return code;
     };
     if (!(flags & AGPL_PLAN_NO_MARGINALS)) {
-        rc = agpl_split_features_build(ctx, N, M, Phi, ldexpf(1.f, e), p->Phi_hi, p->Phi_lo);
+        rc = agpl_split_features_build(ctx, N, M, Mc, Phi, ldexpf(1.f, e), p->Phi_hi, p->Phi_lo);
         if (rc) return fail(rc);
     }
-    rc = agpl_accumulate_image_build(ctx, N, M, Phi, e, hmx, p->Phi_acc);
+    rc = agpl_accumulate_image_build(ctx, N, M, Mc, Phi, e, hmx, p->Phi_acc);
     if (rc) return fail(rc);
     rc = agpl_ws2_reserve(ctx, 16384);
     if (rc) return fail(rc);
     unsigned long long *bad = (unsigned long long *)((char *)ctx->ws2 + 32); // (bytes 8..63 of the small scratch are nobody's)
     if (hipMemsetAsync(bad, 0xff, sizeof(*bad), ctx->stream) != hipSuccess) return fail(AGPL_ERR_HIP);
-    plan_residual_kernel<<<2048, 256, 0, ctx->stream>>>(N, M, Phi, resid, p->resid, bad);
+    plan_residual_kernel<<<2048, 256, 0, ctx->stream>>>(N, Mc, Phi, resid, p->resid, bad);
     if (hipGetLastError() != hipSuccess) return fail(AGPL_ERR_HIP);
     // q(v) = N(0, I) to start from (script.jl:41-42)
     plan_identity_kernel<<<1024, 256, 0, ctx->stream>>>(M, L, p->A_work, p->v, p->v32, p->logdet);
@@ -299,7 +325,7 @@ extern "C" int32_t agpl_plan_destroy(agpl_plan *p) {
 extern "C" int32_t agpl_plan_info(const agpl_plan *p, int64_t *N, int32_t *M, int32_t *L, int32_t *scale_exp, int64_t *bytes) {
     if (!p) return AGPL_ERR_INVALID_ARGUMENT;
     if (N) *N = p->N;
-    if (M) *M = p->M;
+    if (M) *M = p->Mc; // (the caller's count; the state arrays of agpl_plan_state are sized by M rounded up to a multiple of 256)
     if (L) *L = p->L;
     if (scale_exp) *scale_exp = p->scale_exp;
     if (bytes) *bytes = (int64_t)p->bytes;
@@ -326,9 +352,13 @@ extern "C" int32_t agpl_cavi_pass_plan(agpl_plan *p, const agpl_lik_desc *lik, c
     if (!lik) AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "null likelihood descriptor");
     if (lik->nlatent != p->L)
         AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "the likelihood has %d latents, the plan was created for %d", lik->nlatent, p->L);
-    return agpl_cavi_pass_factor_internal(p->ctx, lik, p->N, p->M, nullptr, p->Phi_hi, p->Phi_lo, p->Phi_acc, p->resid, mu0, y,
-                                          p->U_hi, p->U_lo, p->v32, G_out, g_out, c_out, gamma_out, beta_out, p->scale_exp + kUExp,
-                                          elbo_terms_out);
+    if (!G_out || !g_out) AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const bool pad = p->Mc != p->M;
+    rc = agpl_cavi_pass_factor_internal(p->ctx, lik, p->N, p->M, nullptr, p->Phi_hi, p->Phi_lo, p->Phi_acc, p->resid, mu0, y,
+                                        p->U_hi, p->U_lo, p->v32, pad ? p->Gp : G_out, pad ? p->gp : g_out, c_out, gamma_out,
+                                        beta_out, p->scale_exp + kUExp, elbo_terms_out);
+    if (rc || !pad) return rc;
+    return agpl_unpad_natural(p->ctx, p->L, p->Mc, p->M, p->Gp, p->gp, G_out, g_out);
 }
 
 extern "C" int32_t agpl_plan_update(agpl_plan *p, const double *G, const double *g, const double *eta0, double *kl_out) {
@@ -336,6 +366,11 @@ extern "C" int32_t agpl_plan_update(agpl_plan *p, const double *G, const double 
     if (rc) return rc;
     agpl_ctx *ctx = p->ctx;
     if (!G || !g) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->Mc != p->M) { // the caller's M-sized natural parameters at the padded size (zero beyond M: I + G is the identity there)
+        rc = agpl_pad_natural(ctx, p->L, p->Mc, p->M, G, g, eta0, nullptr, p->Gp, p->gp, eta0 ? p->eta0p : nullptr, nullptr);
+        if (rc) return rc;
+        G = p->Gp, g = p->gp, eta0 = eta0 ? p->eta0p : nullptr;
+    }
     rc = agpl_gaussian_factor_async_scaled(ctx, p->M, p->L, G, g, eta0, p->A_work, p->v, p->v32, p->U_hi, p->U_lo, p->logdet, kUExp);
     if (rc) return rc;
     if (kl_out) {
@@ -362,6 +397,14 @@ extern "C" int32_t agpl_gibbs_pass_plan(agpl_plan *p, const agpl_lik_desc *lik, 
     if (!lik) AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "null likelihood descriptor");
     if (lik->nlatent != p->L)
         AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "the likelihood has %d latents, the plan was created for %d", lik->nlatent, p->L);
-    return agpl_gibbs_pass_internal(p->ctx, lik, p->N, p->M, nullptr, p->Phi_acc, true, p->resid, mu0, y, v, sweep, G_out, g_out,
-                                    f_out, omega_out, n_out, nuni_out);
+    if (!v || !G_out || !g_out) AGPL_FAIL(p->ctx, AGPL_ERR_INVALID_ARGUMENT, "null argument");
+    const bool pad = p->Mc != p->M;
+    if (pad) {
+        rc = agpl_pad_natural(p->ctx, p->L, p->Mc, p->M, nullptr, nullptr, nullptr, v, nullptr, nullptr, nullptr, p->vp);
+        if (rc) return rc;
+    }
+    rc = agpl_gibbs_pass_internal(p->ctx, lik, p->N, p->M, nullptr, p->Phi_acc, true, p->resid, mu0, y, pad ? p->vp : v, sweep,
+                                  pad ? p->Gp : G_out, pad ? p->gp : g_out, f_out, omega_out, n_out, nuni_out);
+    if (rc || !pad) return rc;
+    return agpl_unpad_natural(p->ctx, p->L, p->Mc, p->M, p->Gp, p->gp, G_out, g_out);
 }

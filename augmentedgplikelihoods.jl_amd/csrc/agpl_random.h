@@ -3,7 +3,9 @@
 // One Philox4x32-10 stream per (context seed, point index, sweep), so a sweep is reproducible for any launch
 // geometry and resumable from (seed, sweep) alone.  Every PG(1, c) draw of a point lives on a SUB-STREAM of the
 // point's stream (counter word 3 = (point index >> 32) in its low 8 bits, sub-stream id above: draw j of latent k has
-// id 1 + (k << 16) + j, the residual Gamma series id 1 + (k << 16) + 0xFFFF, id 0 is the main stream): the
+// id 1 + (k << 16) + (j mod 65535) and starts its block counter (counter word 0) at (j div 65535) << 20 -- zero for the first
+// 65535 draws, whose streams are what they were before round 6 --, the residual Gamma series id 1 + (k << 16) + 0xFFFF,
+// id 0 is the main stream; b < 2^22 = kPgMaxB, polyagamma.jl:129-134 sums any b): the
 // b = y + r draws of a negative-binomial point are independent work items that the kernels deal across the lanes of
 // a workgroup, sorted by the sampler's branch (pg_int_sum_block, agpl_ops.hip), and sum left to right in draw order -- the order of the sequential draw_sum loop (polyagamma.jl:129-134).  Uniform -> double
 // conversion, randexp and randn are fixed transforms of the stream (52-bit open-interval uniform,
@@ -46,10 +48,10 @@ struct Philox {
         pos = 4;
         nuni = 0;
     }
-    // sub-stream `id` of this point's stream (same key, sweep and point; fresh counter)
-    __device__ __forceinline__ Philox sub(uint32_t id) const {
+    // sub-stream `id` of this point's stream (same key, sweep and point; fresh counter, starting at block `block0`)
+    __device__ __forceinline__ Philox sub(uint32_t id, uint32_t block0 = 0u) const {
         Philox s = *this;
-        s.c0 = 0;
+        s.c0 = block0;
         s.c3 = (c3 & 0xFFu) + (id << 8);
         s.pos = 4;
         s.nuni = 0;
@@ -75,7 +77,7 @@ struct Philox {
     // a fresh (sub-)stream whose first two uniforms -- all four words of block 0 -- are not needed: the state after them, without
     // the ten rounds of the block
     __device__ __forceinline__ void skip_first_block() {
-        c0 = 1u;
+        c0 += 1u; // (a fresh sub-stream: c0 is its first block, pg_draw_block0)
         pos = 4;
         nuni = 2u;
     }
@@ -311,13 +313,23 @@ __device__ inline double rand_gamma_sum(Philox &g, double c, double e) {
 }
 
 constexpr uint32_t kSubResidual = 0xFFFFu;
+// PG(1, c) draw j of a latent: sub-stream id (sub_base =) 1 + (latent << 16) plus pg_draw_id(j), first block pg_draw_block0(j).
+// The id has 16 bits for the draw (0xFFFF is the residual series): draws 0 .. 65534 are numbered by it alone, the block counter of
+// their streams starts at zero -- the layout of rounds 2-5, bit for bit.  Draw j >= 65535 reuses id j mod 65535 and starts its
+// block counter at (j div 65535) << 20: a PG(1, c) draw consumes a handful of blocks (2^20 blocks would be two million uniforms),
+// so the streams of one id never meet.  kPgMaxB = 2^22 bounds b = y + r (the engine's per-wave draw offsets are 32-bit sums over
+// up to 256 owners); beyond it AGPL_ERR_UNSUPPORTED as before.
+constexpr double kPgMaxB = 4194304.0;
+__device__ __forceinline__ uint32_t pg_draw_id(uint32_t j) { return j % 65535u; }
+__device__ __forceinline__ uint32_t pg_draw_block0(uint32_t j) { return (j / 65535u) << 20; }
 
 // rand(PolyaGamma(b,c)) polyagamma.jl:121-154, one lane doing all of a point's draws: draw j of `latent` on sub-stream
-// 1 + (latent << 16) + j, the residual series on 1 + (latent << 16) + 0xFFFF; uniforms consumed are added to g.nuni.
+// 1 + (latent << 16) + pg_draw_id(j) from block pg_draw_block0(j), the residual series on 1 + (latent << 16) + 0xFFFF; uniforms
+// consumed are added to g.nuni.
 __device__ inline double rand_pg(Philox &g, int latent, double b, double c, uint32_t &nterms) {
     // NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin or
-    // throw its DomainError from a(n, 0), polyagamma.jl:175); b >= 65535 would leave the sub-stream id space
-    if (!(b >= 0.0) || !(fabs(c) < __builtin_inf()) || !(b < 65535.0)) return __builtin_nan("");
+    // throw its DomainError from a(n, 0), polyagamma.jl:175); b >= kPgMaxB is outside the numbering of the draws
+    if (!(b >= 0.0) || !(fabs(c) < __builtin_inf()) || !(b < kPgMaxB)) return __builtin_nan("");
     if (b == 0.0) return 0.0;
     const long tb = (long)floor(b);
     const uint32_t base = 1u + ((uint32_t)latent << 16);
@@ -326,7 +338,7 @@ __device__ inline double rand_pg(Philox &g, int latent, double b, double c, uint
         Pg1Params p;
         p.set(c);
         for (long j = 0; j < tb; ++j) {
-            Philox s = g.sub(base + (uint32_t)j);
+            Philox s = g.sub(base + pg_draw_id((uint32_t)j), pg_draw_block0((uint32_t)j));
             acc += sample_pg1(s, p, nterms);
             g.nuni += s.nuni;
         }

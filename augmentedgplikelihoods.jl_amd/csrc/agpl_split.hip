@@ -36,7 +36,8 @@ __device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
 
 // Phi [N][M] float32  ->  blocked hi / lo images (zero rows past N)
 // (scale = 2^e: 1 for the unscaled image of agpl_split_features, the accumulate image's 2^e_A for a plan's self-scaled image)
-__global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, const float *__restrict__ Phi, float scale,
+// Msrc: the features the caller's rows hold (row pitch Msrc floats); features Msrc .. M - 1 of the images are zero
+__global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, int Msrc, const float *__restrict__ Phi, float scale,
                                                              h8 *__restrict__ Ph, h8 *__restrict__ Pl) {
     const int nks = M / KS;
     const int64_t nblk = ((N + NT - 1) / NT) * nks;
@@ -47,9 +48,16 @@ __global__ __launch_bounds__(256) void split_features_kernel(int64_t N, int M, c
         const int64_t n = tile * NT + row;
         h8 hi, lo;
         if (n < N) {
-            const float *src = Phi + n * (int64_t)M + ks * KS + plane * 8;
-            const float4 x0 = *reinterpret_cast<const float4 *>(src), x1 = *reinterpret_cast<const float4 *>(src + 4);
-            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const int fg = ks * KS + plane * 8;
+            const float *src = Phi + n * (int64_t)Msrc + fg;
+            float xs[8];
+            if (!(Msrc & 3) && fg + 8 <= Msrc) {
+                const float4 x0 = *reinterpret_cast<const float4 *>(src), x1 = *reinterpret_cast<const float4 *>(src + 4);
+                xs[0] = x0.x, xs[1] = x0.y, xs[2] = x0.z, xs[3] = x0.w, xs[4] = x1.x, xs[5] = x1.y, xs[6] = x1.z, xs[7] = x1.w;
+            } else { // ragged rows
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xs[j] = fg + j < Msrc ? src[j] : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 _Float16 a, b;
@@ -717,10 +725,11 @@ int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const floa
                                  unsigned *max_bits_out); // agpl_syrk.hip
 
 // internal (agpl_plan.hip): the marginal image of scale * Phi (the plan has checked the features and chosen the scale)
-int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, float scale, void *Phi_hi, void *Phi_lo) {
+int32_t agpl_split_features_build(agpl_ctx *ctx, int64_t N, int32_t M, int32_t Msrc, const float *Phi, float scale, void *Phi_hi,
+                                  void *Phi_lo) {
     int64_t nblk = ((N + NT - 1) / NT) * (M / KS);
     if (nblk > 65535 * 16) nblk = 65535 * 16;
-    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Phi, scale, (h8 *)Phi_hi, (h8 *)Phi_lo);
+    split_features_kernel<<<(unsigned)nblk, 256, 0, ctx->stream>>>(N, M, Msrc, Phi, scale, (h8 *)Phi_hi, (h8 *)Phi_lo);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

@@ -74,7 +74,8 @@ __device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
 // ------------------------------------------------------------------------------------------------
 // max |x| over n floats as the bit pattern of a non-negative float (orders like an unsigned); a NaN ends up above the
 // pattern of +inf, so `bits >= 0x7F800000` says "something is not finite"
-__global__ __launch_bounds__(256) void absmax_kernel(int64_t n4, const float4 *__restrict__ x, unsigned *__restrict__ out) {
+// (ntail < 4 floats behind the n4 float4s -- a feature count that is not a multiple of 4 -- are taken by the first threads)
+__global__ __launch_bounds__(256) void absmax_kernel(int64_t n4, int ntail, const float4 *__restrict__ x, unsigned *__restrict__ out) {
     unsigned m = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = x[i];
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(int64_t n4, const float4 *_
         m = max(m, __float_as_uint(v.z) & 0x7FFFFFFFu);
         m = max(m, __float_as_uint(v.w) & 0x7FFFFFFFu);
     }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
+        m = max(m, __float_as_uint(reinterpret_cast<const float *>(x)[4 * n4 + threadIdx.x]) & 0x7FFFFFFFu);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(256) void find_bad_kernel(int64_t n, const float *_
 }
 
 // one workgroup = one (point slice, feature block): 16 points x 128 features through an LDS transpose
-__global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M, int64_t nps, float scale, int scale_exp,
+// Msrc: the features the caller's rows hold (row pitch Msrc floats); the image's features Msrc .. M - 1 are zero (round 6: a plan
+// pads any feature count to the next multiple of 256 itself)
+__global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M, int Msrc, int64_t nps, float scale, int scale_exp,
                                                                float max_abs, const float *__restrict__ Phi,
                                                                unsigned char *__restrict__ image) {
     __shared__ float tile[16][BS + 1];
@@ -122,9 +127,18 @@ __global__ __launch_bounds__(256) void accumulate_image_kernel(int64_t N, int M,
             const int64_t n = ps * 16 + pt;
             float4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
             if (n < N) {
-                const float *src = Phi + n * (int64_t)M + fb * BS + f0;
-                a = *reinterpret_cast<const float4 *>(src);
-                b = *reinterpret_cast<const float4 *>(src + 4);
+                const int fg = fb * BS + f0;
+                const float *src = Phi + n * (int64_t)Msrc + fg;
+                if (!(Msrc & 3) && fg + 8 <= Msrc) {
+                    a = *reinterpret_cast<const float4 *>(src);
+                    b = *reinterpret_cast<const float4 *>(src + 4);
+                } else { // ragged rows (unaligned, or the row ends inside these eight features)
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = fg + j < Msrc ? src[j] : 0.f;
+                    a = float4{t[0], t[1], t[2], t[3]};
+                    b = float4{t[4], t[5], t[6], t[7]};
+                }
             }
             float *d = &tile[pt][f0];
             d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
@@ -545,6 +559,356 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// syrk_quad_kernel (round 6): the same tile, image, slabs and arithmetic with ONE wave per SIMD.
+// The ISA of syrk_strip_kernel (two waves per SIMD at the 256-register cap, 8 registers spilled) showed what "bound by its
+// instruction stream" meant: the compiler sank the A-fragment reads to within four MFMAs of their use (every row block waits
+// `lgkmcnt(0)` on a read issued 64 cycles earlier), and emitted a step's 48 conversions as one block.  Here a wave owns TWO
+// column strips -- (w, 7 - w), the pair the two waves of a SIMD used to share -- i.e. 256 rows x 64 columns = 16 x 4
+// accumulators = 256 registers of a 512-register budget: every A fragment is read once per SIMD instead of twice (half the LDS
+// read traffic per MFMA), four waves meet at the step barrier instead of eight, and there is room to keep the fragments of three
+// row blocks and three sets of B granules (in use | converted for the next step | raw in flight) in registers without a spill.
+// The order of a step is pinned with sched_barrier: per 16-row block [the two A reads of block i + 3] [12 MFMAs of block i]
+// [one eighth of the step's staging: a DMA piece, or 12 of the 96 conversions]; the raw B granules of step t + 2 are requested
+// at the top of step t (a step and a half of flight), converted in place during the second half of step t + 1.
+// Same sums in the same order per accumulator as syrk_strip_kernel: G and g are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQuadLds = kRing * kStepBytes + 4 * kRing * kRecBytes;
+
+template <bool DIAG>
+__device__ __forceinline__ void syrk_quad_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int chunk, int l,
+                                               int s, int I, int J, const unsigned char *__restrict__ image,
+                                               const float *__restrict__ gb_all, const unsigned *__restrict__ scal,
+                                               float *__restrict__ slabG, float *__restrict__ slabg) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..3
+    const int nb = M / BS;
+    const int c0 = wave, c1 = 7 - wave;                       // the wave's two strips
+    const int i00 = DIAG ? 2 * c0 : 0, i01 = DIAG ? 2 * c1 : 0; // first needed 16-row block of each (diagonal tiles)
+    const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
+    const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
+    const int eA = hdr->scale_exp;
+    const int eB = acc_scale_exp(scal[0]);
+    const float sB = __uint_as_float((unsigned)(127 + eB) << 23);
+
+    const int64_t nbeg = (int64_t)s * chunk;
+    int64_t nend = nbeg + chunk;
+    if (nend > N) nend = N;
+    const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
+    const int64_t ps0 = nbeg / 16;
+    const int64_t slice_pitch = (int64_t)nb * 2 * 256;
+
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int kg = ln >> 4, lr = ln & 15;
+    // A pieces of this wave: quarter qd = wave of both 128-row blocks, both slices, hi and lo: 8 pieces of 1 KB per step
+    const h8 *a_src = blocks + ((ps0 * nb + 2 * I) * 2) * 256 + wave * 64 + lane;
+    const int a_dst = wave * 1024;
+    // B granules of this lane, per strip: rows 32 c + 16 cb + lr of panel J, k-group kg
+    const int R00 = 32 * c0 + lr, R01 = 32 * c1 + lr;
+    const h8 *b_src0 = blocks + (((ps0 + (kg >> 1)) * nb + 2 * J + (R00 >> 7)) * 2) * 256 + (kg & 1) * 128 + (R00 & 127);
+    const h8 *b_src1 = blocks + (((ps0 + (kg >> 1)) * nb + 2 * J + (R01 >> 7)) * 2) * 256 + (kg & 1) * 128 + (R01 & 127);
+    const float *gb_src = gb_all + ((int64_t)l * (Npad / 32) + nbeg / 32) * 64 + lane;
+    float *gbuf = reinterpret_cast<float *>(smem_raw + kRing * kStepBytes + wave * kRing * kRecBytes);
+
+    f32x4 acc[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+    // B granule sets (hi, lo of the four column blocks): F in use, Ra / Rb raw -> converted in place, by step parity
+    u32x4 rah[4], ral[4], rbh[4], rbl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rah[j] = ral[j] = rbh[j] = rbl[j] = u32x4{0, 0, 0, 0};
+    h8 fh[4], fl[4];
+
+#define AGPL_Q_DMA(t_, k_) /* piece k_ = 0..7 of step t_: (128-row block k_ >> 2, slice (k_ >> 1) & 1, hi / lo k_ & 1) */ \
+    do {                                                                                                        \
+        unsigned char *d_ = smem_raw + ((t_) & (kRing - 1)) * kStepBytes + (((k_) >> 1) & 1) * 16384 + ((k_) >> 2) * 8192 +  \
+                            a_dst + ((k_) & 1) * 4096;                                                          \
+        const h8 *src_ = a_src + (int64_t)(2 * AGPL_PROBE_T(t_) + (((k_) >> 1) & 1)) * slice_pitch + ((k_) >> 2) * 512 + \
+                         ((k_) & 1) * 256;                                                                      \
+        if (AGPL_PROBE_LOAD(t_)) __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);              \
+    } while (0)
+#define AGPL_Q_DMAG(t_)                                                                                         \
+    if (AGPL_PROBE_LOAD(t_))                                                                                    \
+    __builtin_amdgcn_global_load_lds(gb_src + (int64_t)(t_) * 64, (lds_void *)(gbuf + ((t_) & (kRing - 1)) * 64), 4, 0, 0)
+    // raw granules of step t_ into set (H_, L_): inline asm (the compiler must not count them: its vmcnt(0) in front of the first
+    // use of an ordinary load would drain the DMA queue); destinations are read-write operands, never behind a condition
+#define AGPL_Q_LOADB(t_, H_, L_)                                                                                \
+    do {                                                                                                        \
+        const h8 *s0_ = b_src0 + (int64_t)(2 * AGPL_PROBE_T(t_)) * slice_pitch, *s0l_ = s0_ + 256;              \
+        const h8 *s1_ = b_src1 + (int64_t)(2 * AGPL_PROBE_T(t_)) * slice_pitch, *s1l_ = s1_ + 256;              \
+        if (AGPL_PROBE_LOAD(t_)) {                                                                              \
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"               \
+                         "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256" \
+                         : "+v"(H_[0]), "+v"(L_[0]), "+v"(H_[1]), "+v"(L_[1])                                   \
+                         : "v"(s0_), "v"(s0l_)                                                                  \
+                         : "memory");                                                                           \
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"               \
+                         "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256" \
+                         : "+v"(H_[2]), "+v"(L_[2]), "+v"(H_[3]), "+v"(L_[3])                                   \
+                         : "v"(s1_), "v"(s1l_)                                                                  \
+                         : "memory");                                                                           \
+        }                                                                                                       \
+    } while (0)
+#define AGPL_Q_CVT(RH_, RL_, g0_, g1_, b0_, b1_, GA_)                                                           \
+    do {                                                                                                        \
+        float x0_, x1_;                                                                                         \
+        AGPL_Q_JOIN2(RH_, RL_, x0_, x1_);                                                                       \
+        if (DIAG) {                                                                                             \
+            AGPL_E_GFMA(GA_, b0_, x0_);                                                                         \
+            AGPL_E_GFMA(GA_, b1_, x1_);                                                                         \
+        }                                                                                                       \
+        AGPL_E_SPLIT2(x0_, g0_, x1_, g1_, RH_, RL_);                                                            \
+    } while (0)
+    // one eighth of a step's conversion: points 4 q .. 4 q + 3 of the lane's k-group (q_ = e_ >> 2 ... see the call sites), column
+    // block j_ of set (H_, L_); tt_ = the step the raw granules belong to
+#define AGPL_Q_CVT8(q_, j_, tt_, keepf_, H_, L_)                                                                \
+    do {                                                                                                        \
+        const float *gq_ = gbuf + ((tt_) & (kRing - 1)) * 64 + 8 * kg + 4 * (q_);                               \
+        float4 g4_ = *reinterpret_cast<const float4 *>(gq_);                                                    \
+        g4_.x *= sB, g4_.y *= sB, g4_.z *= sB, g4_.w *= sB;                                                     \
+        float4 b4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
+        if (DIAG) {                                                                                             \
+            b4_ = *reinterpret_cast<const float4 *>(gq_ + 32);                                                  \
+            if (!(keepf_)) b4_ = float4{0.f, 0.f, 0.f, 0.f};                                                    \
+        }                                                                                                       \
+        if ((q_) == 0) {                                                                                        \
+            AGPL_Q_CVT(H_[j_].x, L_[j_].x, g4_.x, g4_.y, b4_.x, b4_.y, gacc[j_]);                               \
+            AGPL_Q_CVT(H_[j_].y, L_[j_].y, g4_.z, g4_.w, b4_.z, b4_.w, gacc[j_]);                               \
+        } else {                                                                                                \
+            AGPL_Q_CVT(H_[j_].z, L_[j_].z, g4_.x, g4_.y, b4_.x, b4_.y, gacc[j_]);                               \
+            AGPL_Q_CVT(H_[j_].w, L_[j_].w, g4_.z, g4_.w, b4_.z, b4_.w, gacc[j_]);                               \
+        }                                                                                                       \
+    } while (0)
+#define AGPL_Q_TAKE(H_, L_) /* the converted granules become the fragments of the next step */                 \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            fh[j_] = __builtin_bit_cast(h8, H_[j_]);                                                            \
+            fl[j_] = __builtin_bit_cast(h8, L_[j_]);                                                            \
+        }                                                                                                       \
+    } while (0)
+    const int fa = (kg >> 1) * 1024 + (kg & 1) * 128 + lr;
+#define AGPL_Q_AOFF(i_) (fa + ((i_) >> 3) * 512 + ((i_) & 7) * 16)
+    // diagonal tiles: the raw granules of strip c are row blocks 2 c, 2 c + 1 of the A image already in LDS
+#define AGPL_Q_LDSB(t_, H_, L_)                                                                                 \
+    do {                                                                                                        \
+        const u32x4 *sn_ = reinterpret_cast<const u32x4 *>(smem_raw + ((t_) & (kRing - 1)) * kStepBytes);       \
+        H_[0] = sn_[AGPL_Q_AOFF(2 * c0)];                                                                       \
+        L_[0] = sn_[256 + AGPL_Q_AOFF(2 * c0)];                                                                 \
+        H_[1] = sn_[AGPL_Q_AOFF(2 * c0 + 1)];                                                                   \
+        L_[1] = sn_[256 + AGPL_Q_AOFF(2 * c0 + 1)];                                                             \
+        H_[2] = sn_[AGPL_Q_AOFF(2 * c1)];                                                                       \
+        L_[2] = sn_[256 + AGPL_Q_AOFF(2 * c1)];                                                                 \
+        H_[3] = sn_[AGPL_Q_AOFF(2 * c1 + 1)];                                                                   \
+        L_[3] = sn_[256 + AGPL_Q_AOFF(2 * c1 + 1)];                                                             \
+    } while (0)
+
+    // ---- prologue: records and A of steps 0..2; B of step 0 converted (set a); off the diagonal B of step 1 in flight (set b)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nstep) {
+            AGPL_Q_DMAG(t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) AGPL_Q_DMA(t, k);
+        }
+    if (!DIAG) AGPL_Q_LOADB(0, rah, ral);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (DIAG) {
+        __builtin_amdgcn_s_barrier(); // every wave's pieces of step 0 are in LDS
+        AGPL_Q_LDSB(0, rah, ral);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) AGPL_Q_CVT8((e >> 2) & 1, e & 3, 0, true, rah, ral);
+    AGPL_Q_TAKE(rah, ral);
+    if (!DIAG) AGPL_Q_LOADB(nstep > 1 ? 1 : 0, rbh, rbl);
+
+    // One step.  (CH_, CL_): the set whose raw granules (step t + 1) are converted during this step and become the fragments of
+    // the next; (NH_, NL_): the set the raw granules of step t + 2 are requested into (off the diagonal).
+    // Hooks, behind the MFMAs of row block h:
+    //   off the diagonal   0      the raw granules of step t + 2 (8 loads)
+    //                      0..7   one DMA piece of step t + 3 each (0: its record as well)
+    //                      7      wait for everything but this step's 8 loads + 9 pieces: the raw granules of step t + 1 and
+    //                             the A pieces of step t + 2 have landed
+    //                      8..15  one eighth of the conversion of step t + 1's granules each
+    //   diagonal tile      6      wait for this wave's pieces of step t + 1 (all but the 9 of step t + 2), the step's ONE barrier,
+    //                             raw granules from the A slot of step t + 1
+    //                      8..15  one DMA piece of step t + 3 (8: its record as well) and one eighth of the conversion each
+#define AGPL_Q_STEP(t_, CH_, CL_, NH_, NL_)                                                                     \
+    do {                                                                                                        \
+        const int t = (t_);                                                                                     \
+        if (!DIAG) __builtin_amdgcn_s_barrier(); /* every wave's pieces of step t have landed: each waited a step ago */ \
+        const bool more = t + 1 < nstep;                                                                        \
+        const int tl = t + 2 < nstep ? t + 2 : nstep - 1;                                                       \
+        const h8 *st = reinterpret_cast<const h8 *>(smem_raw + (t & (kRing - 1)) * kStepBytes);                 \
+        constexpr int kPre = 3;                                                                                 \
+        h8 af[kPre + 1][2];                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < kPre; ++j) {                                                      \
+            af[j][0] = st[AGPL_Q_AOFF(j)];                                                                      \
+            af[j][1] = st[256 + AGPL_Q_AOFF(j)];                                                                \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                        \
+            if (i + kPre < 16) {                                                                                \
+                af[(i + kPre) % (kPre + 1)][0] = st[AGPL_Q_AOFF(i + kPre)];                                     \
+                af[(i + kPre) % (kPre + 1)][1] = st[256 + AGPL_Q_AOFF(i + kPre)];                               \
+            }                                                                                                   \
+            {                                                                                                   \
+                const h8 ahc = af[i % (kPre + 1)][0], alc = af[i % (kPre + 1)][1];                              \
+                const bool on0 = !DIAG || i >= i00, on1 = !DIAG || i >= i01;                                    \
+                if (on0) {                                                                                      \
+                    acc[i][0] = mfma32(ahc, fh[0], acc[i][0]);                                                  \
+                    acc[i][1] = mfma32(ahc, fh[1], acc[i][1]);                                                  \
+                }                                                                                               \
+                if (on1) {                                                                                      \
+                    acc[i][2] = mfma32(ahc, fh[2], acc[i][2]);                                                  \
+                    acc[i][3] = mfma32(ahc, fh[3], acc[i][3]);                                                  \
+                }                                                                                               \
+                if (on0) {                                                                                      \
+                    acc[i][0] = mfma32(ahc, fl[0], acc[i][0]);                                                  \
+                    acc[i][1] = mfma32(ahc, fl[1], acc[i][1]);                                                  \
+                }                                                                                               \
+                if (on1) {                                                                                      \
+                    acc[i][2] = mfma32(ahc, fl[2], acc[i][2]);                                                  \
+                    acc[i][3] = mfma32(ahc, fl[3], acc[i][3]);                                                  \
+                }                                                                                               \
+                if (on0) {                                                                                      \
+                    acc[i][0] = mfma32(alc, fh[0], acc[i][0]);                                                  \
+                    acc[i][1] = mfma32(alc, fh[1], acc[i][1]);                                                  \
+                }                                                                                               \
+                if (on1) {                                                                                      \
+                    acc[i][2] = mfma32(alc, fh[2], acc[i][2]);                                                  \
+                    acc[i][3] = mfma32(alc, fh[3], acc[i][3]);                                                  \
+                }                                                                                               \
+            }                                                                                                   \
+            if (!DIAG) {                                                                                        \
+                if (i == 0) AGPL_Q_LOADB(tl, NH_, NL_); /* unconditional (clamped: the last steps re-load the last one) */ \
+                if (i < 8 && t + 3 < nstep) {                                                                   \
+                    if (i == 0) AGPL_Q_DMAG(t + 3);                                                             \
+                    AGPL_Q_DMA(t + 3, i);                                                                       \
+                }                                                                                               \
+                if (i == 7) {                                                                                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                    if (t + 3 < nstep) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");                        \
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+                }                                                                                               \
+                if (i >= 8) AGPL_Q_CVT8(((i - 8) >> 2) & 1, (i - 8) & 3, t + 1, more, CH_, CL_);                \
+            } else {                                                                                            \
+                if (i == 6) {                                                                                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                    if (t + 2 < nstep) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                         \
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+                    __builtin_amdgcn_s_barrier();                                                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                    AGPL_Q_LDSB(more ? t + 1 : t, CH_, CL_); /* (behind the last step: a duplicate, finite) */  \
+                }                                                                                               \
+                if (i >= 8) {                                                                                   \
+                    if (t + 3 < nstep) {                                                                        \
+                        if (i == 8) AGPL_Q_DMAG(t + 3);                                                         \
+                        AGPL_Q_DMA(t + 3, i - 8);                                                               \
+                    }                                                                                           \
+                    AGPL_Q_CVT8(((i - 8) >> 2) & 1, (i - 8) & 3, t + 1, more, CH_, CL_);                        \
+                }                                                                                               \
+            }                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+        AGPL_Q_TAKE(CH_, CL_);                                                                                  \
+    } while (0)
+
+    // (off the diagonal the two raw sets alternate: the step that converts one requests the next-but-one step into the other)
+    for (int t2 = 0; t2 < nstep; t2 += 2) {
+        AGPL_Q_STEP(t2, rbh, rbl, rah, ral);
+        if (t2 + 1 < nstep) AGPL_Q_STEP(t2 + 1, rah, ral, rbh, rbl);
+    }
+    // the clamped loads of the last steps land in registers that must not look dead (and be reused) while they are in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(rah[j]), "v"(ral[j]), "v"(rbh[j]), "v"(rbl[j]));
+#undef AGPL_Q_STEP
+#undef AGPL_Q_DMA
+#undef AGPL_Q_DMAG
+#undef AGPL_Q_LOADB
+#undef AGPL_Q_CVT
+#undef AGPL_Q_CVT8
+#undef AGPL_Q_TAKE
+#undef AGPL_Q_LDSB
+#undef AGPL_Q_AOFF
+
+    // ---- slabs (the layout of syrk_strip_body): strip c0 = wave lies in the 128-column block 2 J, strip c1 = 7 - wave in 2 J + 1
+    const float unscale = __uint_as_float((unsigned)(127 - (2 * eA + eB)) << 23);
+    const int npairs = nb * (nb + 1) / 2;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int c = sp ? c1 : c0;
+        const int bj = 2 * J + sp;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int bi = 2 * I + hb;
+            if (DIAG && bi < bj) continue; // the 128 x 128 block above the diagonal is never read back
+            const int p128 = bi * (bi + 1) / 2 + bj;
+            float *slab = slabG + (((int64_t)l * npairs + p128) * nsplit + s) * (int64_t)(BS * BS);
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ii + 4 * kg + r;
+                        const int col = (c & 3) * 32 + 16 * cb + lr;
+                        slab[row * BS + col] = acc[8 * hb + ii][2 * sp + cb][r] * unscale;
+                    }
+        }
+    }
+    if (DIAG) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const int c = sp ? c1 : c0;
+            float ga = gacc[2 * sp], gb1 = gacc[2 * sp + 1];
+            ga += __shfl_xor(ga, 16);
+            ga += __shfl_xor(ga, 32);
+            gb1 += __shfl_xor(gb1, 16);
+            gb1 += __shfl_xor(gb1, 32);
+            const float g1s = __shfl(gb1, (lane - 16) & 63);
+            if (lane < 32) {
+                const int rr = 32 * c + lane;
+                slabg[(((int64_t)l * nb + 2 * I + (rr >> 7)) * nsplit + s) * BS + (rr & 127)] =
+                    (lane < 16 ? ga : g1s) * __uint_as_float((unsigned)(127 - eA) << 23);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void syrk_quad_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
+                                                           const unsigned char *__restrict__ image,
+                                                           const float *__restrict__ gb_all,
+                                                           const unsigned *__restrict__ scal,
+                                                           float *__restrict__ slabG, float *__restrict__ slabg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nsplit8 = (nsplit + 7) / 8;
+    const int per_l = npairs2 * nsplit8 * 8;
+    const int l = blockIdx.x / per_l;
+    const int id = blockIdx.x - l * per_l;
+    const int xcd = id & 7, jj = id >> 3;
+    const int s = (jj / npairs2) * 8 + xcd;
+    const int p2 = jj % npairs2;
+    if (s >= nsplit) return;
+    const int nb2 = M / kPanel;
+    const int noff = nb2 * (nb2 - 1) / 2;
+    int I, J;
+    if (p2 < noff) {
+        I = 1;
+        while ((I + 1) * I / 2 <= p2) ++I;
+        J = p2 - I * (I - 1) / 2;
+    } else {
+        I = J = p2 - noff;
+    }
+    if (I == J) syrk_quad_body<true>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    else syrk_quad_body<false>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
+}
+
 __global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
                                                             const unsigned char *__restrict__ image,
                                                             const float *__restrict__ gb_all,
@@ -596,10 +960,11 @@ int32_t agpl_feature_range_check(agpl_ctx *ctx, int64_t N, int32_t M, const floa
                                  unsigned *max_bits_out) {
     int32_t rc = agpl_ws2_reserve(ctx, 4096);
     if (rc) return rc;
+    if ((uintptr_t)Phi & 15) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the feature matrix must be 16-byte aligned");
     unsigned *mx = (unsigned *)ctx->ws2 + 512; // words 512.. of the small scratch (the info flags live below)
     AGPL_HIP(ctx, hipMemsetAsync(mx, 0, 16, ctx->stream));
-    const int64_t n = N * (int64_t)M, n4 = n / 4; // (M % 128 == 0: whole float4s)
-    absmax_kernel<<<4096, 256, 0, ctx->stream>>>(n4, reinterpret_cast<const float4 *>(Phi), mx);
+    const int64_t n = N * (int64_t)M, n4 = n / 4; // (any M: the rows are contiguous, the last n % 4 floats are taken one by one)
+    absmax_kernel<<<4096, 256, 0, ctx->stream>>>(n4, (int)(n - 4 * n4), reinterpret_cast<const float4 *>(Phi), mx);
     AGPL_LAUNCH_CHECK(ctx);
     unsigned hmx = 0, hlim;
     memcpy(&hlim, &limit, 4);
@@ -645,12 +1010,14 @@ int32_t agpl_image_scale_exp(agpl_ctx *ctx, unsigned hmx, int *eA_out) {
     return AGPL_OK;
 }
 // internal (also agpl_plan.hip): the image of 2^eA Phi; the features have been range-checked
-int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, const float *Phi, int eA, unsigned hmx, void *image_out) {
+// (Msrc <= M: the features the rows of Phi hold; the image's features beyond them are zero)
+int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, int32_t Msrc, const float *Phi, int eA, unsigned hmx,
+                                    void *image_out) {
     float max_abs;
     memcpy(&max_abs, &hmx, 4);
     const float scale = ldexpf(1.f, eA);
     const int64_t nps = ((N + kStagePts - 1) / kStagePts) * 2;
-    accumulate_image_kernel<<<16384, 256, 0, ctx->stream>>>(N, M, nps, scale, eA, max_abs, Phi, (unsigned char *)image_out);
+    accumulate_image_kernel<<<16384, 256, 0, ctx->stream>>>(N, M, Msrc, nps, scale, eA, max_abs, Phi, (unsigned char *)image_out);
     AGPL_LAUNCH_CHECK(ctx);
     if (ctx->checked_image == image_out) ctx->checked_image = nullptr; // (rebuilt in place: its header is looked at again)
     return AGPL_OK;
@@ -694,8 +1061,18 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
         ctx->strip_attr = 1;
     }
+#ifdef AGPL_SYRK_QUAD
+    if (ctx->strip_attr != 2) {
+        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_quad_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kQuadLds));
+        ctx->strip_attr = 2;
+    }
+    syrk_quad_kernel<<<(unsigned)nwg, 256, kQuadLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
+                                                                   scal, slabG, slabg);
+#else
     syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
                                                                      scal, slabG, slabg);
+#endif
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

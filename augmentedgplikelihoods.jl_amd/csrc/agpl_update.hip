@@ -182,11 +182,14 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work);
 size_t agpl_factor_coop_bytes(int32_t M, int32_t L); // agpl_factor.hip
-// the one-launch factorisation takes this shape (else: the two-block form for 512 < M <= 1024, rocSOLVER beyond)
+// the hand-written factorisation (agpl_factor.hip) takes this shape; everything else -- M > 1024, or a feature count that is not a
+// multiple of 32 (128 beyond 512) -- goes to rocSOLVER.  A plan pads to a multiple of 256, so its sweeps take the library route only
+// beyond M = 1024.  (Rounds 4-5 had a third route, two block rows of the M <= 512 kernel around four library GEMMs, for
+// 512 < M <= 1024 with M % 128 != 0 or L > 8: removed in round 6 -- the pipeline form runs eight latents per launch instead.)
 static inline bool factor_one_launch(int32_t M, int32_t L) {
     if (M % 32 || L > 64) return false;
     if (M <= 512) return true;
-    return M <= 1024 && M % 128 == 0 && L <= 8; // the pipeline form's 19 workgroups (F, 2 P, 4 x 4 T) need an XCD to themselves
+    return M <= 1024 && M % 128 == 0;
 }
 
 namespace {
@@ -200,13 +203,6 @@ __global__ void factor_clean_kernel(int M, const double *__restrict__ A, double 
 }
 } // namespace
 
-namespace {
-size_t two_block_ws2_bytes(int32_t L);
-int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                  const double *eta0, double *A_work, double *v_out, float *v32_out,
-                                  double *logdet_out, int **info_dev);
-} // namespace
-
 static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                     const double *eta0, double *S_out, double *m_out, float *Wpack_out,
                                     float *alpha_out, double *logdet_dev) {
@@ -217,24 +213,19 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     if (rc) return rc;
     const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
     const size_t info_off = 16384; // ws2 head is used by the reductions
-    const bool one = factor_one_launch(M, L);
-    const bool two = !one && M > 512;
-    if ((one || (M <= 1024 && L <= 16)) && M % 32 == 0 && L <= 64) {
-        // one-launch factorisation (agpl_factor.hip; two block rows of it for feature counts in (512, 1024] that are not a multiple
-        // of 128): U = chol(I + G)^-1, then S = U'U as one float64 GEMM -- against 3.4 ms for the ~300 launches of potrf + potri
-        const size_t coop_bytes = one ? ((agpl_factor_coop_bytes(M, L) + 255) & ~(size_t)255) : 0;
-        const size_t own = two ? ((two_block_ws2_bytes(L) + 255) & ~(size_t)255) : info_off + 1024;
+    if (factor_one_launch(M, L)) {
+        // hand-written factorisation (agpl_factor.hip): U = chol(I + G)^-1, then S = U'U as one float64 GEMM -- against 3.4 ms for the
+        // ~300 launches of potrf + potri
+        const size_t coop_bytes = (agpl_factor_coop_bytes(M, L) + 255) & ~(size_t)255;
+        const size_t own = info_off + 1024;
         rc = agpl_ws2_reserve(ctx, own + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + coop_bytes + 1024);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         char *p = (char *)ctx->ws2 + own;
         double *T = (double *)p, *Aw = (double *)(p + mat_bytes), *Uz = (double *)(p + 2 * mat_bytes);
         double *S = S_out ? S_out : (double *)(p + 3 * mat_bytes);
-        void *coop = one ? (void *)(p + 3 * mat_bytes + (S_out ? 0 : mat_bytes)) : nullptr;
-        if (two)
-            rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, Aw, nullptr, nullptr, logdet_dev, &info);
-        else
-            rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, coop);
+        void *coop = (void *)(p + 3 * mat_bytes + (S_out ? 0 : mat_bytes));
+        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, coop);
         if (rc) return rc;
         dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
         factor_clean_kernel<<<grid, 128, 0, ctx->stream>>>(M, Aw, Uz);
@@ -257,7 +248,7 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
             AGPL_LAUNCH_CHECK(ctx);
         }
         int hinfo[64];
-        const int ni = two ? 2 * L : L;
+        const int ni = L;
         AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * ni, hipMemcpyDeviceToHost, ctx->stream));
         AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < ni; ++i)
@@ -265,7 +256,7 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
                 AGPL_FAIL(ctx, hinfo[i] < 0 ? AGPL_ERR_HIP : AGPL_ERR_NOT_POSDEF,
                           hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
                                        : "I + G is not positive definite (latent %d, pivot at row %d)",
-                          i % L, (int)hinfo[i] - 1 + (hinfo[i] > 0 && i >= L ? 512 : 0));
+                          i, (int)hinfo[i] - 1);
         return AGPL_OK;
     }
     rc = agpl_ws2_reserve(ctx, info_off + sizeof(rocblas_int) * 2 * (size_t)L + 256 + (S_out ? 0 : mat_bytes));
@@ -335,120 +326,60 @@ __global__ __launch_bounds__(256) void factor_apply_kernel(int M, const double *
 }
 } // namespace
 
+// ---- feature counts the hand-written kernels do not take as they are: zero-padded copies (round 6) ------------------------------
+// Zero features change nothing: G, g have zero rows / columns there, I + G is the identity there, U = chol(I + G)^-1 and v are
+// the caller's in their leading block.  A plan pads to a multiple of 256 (agpl_plan.hip); agpl_gibbs_draw_v pads to the next count
+// the factor kernels take.
 namespace {
-// 512 < M <= 1024: the same factorisation as two block rows (m1 = 512, m2 = M - 512) around the one-launch kernel:
-//     [A11 A21'; A21 A22] = I + G     R11 = chol(A11), U11 = R11^-1                       (factor kernel, m1)
-//     R21 = A21 U11'                  R22 = chol(A22 - R21 R21'), U22 = R22^-1            (GEMMs, factor kernel, m2)
-//     U = [U11 0; -U22 R21 U11  U22]  v = U b: v1 = U11 b1, v2 = U22 (b2 - R21 v1)        (b = g + eta0)
-//     logdet = logdet(A11) + logdet(A22 - R21 R21')
-// -- 2 kernel launches of 0.65 ms + 4 float64 GEMMs of 512^3 instead of rocSOLVER's ~600 dependent launches (3.4 ms).
-__global__ void two_block_extract_kernel(int M, int m1, const double *__restrict__ G, const double *__restrict__ g,
-                                         const double *__restrict__ eta0, double *__restrict__ G11,
-                                         double *__restrict__ G22, double *__restrict__ b1, double *__restrict__ b2) {
-    const int m2 = M - m1;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, l = blockIdx.z;
-    if (j >= M) return;
-    const double x = G[((int64_t)l * M + i) * M + j];
-    if (i < m1 && j < m1) G11[((int64_t)l * m1 + i) * m1 + j] = x;
-    if (i >= m1 && j >= m1) G22[((int64_t)l * m2 + (i - m1)) * m2 + (j - m1)] = x;
-    if (i == 0) {
-        const double b = g[(int64_t)l * M + j] + (eta0 ? eta0[(int64_t)l * M + j] : 0.0);
-        if (j < m1) b1[(int64_t)l * m1 + j] = b;
-        else b2[(int64_t)l * m2 + (j - m1)] = b;
+// dst [L, Mp, Mp] <- src [L, Mc, Mc] in the leading block, zero elsewhere (vectors: [L, Mp] <- [L, Mc]); a null source leaves zeros
+__global__ __launch_bounds__(256) void pad_natural_kernel(int L, int Mc, int Mp, const double *__restrict__ G, const double *__restrict__ g,
+                                                       const double *__restrict__ e, const double *__restrict__ v,
+                                                       double *__restrict__ Gp, double *__restrict__ gp, double *__restrict__ ep,
+                                                       double *__restrict__ vp) {
+    const int64_t nm = (int64_t)L * Mp * Mp, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (G)
+        for (int64_t i = t0; i < nm; i += stride) {
+            const int l = (int)(i / ((int64_t)Mp * Mp));
+            const int64_t r = i - (int64_t)l * Mp * Mp;
+            const int a = (int)(r / Mp), b = (int)(r - (int64_t)a * Mp);
+            Gp[i] = (a < Mc && b < Mc) ? G[((int64_t)l * Mc + a) * Mc + b] : 0.0;
+        }
+    for (int64_t i = t0; i < (int64_t)L * Mp; i += stride) {
+        const int l = (int)(i / Mp), a = (int)(i - (int64_t)l * Mp);
+        const int64_t j = (int64_t)l * Mc + a;
+        if (g) gp[i] = a < Mc ? g[j] : 0.0;
+        if (ep) ep[i] = (e && a < Mc) ? e[j] : 0.0;
+        if (v) vp[i] = a < Mc ? v[j] : 0.0;
+    }
+}
+// the caller's G [L, Mc, Mc], g [L, Mc] <- the leading blocks of the padded ones
+__global__ __launch_bounds__(256) void unpad_natural_kernel(int L, int Mc, int Mp, const double *__restrict__ Gp, const double *__restrict__ gp,
+                                                         double *__restrict__ G, double *__restrict__ g) {
+    const int64_t nm = (int64_t)L * Mc * Mc, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nm; i += stride) {
+        const int l = (int)(i / ((int64_t)Mc * Mc));
+        const int64_t r = i - (int64_t)l * Mc * Mc;
+        const int a = (int)(r / Mc), b = (int)(r - (int64_t)a * Mc);
+        G[i] = Gp[((int64_t)l * Mp + a) * Mp + b];
+    }
+    for (int64_t i = t0; i < (int64_t)L * Mc; i += stride) {
+        const int l = (int)(i / Mc), a = (int)(i - (int64_t)l * Mc);
+        g[i] = gp[(int64_t)l * Mp + a];
     }
 }
 
-// the two diagonal blocks of the factor into A (column-major lower: U[a][b] at A[b * M + a]); block (2, 1) was written
-// by the last GEMM, the triangle above the diagonal stays untouched as on the other routes
-__global__ void two_block_assemble_kernel(int M, int m1, const double *__restrict__ A1, const double *__restrict__ A2,
-                                          const double *__restrict__ v1, const double *__restrict__ v2,
-                                          const double *__restrict__ ld1, const double *__restrict__ ld2,
-                                          double *__restrict__ A, double *__restrict__ v, float *__restrict__ v32,
-                                          double *__restrict__ logdet) {
-    const int m2 = M - m1;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, l = blockIdx.z;
-    if (a >= M) return;
-    if (a >= b) {
-        if (a < m1) A[((int64_t)l * M + b) * M + a] = A1[((int64_t)l * m1 + b) * m1 + a];
-        else if (b >= m1) A[((int64_t)l * M + b) * M + a] = A2[((int64_t)l * m2 + (b - m1)) * m2 + (a - m1)];
-    }
-    if (b == 0) {
-        const double x = a < m1 ? v1[(int64_t)l * m1 + a] : v2[(int64_t)l * m2 + (a - m1)];
-        if (v) v[(int64_t)l * M + a] = x;
-        if (v32) v32[(int64_t)l * M + a] = (float)x;
-        if (a == 0 && logdet) logdet[l] = ld1[l] + ld2[l];
-    }
-}
-
-// bytes of ctx->ws2 the two-block form uses (from its start): callers that keep their own arrays behind it reserve
-// the sum first, so that the reservation inside cannot move the buffer
-size_t two_block_ws2_bytes(int32_t L) {
-    const size_t blk = sizeof(double) * (size_t)L * 512 * 512;
-    const size_t coop_bytes = (agpl_factor_coop_bytes(512, L) + 255) & ~(size_t)255;
-    const size_t vec = (sizeof(double) * (size_t)L * 512 + 255) & ~(size_t)255;
-    return 16384 + 1024 + 9 * blk + coop_bytes + 6 * vec;
-}
-
-int32_t gaussian_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
-                                  const double *eta0, double *A_work, double *v_out, float *v32_out,
-                                  double *logdet_out, int **info_dev /* [2 L] device */) {
-    rocblas_handle h;
-    int32_t rc = get_handle(ctx, &h);
-    if (rc) return rc;
-    const int m1 = 512, m2 = M - m1;
-    const size_t info_off = 16384, blk = sizeof(double) * (size_t)L * m1 * m1;
-    const size_t coop_bytes = (agpl_factor_coop_bytes(512, L) + 255) & ~(size_t)255;
-    const size_t vec = (sizeof(double) * (size_t)L * m1 + 255) & ~(size_t)255;
-    rc = agpl_ws2_reserve(ctx, two_block_ws2_bytes(L));
-    if (rc) return rc;
-    int *info = (int *)((char *)ctx->ws2 + info_off); // [2 L]
-    char *p = (char *)ctx->ws2 + info_off + 1024;
-    double *T = (double *)p, *A1 = (double *)(p + blk), *A2 = (double *)(p + 2 * blk), *Uz1 = (double *)(p + 3 * blk),
-           *Uz2 = (double *)(p + 4 * blk), *G11 = (double *)(p + 5 * blk), *G22 = (double *)(p + 6 * blk),
-           *R21 = (double *)(p + 7 * blk), *W = (double *)(p + 8 * blk);
-    char *q = p + 9 * blk;
-    void *coop = q;
-    q += coop_bytes;
-    double *b1 = (double *)q, *b2 = (double *)(q + vec), *v1 = (double *)(q + 2 * vec), *v2 = (double *)(q + 3 * vec),
-           *ld1 = (double *)(q + 4 * vec), *ld2 = (double *)(q + 5 * vec);
-    const rocblas_stride s11 = (rocblas_stride)m1 * m1, s21 = (rocblas_stride)m2 * m1, s22 = (rocblas_stride)m2 * m2,
-                         sMM = (rocblas_stride)M * M;
-    const double one = 1.0, zero = 0.0, mone = -1.0;
-
-    dim3 gridM((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
-    two_block_extract_kernel<<<gridM, 128, 0, ctx->stream>>>(M, m1, G, g, eta0, G11, G22, b1, b2);
+} // namespace
+int32_t agpl_pad_natural(agpl_ctx *ctx, int L, int Mc, int Mp, const double *G, const double *g, const double *e, const double *v,
+                         double *Gp, double *gp, double *ep, double *vp) {
+    pad_natural_kernel<<<G ? 256 : 8, 256, 0, ctx->stream>>>(L, Mc, Mp, G, g, e, v, Gp, gp, ep, vp);
     AGPL_LAUNCH_CHECK(ctx);
-    rc = agpl_factor_fused(ctx, m1, L, G11, b1, nullptr, T, A1, v1, nullptr, ld1, info, coop);
-    if (rc) return rc;
-    dim3 grid1((unsigned)agpl_cdiv(m1, 128), (unsigned)m1, (unsigned)L);
-    factor_clean_kernel<<<grid1, 128, 0, ctx->stream>>>(m1, A1, Uz1);
-    AGPL_LAUNCH_CHECK(ctx);
-    AGPL_ROCBLAS(ctx, rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
-    // column-major views: A21[i][b] = G[b][m1 + i] sits at (G + m1)[b * M + i]; Uz1 read column-major is U11
-    AGPL_ROCBLAS(ctx, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, m2, m1, m1,
-                                                    &one, G + m1, M, sMM, Uz1, m1, s11, &zero, R21, m2, s21, L));
-    // b2 -= R21 v1 ; G22 -= R21 R21'
-    AGPL_ROCBLAS(ctx, rocblas_dgemv_strided_batched(h, rocblas_operation_none, m2, m1, &mone, R21, m2, s21, v1, 1, m1,
-                                                    &one, b2, 1, m2, L));
-    AGPL_ROCBLAS(ctx, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, m2, m2, m1,
-                                                    &mone, R21, m2, s21, R21, m2, s21, &one, G22, m2, s22, L));
-    rc = agpl_factor_fused(ctx, m2, L, G22, b2, nullptr, T, A2, v2, nullptr, ld2, info + L, coop);
-    if (rc) return rc;
-    dim3 grid2((unsigned)agpl_cdiv(m2, 128), (unsigned)m2, (unsigned)L);
-    factor_clean_kernel<<<grid2, 128, 0, ctx->stream>>>(m2, A2, Uz2);
-    AGPL_LAUNCH_CHECK(ctx);
-    // U21 = -U22 (R21 U11), straight into rows m1.. of columns 0..m1-1 of A
-    AGPL_ROCBLAS(ctx, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, m2, m1, m1, &one,
-                                                    R21, m2, s21, Uz1, m1, s11, &zero, W, m2, s21, L));
-    AGPL_ROCBLAS(ctx, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, m2, m1, m2, &mone,
-                                                    Uz2, m2, s22, W, m2, s21, &zero, A_work + m1, M, sMM, L));
-    two_block_assemble_kernel<<<gridM, 128, 0, ctx->stream>>>(M, m1, A1, A2, v1, v2, ld1, ld2, A_work, v_out, v32_out,
-                                                              logdet_out);
-    AGPL_LAUNCH_CHECK(ctx);
-    *info_dev = info;
     return AGPL_OK;
 }
-} // namespace
+int32_t agpl_unpad_natural(agpl_ctx *ctx, int L, int Mc, int Mp, const double *Gp, const double *gp, double *G, double *g) {
+    unpad_natural_kernel<<<256, 256, 0, ctx->stream>>>(L, Mc, Mp, Gp, gp, G, g);
+    AGPL_LAUNCH_CHECK(ctx);
+    return AGPL_OK;
+}
 
 int32_t agpl_pending_resolve(agpl_ctx *ctx) {
     if (!ctx->pend) return AGPL_OK;
@@ -556,21 +487,6 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
             if (rc) return rc;
         }
         rc = pending_arm(ctx, U_hi ? nullptr : info, L, L);
-        if (rc) return rc;
-        *armed = true;
-        return AGPL_OK;
-    }
-    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) { // (feature counts in (512, 1024] that are not a multiple of 128)
-        int *info2 = nullptr;
-        int32_t rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A_work, v_out, v32_out, logdet_out, &info2);
-        if (rc) return rc;
-        if (U_hi) {
-            rc = pending_prepare(ctx);
-            if (rc) return rc;
-            rc = agpl_pack_factor_split_info(ctx, M, L, A_work, U_hi, U_lo, info2, ctx->pend_host_dev, 2 * L, u_scale_exp);
-            if (rc) return rc;
-        }
-        rc = pending_arm(ctx, U_hi ? nullptr : info2, 2 * L, L);
         if (rc) return rc;
         *armed = true;
         return AGPL_OK;
@@ -721,14 +637,16 @@ __global__ void add_vec_kernel(int n, const double *__restrict__ a, const double
 }
 // m[b] = sum_{a >= b} U[a][b] vf[a],  v[b] = sum_{a >= b} U[a][b] (vf[a] + z[a])   with U[a][b] = A[b * M + a]:
 // one wave per b reads its row of A contiguously; fixed-order butterfly
-__global__ __launch_bounds__(256) void factor_draw_kernel(int M, const double *__restrict__ A,
+// (ld >= M: A [L, ld, ld] and vf [L, ld] are those of a zero-padded problem -- U is block diagonal, the rows a >= M contribute nothing
+//  to the first M entries; z, v_out, m_out are M-sized)
+__global__ __launch_bounds__(256) void factor_draw_kernel(int M, int ld, const double *__restrict__ A,
                                                           const double *__restrict__ vf, const double *__restrict__ z,
                                                           double *__restrict__ v_out, double *__restrict__ m_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), l = blockIdx.y;
     if (b >= M) return;
-    const double *row = A + ((size_t)l * M + b) * M;
-    const double *vl = vf + (size_t)l * M, *zl = z + (size_t)l * M;
+    const double *row = A + ((size_t)l * ld + b) * ld;
+    const double *vl = vf + (size_t)l * ld, *zl = z + (size_t)l * M;
     double am = 0.0, av = 0.0;
     for (int a = b + lane; a < M; a += 64) {
         const double u = row[a], f = vl[a];
@@ -752,25 +670,36 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     if (!ctx) return AGPL_ERR_INVALID_ARGUMENT;
     if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
-    if (factor_one_launch(M, L)) {
+    // the feature count the hand-written factorisation runs on: M itself, or (round 6) M zero-padded to the next count it takes --
+    // a multiple of 32 up to 512, of 128 up to 1024.  The draw z ~ N(0, I) stays M-sized (stream index l M + a, whatever the padding)
+    const int32_t Mf = M <= 512 ? (M + 31) / 32 * 32 : (M <= 1024 ? (M + 127) / 128 * 128 : M);
+    if (factor_one_launch(Mf, L)) {
         // I + G = C C', U = C^-1:  m = U'(U r),  v = m + C^-T z = U'(U r + z)   (one fused factor launch + one matvec)
-        const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
-        const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
+        const size_t mat_bytes = sizeof(double) * (size_t)L * Mf * Mf;
+        const size_t vec_bytes = (sizeof(double) * (size_t)L * Mf + 255) & ~(size_t)255;
         const size_t info_off = 16384;
-        const size_t coop_bytes = agpl_factor_coop_bytes(M, L);
-        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes);
+        const size_t coop_bytes = (agpl_factor_coop_bytes(Mf, L) + 255) & ~(size_t)255;
+        const size_t pad_bytes = Mf != M ? mat_bytes + 2 * vec_bytes : 0;
+        int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes + pad_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         char *p = (char *)ctx->ws2 + info_off + 1024;
         double *T = (double *)p, *A = (double *)(p + mat_bytes);
         double *vf = (double *)(p + 2 * mat_bytes), *z = (double *)(p + 2 * mat_bytes + vec_bytes);
         void *coop = p + 2 * mat_bytes + 2 * vec_bytes + 512;
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A, vf, nullptr, nullptr, info, coop);
+        if (Mf != M) {
+            double *Gp = (double *)((char *)coop + coop_bytes), *gp = (double *)((char *)Gp + mat_bytes),
+                   *ep = (double *)((char *)gp + vec_bytes);
+            rc = agpl_pad_natural(ctx, L, M, Mf, G, g, eta0, nullptr, Gp, gp, eta0 ? ep : nullptr, nullptr);
+            if (rc) return rc;
+            G = Gp, g = gp, eta0 = eta0 ? ep : nullptr;
+        }
+        rc = agpl_factor_fused(ctx, Mf, L, G, g, eta0, T, A, vf, nullptr, nullptr, info, coop);
         if (rc) return rc;
         rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
         if (rc) return rc;
         dim3 gd((unsigned)agpl_cdiv(M, 4), (unsigned)L);
-        factor_draw_kernel<<<gd, 256, 0, ctx->stream>>>(M, A, vf, z, v_out, m_out);
+        factor_draw_kernel<<<gd, 256, 0, ctx->stream>>>(M, Mf, A, vf, z, v_out, m_out);
         AGPL_LAUNCH_CHECK(ctx);
         int hinfo[64];
         AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info, sizeof(int) * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -781,34 +710,6 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
                           hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
                                        : "I + G is not positive definite (latent %d, pivot at row %d)",
                           i, (int)hinfo[i] - 1);
-        return AGPL_OK;
-    }
-    if (M > 512 && M <= 1024 && M % 32 == 0 && L <= 16) {
-        // the same with the two-block factorisation (agpl_gaussian_factor's 512 < M <= 1024 route)
-        const size_t mat_bytes = sizeof(double) * (size_t)L * M * M;
-        const size_t vec_bytes = (sizeof(double) * (size_t)L * M + 255) & ~(size_t)255;
-        const size_t own = (two_block_ws2_bytes(L) + 255) & ~(size_t)255;
-        int32_t rc = agpl_ws2_reserve(ctx, own + mat_bytes + 2 * vec_bytes + 256);
-        if (rc) return rc;
-        char *p = (char *)ctx->ws2 + own;
-        double *A = (double *)p, *vf = (double *)(p + mat_bytes), *z = (double *)(p + mat_bytes + vec_bytes);
-        int *info2 = nullptr;
-        rc = gaussian_factor_two_block(ctx, M, L, G, g, eta0, A, vf, nullptr, nullptr, &info2);
-        if (rc) return rc;
-        rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
-        if (rc) return rc;
-        dim3 gd((unsigned)agpl_cdiv(M, 4), (unsigned)L);
-        factor_draw_kernel<<<gd, 256, 0, ctx->stream>>>(M, A, vf, z, v_out, m_out);
-        AGPL_LAUNCH_CHECK(ctx);
-        int hinfo[32];
-        AGPL_HIP(ctx, hipMemcpyAsync(hinfo, info2, sizeof(int) * 2 * L, hipMemcpyDeviceToHost, ctx->stream));
-        AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < 2 * L; ++i)
-            if (hinfo[i] != 0)
-                AGPL_FAIL(ctx, hinfo[i] < 0 ? AGPL_ERR_HIP : AGPL_ERR_NOT_POSDEF,
-                          hinfo[i] < 0 ? "factor kernel: a cooperating workgroup never arrived (latent %d, %d)"
-                                       : "I + G is not positive definite (latent %d, pivot at row %d)",
-                          i % L, (int)hinfo[i] - 1 + (hinfo[i] > 0 && i >= L ? 512 : 0));
         return AGPL_OK;
     }
     rocblas_handle h;

@@ -97,9 +97,17 @@ def natural_parameter_buffers(L, M, device, extra=0):
     return flat, flat[: L * M * M].view(L, M, M), flat[L * M * M: L * M * M + L * M].view(L, M)
 
 
+def plan_padded(M: int) -> int:
+    """The feature count a plan works on: M rounded up to a multiple of 256 (include/agpl.h: the state arrays of agpl_plan_state
+    are sized by it; the images carry zero features beyond M)."""
+    return (M + 255) // 256 * 256
+
+
 class Plan:
     """agpl_plan (include/agpl.h): the two split-float16 images of Phi (one scale), the Nystrom residual and q(v) in factor form,
-    in ONE torch-owned block of device memory; the float32 features are not referenced after construction."""
+    in ONE torch-owned block of device memory; the float32 features are not referenced after construction.  ANY feature count M:
+    the plan pads to ``Mp = plan_padded(M)`` itself (round 6); ``U_colmajor`` / ``v`` are the Mp-sized state (checkpoints),
+    ``U_lead`` / ``v_lead`` their leading M x M / M blocks -- the caller's q(v)."""
 
     NO_MARGINALS = 1  # AGPL_PLAN_NO_MARGINALS: Gibbs passes only (no marginal image)
 
@@ -109,10 +117,11 @@ class Plan:
         self.N, self.M = Phi.shape
         self.L = L
         self.flags = flags
+        self.Mp = plan_padded(self.M)
         nbytes = _ffi.lib().agpl_plan_bytes(C.c_int64(self.N), C.c_int32(self.M), C.c_int32(L), C.c_uint32(flags))
         if nbytes <= 0:
-            raise _ffi.ArgumentError(-1, f"a plan needs a feature count that is a multiple of 256 (got {self.M}; zero-pad) and "
-                                         f"at most 64 latents (got {L})")
+            raise _ffi.ArgumentError(-1, f"a plan needs N >= 1 points, M >= 1 features (got {self.N}, {self.M}) and at most 64 "
+                                         f"latents (got {L})")
         self.mem = torch.empty(nbytes, dtype=torch.uint8, device=Phi.device)
         self._h = C.c_void_p()
         ctx.call("agpl_plan_create", C.c_int64(self.N), C.c_int32(self.M), C.c_int32(L), _ptr(Phi), _ptr(resid),
@@ -121,7 +130,7 @@ class Plan:
         _ffi.check(ctx._h, _ffi.lib().agpl_plan_state(self._h, C.byref(U), C.byref(v), C.byref(uh), C.byref(ul), C.byref(v32),
                                                       C.byref(ld), None))
         base = self.mem.data_ptr()
-        M = self.M
+        M = self.Mp  # the state arrays are sized by the padded feature count
         view = lambda ptr, nb, dt: self.mem[ptr.value - base: ptr.value - base + nb].view(dt)
         self.U_colmajor = view(U, 8 * L * M * M, torch.float64).view(L, M, M)
         self.v = view(v, 8 * L * M, torch.float64).view(L, M)
@@ -132,6 +141,8 @@ class Plan:
         _ffi.check(ctx._h, _ffi.lib().agpl_plan_info(self._h, None, None, None, C.byref(e), None))
         self.scale_exp = e.value
         self.nbytes = nbytes
+        self.U_lead = self.U_colmajor[:, : self.M, : self.M]
+        self.v_lead = self.v[:, : self.M]
 
     def call(self, name, *args):
         self.ctx.bind()
@@ -184,7 +195,8 @@ def exchange_natural_parameters(G, g, group=None, flat=None):
 class SparseCAVI:
     """CAVI sweeps over N local points and M features.
 
-    Phi: float32 [N, Mp] CUDA tensor (Mp % 128 == 0); kdiag: float32 [N] (d_i above); y as the likelihood
+    Phi: float32 [N, M] CUDA tensor (any M on the plan path, which pads to a multiple of 256 itself; M % 128 == 0 for the
+    float32-input pair); kdiag: float32 [N] (d_i above); y as the likelihood
     wants it (real-valued y: float32); mu0: optional prior mean at the data, float32 [L][N].
     ``group``: a torch.distributed process group over which N is sharded (None = single GPU).
     """
@@ -192,11 +204,11 @@ class SparseCAVI:
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
                  marginal_precision: str = "auto", accumulate_precision: str = "auto", track_elbo: bool = False):
         """Two arithmetics, chosen for both contractions together:
-          * the shipped path ("f16x2-factor" marginals + "f16x2" accumulation; "auto" when the feature count is a multiple of
-            256): ONE plan (agpl_plan_create: both split-float16 images of Phi with one scale, q(v) in factor form) and
-            agpl_cavi_pass_plan / agpl_plan_update per sweep;
-          * "f32" / "f32" ("auto" otherwise): the float32-input MFMA kernels (agpl_cavi_pass + agpl_gaussian_update), the
-            arithmetic SURVEY.md 8(d) prices.
+          * the shipped path ("f16x2-factor" marginals + "f16x2" accumulation; "auto"): ONE plan (agpl_plan_create: both
+            split-float16 images of Phi with one scale, q(v) in factor form; any feature count -- the plan zero-pads to a multiple
+            of 256 itself, G / g / S / m stay M-sized) and agpl_cavi_pass_plan / agpl_plan_update per sweep;
+          * "f32" / "f32" (on request): the float32-input MFMA kernels (agpl_cavi_pass + agpl_gaussian_update), the
+            arithmetic SURVEY.md 8(d) prices; feature count a multiple of 128.
         ``track_elbo``: the per-point ELBO terms ride the pass and the Gaussian KL the update (plan path only); see
         ``elbo_entering``."""
         torch = _torch()
@@ -204,8 +216,6 @@ class SparseCAVI:
         self.lik = lik
         self.Phi = _prep(Phi, torch.float32, "Phi")
         self.N, self.M = self.Phi.shape
-        if self.M % PAD:
-            raise _ffi.ArgumentError(-1, f"feature count {self.M} must be a multiple of {PAD} (zero-pad)")
         self.L = lik._nlatent
         self.kdiag = _prep(kdiag, torch.float32, "kdiag")
         self.y = _prep_y(lik, y, torch.float32)
@@ -213,8 +223,7 @@ class SparseCAVI:
         self.group = group
         split_names = ("f16x2", "f16x2-factor")
         if marginal_precision == "auto":
-            marginal_precision = ("f16x2-factor" if self.M % 256 == 0 else "f32") if accumulate_precision == "auto" \
-                else ("f32" if accumulate_precision == "f32" else "f16x2-factor")
+            marginal_precision = "f32" if accumulate_precision == "f32" else "f16x2-factor"
         if accumulate_precision == "auto":
             accumulate_precision = "f32" if marginal_precision == "f32" else "f16x2"
         if marginal_precision not in ("f32", "f16x2-factor") or accumulate_precision not in ("f32", "f16x2"):
@@ -226,8 +235,9 @@ class SparseCAVI:
             raise _ffi.ArgumentError(-1, "marginal_precision and accumulate_precision must both be 'f32' or both be split-float16")
         self.marginal_precision = marginal_precision
         self.factor = marginal_precision == "f16x2-factor"
-        if self.factor and self.M % 256:
-            raise _ffi.ArgumentError(-1, f"the plan needs a feature count that is a multiple of 256 (got {self.M}; zero-pad)")
+        if not self.factor and self.M % PAD:
+            raise _ffi.ArgumentError(-1, f"the float32-input kernels need a feature count that is a multiple of {PAD} (got {self.M}; "
+                                         "zero-pad, or take the plan path)")
         dev = self.Phi.device
         L, M = self.L, self.M
         f64, f32 = torch.float64, torch.float32
@@ -245,11 +255,11 @@ class SparseCAVI:
             self.resid = self.kdiag  # kdiag is already d_i = k_ii - |phi_i|^2 (agpl_feature_residual / nystrom_residual)
             self.plan = Plan(self.Phi, self.resid, L, self.ctx)
             self._elbo_terms = self._Gg[-1:] if self.track_elbo else None
-            self.A_work, self.v = self.plan.U_colmajor, self.plan.v
+            self.A_work, self.v = self.plan.U_lead, self.plan.v_lead  # (views of the plan's state: the caller's M x M / M blocks)
             self._S = self._m = self.Wpack = self.alpha = None
             return
         if self.track_elbo:
-            raise _ffi.ArgumentError(-1, "track_elbo rides the plan path (defaults, feature count a multiple of 256)")
+            raise _ffi.ArgumentError(-1, "track_elbo rides the plan path (the default arithmetic)")
         # q(v) = N(0, I) (script.jl:41-42): the update of G = 0, g = 0 gives S = I, m = 0 and the packed -I the first pass reads
         self._S = torch.empty((L, M, M), dtype=f64, device=dev)
         self._m = torch.empty((L, M), dtype=f64, device=dev)
@@ -326,7 +336,7 @@ class SparseCAVI:
         examples/bernoulli/script.jl:41-43): q(v) in the plan's factor form, the reduced (G, g) of the last sweep, the sweep count
         and the context's Philox key / draw counter.  qΩ is a function of q(v) and is not stored.  Plan path only."""
         if self.plan is None:
-            raise _ffi.ArgumentError(-1, "state_dict is the plan path's (defaults, feature count a multiple of 256)")
+            raise _ffi.ArgumentError(-1, "state_dict is the plan path's (the default arithmetic)")
         self.check()
         return {"plan": self.plan.state(), "Gg": self._Gg.detach().cpu().clone(), "kl": self._kl.detach().cpu().clone(),
                 "nsweeps": self.nsweeps, "seed": int(self.ctx.seed), "sweep_counter": int(self.ctx.sweep),
@@ -437,21 +447,22 @@ class SparseGibbs:
 
     def __init__(self, lik, Phi, kdiag, y, mu0=None, ctx: Context | None = None, group=None, keep_points=False,
                  accumulate_precision: str = "auto", point_offset: int = 0, plan: "Plan | None" = None):
-        """``accumulate_precision``: "f16x2" (the plan's split-float16 image accumulation; "auto" when the feature count is a
-        multiple of 256) or "f32" (agpl_gibbs_pass: float32-input MFMA).  ``plan``: the plan of a SparseCAVI over the same
+        """``accumulate_precision``: "f16x2" (the plan's split-float16 image accumulation; "auto"; any feature count) or "f32"
+        (agpl_gibbs_pass: float32-input MFMA, feature count a multiple of 128).  ``plan``: the plan of a SparseCAVI over the same
         features (its accumulate image and residual are shared); by default a plan without the marginal image is built here."""
         torch = _torch()
         self.ctx = ctx or default_context()
         if accumulate_precision == "auto":
-            accumulate_precision = "f16x2" if (Phi.shape[1] % 256 == 0 or plan is not None) else "f32"
+            accumulate_precision = "f16x2"
         if accumulate_precision not in ("f32", "f16x2"):
             raise _ffi.ArgumentError(-1, "accumulate_precision must be 'auto', 'f32' or 'f16x2'")
         self.acc_split = 1 if accumulate_precision == "f16x2" else 0
         self.lik = lik
         self.Phi = _prep(Phi, torch.float32, "Phi")
         self.N, self.M = self.Phi.shape
-        if self.M % PAD:
-            raise _ffi.ArgumentError(-1, f"feature count {self.M} must be a multiple of {PAD} (zero-pad)")
+        if not self.acc_split and self.M % PAD:
+            raise _ffi.ArgumentError(-1, f"the float32-input kernels need a feature count that is a multiple of {PAD} (got {self.M}; "
+                                         "zero-pad, or accumulate_precision='f16x2')")
         self.L = lik._nlatent
         self.kdiag = _prep(kdiag, torch.float32, "kdiag")
         self.y = _prep_y(lik, y, torch.float64)
@@ -461,9 +472,6 @@ class SparseGibbs:
         L, M = self.L, self.M
         f64 = torch.float64
         self.plan = None
-        if self.acc_split and M % 256:
-            raise _ffi.ArgumentError(-1, f"the split-float16 accumulation needs a feature count that is a multiple of 256 (got {M}; "
-                                         "zero-pad, or accumulate_precision='f32')")
         if self.acc_split:
             if plan is not None and (plan.N, plan.M, plan.L) != (self.N, M, L):
                 raise _ffi.ArgumentError(-1, "the plan was created for another problem size")

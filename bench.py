@@ -317,15 +317,15 @@ def full_size_marginal_check(cavi, Phi, mu=None, var=None):
     P = Phi[idx].double()
     d = cavi.kdiag[idx].double().clamp_min(0.0)  # (the plan stores round-off below zero as 0)
     for l in range(L):
-        Ut = torch.triu(cavi.plan.U_colmajor[l])  # row-major view of the column-major lower triangle = U'
+        Ut = torch.triu(cavi.plan.U_lead[l])  # row-major view of the column-major lower triangle = U' (the caller's M x M block)
         T = P @ Ut  # T[n, a] = sum_b phi_n[b] U[a][b]
-        mref = T @ cavi.plan.v[l]
+        mref = T @ cavi.plan.v_lead[l]
         vref = d + (T * T).sum(1)
         if cavi.mu0 is not None:
             mref = mref + cavi.mu0[l][idx].double()
         rel_mu = max(rel_mu, float(((mu[l][idx].double() - mref).abs().max() / mref.abs().max().clamp_min(1e-300)).item()))
         rel_var = max(rel_var, float(((var[l][idx].double() - vref).abs().max() / vref.abs().max().clamp_min(1e-300)).item()))
-    U0 = cavi.plan.U_colmajor[0]
+    U0 = cavi.plan.U_lead[0]
     offdiag = float((torch.triu(U0, 1).abs().max()).item())
     return {"max_rel_d_mu": rel_mu, "max_rel_d_var": rel_var, "sampled_points": int(idx.numel()), "sampled_tiles": len(tiles),
             "tile_residues_mod_8": sorted({t % 8 for t in tiles}), "last_tile_points": int(cavi.N - (tiles[-1]) * 128),

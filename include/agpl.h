@@ -100,9 +100,11 @@ AGPL_API int32_t agpl_version(void);
  * Philox4x32-10 stream keyed (ctx seed, point index, sweep)).  f, omega_out are float64.
  * n_out: int64 counts ([L,N] categorical, [N] poisson / heterogauss) or NULL.
  * nuni_out / nterms_out: optional uint32[N] bookkeeping (uniforms consumed, summed series index).
- * Limit: a point's PG(b, c) needs b = y + r (y + n) < 65535 -- its PG(1, c) draws are numbered with 16 bits of the Philox
- *   counter; a larger b returns AGPL_ERR_UNSUPPORTED (that point's outputs are NaN), also from agpl_gibbs_pass* and
- *   agpl_rand_polyagamma.  The reference draws any integer b (polyagamma.jl:129-134).                                  */
+ * Limit: a point's PG(b, c) needs b = y + r (y + n) < 4194304 = 2^22 (round 6; 65535 before: draw j keeps 16 bits of the Philox
+ *   counter's sub-stream id, j mod 65535, and draws beyond 65534 start their block counter at (j div 65535) << 20 -- the streams
+ *   of b < 65535 are unchanged); a larger b returns AGPL_ERR_UNSUPPORTED (that point's outputs are NaN), also from
+ *   agpl_gibbs_pass* and agpl_rand_polyagamma.  The reference draws any integer b (polyagamma.jl:129-134), one PG(1, c)
+ *   draw after the other: 2^22 draws for ONE point are ~1 ms of a whole GPU.                                              */
 AGPL_API int32_t agpl_aux_sample(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t n, const void *y,
                         const double *f, double *omega_out, int64_t *n_out, uint32_t sweep,
                         uint32_t *nuni_out, uint32_t *nterms_out);
@@ -282,8 +284,15 @@ AGPL_API int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, cons
  * (v110's per-generation entry points -- agpl_split_features, agpl_pack_w_split, agpl_marginals_split, agpl_cavi_pass_split,
  * agpl_pack_factor_split, agpl_marginals_factor_split, agpl_cavi_pass_factor_split, agpl_accumulate_image, agpl_accumulate_split,
  * agpl_cavi_pass_factor_image, agpl_gibbs_pass_image -- are gone in v120 with the kernels only they reached.)
- *   agpl_plan_bytes     : device bytes a plan needs for (N, M, L, flags); 0 for sizes a plan does not take (M % 256 != 0, L > 64).
- *   agpl_plan_create    : Phi float32 [M, N] column-major; resid float32 [N] (agpl_feature_residual); flags: 0, or
+ *   feature counts      : ANY M >= 1 (round 6; rounds 3-5 asked the caller to zero-pad to a multiple of 256).  The plan works on
+ *                         Mp = M rounded up to a multiple of 256: its images carry zero features M .. Mp - 1, so G and g are zero
+ *                         there, I + G is the identity there, and U = chol(I + G)^-1, v are the caller's in their leading M x M /
+ *                         M block (identity / zero beyond).  Every array the CALLER passes or receives (Phi, G, g, eta0, the
+ *                         Gibbs draw v) is M-sized; only the state arrays of agpl_plan_state are Mp-sized.  For M == Mp nothing
+ *                         changes; otherwise a pass / update costs two small copy kernels more.
+ *   agpl_plan_bytes     : device bytes a plan needs for (N, M, L, flags); 0 for sizes a plan does not take (N, M < 1, L > 64).
+ *   agpl_plan_create    : Phi float32 [M, N] column-major (M contiguous floats per point, 16-byte aligned base; M % 4 != 0 is read
+ *                         element-wise); resid float32 [N] (agpl_feature_residual); flags: 0, or
  *                         AGPL_PLAN_NO_MARGINALS for a plan that serves Gibbs passes only (no marginal image: half the bytes);
  *                         storage: agpl_plan_bytes bytes of caller-owned device memory that stay valid for the plan's life, or
  *                         NULL (the library allocates and frees).  q(v) starts at N(0, I) (examples/bernoulli/script.jl:41-42).
@@ -311,9 +320,10 @@ AGPL_API int32_t agpl_feature_residual(agpl_ctx *ctx, int64_t N, int32_t M, cons
  *   agpl_gibbs_pass_plan: agpl_gibbs_pass with the plan's residual and accumulate image; the projection phi_i' v is formed from the
  *                         image too (x = (hi + lo) 2^-e: the features to 2^-22 relative, float64 accumulation in a fixed order),
  *                         so a Gibbs chain needs the float32 features at plan creation only.
- *   agpl_plan_info      : sizes, the images' scale exponent, bytes.
- *   agpl_plan_state     : device pointers to everything an update rewrites -- U (float64 [L, M, M], column-major lower triangle),
- *                         v (float64 [L, M]), the float16 images of 2^15 U (L M M halves each), v as float32 [L, M],
+ *   agpl_plan_info      : sizes (M: the caller's), the images' scale exponent, bytes.
+ *   agpl_plan_state     : device pointers to everything an update rewrites -- U (float64 [L, Mp, Mp], column-major lower triangle,
+ *                         Mp = M rounded up to a multiple of 256: the caller's U is the leading M x M block, leading dimension Mp),
+ *                         v (float64 [L, Mp]), the float16 images of 2^15 U (L Mp Mp halves each), v as float32 [L, Mp],
  *                         log det(I + G) [L] -- and to the plan's residual copy; any out pointer may be NULL.  To form S = U'U,
  *                         m = U'v; for repeatability checks; and as the CHECKPOINT of a sweep loop: copy the five arrays out
  *                         (with the context's seed and the host's sweep counter), and into the same pointers of a plan created

@@ -274,7 +274,8 @@ end
 
 State of the sparse CAVI loop (`cavi!`, examples/bernoulli/script.jl:29-39, in the sparse whitened form of
 docs/src/index.md:154-163) on the shipped device path, i.e. ONE plan (include/agpl.h, agpl_plan_create): Φ::ROCMatrix{Float32}
-is M x N column-major -- exactly Julia's layout of K_ZX (whitened: Φ = L⁻¹ K_ZX), M a multiple of 256 (zero-pad) -- `d` the
+is M x N column-major -- exactly Julia's layout of K_ZX (whitened: Φ = L⁻¹ K_ZX), any M (the plan zero-pads to a multiple of 256
+inside; G, g stay M-sized) -- `d` the
 Nyström residual k_nn - |φ_n|².  The plan builds both split-float16 images of Φ (one scale) and carries q(v) as (U, v) with
 S = UᵀU, m = Uᵀv; after construction Φ itself is no longer read by the sweep and may be freed by the caller.
 """
@@ -298,7 +299,7 @@ function SparseSweep(lik, Φ::ROCMatrix{Float32}, d::ROCVector{Float32}, y::ROCA
     M, N = size(Φ)
     L = nlatent(lik)
     nbytes = ccall((:agpl_plan_bytes, libagpl), Int64, (Int64, Int32, Int32, UInt32), N, M, L, 0)
-    nbytes > 0 || throw(ArgumentError("feature count $M must be a multiple of 256 (zero-pad) and nlatent <= 64"))
+    nbytes > 0 || throw(ArgumentError("need N >= 1 points, M >= 1 features and nlatent <= 64 (got N = $N, M = $M)"))
     mem = ROCVector{UInt8}(undef, nbytes)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(c.h, ccall((:agpl_plan_create, libagpl), Int32,
@@ -357,8 +358,9 @@ function moments(s::SparseSweep)
     check(ctx().h, ccall((:agpl_plan_state, libagpl), Int32,
                          (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                          s.plan, U_p, v_p, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
-    A = Array(unsafe_wrap(ROCArray, U_p[], (M, M, L)))
-    v = Array(unsafe_wrap(ROCArray, v_p[], (M, L)))
+    Mp = 256 * cld(M, 256)      # the plan's state arrays are sized by M rounded up to a multiple of 256 (include/agpl.h)
+    A = Array(unsafe_wrap(ROCArray, U_p[], (Mp, Mp, L)))[1:M, 1:M, :]   # the caller's U: the leading M x M block
+    v = Array(unsafe_wrap(ROCArray, v_p[], (Mp, L)))[1:M, :]
     U = [LowerTriangular(A[:, :, l]) for l in 1:L]
     return [U[l]' * v[:, l] for l in 1:L], [U[l]' * U[l] for l in 1:L]
 end

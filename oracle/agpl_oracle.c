@@ -296,10 +296,20 @@ static double rand_gamma_sum(agplo_rng *g, double c, double e) {
  * truncated Gamma series on the residual (:137-154; identical draws when the residual is zero).
  * STREAM LAYOUT (shared bit for bit with agpl_random.h): every PG(1, c) draw lives on a SUB-STREAM of its point's
  * Philox stream -- counter word 3 carries (point index >> 32) in its low 8 bits and the sub-stream id above them;
- * draw j of latent k uses id 1 + (k << 16) + j, the residual series id 1 + (k << 16) + 0xFFFF; id 0 is the point's
+ * draw j of latent k uses id 1 + (k << 16) + (j mod 65535) and starts its block counter (counter word 0) at
+ * (j div 65535) << 20 (zero for j < 65535: the layout of rounds 2-5; round 6 lifted b < 65535 to b < 2^22 this way --
+ * polyagamma.jl:129-134 sums any b), the residual series id 1 + (k << 16) + 0xFFFF; id 0 is the point's
  * main stream (noise, Gamma / Poisson / inverse-Gaussian draws).  The draws of one point are therefore independent
  * work items (the device deals them across the lanes of a wave), summed left to right in draw order, residual last. */
 #define AGPLO_SUB_RESIDUAL 0xFFFFu
+#define AGPLO_PG_MAX_B 4194304.0
+static void rng_sub_at(const agplo_rng *g, uint32_t id, uint32_t block0, agplo_rng *s) {
+    *s = *g;
+    s->ctr[0] = block0;
+    s->ctr[3] = (g->ctr[3] & 0xFFu) + (id << 8);
+    s->pos = 4;
+    s->nuni = 0;
+}
 static void rng_sub(const agplo_rng *g, uint32_t id, agplo_rng *s) {
     *s = *g;
     s->ctr[0] = 0;
@@ -310,14 +320,14 @@ static void rng_sub(const agplo_rng *g, uint32_t id, agplo_rng *s) {
 static double rand_pg(agplo_rng *g, int latent, double b, double c, uint32_t *nterms) {
     /* NaN / Inf in, NaN out: the accept loops never terminate on a non-finite tilt (the reference would spin
      * or throw its DomainError from a(n, 0), polyagamma.jl:175) */
-    if (!(b >= 0.0) || !(fabs(c) < INFINITY) || !(b < 65535.0)) return NAN;
+    if (!(b >= 0.0) || !(fabs(c) < INFINITY) || !(b < AGPLO_PG_MAX_B)) return NAN;
     if (b == 0.0) return 0.0;
     const long tb = (long)floor(b);
     const uint32_t base = 1u + ((uint32_t)latent << 16);
     double acc = 0.0;
     agplo_rng s;
     for (long j = 0; j < tb; ++j) {
-        rng_sub(g, base + (uint32_t)j, &s);
+        rng_sub_at(g, base + (uint32_t)(j % 65535), (uint32_t)(j / 65535) << 20, &s);
         acc += sample_pg1(&s, c, nterms);
         g->nuni += s.nuni;
     }

@@ -94,3 +94,23 @@ def test_product_never_touches_the_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 assert "oracle" not in open(os.path.join(dp, f)).read().lower(), (dp, f)
+
+
+def test_plan_takes_any_feature_count(built):
+    """agpl_plan_bytes is host arithmetic (no device call): a plan exists for every feature count M >= 1 -- the library pads to the next
+    multiple of 256 itself (round 6) -- and a padded count costs exactly the M-sized staging of (G, g, eta0, v) on top of the plan
+    of the padded size."""
+    import ctypes as C
+
+    from agpl_amd import _ffi
+
+    lib = _ffi.lib()
+    nbytes = lambda N, M, L, fl=0: lib.agpl_plan_bytes(C.c_int64(N), C.c_int32(M), C.c_int32(L), C.c_uint32(fl))
+    for M in (1, 37, 64, 200, 256, 1000, 1024, 1280, 2048):
+        b = nbytes(100_000, M, 1)
+        Mp = (M + 255) // 256 * 256
+        assert b > 0, M
+        stage = 8 * (Mp * Mp + 3 * Mp)
+        assert b == nbytes(100_000, Mp, 1) + (0 if M == Mp else (stage + 255) // 256 * 256), M
+    assert nbytes(100_000, 0, 1) == 0 and nbytes(0, 256, 1) == 0 and nbytes(100_000, 256, 65) == 0 and nbytes(100_000, 256, 1, 2) == 0
+    assert 0 < nbytes(100_000, 200, 3, 1) < nbytes(100_000, 200, 3, 0)  # AGPL_PLAN_NO_MARGINALS

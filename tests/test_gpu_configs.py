@@ -1,7 +1,7 @@
 """BASELINE.json configs C3 and C4 at their own shapes (run with -m gpu on an MI355X), on the path bench.py ships
 (factor-form split-float16 marginals + split-float16 accumulation):
 
-  C3  NegativeBinomialLikelihood(r = 15), M = 1024: the two-block M x M factor route inside a CAVI sweep
+  C3  NegativeBinomialLikelihood(r = 15), M = 1024: the one-launch factor pipeline (factor_pipe_kernel) inside a CAVI sweep
       (/root/reference/src/likelihoods/negativebinomial.jl:20-49) -- 10 sweeps against the oracle at a size it
       finishes in seconds; the two-rank sharded variant lives in test_gpu_distributed.py.
   C4  CategoricalLikelihood(LogisticSoftMaxLink(zeros(10))), K = 10 latent GPs, M = 256
@@ -160,8 +160,8 @@ def test_c2_bernoulli_m512_ten_sweeps_match_oracle(A, ctx, oracle):
 
 @pytest.mark.timeout(900)
 def test_c3_negbin_m1024_ten_sweeps_match_oracle(A, ctx, oracle):
-    """C3's likelihood and M: NegBin r = 15 (examples/negativebinomial/script.jl:17), M = 1024 -> the M x M update takes
-    the two-block factor route (agpl_update.hip gaussian_factor_two_block) ten times inside the sweep loop."""
+    """C3's likelihood and M: NegBin r = 15 (examples/negativebinomial/script.jl:17), M = 1024 -> the M x M update is ONE launch of
+    factor_pipe_kernel (agpl_factor.hip, since round 5; the two-block route of round 4 is gone) ten times inside the sweep loop."""
     O = oracle
     lik, olik = A.NegativeBinomialLikelihood(15.0), O.negbinomial(15.0)
     ten_sweeps_against_oracle(A, ctx, O, lik, olik, 20_000, 1024)
@@ -209,7 +209,7 @@ def test_c3_per_rank_full_size_properties(A, ctx):
     """C3 at the size ONE rank of its 8-GPU configuration holds (NegBin r = 15, N = 1e7 / 8 = 1.25e6, M = 1024): sizes the
     oracle cannot reach, so size-independent properties of the shipped path -- exact symmetry, bitwise reproducibility,
     tr G = sum_n gamma_n |phi_n|^2 and g = Phi beta against float64 reductions, gamma = (y + r) tanh(c / 2) / (2 c) in
-    (0, (y + r) / 4], additivity over N (the sharding identity), a full sweep through the two-block M x M factor route, and
+    (0, (y + r) / 4], additivity over N (the sharding identity), a full sweep through the one-launch M x M factor pipeline, and
     one Gibbs point pass with finite positive draws (negativebinomial.jl:20-49)."""
     N, M, r = 1_250_000, 1024, 15.0
     lik = A.NegativeBinomialLikelihood(r)

@@ -205,17 +205,49 @@ def test_aux_sample_edge_cases(A, ctx, oracle):
     assert np.isnan(got[0]) and np.isfinite(got[1]) and np.isnan(got[2]) and np.isnan(got[3])
     with pytest.raises(ValueError):  # the oracle refuses the same input
         oracle.aux_sample(oracle.categorical([5.0, 5.0, -30.0]), np.zeros((4, 3), np.uint8), np.full((4, 3), 40.0), seed=1)
-    # b = y + r >= 65535 leaves the 16-bit draw index of a point's sub-streams: reported (UNSUPPORTED), not a silent NaN
+    # b = y + r >= 2^22 is outside the numbering of a point's draws (agpl_random.h kPgMaxB): reported (UNSUPPORTED), not a silent NaN
     nb = A.NegativeBinomialLikelihood(15.0)
-    yb = dev(np.array([3, 65519, 65520, 7], np.int32))  # b = 18, 65534 (the largest accepted), 65535, 22
+    yb = dev(np.array([3, 65519, (1 << 22) - 15, 7], np.int32))  # b = 18, 65534, 2^22 (the first refused), 22
     fb = dev(np.array([0.3, 6.0, 6.0, -0.2]))
     ok = host(A.aux_sample(nb, yb[:2].contiguous(), fb[:2].contiguous(), ctx=ctx, sweep=3).ω)
     assert np.isfinite(ok).all() and ok[1] == pytest.approx(65534 / (2 * 6.0) * np.tanh(3.0), rel=0.05)
     with pytest.raises(A.AGPLError) as ei:
         A.aux_sample(nb, yb, fb, ctx=ctx, sweep=3)
-    assert ei.value.code == -3 and "65535" in str(ei.value)
+    assert ei.value.code == -3 and "4194304" in str(ei.value)
     with pytest.raises(A.AGPLError):
-        A.rand_polyagamma(65535.0, 1.0, torch.empty(4, dtype=torch.float64, device="cuda"), ctx=ctx)
+        A.rand_polyagamma(4194304.0, 1.0, torch.empty(4, dtype=torch.float64, device="cuda"), ctx=ctx)
+
+
+def test_polyagamma_beyond_the_sixteen_bit_draw_index(A, ctx, oracle):
+    """polyagamma.jl:129-134 sums ANY integer b; rounds 2-5 stopped at b < 65535 (16 bits of the sub-stream id).  Round 6: draw
+    j >= 65535 reuses id j mod 65535 and starts its block counter at (j div 65535) << 20 -- device and oracle agree on the stream
+    (values, uniforms consumed, series indices), and the draws of b < 65535 are what they were (every golden fixture still passes).
+    rand(PolyaGamma(200 000, c)), a negative-binomial and a Poisson point with y = 1e5 among ordinary ones."""
+    O = oracle
+    out = torch.empty(3, dtype=torch.float64, device="cuda")
+    got, nuni, nterms = A.rand_polyagamma(200_000.0, 1.7, out, ctx=ctx, sweep=0, stats=True)
+    ref, runi, rterms = O.rand_pg(200_000.0, 1.7, 3, seed=SEED, stats=True)
+    assert np.array_equal(host(nuni).astype(np.uint32), runi) and np.array_equal(host(nterms).astype(np.uint32), rterms)
+    assert np.allclose(host(got), ref, rtol=1e-10, atol=0)
+    assert host(got)[0] == pytest.approx(200_000 / (2 * 1.7) * np.tanh(0.85), rel=5e-3)  # mean(PG(b, c)), polyagamma.jl:25-31
+    # non-integer b: floor(b) draws + the residual series on its own id (0xFFFF is never a draw's id)
+    got2 = A.rand_polyagamma(70_000.4, 0.9, torch.empty(2, dtype=torch.float64, device="cuda"), ctx=ctx, sweep=0)
+    ref2 = O.rand_pg(70_000.4, 0.9, 2, seed=SEED)
+    assert np.allclose(host(got2), ref2, rtol=1e-10, atol=0)
+    # the vector entry point: the workgroup engine deals the 100 015 draws of one point across its wave
+    nb, onb = A.NegativeBinomialLikelihood(15.0), O.negbinomial(15.0)
+    y = np.array([3, 100_000, 0, 7, 65_520, 65_521, 11], np.int32)  # b = 18, 100015, 15, 22, 65535, 65536, 26
+    f = np.array([0.3, 2.0, -1.0, -0.2, 0.7, -3.3, 0.0])
+    Om, nu, nt = A.aux_sample_(A.init_aux_variables(nb, y.size, ctx=ctx), nb, dev(y), dev(f), ctx=ctx, sweep=5, stats=True)
+    r = O.aux_sample(onb, y, f, seed=SEED, sweep=5, stats=True)
+    assert np.array_equal(host(nu).astype(np.uint32), r["nuni"]) and np.array_equal(host(nt).astype(np.uint32), r["nterms"])
+    assert np.allclose(host(Om.ω), r["omega"], rtol=1e-10, atol=0)
+    po, opo = A.PoissonLikelihood(10.0), O.poisson(10.0)
+    yp = np.array([4, 100_000, 9], np.int32)
+    fp = np.array([0.2, 1.5, -0.4])
+    Op = A.aux_sample(po, dev(yp), dev(fp), ctx=ctx, sweep=6)
+    rp = O.aux_sample(opo, yp, fp, seed=SEED, sweep=6)
+    assert np.array_equal(host(Op.n), rp["n"]) and np.allclose(host(Op.ω), rp["omega"], rtol=1e-10, atol=0)
 
 
 @pytest.mark.parametrize("name", ["bernoulli", "negbin"])
@@ -404,7 +436,7 @@ def test_accumulate_linearity_at_scale(A, ctx):
 
 @pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 768), (1, 1024), (1, 1152)])
 def test_gaussian_update_against_lapack(A, ctx, oracle, L, M):
-    """S, m against LAPACK on all three routes: factor kernel (M <= 512), its two-block form (M <= 1024), rocSOLVER."""
+    """S, m against LAPACK on every route: factor kernel (M <= 512), factor pipeline (M <= 1024, M % 128 == 0), rocSOLVER (1152)."""
     rng = np.random.default_rng(11 + M)
     B = rng.normal(size=(L, M, 3 * M)) / np.sqrt(M / 256.0)
     G = B @ B.transpose(0, 2, 1)
@@ -585,10 +617,11 @@ def test_gibbs_pass_matches_oracle(A, ctx, oracle, name):
     assert relmax(host(g), gr) < 5e-6
 
 
-@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 640), (1, 1024), (1, 1280)])
+@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 640), (1, 1024), (1, 1280), (2, 200), (1, 37), (1, 600), (10, 1024)])
 def test_gibbs_draw_v_matches_oracle(A, ctx, oracle, L, M):
-    """All three routes of the conditional draw: the one-launch factor kernel (M <= 512), the two-block form around
-    it (M <= 1024) and rocSOLVER (beyond)."""
+    """Every route of the conditional draw: the one-launch factor kernel (M <= 512), the factor pipeline (M <= 1024; ten latents in
+    two launches), rocSOLVER (beyond), and -- round 6 -- feature counts the kernels do not take as they are (200, 37, 600), which
+    agpl_gibbs_draw_v zero-pads to the next one they do; the draw z stays M-sized (the oracle's stream indices)."""
     import ctypes as C
 
     rng = np.random.default_rng(23 + M)
@@ -709,11 +742,18 @@ def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
 
 
 # ------------------------------------------------------------------------------------------ the plan path (factor form)
-def test_plan_path_rejects_unpadded_feature_count(A, ctx):
+def test_plan_path_takes_an_unpadded_feature_count(A, ctx):
+    """Rounds 3-5 refused a feature count that is not a multiple of 256 on the plan path; round 6 pads inside the plan."""
     x = torch.zeros((64, 128), dtype=torch.float32, device="cuda")
-    with pytest.raises(A.ArgumentError):
-        A.SparseCAVI(A.BernoulliLikelihood(), x, torch.ones(64, device="cuda"),
+    c = A.SparseCAVI(A.BernoulliLikelihood(), x, torch.ones(64, device="cuda"),
                      torch.zeros(64, dtype=torch.uint8, device="cuda"), ctx=ctx, marginal_precision="f16x2-factor")
+    assert c.plan is not None and c.plan.Mp == 256 and tuple(c.G.shape) == (1, 128, 128)
+    c.sweep()
+    c.check()
+    with pytest.raises(A.ArgumentError):  # the two arithmetics do not mix
+        A.SparseCAVI(A.BernoulliLikelihood(), x, torch.ones(64, device="cuda"),
+                     torch.zeros(64, dtype=torch.uint8, device="cuda"), ctx=ctx, marginal_precision="f16x2-factor",
+                     accumulate_precision="f32")
 
 
 @pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 200), ("negbin", 6_000, 256), ("cat", 4_000, 250),
@@ -746,8 +786,9 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
 @pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (256, 1), (352, 1), (384, 3), (512, 2), (544, 1), (640, 3),
                                  (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 8), (1024, 9), (1536, 1), (256, 30), (512, 9), (256, 20), (512, 40)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
-    """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernel (M <= 1024, every block count and both
-    latent-per-XCD packings) and the rocSOLVER route (M = 1536) satisfy the same identities: U'U = (I+G)^-1,
+    """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernels (M <= 1024: every block count, both
+    latent-per-XCD packings, nine latents at M = 1024 in two launches of the pipeline) and the rocSOLVER route (M = 1536, and 544:
+    not a multiple of 128 beyond 512) satisfy the same identities: U'U = (I+G)^-1,
     U'v = (I+G)^-1 (g + eta0), log det."""
     import ctypes as C
 
@@ -825,7 +866,7 @@ def test_gaussian_factor_reports_indefinite_matrix(A, ctx, M, first_bad):
     import ctypes as C
 
     d = np.zeros(M)
-    d[first_bad:] = -2.0  # I + G = diag(1, ..., 1, -1, ..., -1): either block of the two-block form must report it
+    d[first_bad:] = -2.0  # I + G = diag(1, ..., 1, -1, ..., -1): whichever block step meets the first bad pivot must report it
     G = np.diag(d)[None]
     dG, dg = dev(G), dev(np.zeros((1, M)))
     Aw = torch.empty((1, M, M), dtype=torch.float64, device="cuda")

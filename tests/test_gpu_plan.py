@@ -199,7 +199,10 @@ def test_elbo_tracking_is_refused_where_the_reference_defines_no_terms(A):
 def test_plan_argument_and_domain_errors(A):
     ctx = A.Context(0, seed=4)
     lib = A._ffi.lib()
-    assert lib.agpl_plan_bytes(C.c_int64(1000), C.c_int32(384), C.c_int32(1), C.c_uint32(0)) == 0  # M % 256 != 0
+    # any feature count (round 6): the plan pads to the next multiple of 256 itself -- a padded count costs only the staging copies
+    b384, b512 = (lib.agpl_plan_bytes(C.c_int64(1000), C.c_int32(m), C.c_int32(1), C.c_uint32(0)) for m in (384, 512))
+    assert b512 < b384 <= b512 + 8 * (512 * 512 + 3 * 512) + 1024
+    assert lib.agpl_plan_bytes(C.c_int64(1000), C.c_int32(0), C.c_int32(1), C.c_uint32(0)) == 0
     assert lib.agpl_plan_bytes(C.c_int64(1000), C.c_int32(256), C.c_int32(65), C.c_uint32(0)) == 0
     assert 0 < lib.agpl_plan_bytes(C.c_int64(1000), C.c_int32(256), C.c_int32(1), C.c_uint32(1)) < lib.agpl_plan_bytes(
         C.c_int64(1000), C.c_int32(256), C.c_int32(1), C.c_uint32(0))  # AGPL_PLAN_NO_MARGINALS
@@ -208,8 +211,8 @@ def test_plan_argument_and_domain_errors(A):
     resid = torch.ones(N, dtype=torch.float32, device="cuda")
     h = C.c_void_p()
     p = lambda t: C.c_void_p(t.data_ptr())
-    with pytest.raises(A.ArgumentError, match="multiple of 256"):
-        ctx.call("agpl_plan_create", C.c_int64(N), C.c_int32(384), C.c_int32(1), p(Phi), p(resid), C.c_uint32(0), C.c_void_p(0), C.byref(h))
+    with pytest.raises(A.ArgumentError, match="bad sizes"):
+        ctx.call("agpl_plan_create", C.c_int64(N), C.c_int32(0), C.c_int32(1), p(Phi), p(resid), C.c_uint32(0), C.c_void_p(0), C.byref(h))
     Phi[617, 33] = float("nan")
     with pytest.raises(A.DomainError, match=r"point 617, feature 33"):
         ctx.call("agpl_plan_create", C.c_int64(N), C.c_int32(M), C.c_int32(1), p(Phi), p(resid), C.c_uint32(0), C.c_void_p(0), C.byref(h))
@@ -285,3 +288,76 @@ def test_gibbs_pass_plan_matches_oracle_on_the_image_features(A, oracle, name, M
     if name == "cat":
         assert np.array_equal(host(gib.n), pts["n"])
     assert relmax(host(gib.G), Gr) < 5e-6 and relmax(host(gib.g), gr) < 5e-6
+
+
+# ---- round 6: one fast path for every feature count -------------------------------------------------------
+def _svgp_raw(A, ctx, lik, N, M):
+    """The SVGP workload at its OWN feature count: no padding on the host (se_features / whiten_features work on a multiple of
+    128; the first M columns are the features)."""
+    _, y, Phi, kd = _svgp(A, ctx, lik, N, M, pad=128)
+    return y, Phi[:, :M].contiguous(), kd
+
+
+@pytest.mark.parametrize("name,N,M", [("bernoulli", 10_000, 64), ("bernoulli", 9_000, 200), ("negbin", 7_000, 200), ("bernoulli", 5_003, 37),
+                                      ("bernoulli", 3_000, 1280), ("bernoulli", 2_000, 2048), ("catbij", 4_000, 100)])
+def test_plan_path_at_any_feature_count_ten_sweeps(A, oracle, name, N, M):
+    """`S .= inv(Symmetric(inv(K) + Diagonal(λ)))`, `m .= S * (h + K \\ mean(fz))` (examples/bernoulli/script.jl:35-36;
+    docs/src/index.md:154-163) has no shape restriction.  Rounds 3-5 sent M % 256 != 0 to the float32-input kernels (4 x slower) unless
+    the caller zero-padded; now agpl_plan_create pads the images itself and G, g, U, v come back at the caller's M: ten CAVI sweeps
+    at M = 64 (BASELINE C1's count), 200, 37 (not a multiple of 4: ragged rows), 1280 and 2048 (beyond the one-launch
+    factorisation: the library route for the M x M update) against the oracle's float64 sweep on the same features."""
+    O = oracle
+    lik, olik = _liks(A, O)[name]
+    ctx = A.Context(0, seed=5)
+    y, Phi, kd = _svgp_raw(A, ctx, lik, N, M)
+    assert Phi.shape[1] == M
+    cavi = A.SparseCAVI(lik, Phi, kd, y, ctx=ctx)
+    assert cavi.plan is not None and cavi.plan.Mp % 256 == 0 and cavi.plan.Mp - M < 256
+    L = olik.nlatent
+    assert tuple(cavi.G.shape) == (L, M, M) and tuple(cavi.g.shape) == (L, M)
+    Phi_h, kd_h, y_h = host(Phi), host(kd.clamp_min(0)).astype(np.float64), host(y)
+    S, m = np.tile(np.eye(M), (L, 1, 1)), np.zeros((L, M))
+    for it in range(10):
+        cavi.sweep()
+        G, g = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m)
+        S, m = O.gaussian_update(G, g)
+    cavi.check()
+    assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
+    assert relmax(host(cavi.g), g) < NAT_TOL, relmax(host(cavi.g), g)
+    # q(v) in the caller's size: S = U'U, m = U'v from the leading blocks of the plan's state; beyond M the state is the identity
+    assert relmax(host(cavi.S), S) < 1e-5 and relmax(host(cavi.m), m) < 1e-5 * max(1.0, 1.0 / max(np.abs(m).max(), 1e-30)) + 1e-5
+    Mp = cavi.plan.Mp
+    if Mp != M:
+        Ufull = host(torch.triu(cavi.plan.U_colmajor))
+        assert np.array_equal(Ufull[:, M:, M:], np.tile(np.eye(Mp - M), (L, 1, 1))) and not Ufull[:, :M, M:].any()
+        assert not host(cavi.plan.v)[:, M:].any()
+    mu, var = cavi.marginals()
+    _, _, pts = O.cavi_pass(olik, Phi_h, kd_h, y_h, -S, m, want_points=True)
+    assert np.abs(host(mu).T.reshape(pts["mu"].shape) - pts["mu"]).max() < 2e-5 * max(1.0, np.abs(pts["mu"]).max())
+    assert np.abs(host(var).T.reshape(pts["var"].shape) - pts["var"]).max() < 2e-5 * max(1.0, np.abs(pts["var"]).max())
+
+
+def test_gibbs_pass_plan_at_a_ragged_feature_count(A, oracle):
+    """The Gibbs pass on a plan with M = 200 (padded to 256 inside): the caller's v, G, g are M-sized."""
+    O = oracle
+    lik, olik = A.NegativeBinomialLikelihood(15.0), O.negbinomial(15.0)
+    rng = np.random.default_rng(23)
+    N, M = 3001, 200
+    Phi = (rng.standard_normal((N, M)) * 0.15).astype(np.float32)
+    kd = rng.uniform(0.0, 0.3, size=N).astype(np.float32)
+    y = rng.poisson(4.0, size=N).astype(np.int32)
+    ctx = A.Context(0, seed=SEED)
+    gib = A.SparseGibbs(lik, torch.from_numpy(Phi).cuda(), torch.from_numpy(kd).cuda(), torch.from_numpy(y).cuda(), ctx=ctx,
+                        keep_points=True)
+    assert gib.plan is not None and gib.plan.Mp == 256 and tuple(gib.G.shape) == (1, M, M)
+    v = rng.normal(size=(1, M))
+    gib.v.copy_(torch.from_numpy(v).cuda())
+    gib.accumulate()
+    Phi_img, e = image_features(Phi)
+    Gr, gr, pts = O.gibbs_pass(olik, Phi_img.astype(np.float32), kd.astype(np.float64), y, v, seed=SEED, sweep=gib.sweep_index)
+    assert np.abs(host(gib.f) - pts["f"]).max() < 1e-12 * max(1.0, np.abs(pts["f"]).max())
+    assert np.allclose(host(gib.omega), pts["omega"], rtol=1e-9, atol=0)
+    assert relmax(host(gib.G), Gr) < 5e-6 and relmax(host(gib.g), gr) < 5e-6
+    gib.exchange()
+    gib.draw()  # v ~ N(m, S) at the caller's M
+    assert tuple(gib.v.shape) == (1, M) and torch.isfinite(gib.v).all()

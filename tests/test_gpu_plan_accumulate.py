@@ -154,15 +154,20 @@ def test_sweep_reports_a_non_finite_expected_precision(A, oracle):
         cavi.check()
 
 
-def test_plan_needs_a_padded_feature_count(A, ctx):
+def test_plan_pads_the_feature_count_itself(A, ctx):
+    """Round 6: a feature count that is not a multiple of 256 no longer falls to the float32-input kernels (4 x slower) or asks the
+    caller to zero-pad: the plan pads its images, G / g / U stay M-sized for the caller."""
     Phi = torch.zeros((10, 384), dtype=torch.float32, device="cuda")
     kd, y = torch.ones(10, device="cuda"), torch.zeros(10, dtype=torch.uint8, device="cuda")
-    with pytest.raises(A.ArgumentError):
-        A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision="f16x2-factor")
-    c = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx)  # "auto": 384 is not a multiple of 256 -> the float32 pair
-    assert c.plan is None and c.marginal_precision == "f32"
+    c = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx)  # "auto": the plan path at any feature count
+    assert c.plan is not None and c.marginal_precision == "f16x2-factor" and c.plan.Mp == 512 and c.plan.M == 384
     c.sweep()
     c.check()
+    assert tuple(c.G.shape) == (1, 384, 384) and tuple(c.S.shape) == (1, 384, 384) and tuple(c.m.shape) == (1, 384)
+    f = A.SparseCAVI(A.BernoulliLikelihood(), Phi, kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
+    assert f.plan is None  # the float32-input pair on request (feature count a multiple of 128)
+    with pytest.raises(A.ArgumentError, match="multiple of 128"):
+        A.SparseCAVI(A.BernoulliLikelihood(), Phi[:, :200].contiguous(), kd, y, ctx=ctx, marginal_precision="f32", accumulate_precision="f32")
 
 
 def test_sparse_cavi_default_path_uses_the_plan(A, ctx, oracle):

@@ -619,3 +619,21 @@ def test_conditioning_budget_of_an_unwhitened_on_the_fly_marginal_pass():
     assert err_w < 5e-6            # the shipped (whitened) operand pair
     assert err_u > 10 * err_w      # the un-whitened pair: measured 18-30x worse (|U L^-1| ~ 12 against |U| ~ 0.4)
     assert err_u > 1e-5            # i.e. at / above the bar before any accumulation error is added
+
+
+def test_pg_draw_index_beyond_sixteen_bits(oracle):
+    """polyagamma.jl:129-134 sums any integer b.  Draw j of a point keeps 16 bits of the Philox sub-stream id (j mod 65535) and, from
+    j = 65535 on, starts its block counter at (j div 65535) << 20: (i) the draws of b < 65535 are those of the round 2-5 layout (the
+    golden fixtures pin them; here: the b-th draw is the difference of consecutive sums); (ii) draw 65535 reuses the id of draw 0
+    but is NOT draw 0; (iii) the sample mean at b = 70 000 sits on b / (2c) tanh(c / 2) (polyagamma.jl:25-31); (iv) b >= 2^22 is
+    refused (NaN), as the device build refuses it."""
+    O = oracle
+    c, seed = 1.0, 5
+    s = {b: O.rand_pg(float(b), c, 4, seed=seed) for b in (1, 65534, 65535, 65536, 65537)}
+    d0, d65534, d65535, d65536 = s[1], s[65535] - s[65534], s[65536] - s[65535], s[65537] - s[65536]
+    assert (d65534 > 0).all() and (d65535 > 0).all() and (d65536 > 0).all()
+    assert not np.allclose(d65535, d0, rtol=1e-6) and not np.allclose(d65536, O.rand_pg(2.0, c, 4, seed=seed) - d0, rtol=1e-6)
+    big = O.rand_pg(70_000.0, c, 8, seed=seed)
+    mean, sd = 70_000 / (2 * c) * np.tanh(c / 2), np.sqrt(70_000 * 0.0363)  # var PG(1, 1) ~ 0.036
+    assert np.abs(big - mean).max() < 5 * sd
+    assert np.isnan(O.rand_pg(4194304.0, c, 1, seed=seed)[0]) and np.isfinite(O.rand_pg(4194303.0, 30.0, 1, seed=seed)[0])
