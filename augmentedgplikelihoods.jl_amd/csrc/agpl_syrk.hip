@@ -486,9 +486,6 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
                 acc[i][1] = mfma32(alc, bh1, acc[i][1]);
             }
             AGPL_S_HOOK(i);
-#ifdef AGPL_S_PIN
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             if (i == (DIAG ? 12 : 10)) { // the converted granules are kept aside until this step's MFMAs are through with the old ones
                 nbh0 = __builtin_bit_cast(h8, rh0);
                 nbl0 = __builtin_bit_cast(h8, rl0);
@@ -563,451 +560,16 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// syrk_quad_kernel (round 6): the same tile, image, slabs and arithmetic with ONE wave per SIMD.
-// The ISA of syrk_strip_kernel (two waves per SIMD at the 256-register cap, 8 registers spilled) showed what "bound by its
-// instruction stream" meant: the compiler sank the A-fragment reads to within four MFMAs of their use (every row block waits
-// `lgkmcnt(0)` on a read issued 64 cycles earlier), and emitted a step's 48 conversions as one block.  Here a wave owns TWO
-// column strips -- (w, 7 - w), the pair the two waves of a SIMD used to share -- i.e. 256 rows x 64 columns = 16 x 4
-// accumulators = 256 registers of a 512-register budget: every A fragment is read once per SIMD instead of twice (half the LDS
-// read traffic per MFMA), four waves meet at the step barrier instead of eight, and there is room to keep the fragments of three
-// row blocks and three sets of B granules (in use | converted for the next step | raw in flight) in registers without a spill.
-// The order of a step is pinned with sched_barrier: per 16-row block [the two A reads of block i + 3] [12 MFMAs of block i]
-// [one eighth of the step's staging: a DMA piece, or 12 of the 96 conversions]; the raw B granules of step t + 2 are requested
-// at the top of step t (a step and a half of flight), converted in place during the second half of step t + 1.
-// Same sums in the same order per accumulator as syrk_strip_kernel: G and g are bit-identical.
-// ------------------------------------------------------------------------------------------------
-constexpr int kQuadLds = kRing * kStepBytes + 4 * kRing * kRecBytes;
-#ifndef AGPL_QX_NOCVT
-#define AGPL_QX_NOCVT 0
-#endif
-
-template <bool DIAG>
-__device__ __forceinline__ void syrk_quad_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int chunk, int l,
-                                               int s, int I, int J, const unsigned char *__restrict__ image,
-                                               const float *__restrict__ gb_all, const unsigned *__restrict__ scal,
-                                               float *__restrict__ slabG, float *__restrict__ slabg) {
-    typedef __attribute__((address_space(3))) void lds_void;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0..3
-    const int nb = M / BS;
-    const int c0 = wave, c1 = 7 - wave;                       // the wave's two strips
-    const int i00 = DIAG ? 2 * c0 : 0, i01 = DIAG ? 2 * c1 : 0; // first needed 16-row block of each (diagonal tiles)
-    const AccImageHeader *hdr = reinterpret_cast<const AccImageHeader *>(image);
-    const h8 *blocks = reinterpret_cast<const h8 *>(image + sizeof(AccImageHeader));
-    const int eA = hdr->scale_exp;
-    const int eB = acc_scale_exp(scal[0]);
-    const float sB = __uint_as_float((unsigned)(127 + eB) << 23);
-
-    const int64_t nbeg = (int64_t)s * chunk;
-    int64_t nend = nbeg + chunk;
-    if (nend > N) nend = N;
-    const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
-    const int nstep2 = (nstep + 1) & ~1; // the loop runs two steps per iteration: an odd count gets one more step whose gamma reads as zero
-    const int64_t ps0 = nbeg / 16;
-    const int64_t slice_pitch = (int64_t)nb * 2 * 256;
-
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int kg = ln >> 4, lr = ln & 15;
-    const h8 *a_src = blocks + ((ps0 * nb + 2 * I) * 2) * 256 + wave * 64 + lane;
-    const int a_dst = wave * 1024;
-    const int R00 = 32 * c0 + lr, R01 = 32 * c1 + lr;
-    const h8 *b_src0 = blocks + (((ps0 + (kg >> 1)) * nb + 2 * J + (R00 >> 7)) * 2) * 256 + (kg & 1) * 128 + (R00 & 127);
-    const h8 *b_src1 = blocks + (((ps0 + (kg >> 1)) * nb + 2 * J + (R01 >> 7)) * 2) * 256 + (kg & 1) * 128 + (R01 & 127);
-    const float *gb_src = gb_all + ((int64_t)l * (Npad / 32) + nbeg / 32) * 64 + lane;
-    float *gbuf = reinterpret_cast<float *>(smem_raw + kRing * kStepBytes + wave * kRing * kRecBytes);
-
-    f32x4 acc[16][4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (an "a"-constrained operand anywhere in the function makes the compiler select the MFMAs with their accumulators in the AGPR half
-    //  of the 512-register file; without it they are selected in VGPR form, the 256 accumulator registers fill the VGPR half and
-    //  everything else -- fragments, granules, addresses -- spills through AGPRs into scratch: 154 registers in the first build)
-    asm volatile("" : "+a"(acc[0][0]));
-    float gacc[4] = {0.f, 0.f, 0.f, 0.f};
-    // B granules (hi, lo of the four column blocks): two fragment sets F0 / F1 (in use in even / odd steps; the conversion writes
-    // the other one) and two raw sets Na / Nb (requested in even / odd steps)
-    // (the fragment sets as dwords: the conversion writes them one dword at a time; an MFMA takes four of them as its B operand)
-    unsigned f0h[4][4], f0l[4][4], f1h[4][4], f1l[4][4];
-    u32x4 nah[4], nal[4], nbh[4], nbl[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        nah[j] = nal[j] = nbh[j] = nbl[j] = u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) f0h[j][w] = f0l[j][w] = f1h[j][w] = f1l[j][w] = 0u;
-    }
-
-    // step index for addresses: the extra step of an odd slice re-reads the last one (its gamma reads as zero)
-#define AGPL_Q_TC(t_) ((t_) < nstep ? (t_) : nstep - 1)
-#define AGPL_Q_DMA(t_, k_) /* piece k_ = 0..7 of step t_: (128-row block k_ >> 2, slice (k_ >> 1) & 1, hi / lo k_ & 1) */ \
-    do {                                                                                                        \
-        unsigned char *d_ = smem_raw + ((t_) & (kRing - 1)) * kStepBytes + (((k_) >> 1) & 1) * 16384 + ((k_) >> 2) * 8192 +  \
-                            a_dst + ((k_) & 1) * 4096;                                                          \
-        const h8 *src_ = a_src + (int64_t)(2 * AGPL_PROBE_T(AGPL_Q_TC(t_)) + (((k_) >> 1) & 1)) * slice_pitch + ((k_) >> 2) * 512 + \
-                         ((k_) & 1) * 256;                                                                      \
-        if (AGPL_PROBE_LOAD(t_)) __builtin_amdgcn_global_load_lds(src_, (lds_void *)d_, 16, 0, 0);              \
-    } while (0)
-#define AGPL_Q_DMAG(t_)                                                                                         \
-    if (AGPL_PROBE_LOAD(t_))                                                                                    \
-    __builtin_amdgcn_global_load_lds(gb_src + (int64_t)AGPL_Q_TC(t_) * 64, (lds_void *)(gbuf + ((t_) & (kRing - 1)) * 64), 4, 0, 0)
-#define AGPL_Q_LOADB(t_, H_, L_)                                                                                \
-    do {                                                                                                        \
-        const h8 *s0_ = b_src0 + (int64_t)(2 * AGPL_PROBE_T(AGPL_Q_TC(t_))) * slice_pitch, *s0l_ = s0_ + 256;   \
-        const h8 *s1_ = b_src1 + (int64_t)(2 * AGPL_PROBE_T(AGPL_Q_TC(t_))) * slice_pitch, *s1l_ = s1_ + 256;   \
-        if (AGPL_PROBE_LOAD(t_)) {                                                                              \
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"               \
-                         "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256" \
-                         : "+v"(H_[0]), "+v"(L_[0]), "+v"(H_[1]), "+v"(L_[1])                                   \
-                         : "v"(s0_), "v"(s0l_)                                                                  \
-                         : "memory");                                                                           \
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"               \
-                         "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %5, off offset:256" \
-                         : "+v"(H_[2]), "+v"(L_[2]), "+v"(H_[3]), "+v"(L_[3])                                   \
-                         : "v"(s1_), "v"(s1l_)                                                                  \
-                         : "memory");                                                                           \
-        }                                                                                                       \
-    } while (0)
-    const int fa = (kg >> 1) * 1024 + (kg & 1) * 128 + lr;
-#define AGPL_Q_AOFF(i_) (fa + ((i_) >> 3) * 512 + ((i_) & 7) * 16)
-#define AGPL_Q_LDSB(t_, H_, L_)                                                                                 \
-    do {                                                                                                        \
-        const u32x4 *sn_ = reinterpret_cast<const u32x4 *>(smem_raw + ((t_) & (kRing - 1)) * kStepBytes);       \
-        H_[0] = sn_[AGPL_Q_AOFF(2 * c0)];                                                                       \
-        L_[0] = sn_[256 + AGPL_Q_AOFF(2 * c0)];                                                                 \
-        H_[1] = sn_[AGPL_Q_AOFF(2 * c0 + 1)];                                                                   \
-        L_[1] = sn_[256 + AGPL_Q_AOFF(2 * c0 + 1)];                                                             \
-        H_[2] = sn_[AGPL_Q_AOFF(2 * c1)];                                                                       \
-        L_[2] = sn_[256 + AGPL_Q_AOFF(2 * c1)];                                                                 \
-        H_[3] = sn_[AGPL_Q_AOFF(2 * c1 + 1)];                                                                   \
-        L_[3] = sn_[256 + AGPL_Q_AOFF(2 * c1 + 1)];                                                             \
-    } while (0)
-    // The conversion of two points' granule words (RH_, RL_: one dword of the raw hi / lo granule = two halves) of column block j_
-    // into the fragment words (OH_, OL_), in slices of at most two VALU instructions -- one slice goes behind each MFMA (a single wave
-    // issues in order: work placed behind a row block's twelve MFMAs runs with the matrix pipe idle, work placed BETWEEN them rides in
-    // the eight issue cycles an MFMA leaves free).  x0, x1: the rebuilt float32 features (exact); g0_, g1_: the points' scaled gamma.
-#define AGPL_Q_JOIN(RH_, RL_) AGPL_Q_JOIN2(RH_, RL_, cx0, cx1)
-#define AGPL_Q_GF(j_, b0_, b1_)                                                                                 \
-    do {                                                                                                        \
-        if (DIAG) {                                                                                             \
-            AGPL_E_GFMA(gacc[j_], b0_, cx0);                                                                    \
-            AGPL_E_GFMA(gacc[j_], b1_, cx1);                                                                    \
-        }                                                                                                       \
-    } while (0)
-#define AGPL_Q_SPLITH(g0_, g1_, OH_)                                                                            \
-    do {                                                                                                        \
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(OH_) : "v"(cx0), "v"(g0_));                                  \
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(OH_) : "v"(cx1), "v"(g1_));                                  \
-    } while (0)
-#define AGPL_Q_SPLITL(g0_, g1_, OH_, OL_)                                                                       \
-    do {                                                                                                        \
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(OL_) : "v"(cx0), "v"(g0_), "v"(OH_));    \
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(OL_) : "v"(cx1), "v"(g1_), "v"(OH_)); \
-    } while (0)
-    // slice m_ (0..11) of conversion eighth e_ (q = (e_ >> 2) & 1: points 4 q .. 4 q + 3 of the lane's k-group; j = e_ & 3: column
-    // block) of the raw set (RH_, RL_) of step tt_ into the fragment set (OH_, OL_)
-#define AGPL_Q_WORD(V_, q_, w_) ((q_) == 0 ? ((w_) == 0 ? V_.x : V_.y) : ((w_) == 0 ? V_.z : V_.w))
-    // LDS reads of the step loop are inline asm and their waits are written out (AGPL_Q_LGKM): the compiler's own waits in front of
-    // the MFMAs were `lgkmcnt(0)` -- every row block waited for the two fragment reads it had just issued for a row block three
-    // further on, ~120 cycles with the matrix pipe idle per 192 cycles of MFMAs (probe builds: without operand loads and without
-    // conversions the loop still ran at 46 % of the pipe's rate).  LDS returns in order: a wait for "all but the N youngest" is
-    // exact when N counts every LDS operation issued behind the wanted one; operations this count does not know (the compiler's
-    // own reads) only make a wait stricter.
-#define AGPL_Q_CVTREAD(e_, tt_) /* gamma (and, on a diagonal tile, beta) of the four points of eighth e_: 1 (2) LDS operations */ \
-    do {                                                                                                        \
-        const unsigned ga_ = gaddr + (unsigned)(((tt_) & (kRing - 1)) * 256 + 16 * (((e_) >> 2) & 1));          \
-        if (DIAG) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:128" : "=&v"(cg4), "=&v"(cb4) : "v"(ga_)); \
-        else asm volatile("ds_read_b128 %0, %1" : "=v"(cg4) : "v"(ga_));                                         \
-    } while (0)
-#define AGPL_Q_CVTS(m_, e_, tt_, zero_, RH_, RL_, OH_, OL_)                                                     \
-    do {                                                                                                        \
-        const int q_ = ((e_) >> 2) & 1, j_ = (e_) & 3;                                                          \
-        if ((m_) == 0) {                                                                                        \
-            const float sc_ = (zero_) ? 0.f : sB;                                                               \
-            cg4[0] *= sc_, cg4[1] *= sc_;                                                                         \
-        }                                                                                                       \
-        if ((m_) == 1) {                                                                                        \
-            const float sc_ = (zero_) ? 0.f : sB;                                                               \
-            cg4[2] *= sc_, cg4[3] *= sc_;                                                                         \
-            if (DIAG && (zero_)) cb4 = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
-        }                                                                                                       \
-        if ((m_) == 2) AGPL_Q_JOIN(AGPL_Q_WORD(RH_[j_], q_, 0), AGPL_Q_WORD(RL_[j_], q_, 0));                   \
-        if ((m_) == 3) {                                                                                        \
-            AGPL_Q_GF(j_, cb4[0], cb4[1]);                                                                        \
-            AGPL_Q_SPLITH(cg4[0], cg4[1], OH_[j_][2 * q_]);                                                       \
-        }                                                                                                       \
-        if ((m_) == 4) AGPL_Q_SPLITL(cg4[0], cg4[1], OH_[j_][2 * q_], OL_[j_][2 * q_]);                           \
-        if ((m_) == 5) AGPL_Q_JOIN(AGPL_Q_WORD(RH_[j_], q_, 1), AGPL_Q_WORD(RL_[j_], q_, 1));                   \
-        if ((m_) == 6) {                                                                                        \
-            AGPL_Q_GF(j_, cb4[2], cb4[3]);                                                                        \
-            AGPL_Q_SPLITH(cg4[2], cg4[3], OH_[j_][2 * q_ + 1]);                                                   \
-        }                                                                                                       \
-        if ((m_) == 7) AGPL_Q_SPLITL(cg4[2], cg4[3], OH_[j_][2 * q_ + 1], OL_[j_][2 * q_ + 1]);                   \
-    } while (0)
-    float cx0 = 0.f, cx1 = 0.f;
-    f32x4 cg4 = {0.f, 0.f, 0.f, 0.f}, cb4 = {0.f, 0.f, 0.f, 0.f};
-    const unsigned gaddr = (unsigned)(uintptr_t)(lds_void *)gbuf + 32u * (unsigned)kg; // this lane's gamma words of record slot 0
-    const unsigned aaddr0 = (unsigned)(uintptr_t)(lds_void *)smem_raw + 16u * (unsigned)fa; // its first A fragment of ring slot 0
-#define AGPL_Q_LGKM(n_) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n_))
-    // the two fragment reads (hi, lo) of row block i_ of the step whose ring slot starts at LDS byte address base_ (+ this lane)
-#define AGPL_Q_AREAD(S_, base_, i_)                                                                             \
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                \
-                 : "=&v"(af[S_][0]), "=&v"(af[S_][1])                                                           \
-                 : "v"(base_), "i"(((i_) >> 3) * 8192 + ((i_) & 7) * 256), "i"(((i_) >> 3) * 8192 + ((i_) & 7) * 256 + 4096))
-
-    // ---- prologue: records and A of steps 0..2; B of step 0 converted into F0; off the diagonal B of step 1 in flight (Nb)
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (t < nstep2) {
-            AGPL_Q_DMAG(t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) AGPL_Q_DMA(t, k);
-        }
-    if (!DIAG) AGPL_Q_LOADB(0, nah, nal);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier(); // every wave's pieces of steps 0..2 are in LDS
-    if (DIAG) AGPL_Q_LDSB(0, nah, nal);
-#define AGPL_Q_CVTALL(e_, tt_, zero_, RH_, RL_, OH_, OL_)                                                       \
-    do {                                                                                                        \
-        AGPL_Q_CVTREAD(e_, tt_);                                                                                \
-        AGPL_Q_LGKM(0);                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        AGPL_Q_CVTS(0, e_, tt_, zero_, RH_, RL_, OH_, OL_); AGPL_Q_CVTS(1, e_, tt_, zero_, RH_, RL_, OH_, OL_);  \
-        AGPL_Q_CVTS(2, e_, tt_, zero_, RH_, RL_, OH_, OL_); AGPL_Q_CVTS(3, e_, tt_, zero_, RH_, RL_, OH_, OL_);  \
-        AGPL_Q_CVTS(4, e_, tt_, zero_, RH_, RL_, OH_, OL_); AGPL_Q_CVTS(5, e_, tt_, zero_, RH_, RL_, OH_, OL_);  \
-        AGPL_Q_CVTS(6, e_, tt_, zero_, RH_, RL_, OH_, OL_); AGPL_Q_CVTS(7, e_, tt_, zero_, RH_, RL_, OH_, OL_);  \
-    } while (0)
-    AGPL_Q_CVTALL(0, 0, false, nah, nal, f0h, f0l); AGPL_Q_CVTALL(1, 0, false, nah, nal, f0h, f0l);
-    AGPL_Q_CVTALL(2, 0, false, nah, nal, f0h, f0l); AGPL_Q_CVTALL(3, 0, false, nah, nal, f0h, f0l);
-    AGPL_Q_CVTALL(4, 0, false, nah, nal, f0h, f0l); AGPL_Q_CVTALL(5, 0, false, nah, nal, f0h, f0l);
-    AGPL_Q_CVTALL(6, 0, false, nah, nal, f0h, f0l); AGPL_Q_CVTALL(7, 0, false, nah, nal, f0h, f0l);
-    if (!DIAG) AGPL_Q_LOADB(1, nbh, nbl);
-
-    // The A fragments run kPre = 3 row blocks ahead of their MFMAs ACROSS the step boundary: behind a step's barrier every wave's
-    // pieces of the NEXT step are in LDS as well (each wave waited for its own at hook 7 of the previous step -- hook 6 of this one on
-    // a diagonal tile -- and has passed a barrier since), so row blocks 0..2 of step t + 1 are requested behind row blocks 13..15 of
-    // step t and are in registers when the barrier opens (16 row blocks = 4 rotations of the 4 fragment slots).
-    constexpr int kPre = 3;
-    h8 af[kPre + 1][2];
-    AGPL_Q_AREAD(0, aaddr0, 0);
-    AGPL_Q_AREAD(1, aaddr0, 1);
-    AGPL_Q_AREAD(2, aaddr0, 2);
-    AGPL_Q_LGKM(0); // (the loop's counted waits assume a steady state: everything requested so far is in)
-    __builtin_amdgcn_sched_barrier(0);
-
-    // One step.  (UH_, UL_): the fragments in use; (OH_, OL_): the other fragment set, written by this step's conversion of
-    // (CH_, CL_) = the raw granules of step t + 1; (LH_, LL_): the raw set the granules of step t + 2 are requested into.
-    // Staging work by row block h, in slices behind the block's MFMAs (AGPL_Q_FILL):
-    //   off the diagonal   0..7   one DMA piece of step t + 3 each (0: its record as well)
-    //                      7      (end) wait for everything but those 9: the raw granules of step t + 1 (requested at row block 8 of
-    //                             the previous step) and the A pieces of step t + 2 have landed
-    //                      8      (end) the raw granules of step t + 2 (8 loads: 15/16 of a step of flight)
-    //                      8..15  one eighth of the conversion of step t + 1's granules each
-    //   diagonal tile      6      (end) wait for this wave's pieces of step t + 1, the step's ONE barrier, raw granules from LDS
-    //                      8..15  one DMA piece of step t + 3 (8: its record as well) and one eighth of the conversion each
-#define AGPL_Q_FILL(i_, m_, t_, zero_, CH_, CL_, OH_, OL_)                                                      \
-    do {                                                                                                        \
-        if (!DIAG) {                                                                                            \
-            if ((i_) < 8 && (m_) == 5 && (t_) + 3 < nstep2) {                                                   \
-                if ((i_) == 0) AGPL_Q_DMAG((t_) + 3);                                                           \
-                AGPL_Q_DMA((t_) + 3, (i_));                                                                     \
-            }                                                                                                   \
-        } else {                                                                                                \
-            if ((i_) >= 8 && (m_) == 9 && (t_) + 3 < nstep2) {                                                  \
-                if ((i_) == 8) AGPL_Q_DMAG((t_) + 3);                                                           \
-                AGPL_Q_DMA((t_) + 3, (i_) - 8);                                                                 \
-            }                                                                                                   \
-        }                                                                                                       \
-        /* gamma of the next row block's eighth is requested behind this row block's last but one MFMA */     \
-        if ((i_) >= 7 && (i_) < 15 && (m_) == 10 && !AGPL_QX_NOCVT) AGPL_Q_CVTREAD((i_) - 7, (t_) + 1);         \
-        if ((i_) >= 8 && !AGPL_QX_NOCVT) AGPL_Q_CVTS(m_, (i_) - 8, (t_) + 1, zero_, CH_, CL_, OH_, OL_);        \
-    } while (0)
-#define AGPL_Q_MF(i_, m_, on_, A_, B_, j_, t_, zero_, CH_, CL_, OH_, OL_)                                       \
-    do {                                                                                                        \
-        if ((m_) == 0 && (i_) >= 8 && !AGPL_QX_NOCVT) { /* this row block's gamma: behind it only the two fragment reads just issued */ \
-            AGPL_Q_LGKM(2);                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-        }                                                                                                       \
-        if (on_) acc[i_][j_] = mfma32(A_, __builtin_bit_cast(h8, u32x4{B_[j_][0], B_[j_][1], B_[j_][2], B_[j_][3]}), acc[i_][j_]); \
-        AGPL_Q_FILL(i_, m_, t_, zero_, CH_, CL_, OH_, OL_);                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    } while (0)
-    // LDS operations a row block k issues behind its fragment reads: the gamma (+ beta) read of the next row block's conversion
-#define AGPL_Q_NG(k_) ((((k_) & 15) >= 7 && ((k_) & 15) <= 14 && !AGPL_QX_NOCVT) ? (DIAG ? 2 : 1) : 0)
-#define AGPL_Q_ROW(i_, t_, zero_, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_)                                       \
-    do {                                                                                                        \
-        /* fragments of row block i + 3 (of the next step from row block 13 on: behind the last step stale bytes, unused) */ \
-        if ((i_) + kPre < 16) AGPL_Q_AREAD(((i_) + kPre) % (kPre + 1), abase, (i_) + kPre);                     \
-        else AGPL_Q_AREAD(((i_) + kPre) % (kPre + 1), abasen, (i_) + kPre - 16);                                \
-        /* this row block's own: behind them the reads of three row blocks (6) and the gamma reads of row blocks i - 3 .. i - 1 */ \
-        AGPL_Q_LGKM(6 + AGPL_Q_NG((i_) + 13) + AGPL_Q_NG((i_) + 14) + AGPL_Q_NG((i_) + 15));                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        const h8 ahc = af[(i_) % (kPre + 1)][0], alc = af[(i_) % (kPre + 1)][1];                                \
-        const bool on0 = !DIAG || (i_) >= i00, on1 = !DIAG || (i_) >= i01;                                      \
-        AGPL_Q_MF(i_, 0, on0, ahc, UH_, 0, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 1, on0, ahc, UH_, 1, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 2, on1, ahc, UH_, 2, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 3, on1, ahc, UH_, 3, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 4, on0, ahc, UL_, 0, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 5, on0, ahc, UL_, 1, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 6, on1, ahc, UL_, 2, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 7, on1, ahc, UL_, 3, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 8, on0, alc, UH_, 0, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 9, on0, alc, UH_, 1, t_, zero_, CH_, CL_, OH_, OL_);                                      \
-        AGPL_Q_MF(i_, 10, on1, alc, UH_, 2, t_, zero_, CH_, CL_, OH_, OL_);                                     \
-        AGPL_Q_MF(i_, 11, on1, alc, UH_, 3, t_, zero_, CH_, CL_, OH_, OL_);                                     \
-        if (!DIAG) {                                                                                            \
-            if ((i_) == 7) {                                                                                    \
-                if ((t_) + 3 < nstep2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                         \
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
-            }                                                                                                   \
-            if ((i_) == 8) AGPL_Q_LOADB((t_) + 2, LH_, LL_); /* unconditional (clamped: the last steps re-load the last one) */ \
-        } else if ((i_) == 6) {                                                                                 \
-            if ((t_) + 2 < nstep2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                             \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
-            __builtin_amdgcn_s_barrier();                                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-            AGPL_Q_LDSB((t_) + 1, CH_, CL_); /* (behind the last step: stale bytes of the ring, finite, scaled by zero) */ \
-        }                                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    } while (0)
-#define AGPL_Q_STEP(T_, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_)                                                 \
-    do {                                                                                                        \
-        const int t = (T_);                                                                                     \
-        /* the WAR barrier of slot (t + 3) & 3 = (t - 1) & 3: every wave is through with step t - 1 before anyone's piece of t + 3 */ \
-        if (!DIAG && t > 0) __builtin_amdgcn_s_barrier();                                                       \
-        const bool zero = t + 1 >= nstep; /* the granules converted in this step belong to a step beyond the slice: gamma = 0 */ \
-        const unsigned abase = aaddr0 + (unsigned)((t & (kRing - 1)) * kStepBytes);                             \
-        const unsigned abasen = aaddr0 + (unsigned)(((t + 1) & (kRing - 1)) * kStepBytes);                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        AGPL_Q_ROW(0, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(1, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(2, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(3, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(4, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(5, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(6, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(7, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(8, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(9, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                         \
-        AGPL_Q_ROW(10, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-        AGPL_Q_ROW(11, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-        AGPL_Q_ROW(12, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-        AGPL_Q_ROW(13, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-        AGPL_Q_ROW(14, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-        AGPL_Q_ROW(15, t, zero, UH_, UL_, OH_, OL_, CH_, CL_, LH_, LL_);                                        \
-    } while (0)
-
-    // two steps per iteration: even steps multiply F0 and convert into F1, odd steps the reverse; the raw sets alternate likewise
-    for (int t2 = 0; t2 < nstep2; t2 += 2) {
-        AGPL_Q_STEP(t2, f0h, f0l, f1h, f1l, nbh, nbl, nah, nal);
-        AGPL_Q_STEP(t2 + 1, f1h, f1l, f0h, f0l, nah, nal, nbh, nbl);
-    }
-    // the clamped loads of the last steps land in registers that must not look dead (and be reused) while they are in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(nah[j]), "v"(nal[j]), "v"(nbh[j]), "v"(nbl[j]));
-#undef AGPL_Q_STEP
-#undef AGPL_Q_ROW
-#undef AGPL_Q_NG
-#undef AGPL_Q_MF
-#undef AGPL_Q_AREAD
-#undef AGPL_Q_LGKM
-#undef AGPL_Q_FILL
-#undef AGPL_Q_CVTALL
-#undef AGPL_Q_CVTS
-#undef AGPL_Q_CVTREAD
-#undef AGPL_Q_WORD
-#undef AGPL_Q_SPLITL
-#undef AGPL_Q_SPLITH
-#undef AGPL_Q_GF
-#undef AGPL_Q_JOIN
-#undef AGPL_Q_DMA
-#undef AGPL_Q_DMAG
-#undef AGPL_Q_LOADB
-#undef AGPL_Q_LDSB
-#undef AGPL_Q_AOFF
-#undef AGPL_Q_TC
-
-    // ---- slabs (the layout of syrk_strip_body): strip c0 = wave lies in the 128-column block 2 J, strip c1 = 7 - wave in 2 J + 1
-    const float unscale = __uint_as_float((unsigned)(127 - (2 * eA + eB)) << 23);
-    const int npairs = nb * (nb + 1) / 2;
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-        const int c = sp ? c1 : c0;
-        const int bj = 2 * J + sp;
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int bi = 2 * I + hb;
-            if (DIAG && bi < bj) continue; // the 128 x 128 block above the diagonal is never read back
-            const int p128 = bi * (bi + 1) / 2 + bj;
-            float *slab = slabG + (((int64_t)l * npairs + p128) * nsplit + s) * (int64_t)(BS * BS);
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * ii + 4 * kg + r;
-                        const int col = (c & 3) * 32 + 16 * cb + lr;
-                        slab[row * BS + col] = acc[8 * hb + ii][2 * sp + cb][r] * unscale;
-                    }
-        }
-    }
-    if (DIAG) {
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const int c = sp ? c1 : c0;
-            float ga = gacc[2 * sp], gb1 = gacc[2 * sp + 1];
-            ga += __shfl_xor(ga, 16);
-            ga += __shfl_xor(ga, 32);
-            gb1 += __shfl_xor(gb1, 16);
-            gb1 += __shfl_xor(gb1, 32);
-            const float g1s = __shfl(gb1, (lane - 16) & 63);
-            if (lane < 32) {
-                const int rr = 32 * c + lane;
-                slabg[(((int64_t)l * nb + 2 * I + (rr >> 7)) * nsplit + s) * BS + (rr & 127)] =
-                    (lane < 16 ? ga : g1s) * __uint_as_float((unsigned)(127 - eA) << 23);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void syrk_quad_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
-                                                           const unsigned char *__restrict__ image,
-                                                           const float *__restrict__ gb_all,
-                                                           const unsigned *__restrict__ scal,
-                                                           float *__restrict__ slabG, float *__restrict__ slabg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int nsplit8 = (nsplit + 7) / 8;
-    const int per_l = npairs2 * nsplit8 * 8;
-    const int l = blockIdx.x / per_l;
-    const int id = blockIdx.x - l * per_l;
-    const int xcd = id & 7, jj = id >> 3;
-    const int s = (jj / npairs2) * 8 + xcd;
-    const int p2 = jj % npairs2;
-    if (s >= nsplit) return;
-    const int nb2 = M / kPanel;
-    const int noff = nb2 * (nb2 - 1) / 2;
-    int I, J;
-    if (p2 < noff) {
-        I = 1;
-        while ((I + 1) * I / 2 <= p2) ++I;
-        J = p2 - I * (I - 1) / 2;
-    } else {
-        I = J = p2 - noff;
-    }
-#if defined(AGPL_QX_ONLY) && AGPL_QX_ONLY == 0
-    syrk_quad_body<false>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
-#elif defined(AGPL_QX_ONLY) && AGPL_QX_ONLY == 1
-    syrk_quad_body<true>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
-#else
-    if (I == J) syrk_quad_body<true>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
-    else syrk_quad_body<false>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
-#endif
-}
-
+// Round 6 built one complete alternative to this kernel and removed it again -- record: profiles/NOTES_r06.md,
+// profiles/r06_ab_syrk_quad.jsonl, commit "syrk_quad_kernel v3".  syrk_quad_kernel: ONE wave per SIMD owning the two strips (w, 7 - w)
+// the two waves of a SIMD share here (256 x 64 = 256 accumulator registers in AGPRs; every A fragment read once per SIMD; fragments
+// three row blocks ahead across the step boundary; the step's conversions and DMA issue cut into <= 2-instruction slices behind
+// each MFMA; LDS reads by inline asm with counted waits).  G and g bit-identical; 10.3 ms against 6.5 ms at C2, 16.2 against 10.7 at
+// N = 5e6, M = 1024.  Its bare probe (no operand loads, no conversions: MFMAs + fragment reads + barrier, a near-ideal instruction
+// stream) still took 7.7 ms = 2.1 x the matrix-pipe floor: one wave per SIMD does not issue v_mfma_f32_16x16x32_f16 back to back on
+// this device -- the second wave of a SIMD is what fills the pipe, whatever the first one's stream looks like.  Pinning the order
+// of THIS kernel's row blocks with sched_barrier (the compiler sinks the fragment reads to within four MFMAs of their use) is worth
+// 0-1 % (profiles/r06_ab_syrk_pinned.jsonl): with two waves per SIMD the partner covers it.
 __global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
                                                             const unsigned char *__restrict__ image,
                                                             const float *__restrict__ gb_all,
@@ -1160,18 +722,8 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
         ctx->strip_attr = 1;
     }
-#ifdef AGPL_SYRK_QUAD
-    if (ctx->strip_attr != 2) {
-        AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_quad_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kQuadLds));
-        ctx->strip_attr = 2;
-    }
-    syrk_quad_kernel<<<(unsigned)nwg, 256, kQuadLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
-                                                                   scal, slabG, slabg);
-#else
     syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
                                                                      scal, slabG, slabg);
-#endif
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }
