@@ -626,6 +626,16 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     }
 }
 
+// Round 6 built the alternative the round-5 analysis called for and removed it again -- record:
+// profiles/NOTES_r06.md section 2, profiles/r06_ab_marginal_pair.jsonl, commit "marginal_factor_pair_kernel".  Same items, queues,
+// images, ring and arithmetic with 8 waves of 224 registers (two per SIMD) instead of 16 of 128: a wave owned 128 rows x 64 points
+// (8 x 4 accumulators), the two waves of a SIMD took the item's 16-row blocks alternately so that both kept the same share of the
+// diagonal block's shrinking work to the item's last stage, B fragments held for the stage, A fragments two row blocks ahead by
+// inline asm with counted waits.  Ten-sweep parity and bitwise-repeat tests green; 7.03-7.09 ms against 5.89-5.99 at C2, 11.58
+// against 9.75 at N = 5e6, M = 1024 (+ 19 % at both): fewer, fatter waves issue MFMAs at a lower rate on this device (the quad
+// accumulation experiment: one wave per SIMD reaches half the pipe's rate) -- the four waves per SIMD of this kernel are what keeps
+// the pipe at 58 %, and the diagonal stages' idle waves cost less than halving the wave count does.
+
 // var_n = resid_n + sum_rb qpart[rb][l][n], mu_n = mu0_n + sum_rb mpart[rb][l][n]  (row blocks in ascending order)
 __global__ __launch_bounds__(256) void marginal_combine_kernel(int64_t N, int L, int nb2, const float *__restrict__ resid,
                                                                const float *__restrict__ mu0,

@@ -325,7 +325,9 @@ def test_plan_path_at_any_feature_count_ten_sweeps(A, oracle, name, N, M):
     assert relmax(host(cavi.G), G) < NAT_TOL, relmax(host(cavi.G), G)
     assert relmax(host(cavi.g), g) < NAT_TOL, relmax(host(cavi.g), g)
     # q(v) in the caller's size: S = U'U, m = U'v from the leading blocks of the plan's state; beyond M the state is the identity
-    assert relmax(host(cavi.S), S) < 1e-5 and relmax(host(cavi.m), m) < 1e-5 * max(1.0, 1.0 / max(np.abs(m).max(), 1e-30)) + 1e-5
+    # (the M x M solve amplifies the natural-parameter difference by cond(I + G): the bar of test_cavi_factor_form_matches_oracle)
+    kappa = max(np.linalg.cond(np.eye(M) + G[l]) for l in range(L))
+    assert relmax(host(cavi.S), S) < max(1e-4, NAT_TOL * kappa) and relmax(host(cavi.m), m) < max(1e-4, NAT_TOL * kappa)
     Mp = cavi.plan.Mp
     if Mp != M:
         Ufull = host(torch.triu(cavi.plan.U_colmajor))
