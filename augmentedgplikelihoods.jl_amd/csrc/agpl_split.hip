@@ -213,8 +213,8 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
     // route that does not forward it (M > 1024: library factorisation) must not leave a stale flag for a later problem
     if (zero2 && blockIdx.x == 0 && threadIdx.x == 2) queues[8] = 0u;
     constexpr int kSlot = KU * 8 * 4096;
-    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][M] floats (v of the item, by item parity)
-    float *qred = alpha_s + 2 * M;                                     // [2][4 x 256] by item parity
+    float *alpha_s = reinterpret_cast<float *>(smem_raw + R * kSlot); // [2][256] floats (v of the item's 256-row block, by item parity)
+    float *qred = alpha_s + 2 * NT2;                                   // [2][4 x 256] by item parity
     float *mred = qred + 2 * 4 * NT2;                                  // [2][4 x 256]
     int *qi = reinterpret_cast<int *>(mred + 2 * 4 * NT2);             // [4][4] this workgroup's items, decoded
 
@@ -434,11 +434,12 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             if (threadIdx.x == 0) AGPL_Q_STORE(ck + 1, fetched);
             fetch_pending = false;
         }
-        if (ks == 0 && wave < M / NT2) {
-            // first stage of an item: v of its latent into the item's parity buffer, 1 KB per wave by the DMA path (in LDS behind
-            // the next barrier; first read at the end of the item's second stage)
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(v_all + (int64_t)cl * M + wave * NT2) + lane_v,
-                                             (lds_void *)(alpha_s + (ck & 1) * M + wave * NT2), 16, 0, 0);
+        if (ks == 0 && wave == 0) {
+            // first stage of an item: the 256 entries of v that belong to the item's row block into the item's parity buffer, one
+            // 1 KB piece by the DMA path (in LDS behind the next barrier; first read at the end of the item's second stage).
+            // (Rounds 4-5 kept all M entries: 8 M bytes of LDS, which put M >= 2048 beyond the 160 KB of a CU -- round 6.)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(v_all + (int64_t)cl * M + rb * NT2) + lane_v,
+                                             (lds_void *)(alpha_s + (ck & 1) * NT2), 16, 0, 0);
         }
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(1024, 1) void marginal_factor_queue_kernel(
             // row groups 0..2: in their first idle stage of the item's diagonal block (their rows are complete); row group 3: behind
             // its (= the item's) last stage
             const int s_idle = ks - (rb * 16 + 4 * (wr + 1));
-            const float *vrow = alpha_s + (ck & 1) * M + rb * NT2 + wr * 64 + 4 * kg;
+            const float *vrow = alpha_s + (ck & 1) * NT2 + wr * 64 + 4 * kg;
             float *qr = qred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64, *mr = mred + (ck & 1) * 4 * NT2 + wr * NT2 + wc * 64;
             constexpr bool kNoSums = AGPL_MPROBE == 4;
             if (wr < 3 ? s_idle == 0 : ks + KU == 16 * (rb + 1)) {
@@ -793,7 +794,7 @@ int32_t agpl_marginals_factor_parts(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
     if (rc) return rc;
     float *qpart = (float *)ctx->ws, *mpart = (float *)((char *)ctx->ws + ((part_bytes + 255) & ~(size_t)255));
     unsigned *queues = (unsigned *)((char *)ctx->ws2 + 8192); // zero between launches (agpl_ws2_reserve)
-    const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * M + 16 * NT2) + 64; // (+ 64: the four decoded items)
+    const size_t ldsq = (size_t)2 * 2 * 8 * 4096 + sizeof(float) * (size_t)(2 * NT2 + 16 * NT2) + 64; // (+ 64: the four decoded items)
     if (!ctx->queue_attr) { // once per context
         AGPL_HIP(ctx, hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&marginal_factor_queue_kernel),

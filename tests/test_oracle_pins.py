@@ -588,7 +588,7 @@ def test_conditioning_budget_of_an_unwhitened_on_the_fly_marginal_pass():
     format emulated exactly (every float32 operand carried as hi + lo float16, the lo x lo product dropped): the
     un-whitened product loses more than an order of magnitude of accuracy in sum_a T[a,n]^2 (the variance projection),
     which puts it AT the 1e-5 natural-parameter bar with no margin where the whitened path clears it by ~10x.
-    That is why row (f3) is not built (DESIGN.md 8.6): the images it would save cost the path its tolerance."""
+    That is why row (f3) is not built (DESIGN.md 8.5): the images it would save cost the path its tolerance."""
     import scipy.linalg as sla
 
     rng = np.random.default_rng(0)
