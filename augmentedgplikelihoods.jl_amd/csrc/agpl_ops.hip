@@ -70,6 +70,7 @@ struct PgBlockScratch {
     unsigned char owner[kPgWaves][256];  // owner lane of each dealt draw
     double etheta[64];                   // categorical kinds: exp(log theta_k), filled once per kernel (pg_scratch_init)
     int qn, q2n, qhead, rn, tmax;
+    int stats;                           // nonzero: the caller reads the uniform / series-term counts (set once per kernel)
     int wqn[kPgWaves], wq2n[kPgWaves], wqhead[kPgWaves], wrn[kPgWaves]; // the same counters per wave (kPgWaveLocal)
 #ifdef AGPL_PG_TRACE
     unsigned long long trace[8];
@@ -77,7 +78,8 @@ struct PgBlockScratch {
 };
 
 // once per kernel, by the whole workgroup
-__device__ __forceinline__ void pg_scratch_init(PgBlockScratch *scr, const agpl_lik_dev &lik) {
+__device__ __forceinline__ void pg_scratch_init(PgBlockScratch *scr, const agpl_lik_dev &lik, bool stats) {
+    if (threadIdx.x == 0) scr->stats = stats ? 1 : 0;
     if ((lik.kind == AGPL_LIK_CATEGORICAL || lik.kind == AGPL_LIK_CATEGORICAL_BIJ) && (int)threadIdx.x < lik.nlatent)
         scr->etheta[threadIdx.x] = exp(lik.logtheta[threadIdx.x]);
     __syncthreads();
@@ -220,6 +222,9 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         }
     scr->nuni[wave][lane] = 0u;
     scr->nterms[wave][lane] = 0u;
+    // the per-owner counts are same-address LDS atomics (about floor(b) lanes per owner): taken only when a caller reads them --
+    // they were most of the engine's LDS bank conflicts (profiles/NOTES_r06.md); the draws do not depend on them.  (The flag is
+    // read from LDS at each site: held in a register across the phases it cost the Gibbs point pass a spill.)
     int off[NB], T = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) { // owners in the order (latent, lane)
@@ -288,8 +293,10 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                     uint32_t nt = 0;
                     if (pg_series_accept<true>(s, x, nt)) {
                         scr->draws[wave][t - cb] = x / 4.0;
-                        atomicAdd(&scr->nuni[wave][lo & 63], s.nuni);
-                        atomicAdd(&scr->nterms[wave][lo & 63], nt);
+                        if (scr->stats) {
+                            atomicAdd(&scr->nuni[wave][lo & 63], s.nuni);
+                            atomicAdd(&scr->nterms[wave][lo & 63], nt);
+                        }
                     } else
                         to_c = true;
                 } else if (1.0 / z > kPgT) // (the test of rand_truncated_inverse_gaussian, polyagamma.jl:197)
@@ -412,8 +419,10 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                 uint32_t nt = 0;
                 if (pg_series_accept<false>(s, x, nt)) {
                     scr->draws[w][slot] = x / 4.0;
-                    atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
-                    atomicAdd(&scr->nterms[w][lo & 63], nt);
+                    if (scr->stats) {
+                        atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
+                        atomicAdd(&scr->nterms[w][lo & 63], nt);
+                    }
                 } else
                     to_c = true;
             }
@@ -439,8 +448,10 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             p.set(2.0 * PG_OWNER_Z(w, lo)); // (z = |c| / 2 exactly)
             uint32_t nt = 0;
             scr->draws[w][slot] = sample_pg1(s, p, nt);
-            atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
-            atomicAdd(&scr->nterms[w][lo & 63], nt);
+            if (scr->stats) {
+                atomicAdd(&scr->nuni[w][lo & 63], s.nuni);
+                atomicAdd(&scr->nterms[w][lo & 63], nt);
+            }
         }
         PG_SYNC();
         PGT_MARK(6);
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(kBlock, sampler_wps(KIND)) void aux_sample_kernel(a
                                                             uint32_t *__restrict__ nterms_out,
                                                             int *__restrict__ bad) {
     __shared__ PgBlockScratch scratch;
-    pg_scratch_init(&scratch, lik);
+    pg_scratch_init(&scratch, lik, nuni_out != nullptr || nterms_out != nullptr);
 #ifdef AGPL_PG_TRACE
     if (threadIdx.x < 8) scratch.trace[threadIdx.x] = 0ull;
     __syncthreads();
@@ -2283,7 +2294,7 @@ __global__ __launch_bounds__(256, gibbs_wps(KIND)) void gibbs_sample_kernel(
     uint32_t *__restrict__ nuni_out, int *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     __shared__ PgBlockScratch scratch;
-    pg_scratch_init(&scratch, lik);
+    pg_scratch_init(&scratch, lik, nuni_out != nullptr);
     const int Lf = lik.nlatent;
     const int Lo = KIND == AGPL_LIK_HETEROGAUSS ? 1 : lik.nlatent;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -49,8 +49,8 @@ sys.path.insert(0, ROOT)
 SEED = 20240807
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense
-PMC_PROFILE = "r05_pmc_traffic_c2.json"  # HBM bytes per launch of the two contraction kernels (separate --pmc passes)
-PMC_PROFILE_M1024 = "r05_pmc_traffic_m1024.json"  # the same at the north-star target configuration (N = 1e7, M = 1024)
+PMC_PROFILE = "r06_pmc_traffic_c2.json"  # HBM bytes per launch of the two contraction kernels (separate --pmc passes)
+PMC_PROFILE_M1024 = "r06_pmc_traffic_m1024.json"  # the same at the north-star target configuration (N = 1e7, M = 1024)
 RENDEZVOUS_TIMEOUT_S = 300  # a rank that cannot join (or whose first collective hangs) exits non-zero after this
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGPL_VERSION 120
+#define AGPL_VERSION 121 /* 121 (round 6): same 45 entry points; a plan takes any feature count, PG(b, c) takes b < 2^22 */
 
 #if defined(__GNUC__)
 #define AGPL_API __attribute__((visibility("default")))

@@ -152,4 +152,4 @@ def test_header_is_self_contained_for_c_and_cxx(tmp_path, lang, compiler, std):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
-    assert r.stdout.split()[0] == "120"  # AGPL_VERSION: 45 exports
+    assert r.stdout.split()[0] == "121"  # AGPL_VERSION: 45 exports
