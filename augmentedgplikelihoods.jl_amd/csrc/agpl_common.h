@@ -29,6 +29,8 @@ struct agpl_ctx {
     size_t ws2_bytes = 0;
     unsigned *pg_retry = nullptr; // PG(1) kernels: [0] entries, [1] workgroups done (both zero between launches), [2 ..] the point list
     size_t pg_retry_entries = 0;
+    unsigned *red_cnt = nullptr; // arrival counters of the slab reduction (one per 1 KB of G and per half block of g), zero between launches
+    size_t red_cnt_entries = 0;
     double *logtheta_dev = nullptr; // categorical link parameters mirrored on device
     int logtheta_cap = 0;
     double logtheta_host[128];      // last uploaded values (skip the copy when unchanged)
@@ -111,6 +113,7 @@ int32_t agpl_timing_end(agpl_ctx *ctx, int which);
 // grow-only scratch
 int32_t agpl_ws_reserve(agpl_ctx *ctx, size_t bytes);
 int32_t agpl_ws2_reserve(agpl_ctx *ctx, size_t bytes);
+int32_t agpl_red_cnt_reserve(agpl_ctx *ctx, int64_t n); // the slab reduction's arrival counters (agpl_core.hip)
 int32_t agpl_pg_retry_reserve(agpl_ctx *ctx, int64_t n); // the retry list of the PG(1) kernels for n points (agpl_core.hip)
 
 // device-side view of a likelihood descriptor (logtheta mirrored to device memory)

@@ -44,6 +44,7 @@ extern "C" int32_t agpl_ctx_destroy(agpl_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->pg_retry) (void)hipFree(ctx->pg_retry);
+    if (ctx->red_cnt) (void)hipFree(ctx->red_cnt);
     if (ctx->elbo_part) (void)hipFree(ctx->elbo_part);
     if (ctx->logtheta_dev) (void)hipFree(ctx->logtheta_dev);
     if (ctx->pend_host) (void)hipHostFree(ctx->pend_host);
@@ -137,6 +138,22 @@ int32_t agpl_pg_retry_reserve(agpl_ctx *ctx, int64_t n) {
         AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the PG retry list failed", bytes);
     AGPL_HIP(ctx, hipMemsetAsync(ctx->pg_retry, 0, 2 * sizeof(unsigned), ctx->stream));
     ctx->pg_retry_entries = (size_t)n;
+    return AGPL_OK;
+}
+
+// Arrival counters of reduce_slab_kernel (agpl_mfma.hip): the workgroup that finds its counter at ngroup - 1 sums the group partials
+// and sets the counter back to zero, so that the words are zero between launches; a fresh allocation is zeroed once.
+int32_t agpl_red_cnt_reserve(agpl_ctx *ctx, int64_t n) {
+    if ((size_t)n <= ctx->red_cnt_entries) return AGPL_OK;
+    AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->red_cnt) AGPL_HIP(ctx, hipFree(ctx->red_cnt));
+    ctx->red_cnt = nullptr;
+    ctx->red_cnt_entries = 0;
+    const size_t bytes = sizeof(unsigned) * (size_t)n;
+    if (hipMalloc((void **)&ctx->red_cnt, bytes) != hipSuccess)
+        AGPL_FAIL(ctx, AGPL_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) for the reduction counters failed", bytes);
+    AGPL_HIP(ctx, hipMemsetAsync(ctx->red_cnt, 0, bytes, ctx->stream));
+    ctx->red_cnt_entries = (size_t)n;
     return AGPL_OK;
 }
 

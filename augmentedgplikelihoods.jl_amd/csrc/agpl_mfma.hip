@@ -379,21 +379,57 @@ __device__ __forceinline__ f32x16 mfma16(h8v a, h8v b, f32x16 c) {
 
 size_t syrk_lds_bytes() { return sizeof(float) * (size_t)(4 * KT * BS + 4 * KT + 128); }
 
-// Fixed-order float64 reduction of the f32 slabs, two levels (HBM-bound streaming, 16 B per lane):
+// Fixed-order float64 reduction of the f32 slabs, two levels in ONE launch (HBM-bound streaming, 16 B per lane):
 //   level 1: one workgroup = 1 KB of one tile (256 consecutive elements) x one group of kRedGroup slices;
 //            wave w sums slices w, w+4, ... of the group (float4 loads, 8 in flight), waves combined in LDS
 //            in wave order -> partial[p][group][16384] (float64)
-//   level 2: G[row][col] = sum over groups (in order) of the lower-triangle partial, mirrored.
+//   level 2: G[row][col] = sum over groups (in order) of the lower-triangle partial, mirrored -- by whichever workgroup of
+//            the 1 KB segment arrives LAST at the segment's counter (release / acquire at device scope).  The sum runs over the
+//            groups in index order whoever performs it, so the result does not depend on the arrival order.
+// (Rounds 1-5 ran level 2 as a second kernel, reduce_G_kernel: one launch and 24-49 us more per sweep.)
 constexpr int kRedGroup = 64;
 
+__device__ __forceinline__ double red_load(const double *p) { // a partial another workgroup (possibly on another XCD's L2) wrote
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void red_store(double *p, double x) { // write-through (sc1): visible to every XCD once the store has drained
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// the 16-byte form (the 8-byte one costs 2.7 x per byte on the fabric: MI355X_MICROARCH.md, visibility table).  s_nop 1: a VMEM
+// store of more than 8 bytes reads its data registers for two cycles after issue and the hazard recogniser does not look into inline asm
+typedef double red_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void red_store2(double *p, double a, double b) {
+    red_d2 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// True in every lane of the calling wave iff this wave's arrival is the ngroup-th at `cnt` (which it then zeroes).  The wave's
+// partials were stored write-through and are drained here before the arrival; the consumer reads them by sc1 loads behind the
+// counter: no fence on either side (a device-scope fence per workgroup writes back and invalidates the whole L2 -- measured in
+// round 6: the C2 sweep 13.1 -> 17.2 ms with 25 000 such workgroups per sweep; cdna_hip_programming.md Guideline 16).
+__device__ __forceinline__ bool red_last_arrival(unsigned *cnt, int ngroup, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0u;
+    if (lane == 0) {
+        old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(ngroup - 1)) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    return old == (unsigned)(ngroup - 1);
+}
+
 // blockIdx.z < npl: tile pl = l * npairs + p of G; beyond: 128-row block bl = l * nb + bi of g (one launch for both)
-__global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup, int npl, const float *__restrict__ slab,
-                                                          double *__restrict__ partial, const float *__restrict__ slabg,
-                                                          double *__restrict__ partialg) {
+__global__ __launch_bounds__(256) void reduce_slab_kernel(int M, int nsplit, int ngroup, int npairs, int npl,
+                                                          const float *__restrict__ slab, double *partial,
+                                                          const float *__restrict__ slabg, double *partialg,
+                                                          unsigned *__restrict__ cnt, double *__restrict__ G,
+                                                          double *__restrict__ g) {
     __shared__ double sm[3][64][4];
     const int seg = blockIdx.x;  // 1 KB segment of the 128 x 128 tile (64 of them)
     const int grp = blockIdx.y;
     const int pl = blockIdx.z;   // l * npairs + p
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (pl >= npl) { // the g slabs: 128 floats per (row block, slice)
         if (seg != 0 || threadIdx.x >= BS) return;
         const int bl = pl - npl;
@@ -410,10 +446,22 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup
             a3 += (double)base[(int64_t)(s + 3) * BS];
         }
         for (; s < s1; ++s) a0 += (double)base[(int64_t)s * BS];
-        partialg[((int64_t)bl * ngroup + grp) * BS + threadIdx.x] = (a0 + a1) + (a2 + a3);
+        red_store(partialg + ((int64_t)bl * ngroup + grp) * BS + threadIdx.x, (a0 + a1) + (a2 + a3));
+        // (each of the two waves counts for its own 64 entries)
+        if (!red_last_arrival(cnt + (int64_t)npl * 64 + 2 * bl + wave, ngroup, lane)) return;
+        const double *src = partialg + ((int64_t)bl * ngroup) * BS + threadIdx.x;
+        double acc = 0.0;
+        for (int g0 = 0; g0 < ngroup; g0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = red_load(src + (int64_t)(g0 + u < ngroup ? g0 + u : ngroup - 1) * BS);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (g0 + u < ngroup) acc += v[u];
+        }
+        g[(int64_t)bl * BS + threadIdx.x] = acc; // (bl * BS + t = l * M + bi * BS + t)
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *base = slab + ((int64_t)pl * nsplit) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
     const int s0 = grp * kRedGroup;
     int s1 = s0 + kRedGroup;
@@ -446,51 +494,50 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(int nsplit, int ngroup
         sm[wave - 1][lane][3] = a3;
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave != 0) return;
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            a0 += sm[w][lane][0];
-            a1 += sm[w][lane][1];
-            a2 += sm[w][lane][2];
-            a3 += sm[w][lane][3];
+    for (int w = 0; w < 3; ++w) {
+        a0 += sm[w][lane][0];
+        a1 += sm[w][lane][1];
+        a2 += sm[w][lane][2];
+        a3 += sm[w][lane][3];
+    }
+    double *dst = partial + ((int64_t)pl * ngroup + grp) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
+    red_store2(dst + 0, a0, a1);
+    red_store2(dst + 2, a2, a3);
+    if (!red_last_arrival(cnt + (int64_t)pl * 64 + seg, ngroup, lane)) return;
+    // level 2 for this segment: rows 2 seg, 2 seg + 1 of the tile, columns 4 (lane % 32) .. + 3
+    const int l = pl / npairs, p = pl - l * npairs;
+    int rb = 0;
+    while ((rb + 1) * (rb + 2) / 2 <= p) ++rb;
+    const int cb = p - rb * (rb + 1) / 2;
+    const int tr = 2 * seg + (lane >> 5), tc = 4 * (lane & 31);
+    const double *src = partial + ((int64_t)pl * ngroup) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g0 = 0; g0 < ngroup; g0 += 8) { // 32 loads in flight (each is a trip to the memory side), summed in group order
+        double v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int gi = g0 + u < ngroup ? g0 + u : ngroup - 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = red_load(src + (int64_t)gi * BS * BS + e);
         }
-        double *dst = partial + ((int64_t)pl * ngroup + grp) * (int64_t)(BS * BS) + seg * 256 + lane * 4;
-        dst[0] = a0;
-        dst[1] = a1;
-        dst[2] = a2;
-        dst[3] = a3;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (g0 + u < ngroup) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
+            }
     }
-}
-
-// blockIdx.y < M: row of G; == M: g (its group partials), so that the pair is one launch
-__global__ __launch_bounds__(128) void reduce_G_kernel(int M, int ngroup, const double *__restrict__ partial,
-                                                       double *__restrict__ G, const double *__restrict__ partialg,
-                                                       double *__restrict__ g) {
-    const int nb = M / BS;
-    const int npairs = nb * (nb + 1) / 2;
-    const int l = blockIdx.z;
-    const int row = blockIdx.y;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= M) return;
-    if (row == M) {
-        const double *src = partialg + (((int64_t)l * nb + col / BS) * ngroup) * BS + (col % BS);
-        double acc = 0.0;
-        for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS];
-        g[(int64_t)l * M + col] = acc;
-        return;
+    double *Gl = G + (int64_t)l * M * M;
+    const int r = rb * BS + tr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = cb * BS + tc + e;
+        if (r < c) continue; // (a diagonal tile's upper half: its mirror image is what G takes -- exact symmetry)
+        Gl[(int64_t)r * M + c] = acc[e];
+        if (r != c) Gl[(int64_t)c * M + r] = acc[e];
     }
-    int r = row, c = col;
-    if (r < c) { // mirror: always read the lower-triangle element (exact symmetry)
-        int t = r;
-        r = c;
-        c = t;
-    }
-    const int rb = r / BS, cb = c / BS;
-    const int p = rb * (rb + 1) / 2 + cb;
-    const double *src = partial + (((int64_t)l * npairs + p) * ngroup) * (int64_t)(BS * BS) + (r % BS) * BS + (c % BS);
-    double acc = 0.0;
-    for (int gi = 0; gi < ngroup; ++gi) acc += src[(int64_t)gi * BS * BS];
-    G[((int64_t)l * M + row) * M + col] = acc;
 }
 
 // g: level 1 = one workgroup of 128 threads per (row block, group of slices); level 2 sums the groups
@@ -594,6 +641,8 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     double *partG = (double *)((char *)slab_mem + lo.partG);
     double *partg = (double *)((char *)slab_mem + lo.partg);
     const size_t lds = syrk_lds_bytes();
+    int32_t rc_cnt = agpl_red_cnt_reserve(ctx, (int64_t)L * npairs * 64 + 2 * (int64_t)L * nb);
+    if (rc_cnt) return rc_cnt;
     const int64_t nwg = (int64_t)L * npairs * ((ns + 7) / 8) * 8;
     if (nwg > 0x7fffffffLL) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "problem too large for one launch");
     if (!use_image && !Phi)
@@ -616,10 +665,8 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     if (rc) return rc;
     // fixed-order float64 reduction of the slabs, G and g together: slices -> groups of kRedGroup, groups -> G, g
     dim3 r1(64, (unsigned)ng, (unsigned)(L * npairs + L * nb));
-    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(ns, ng, L * npairs, slabG, partG, slabg, partg);
-    AGPL_LAUNCH_CHECK(ctx);
-    dim3 rg((unsigned)agpl_cdiv(M, 128), (unsigned)M + 1, (unsigned)L);
-    reduce_G_kernel<<<rg, 128, 0, ctx->stream>>>(M, ng, partG, G_out, partg, g_out);
+    reduce_slab_kernel<<<r1, 256, 0, ctx->stream>>>(M, ns, ng, npairs, L * npairs, slabG, partG, slabg, partg, ctx->red_cnt, G_out,
+                                                    g_out);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
 }

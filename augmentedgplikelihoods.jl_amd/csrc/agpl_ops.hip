@@ -54,20 +54,28 @@ __device__ unsigned long long g_pgtrace[8];
 #define PGT_MARK(k_)
 #endif
 constexpr int kPgWaves = kBlock / 64;
+// draws per chunk of the engine (one wave's queues and draw slots).  512 was measured again in round 6, with nothing spilling any
+// more (profiles/NOTES_r06.md): build with -DAGPL_PG_CHUNK_LOG=9.
+#ifndef AGPL_PG_CHUNK_LOG
+#define AGPL_PG_CHUNK_LOG 8
+#endif
+constexpr int kPgChunkLog = AGPL_PG_CHUNK_LOG;
+constexpr int kPgChunk = 1 << kPgChunkLog;
+static_assert(kPgChunk >= 256 && kPgWaves * kPgChunk <= 65536, "queue entries are 16-bit (wave, slot) words; a chunk holds every owner's parameters");
 constexpr int kPgMaxLat = 4;                 // latents dealt together by one engine call (owner o = 64 j + lane fits the owner byte)
 constexpr int kPgMaxOwners = 64 * kPgMaxLat;
 struct PgBlockScratch {
-    double draws[kPgWaves][256];        // the dealt draws of each wave's current chunk
+    double draws[kPgWaves][kPgChunk];        // the dealt draws of each wave's current chunk
     double par[kPgWaves][256];          // owners' parameters: one latent per call -- (z, K, bracket of r) of lane l at [4 l ..];
                                         // NB > 1 latents per call -- z of owner o = 64 j + lane at [o] (the rest per draw)
     int off[kPgWaves][kPgMaxOwners + 1]; // exclusive prefix sums of floor(b) over the owners; off[.][owners] = total
     unsigned nuni[kPgWaves][64], nterms[kPgWaves][64];
     unsigned long long index0[kPgWaves]; // point index (40 bits) of lane 0 of each wave
-    unsigned short queue[kPgWaves * 256]; // phase-B queue: (wave << 8) | slot
-    unsigned short queue2[kPgWaves * 256]; // phase-B queue of the mu <= t branch
-    unsigned short retry[kPgWaves * 256]; // phase-C queue
-    unsigned st[kPgWaves * 256];         // stream position of a parked proposal: (refills << 3) | words used
-    unsigned char owner[kPgWaves][256];  // owner lane of each dealt draw
+    unsigned short queue[kPgWaves * kPgChunk]; // phase-B queue: (wave << 8) | slot
+    unsigned short queue2[kPgWaves * kPgChunk]; // phase-B queue of the mu <= t branch
+    unsigned short retry[kPgWaves * kPgChunk]; // phase-C queue
+    unsigned st[kPgWaves * kPgChunk];         // stream position of a parked proposal: (refills << 3) | words used
+    unsigned char owner[kPgWaves][kPgChunk];  // owner lane of each dealt draw
     double etheta[64];                   // categorical kinds: exp(log theta_k), filled once per kernel (pg_scratch_init)
     int qn, q2n, qhead, rn, tmax;
     int stats;                           // nonzero: the caller reads the uniform / series-term counts (set once per kernel)
@@ -196,7 +204,7 @@ constexpr bool kPgWaveLocal = AGPL_PG_WAVE_LOCAL != 0;
         else __syncthreads();                                                                                         \
     } while (0)
 #define PG_CNT(name_) (kPgWaveLocal ? scr->w##name_[wave] : scr->name_)
-#define PG_Q(name_) (kPgWaveLocal ? scr->name_ + wave * 256 : scr->name_)
+#define PG_Q(name_) (kPgWaveLocal ? scr->name_ + wave * kPgChunk : scr->name_)
 #define PG_QSTRIDE (kPgWaveLocal ? 64 : kBlock)
 #define PG_QFIRST (kPgWaveLocal ? lane : (int)threadIdx.x)
 #define PG_LEADER (kPgWaveLocal ? lane == 0 : threadIdx.x == 0)
@@ -261,10 +269,10 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
 #define PG_OWNER_Z(w_, o_) (NB == 1 ? scr->par[w_][4 * (o_)] : scr->par[w_][o_])
 #define PG_ST(e_) scr->st[e_] /* (e = (wave << 8) | slot: every wave's own 256 words in either form) */
 #define PG_OWNER_SUB(o_) (1u + ((uint32_t)(latent0 + ((o_) >> 6)) << 16))
-    for (int cb = 0; cb < tmax; cb += 256) {
+    for (int cb = 0; cb < tmax; cb += kPgChunk) {
         asm volatile("; agpl-pg-phases-begin"); // (markers in the generated code: tests/test_isa_guards.py looks between them)
         // ---- phase A
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < kPgChunk / 64; ++r) {
             const int t = cb + 64 * r + lane;
             bool to_b = false, to_b2 = false, to_c = false;
             if (t < T) {
@@ -309,19 +317,19 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&PG_CNT(q2n), __popcll(mb2));
                 base = __shfl(base, 0);
-                if (to_b2) PG_Q(queue2)[base + __popcll(mb2 & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_b2) PG_Q(queue2)[base + __popcll(mb2 & ((1ull << lane) - 1ull))] = (unsigned short)((wave << kPgChunkLog) | (t - cb));
             }
             if (mb) { // (wave-uniform)
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&PG_CNT(qn), __popcll(mb));
                 base = __shfl(base, 0);
-                if (to_b) PG_Q(queue)[base + __popcll(mb & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_b) PG_Q(queue)[base + __popcll(mb & ((1ull << lane) - 1ull))] = (unsigned short)((wave << kPgChunkLog) | (t - cb));
             }
             if (mc) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&PG_CNT(rn), __popcll(mc));
                 base = __shfl(base, 0);
-                if (to_c) PG_Q(retry)[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)((wave << 8) | (t - cb));
+                if (to_c) PG_Q(retry)[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)((wave << kPgChunkLog) | (t - cb));
             }
         }
         PGT_MARK(2);
@@ -353,7 +361,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
                         e = -1;
                         if (idx < qn) {
                             e = PG_Q(queue)[idx];
-                            w = e >> 8, slot = e & 255;
+                            w = e >> kPgChunkLog, slot = e & (kPgChunk - 1);
                             const int lo = scr->owner[w][slot];
                             s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
                             // the branch uniform (drawn in phase A) and the first `while (alpha < rand())` (alpha = 0: always entered, u is
@@ -388,7 +396,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         if (q2n) {
             for (int q = PG_QFIRST; q < q2n; q += PG_QSTRIDE) {
                 const int e = PG_Q(queue2)[q];
-                const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+                const int w = e >> kPgChunkLog, slot = e & (kPgChunk - 1), lo = scr->owner[w][slot];
                 Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
                 const uint32_t c0first = s.c0;
                 (void)s.u01();
@@ -405,7 +413,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
             int e = 0;
             if (q < qn + q2n) {
                 e = q < qn ? PG_Q(queue)[q] : PG_Q(queue2)[q - qn];
-                const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+                const int w = e >> kPgChunkLog, slot = e & (kPgChunk - 1), lo = scr->owner[w][slot];
                 Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
                 const uint32_t st = PG_ST(e), c0 = st >> 3, pos = st & 7u; // the stream where the proposal left it (blocks since its first)
                 if (pos < 4u) {
@@ -442,7 +450,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         const int rn = PG_CNT(rn);
         for (int q = PG_QFIRST; q < rn; q += PG_QSTRIDE) {
             const int e = PG_Q(retry)[q];
-            const int w = e >> 8, slot = e & 255, lo = scr->owner[w][slot];
+            const int w = e >> kPgChunkLog, slot = e & (kPgChunk - 1), lo = scr->owner[w][slot];
             Philox s = pg_substream(g, scr->index0[w] + (uint64_t)(lo & 63), PG_OWNER_SUB(lo), (uint32_t)(cb + slot - scr->off[w][lo]));
             Pg1Params p;
             p.set(2.0 * PG_OWNER_Z(w, lo)); // (z = |c| / 2 exactly)
@@ -458,7 +466,7 @@ __device__ __forceinline__ void pg_int_sum_block(PgBlockScratch *scr, int wave, 
         if (PG_LEADER) PG_CNT(qn) = PG_CNT(q2n) = PG_CNT(qhead) = PG_CNT(rn) = 0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int a0 = off[j] > cb ? off[j] : cb, a1 = (off[j] + tb[j]) < (cb + 256) ? (off[j] + tb[j]) : (cb + 256);
+            const int a0 = off[j] > cb ? off[j] : cb, a1 = (off[j] + tb[j]) < (cb + kPgChunk) ? (off[j] + tb[j]) : (cb + kPgChunk);
             for (int t = a0; t < a1; ++t) acc[j] += scr->draws[wave][t - cb];
         }
         PG_SYNC();

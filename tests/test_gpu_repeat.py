@@ -71,3 +71,41 @@ def test_every_hot_kernel_repeats_bit_for_bit(A, likname, N, M):
         gib.accumulate()
 
     assert _count(gpass, lambda: (gib.G, gib.g, gib.f, gib.omega)) == 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("N,M,L", [(1_000_000, 256, 2), (2_000_000, 512, 1), (700_001, 384, 1)])
+def test_slab_reduction_second_level_inside_the_launch(A, N, M, L):
+    """Round 6: the second level of the slab reduction (groups of 64 slices -> G, g) runs inside reduce_slab_kernel, by the workgroup
+    that arrives last at a segment's counter.  60 launches into NaN-filled outputs: every element written (a skipped segment would
+    keep its NaN), symmetric, equal to float64 within the float32 kernel's bar, and the same bits every time (the sum runs over the
+    groups in index order whoever performs it; a partial read before it was visible would differ).  tools/soak_reduce.py is the
+    long form (profiles/r06_soak_reduce.json)."""
+    ctx = A.Context(0, seed=5)
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    Phi = (torch.randn((N, M), dtype=torch.float32, device="cuda", generator=gen) / M ** 0.5).contiguous()
+    gamma = torch.rand((L, N), dtype=torch.float32, device="cuda", generator=gen) * 0.25
+    beta = torch.randn((L, N), dtype=torch.float32, device="cuda", generator=gen)
+    G = torch.empty((L, M, M), dtype=torch.float64, device="cuda")
+    g = torch.empty((L, M), dtype=torch.float64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ref = None
+    for i in range(60):
+        G.fill_(float("nan"))
+        g.fill_(float("nan"))
+        ctx.call("agpl_accumulate", C.c_int64(N), C.c_int32(M), C.c_int32(L), p(Phi), p(beta), p(gamma), p(G), p(g))
+        torch.cuda.synchronize()
+        if ref is None:
+            assert bool(torch.isfinite(G).all()) and bool(torch.isfinite(g).all())
+            assert torch.equal(G, G.transpose(1, 2))
+            for l in range(L):
+                Gr = torch.zeros((M, M), dtype=torch.float64, device="cuda")
+                for s in range(0, N, 250_000):
+                    P = Phi[s:s + 250_000].double()
+                    Gr += (P * gamma[l, s:s + 250_000].double().unsqueeze(1)).T @ P
+                assert float(((G[l] - Gr).abs().max() / Gr.abs().max()).item()) < 1e-5
+                gr = Phi.double().T @ beta[l].double()
+                assert float(((g[l] - gr).abs().max() / gr.abs().max()).item()) < 1e-5
+            ref = (G.clone(), g.clone())
+        else:
+            assert torch.equal(G, ref[0]) and torch.equal(g, ref[1]), f"launch {i} differs"
