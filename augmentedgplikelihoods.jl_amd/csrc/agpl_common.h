@@ -80,6 +80,45 @@ inline int agpl_slice_points(int64_t N, int M, int L) {
     while (chunk < 16384 && (int64_t)L * pairs * ((N + 2 * chunk - 1) / (2 * chunk)) >= AGPL_SLICE_MIN_WG * 256) chunk *= 2;
     return chunk;
 }
+// The slices of one accumulation (round 6): `nbig` slices of `chunk` points, then the rest of the points in slices of chunk / 4.
+// A launch of equal workgroups of 0.2-0.45 ms each ends with a tail of about one of them on a mostly idle device -- measured as a
+// fixed 0.21 ms per launch at M = 512 whatever N is (kernel time = 0.21 + 0.217 ms x rounds of 256 workgroups:
+// profiles/NOTES_r06.md), which is 3 % of the launch at N = 1e7 and 23 % of it at a rank's N / 8.  So the last round's worth of
+// workgroups (256 / (L x 256-tile pairs) slices) is cut four times finer; a slab is written per slice and tile whatever its length, so
+// the finer tail adds about one round of slabs.  A function of (N, M, L) only: results repeat.
+struct agpl_slices {
+    int chunk, small; // points per big / small slice (multiples of 32)
+    int nbig, ns;     // big slices; slices in all
+};
+#ifndef AGPL_SLICE_TAIL_DIV
+#define AGPL_SLICE_TAIL_DIV 4 // (1: no finer tail -- the slices of rounds 1-5)
+#endif
+inline agpl_slices agpl_slice_plan(int64_t N, int M, int L) {
+    agpl_slices o;
+    o.chunk = agpl_slice_points(N, M, L);
+    o.small = o.chunk / AGPL_SLICE_TAIL_DIV;
+    const int64_t nfull = (N + o.chunk - 1) / o.chunk;
+    const int64_t nb2 = (M + 255) / 256, wg_per_slice = (int64_t)L * nb2 * (nb2 + 1) / 2;
+    int64_t tail = (256 + wg_per_slice - 1) / wg_per_slice; // big slices that make one round of workgroups
+    // measured (profiles/NOTES_r06.md): worth 0.05-0.11 ms per launch at M >= 512 and for launches of up to two rounds at any M;
+    // a longer launch of diagonal tiles only (M = 256: C4, ten latents, 4.8 rounds) ran 0.08 ms slower with it
+    if (AGPL_SLICE_TAIL_DIV == 1 || (M < 512 && nfull * wg_per_slice > 512)) tail = 0;
+    o.nbig = (int)(nfull > tail ? nfull - tail : 0);
+    const int64_t rest = N - (int64_t)o.nbig * o.chunk;
+    o.ns = o.nbig + (int)((rest + o.small - 1) / o.small);
+    return o;
+}
+// points [nbeg, nend) of slice s
+__host__ __device__ inline void agpl_slice_range(int s, int chunk, int nbig, int small, int64_t N, int64_t &nbeg, int64_t &nend) {
+    if (s < nbig) {
+        nbeg = (int64_t)s * chunk;
+        nend = nbeg + chunk;
+    } else {
+        nbeg = (int64_t)nbig * chunk + (int64_t)(s - nbig) * small;
+        nend = nbeg + small;
+    }
+    if (nend > N) nend = N;
+}
 
 // reports (and clears) the deferred outcome of the last asynchronous factorisation; AGPL_OK when none is pending
 int32_t agpl_pending_resolve(agpl_ctx *ctx);

@@ -228,7 +228,7 @@ size_t marginal_lds_bytes(int M) {
 // one L2.  One workgroup = one 128 x 128 tile pair x one slice of agpl_chunk_points(M) points, accumulated in f32
 // (chains of <= 8192 terms) and written as an f32 slab; the slabs are summed in float64 by the reduce kernels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npairs, int nsplit, int chunk,
+__global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npairs, int nsplit, int chunk, int nbig, int small,
                                                       const float *__restrict__ Phi,
                                                       const float *__restrict__ gamma_all,
                                                       const float *__restrict__ beta_all,
@@ -263,9 +263,8 @@ __global__ __launch_bounds__(256, 4) void syrk_kernel(int64_t N, int M, int npai
     // frees its SIMD's matrix pipe for the other resident workgroups.
     const bool active = !(diag && wr < wc);
 
-    const int64_t nbeg = (int64_t)s * chunk;
-    int64_t nend = nbeg + chunk;
-    if (nend > N) nend = N;
+    int64_t nbeg, nend;
+    agpl_slice_range(s, chunk, nbig, small, N, nbeg, nend);
     const int nstage = (int)((nend - nbeg + KT - 1) / KT);
     const float *gam = gamma_all + (int64_t)l * N;
     const float *bet = beta_all + (int64_t)l * N;
@@ -588,15 +587,18 @@ extern "C" int32_t agpl_transform_features(agpl_ctx *ctx, int64_t N, int32_t M, 
 
 // scratch layout of one accumulation: [f32 slabs G][f32 slabs g][f64 partials G][f64 partials g]
 struct SlabLayout {
-    int ns, ng, nb, chunk;
+    int ns, ng, nb, chunk, nbig, small;
     int64_t npairs;
     size_t slabG, slabg, partG, partg, sgam, ctr; // byte offsets
     size_t total;
 };
 static SlabLayout slab_layout(int64_t N, int32_t M, int32_t L) {
     SlabLayout o;
-    o.chunk = agpl_slice_points(N, M, L);
-    o.ns = (int)agpl_cdiv(N, o.chunk);
+    const agpl_slices sl = agpl_slice_plan(N, M, L);
+    o.chunk = sl.chunk;
+    o.nbig = sl.nbig;
+    o.small = sl.small;
+    o.ns = sl.ns;
     o.ng = (o.ns + kRedGroup - 1) / kRedGroup;
     o.nb = M / BS;
     o.npairs = (int64_t)o.nb * (o.nb + 1) / 2;
@@ -618,7 +620,7 @@ size_t agpl_slab_bytes(int64_t N, int32_t M, int32_t L) { return slab_layout(N, 
 // internal: accumulate with caller-provided slab storage (used by agpl_accumulate and agpl_cavi_pass)
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
-                               float *slabg, int ns, int chunk, bool records_ready); // agpl_syrk.hip
+                               float *slabg, int ns, int chunk, int nbig, int small, bool records_ready); // agpl_syrk.hip
 
 // acc_image != nullptr (and M % 256 == 0): the point-major split-float16 image of agpl_accumulate_image is the operand
 // (syrk_strip_kernel, agpl_syrk.hip) and Phi is not read; otherwise Phi is, by the kernel ctx->accumulate_split selects.
@@ -653,12 +655,12 @@ int32_t agpl_accumulate_impl(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L, con
     if (use_image) {
         const int64_t Npad = ((N + 31) & ~(int64_t)31) + 32;
         launch_rc = agpl_syrk_image_launch(ctx, N, Npad, M, L, acc_image, gamma, beta, (float *)((char *)slab_mem + lo.sgam),
-                                           (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, lo.chunk, records_ready);
+                                           (unsigned *)((char *)slab_mem + lo.ctr), slabG, slabg, ns, lo.chunk, lo.nbig, lo.small, records_ready);
     } else if (ctx->accumulate_split) {
         launch_rc = AGPL_ERR_INVALID_ARGUMENT; // (internal: the split-float16 accumulation exists on the image only)
         snprintf(ctx->err, sizeof(ctx->err), "the split-float16 accumulation needs the accumulate image and M %% 256 == 0");
     } else
-        syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, lo.chunk, Phi, gamma, beta, slabG, slabg);
+        syrk_kernel<<<(unsigned)nwg, 256, lds, ctx->stream>>>(N, M, npairs, ns, lo.chunk, lo.nbig, lo.small, Phi, gamma, beta, slabG, slabg);
     rc = agpl_timing_end(ctx, 1);
     if (launch_rc) return launch_rc;
     AGPL_LAUNCH_CHECK(ctx);

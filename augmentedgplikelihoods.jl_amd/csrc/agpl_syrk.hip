@@ -253,7 +253,7 @@ constexpr int kRecBytes = 256;                     // one gamma | beta record
 constexpr int kStripLds = kRing * kStepBytes + 8 * kRing * kRecBytes;
 
 template <bool DIAG>
-__device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int chunk, int l,
+__device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t N, int64_t Npad, int M, int nsplit, int chunk, int nbig, int small, int l,
                                                 int s, int I, int J, const unsigned char *__restrict__ image,
                                                 const float *__restrict__ gb_all, const unsigned *__restrict__ scal,
                                                 float *__restrict__ slabG, float *__restrict__ slabg) {
@@ -270,10 +270,8 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
     const int eB = acc_scale_exp(scal[0]);
     const float sB = __uint_as_float((unsigned)(127 + eB) << 23); // gamma is scaled as it is used (exact)
 
-    const int64_t nbeg = (int64_t)s * chunk;
-    int64_t nend = nbeg + chunk;
-
-    if (nend > N) nend = N;
+    int64_t nbeg, nend;
+    agpl_slice_range(s, chunk, nbig, small, N, nbeg, nend);
     const int nstep = (int)((nend - nbeg + kStagePts - 1) / kStagePts);
     const int64_t ps0 = nbeg / 16;
     const int64_t slice_pitch = (int64_t)nb * 2 * 256; // h8 units between consecutive point slices
@@ -570,19 +568,22 @@ __device__ __forceinline__ void syrk_strip_body(unsigned char *smem_raw, int64_t
 // this device -- the second wave of a SIMD is what fills the pipe, whatever the first one's stream looks like.  Pinning the order
 // of THIS kernel's row blocks with sched_barrier (the compiler sinks the fragment reads to within four MFMAs of their use) is worth
 // 0-1 % (profiles/r06_ab_syrk_pinned.jsonl): with two waves per SIMD the partner covers it.
-__global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int npairs2, int nsplit, int chunk,
+__global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t Npad, int M, int nlat, int npairs2, int nsplit, int chunk, int nbig, int small,
                                                             const unsigned char *__restrict__ image,
                                                             const float *__restrict__ gb_all,
                                                             const unsigned *__restrict__ scal,
                                                             float *__restrict__ slabG, float *__restrict__ slabg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int nsplit8 = (nsplit + 7) / 8;
-    const int per_l = npairs2 * nsplit8 * 8;
-    const int l = blockIdx.x / per_l;
-    const int id = blockIdx.x - l * per_l;
+    // workgroup -> (slice, latent, tile): id % 8 labels the XCD (speed only); an XCD walks the slices s = 8 t + xcd, and for every slice
+    // all latents' tiles before the next slice (round 6: latent-major order streamed the image L times -- C4, L = 10, fetched 5.2 x
+    // its image -- and put every latent's short tail slices in the middle of the launch)
+    const int id = blockIdx.x;
     const int xcd = id & 7, jj = id >> 3;
-    const int s = (jj / npairs2) * 8 + xcd;
-    const int p2 = jj % npairs2;
+    const int per_s = nlat * npairs2;
+    const int s = (jj / per_s) * 8 + xcd;
+    const int rem = jj % per_s;
+    const int l = rem / npairs2;
+    const int p2 = rem - l * npairs2;
     if (s >= nsplit) return;
     const int nb2 = M / kPanel;
     const int noff = nb2 * (nb2 - 1) / 2;
@@ -594,8 +595,8 @@ __global__ __launch_bounds__(512, 2) void syrk_strip_kernel(int64_t N, int64_t N
     } else {
         I = J = p2 - noff;
     }
-    if (I == J) syrk_strip_body<true>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
-    else syrk_strip_body<false>(smem_raw, N, Npad, M, nsplit, chunk, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    if (I == J) syrk_strip_body<true>(smem_raw, N, Npad, M, nsplit, chunk, nbig, small, l, s, I, J, image, gb_all, scal, slabG, slabg);
+    else syrk_strip_body<false>(smem_raw, N, Npad, M, nsplit, chunk, nbig, small, l, s, I, J, image, gb_all, scal, slabG, slabg);
 }
 
 } // namespace
@@ -689,7 +690,7 @@ int32_t agpl_accumulate_image_build(agpl_ctx *ctx, int64_t N, int32_t M, int32_t
 // of a gamma that is negative or not finite).  records_ready: both are filled already; gamma / beta are not read.
 int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M, int32_t L, const void *image,
                                const float *gamma, const float *beta, float *gb, unsigned *scal, float *slabG,
-                               float *slabg, int ns, int chunk, bool records_ready) {
+                               float *slabg, int ns, int chunk, int nbig, int small, bool records_ready) {
     if (M % kPanel) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "the image accumulation needs M %% 256 == 0 (M = %d)", M);
     if (ctx->checked_image != image || ctx->checked_image_N != N || ctx->checked_image_M != M) {
         // the header, once per (image, N, M): an image of another (N, M), or a buffer that never was one, would otherwise give
@@ -722,7 +723,7 @@ int32_t agpl_syrk_image_launch(agpl_ctx *ctx, int64_t N, int64_t Npad, int32_t M
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds));
         ctx->strip_attr = 1;
     }
-    syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, npairs2, ns, chunk, (const unsigned char *)image, gb,
+    syrk_strip_kernel<<<(unsigned)nwg, 512, kStripLds, ctx->stream>>>(N, Npad, M, L, npairs2, ns, chunk, nbig, small, (const unsigned char *)image, gb,
                                                                      scal, slabG, slabg);
     AGPL_LAUNCH_CHECK(ctx);
     return AGPL_OK;
