@@ -61,7 +61,10 @@ def _float64_sums(Phi, gamma, beta):
 # edge cases the reference's sweep can produce: one point, a ragged last stage / slice, several slices, L > 1, every panel
 # count the plan accepts (M = 256, 512, 768, 1024)
 @pytest.mark.parametrize("N,M,L", [(1, 256, 1), (31, 256, 1), (33, 512, 1), (4096, 256, 2), (4097, 512, 1),
-                                   (20011, 512, 2), (9011, 768, 1), (9011, 1024, 1), (70001, 256, 3), (300007, 512, 1)])
+                                   (20011, 512, 2), (9011, 768, 1), (9011, 1024, 1), (70001, 256, 3), (300007, 512, 1),
+                                   # round 6, agpl_slice_plan: exactly one round of big slices (all of them cut fine), one point more
+                                   # (one big slice + a ragged fine tail), and a long M = 256 launch (no fine tail)
+                                   (352256, 512, 1), (352257, 512, 1), (430001, 256, 10)])
 def test_plan_accumulation_against_float64(A, ctx, oracle, N, M, L):
     rng = np.random.default_rng(N + 7 * M + L)
     Phi = (rng.standard_normal((N, M)) * 0.3).astype(np.float32)
