@@ -21,6 +21,11 @@
 
 int32_t agpl_launch_randn(agpl_ctx *ctx, int64_t n, uint32_t sweep, double *out);
 int32_t agpl_get_rocblas(agpl_ctx *ctx, void **handle_out);
+// agpl_factor.hip: U = chol(I + G)^-1 of an M x M block in ONE launch (M <= 1024; the M x M update of the sparse sweep)
+int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0,
+                          double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
+                          int *info_dev, void *coop_work);
+size_t agpl_factor_coop_bytes(int32_t M, int32_t L);
 
 namespace {
 
@@ -39,7 +44,8 @@ __global__ __launch_bounds__(256) void build_b_kernel(int64_t N, const double *_
     const double sr = sqrt(gamma[row]);
     const double *Kr = K + row * N;
     double *Br = B + row * N;
-    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; c < N;
+    // only the triangle every factorisation below reads: LAPACK-lower of the column-major view = columns c >= row of this row
+    for (int64_t c = (row & ~(int64_t)1) + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; c < N;
          c += (int64_t)gridDim.x * blockDim.x * 2) {
         if (c + 1 < N) {
             const double2 k = *reinterpret_cast<const double2 *>(Kr + c);
@@ -105,10 +111,13 @@ constexpr int kTStage = kTK * kTPitch; // doubles per operand and stage
 // X[r][q] = Xp[r + q ldx], Y[c][q] = Yp[c + q ldy], C[r][c] = Cp[r + c ldc]; rows r < rmax and columns c < cmax exist (loads beyond
 // are clamped, stores guarded).  DIAG: X and Y are the same rows (one load) and only r >= c is stored.  ASSIGN: C = X Y' instead of
 // C -= X Y' (the in-block panel solve B <- B U': C may alias X because a tile reads all of its X rows before it writes).
-template <bool DIAG, bool ASSIGN>
+// COPY: the new value of every stored element with r >= r2, c < c2 also goes to C2[(r - r2) + c ld2] (the update's tiles of the next
+// block column leave the raw panel of the next step where its panel product reads it: no copy pass)
+template <bool DIAG, bool ASSIGN, bool COPY = false>
 __device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int64_t ldx, const double *Yp, int64_t ldy,
                                              double *Cp, int64_t ldc, int w, int64_t r0, int64_t c0, int64_t rmax,
-                                             int64_t cmax) {
+                                             int64_t cmax, double *C2 = nullptr, int64_t ld2 = 0, int64_t r2 = 0,
+                                             int64_t c2 = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
     const int li = lane & 15, lq = lane >> 4;
@@ -196,7 +205,12 @@ __device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int
                 const int64_t r = r0 + wr * 64 + 16 * n + li;
                 if (r < rmax && c < cmax && (!DIAG || r >= c)) {
                     if (ASSIGN) Cp[r + c * ldc] = acc[m][n][rr];
-                    else Cp[r + c * ldc] -= acc[m][n][rr];
+                    else if (!COPY) Cp[r + c * ldc] -= acc[m][n][rr];
+                    else {
+                        const double v = Cp[r + c * ldc] - acc[m][n][rr];
+                        Cp[r + c * ldc] = v;
+                        if (r >= r2 && c < c2) C2[(r - r2) + c * ld2] = v;
+                    }
                 }
             }
         }
@@ -213,6 +227,35 @@ __global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, doub
     const double *P = A + k0 * N; // the panel: P[r][q] = A[r][k0 + q]
     if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
     else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
+}
+
+// The same update on a 1-D grid of the lower-triangle tiles only, column by column (round 6, the inverse-block route: a 2-D grid
+// dispatches nt^2 / 2 workgroups that exit at once, each of which still takes a slot with 74 KB of LDS for a few microseconds --
+// ~16 ms over the 63 updates of a C5 step)
+__global__ __launch_bounds__(256, 2) void trailing_update_tri_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int nt,
+                                                                     double *__restrict__ Pnext) {
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    // tiles before column J: J nt - J (J - 1) / 2; J from the quadratic, corrected for rounding
+    const int64_t idx = blockIdx.x;
+    const double bq = 2.0 * nt + 1.0;
+    int64_t J = (int64_t)((bq - sqrt(bq * bq - 8.0 * (double)idx)) * 0.5);
+    if (J < 0) J = 0;
+    if (J > nt - 1) J = nt - 1;
+    while (J > 0 && J * nt - J * (J - 1) / 2 > idx) --J;
+    while (J + 1 < nt && (J + 1) * nt - (J + 1) * J / 2 <= idx) ++J;
+    const int64_t I = J + (idx - (J * nt - J * (J - 1) / 2));
+    const int64_t e = k0 + w;
+    const double *P = A + k0 * N;
+    // tiles of the next block column (J < w / 128) below the next diagonal block: their new values are the next step's raw panel
+    // P_next[r - (e + w)][c - e] (pointer arithmetic: the tile routine indexes C2 with the absolute column)
+    if (J * kTT < w && (I + 1) * kTT > w) {
+        double *C2 = Pnext - e * N; // (column c of the matrix is column c - e of the buffer; ld = N)
+        if (I == J) gemm_nt_tile<true, false, true>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N, C2, N, e + w, e + w);
+        else gemm_nt_tile<false, false, true>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N, C2, N, e + w, e + w);
+        return;
+    }
+    if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N);
+    else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,6 +470,148 @@ int32_t blocked_potrs_vec(agpl_ctx *ctx, rocblas_handle h, int64_t N, const doub
     }
     return AGPL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the solve of the Gibbs step WITHOUT a chain of small kernels beside the update.  The step needs
+// x = B^-1 r, not the factor: per 1024-wide block k
+//     U_k = chol(D_k)^-1            the sparse sweep's one-launch factorisation (factor_pipe_kernel: 0.43 ms; D_k >= I because B >= I)
+//     A[e:, k] <- A[e:, k] U_k'     the panel, ONE launch of the tile routine (U_k lower triangular: a column tile stops at its diagonal)
+//     A[e:, e:] -= panel panel'     trailing_update_kernel, one launch
+// all in stream order on one stream: every flop of the panels runs at the matrix rate (rocBLAS dtrsm: 258 ms of kernel time beside
+// the update), nothing shares the device with the update, and the 2 x 1024 dependent 64-column steps of the look-ahead chain
+// (potrf64 83 us each) are 64 launches of 0.43 ms.  The diagonal blocks of A are left as they were (the triangular solves use U_k,
+// which is kept: 64 x 8 MB); below them A holds the factor's panels.  Needs N % 1024 == 0 (C5: 65 536).
+// ------------------------------------------------------------------------------------------------
+constexpr int kDB = 1024;
+
+// G (row-major, lower triangle and diagonal; the factorisation reads nothing else) = A[k + r][k + c] - (r == c)
+__global__ __launch_bounds__(256) void extract_block_kernel(int64_t N, const double *__restrict__ A, int64_t k, double *__restrict__ G) {
+    __shared__ double t[32][33];
+    const int bc = blockIdx.x, br = blockIdx.y;
+    if (bc > br) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) t[j][tx] = A[(k + 32 * br + tx) + (k + 32 * bc + j) * N]; // [column j][row tx]
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = 32 * br + j, c = 32 * bc + tx;
+        G[(int64_t)r * kDB + c] = t[tx][j] - (r == c ? 1.0 : 0.0);
+    }
+}
+// the factor kernels leave I + G in the other triangle of their output: U(a, b) sits at U[b * M + a] for b <= a; zero the rest
+__global__ __launch_bounds__(256) void zero_upper_kernel(double *__restrict__ U) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(i / kDB), a = (int)(i % kDB);
+    if (a < b) U[i] = 0.0;
+}
+__global__ void merge_info_kernel(const int *__restrict__ blk, rocblas_int *__restrict__ info, int k) {
+    if (threadIdx.x == 0 && info[0] == 0 && blk[0] != 0) info[0] = blk[0] > 0 ? k + blk[0] : -1;
+}
+// P[r + q ldp] = A[(e + r) + (k + q) N]: the raw panel, set aside (the tile routine cannot write a row block in place while
+// other column tiles of the same rows still read it)
+__global__ __launch_bounds__(256) void copy_panel_kernel(int64_t N, const double *__restrict__ A, int64_t e, int64_t k, int64_t m,
+                                                         double *__restrict__ P, int64_t ldp) {
+    const int64_t q = blockIdx.y;
+    const double *src = A + e + (k + q) * N;
+    double *dst = P + q * ldp;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; r < m; r += (int64_t)gridDim.x * blockDim.x * 2) {
+        if (r + 1 < m) *reinterpret_cast<double2 *>(dst + r) = *reinterpret_cast<const double2 *>(src + r);
+        else dst[r] = src[r];
+    }
+}
+// C = X Y' on the tile routine: C[r][c], r < rows, c < cols, w columns of X and Y; ytri: Y[c][q] = 0 for q > c
+__global__ __launch_bounds__(256, 2) void gemm_nt_assign_kernel(const double *__restrict__ X, int64_t ldx, const double *__restrict__ Y,
+                                                                int64_t ldy, double *__restrict__ Cm, int64_t ldc, int64_t rows,
+                                                                int64_t cols, int w, int ytri) {
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    // (ytri: a column tile's cost grows with its column; the longest first, so that the launch ends on the short ones)
+    const int64_t r0 = (int64_t)blockIdx.x * kTT, c0 = (int64_t)(ytri ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * kTT;
+    int we = w;
+    if (ytri && c0 + kTT < we) we = (int)(c0 + kTT);
+    gemm_nt_tile<false, true>(tsm, X, ldx, Y, ldy, Cm, ldc, we, r0, c0, rows, cols);
+}
+
+struct InvBlocks { // where the pieces of the inverse-block route live in the workspace (doubles from `base`)
+    double *U, *G, *T, *P, *gz, *vo;
+    void *coop;
+    int *info_blk;
+    size_t bytes;
+};
+InvBlocks inv_blocks_layout(int64_t N, char *base) {
+    InvBlocks o;
+    const size_t nblk = (size_t)(N / kDB), bb = (size_t)kDB * kDB;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + at : nullptr; at += (bytes + 255) & ~(size_t)255; return p; };
+    o.U = (double *)take(sizeof(double) * nblk * bb);
+    o.G = (double *)take(sizeof(double) * bb);
+    o.T = (double *)take(sizeof(double) * bb);
+    o.P = (double *)take(sizeof(double) * (size_t)N * kDB);
+    o.gz = (double *)take(sizeof(double) * kDB);
+    o.vo = (double *)take(sizeof(double) * kDB);
+    o.coop = take(agpl_factor_coop_bytes(kDB, 1));
+    o.info_blk = (int *)take(256);
+    o.bytes = at;
+    return o;
+}
+
+// the factor in the form above; info[0] = 0, the 1-based index of the first non-positive pivot, or -1 (an internal loss of the
+// factor pipeline's co-residency: cannot happen in stream order on a device this process has to itself)
+int32_t inverse_block_factor(agpl_ctx *ctx, int64_t N, double *A, const InvBlocks &w, rocblas_int *info) {
+    hipStream_t S = ctx->stream;
+    const size_t lds = sizeof(double) * 4 * kTStage;
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trailing_update_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_assign_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trailing_update_tri_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), S));
+    AGPL_HIP(ctx, hipMemsetAsync(w.gz, 0, sizeof(double) * kDB, S));
+    for (int64_t k = 0; k < N; k += kDB) {
+        const int64_t e = k + kDB, m = N - e;
+        double *Uk = w.U + (size_t)(k / kDB) * kDB * kDB;
+        extract_block_kernel<<<dim3(kDB / 32, kDB / 32), 256, 0, S>>>(N, A, k, w.G);
+        AGPL_LAUNCH_CHECK(ctx);
+        const int32_t rc = agpl_factor_fused(ctx, kDB, 1, w.G, w.gz, nullptr, w.T, Uk, w.vo, nullptr, nullptr, w.info_blk, w.coop);
+        if (rc) return rc;
+        zero_upper_kernel<<<kDB * kDB / 256, 256, 0, S>>>(Uk);
+        merge_info_kernel<<<1, 64, 0, S>>>(w.info_blk, info, (int)k);
+        AGPL_LAUNCH_CHECK(ctx);
+        if (m > 0) {
+            const unsigned nt = (unsigned)((m + kTT - 1) / kTT);
+            unsigned cb = (unsigned)((m + 511) / 512);
+            if (cb > 256) cb = 256;
+            if (k == 0) copy_panel_kernel<<<dim3(cb, kDB), 256, 0, S>>>(N, A, e, k, m, w.P, N); // (later panels: left there by the update)
+            gemm_nt_assign_kernel<<<dim3(nt, kDB / kTT), 256, lds, S>>>(w.P, N, Uk, kDB, A + e + k * N, N, m, kDB, kDB, 1);
+            trailing_update_tri_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, lds, S>>>(N, A, k, kDB, (int)nt, w.P);
+            AGPL_LAUNCH_CHECK(ctx);
+        }
+    }
+    return AGPL_OK;
+}
+
+// x <- B^-1 x with that factor: L_kk^-1 = U_k (dtrmv on the kept blocks), everything below the diagonal blocks a dgemv at HBM speed
+int32_t inverse_block_solve_vec(agpl_ctx *ctx, rocblas_handle h, int64_t N, const double *A, const double *U, double *x) {
+    AGPL_ROCBLAS(ctx, rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
+    const double one = 1.0, mone = -1.0;
+    for (int64_t k = 0; k < N; k += kDB) { // L y = x
+        const int64_t e = k + kDB;
+        AGPL_ROCBLAS(ctx, rocblas_dtrmv(h, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, kDB,
+                                        U + (size_t)(k / kDB) * kDB * kDB, kDB, x + k, 1));
+        if (e < N)
+            AGPL_ROCBLAS(ctx, rocblas_dgemv(h, rocblas_operation_none, (rocblas_int)(N - e), kDB, &mone, A + e + k * N,
+                                            (rocblas_int)N, x + k, 1, &one, x + e, 1));
+    }
+    for (int64_t k = N - kDB; k >= 0; k -= kDB) { // L' z = y
+        const int64_t e = k + kDB;
+        if (e < N)
+            AGPL_ROCBLAS(ctx, rocblas_dgemv(h, rocblas_operation_transpose, (rocblas_int)(N - e), kDB, &mone, A + e + k * N,
+                                            (rocblas_int)N, x + e, 1, &one, x + k, 1));
+        AGPL_ROCBLAS(ctx, rocblas_dtrmv(h, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, kDB,
+                                        U + (size_t)(k / kDB) * kDB * kDB, kDB, x + k, 1));
+    }
+    return AGPL_OK;
+}
+
 } // namespace
 
 extern "C" int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A, double *L_out) {
@@ -471,10 +656,13 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     int32_t rc = agpl_get_rocblas(ctx, &hv);
     if (rc) return rc;
     rocblas_handle h = (rocblas_handle)hv;
-    // scratch: beta, gamma, z (2N), f0, r
-    rc = agpl_ws_reserve(ctx, sizeof(double) * 6 * (size_t)N + 1024);
+    // scratch: beta, gamma, z (2N), f0, r; then the kept inverse blocks and the panel buffer of the inverse-block route
+    const bool inv_route = N >= 8192 && N % kDB == 0;
+    const size_t vec_bytes = (sizeof(double) * 6 * (size_t)N + 1024 + 255) & ~(size_t)255;
+    rc = agpl_ws_reserve(ctx, vec_bytes + (inv_route ? inv_blocks_layout(N, nullptr).bytes : 0));
     if (rc) return rc;
     double *beta = (double *)ctx->ws, *gamma = beta + N, *z = gamma + N, *f0 = z + 2 * N, *r = f0 + N;
+    const InvBlocks ib = inv_route ? inv_blocks_layout(N, (char *)ctx->ws + vec_bytes) : InvBlocks{};
 
     // 1. Omega <- aux_sample!(lik, y, f) ; beta, gamma = auglik_potential / auglik_precision     script.jl:81-83
     rc = agpl_aux_sample(ctx, lik, N, y, f_inout, omega_out, n_out, sweep, nullptr, nullptr);
@@ -497,16 +685,20 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     rc = agpl_ws2_reserve(ctx, 65536);
     if (rc) return rc;
     rocblas_int *info = (rocblas_int *)((char *)ctx->ws2 + 16384);
-    if (N >= 8192) {
+    if (inv_route) {
+        rc = inverse_block_factor(ctx, N, B_work, ib, info);
+        if (rc) return rc;
+        rc = inverse_block_solve_vec(ctx, h, N, B_work, ib.U, r);
+        if (rc) return rc;
+    } else if (N >= 8192) {
         rc = blocked_potrf(ctx, h, N, B_work, info);
+        if (rc) return rc;
+        rc = blocked_potrs_vec(ctx, h, N, B_work, r);
         if (rc) return rc;
     } else {
         AGPL_ROCBLAS(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)N, B_work, (rocblas_int)N, info));
     }
-    if (N >= 8192) {
-        rc = blocked_potrs_vec(ctx, h, N, B_work, r);
-        if (rc) return rc;
-    } else {
+    if (N < 8192) {
         AGPL_ROCBLAS(ctx, rocsolver_dpotrs(h, rocblas_fill_lower, (rocblas_int)N, 1, B_work, (rocblas_int)N, r,
                                            (rocblas_int)N));
     }
@@ -521,6 +713,7 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     rocblas_int hinfo = 0;
     AGPL_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
     AGPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hinfo < 0) AGPL_FAIL(ctx, AGPL_ERR_HIP, "the block factorisation lost its co-resident workgroups (another process on the device?)");
     if (hinfo != 0)
         AGPL_FAIL(ctx, AGPL_ERR_NOT_POSDEF, "I + D^1/2 K D^1/2 is not positive definite (potrf info = %d)", (int)hinfo);
     return AGPL_OK;

@@ -246,7 +246,9 @@ AGPL_API int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const do
  *   array (= the upper triangle of a row-major view); the other triangle keeps A.  PosDefException -> -5.
  * agpl_dense_gibbs_step: Omega <- aux_sample!(lik, y, f) (:81); f ~ N(mu, Sigma) with
  *   Sigma = (K^-1 + Diag(gamma))^-1, mu = Sigma (beta + K^-1 mu0) (:82-84), evaluated with one Cholesky of
- *   B = I + D^1/2 K D^1/2 (written to B_work, N x N float64) and no inverse -- an exact draw (Matheron's rule).
+ *   B = I + D^1/2 K D^1/2 (B_work, N x N float64: scratch -- what it holds afterwards depends on the route) and no
+ *   inverse of B -- an exact draw (Matheron's rule).  N % 1024 == 0, N >= 8192: block by block on the one-launch M x M
+ *   factorisation of the sparse sweep, panels and trailing updates on the float64 matrix cores, one stream.
  *   Normals: Philox streams (seed, 0..2N-1, sweep | 2^31).  Single-latent likelihoods.  f_inout: f in, new f out. */
 AGPL_API int32_t agpl_dense_cholesky(agpl_ctx *ctx, int64_t N, const double *A, double *L_out);
 AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_t N, const double *K,

@@ -716,6 +716,44 @@ def test_dense_gibbs_step_blocked_routes_match_oracle(A, ctx, oracle):
         assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max())
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N", [8192, 9216])
+def test_dense_gibbs_step_inverse_block_route_matches_oracle(A, ctx, oracle, N):
+    """Round 6: for N a multiple of 1024 (C5's 65 536) the step's solve runs block by block on the sparse sweep's one-launch
+    factorisation -- U_k = chol(D_k)^-1, panel <- panel U_k' on the tile routine, trailing update, all in stream order; the
+    triangular solves use the kept U_k.  Two sweeps against the numpy chain (np.linalg.cholesky of the same B), Student-t and --
+    with gamma_i = 0 rows -- Poisson; a matrix that is not positive definite reports AGPL_ERR_NOT_POSDEF."""
+    O = oracle
+    rng = np.random.default_rng(41 + N)
+    x = np.sort(rng.uniform(-400, 400, size=N))
+    K = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 2.0) ** 2) + 1e-3 * np.eye(N)
+    Lk = np.linalg.cholesky(K)
+    for name in ("studentt", "poisson") if N == 8192 else ("studentt",):
+        lik, olik = lik_pairs(A, O)[name]
+        y = gen_y(O, olik, N, rng)
+        dctx = A.Context(0, seed=123)
+        dg = A.DenseGibbs(lik, dev(K), dev(y), ctx=dctx)
+        f = np.zeros(N)
+        for sweep in range(2):
+            dg.sweep()
+            f, d = O.dense_gibbs_step(olik, K, Lk, y, f, seed=123, sweep=sweep)
+            assert np.allclose(host(dg.omega), d["omega"], rtol=1e-6), name
+            assert np.abs(host(dg.f) - f).max() < 1e-6 * max(1.0, np.abs(f).max()), name
+        f1 = host(dg.f).copy()
+        del dg
+    # not positive definite: K with a negative eigenvalue and a large gamma (Student-t precision is positive)
+    Kbad = K.copy()
+    Kbad[N // 2, N // 2] = -50.0
+    lik, olik = lik_pairs(A, O)["studentt"]
+    y = gen_y(O, olik, N, rng)
+    dctx = A.Context(0, seed=5)
+    dg = A.DenseGibbs(lik, dev(K), dev(y), ctx=dctx)
+    dg.K = dev(Kbad)
+    with pytest.raises(Exception) as ei:
+        dg.sweep()
+    assert "positive definite" in str(ei.value)
+
+
 def test_elbo_matches_oracle_and_increases(A, ctx, oracle):
     """aug_elbo (examples/bernoulli/script.jl:65-70) on the device against the float64 oracle evaluation, and the
     CAVI property the reference's commented-out test was after: the ELBO does not decrease across sweeps."""
