@@ -216,29 +216,18 @@ __device__ __forceinline__ void gemm_nt_tile(double *smem, const double *Xp, int
         }
 }
 
-// grid (tile rows, tile columns): tile (I, j0 + blockIdx.y) of the lower triangle of A[e:lim, e:lim], e = k0 + w; the upper
-// block triangle exits
-__global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int j0,
-                                                                 int64_t lim) {
+// The update on a 1-D grid of the lower-triangle tiles only, column by column: tile (I, J), J <= I < nt, of A[e:lim, e:lim], e = k0 + w,
+// has index J nt - J (J - 1) / 2 + (I - J); the launch covers the indices base .. base + gridDim.x - 1 (whole columns: the look-ahead
+// route launches the next block column first).  Rounds 3-5 used a 2-D grid whose upper half exits at once: nt^2 / 2 workgroups that
+// each still take a slot with 74 KB of LDS for a few microseconds -- 70 ms of a C5 step.
+// Pnext (may be null): the tiles of the next block column below the next diagonal block also store their new values there, as the
+// next step's raw panel P_next[r - (e + w)][c - e] (ld = N): the inverse-block route's panel product reads it, no copy pass.
+__global__ __launch_bounds__(256, 2) void trailing_update_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int nt,
+                                                                 int64_t base, int64_t lim, double *__restrict__ Pnext) {
     extern __shared__ __attribute__((aligned(16))) double tsm[];
-    const int64_t I = blockIdx.x, J = (int64_t)j0 + blockIdx.y;
-    if (I < J) return;
-    const int64_t e = k0 + w;
-    const double *P = A + k0 * N; // the panel: P[r][q] = A[r][k0 + q]
-    if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
-    else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
-}
-
-// The same update on a 1-D grid of the lower-triangle tiles only, column by column (round 6, the inverse-block route: a 2-D grid
-// dispatches nt^2 / 2 workgroups that exit at once, each of which still takes a slot with 74 KB of LDS for a few microseconds --
-// ~16 ms over the 63 updates of a C5 step)
-__global__ __launch_bounds__(256, 2) void trailing_update_tri_kernel(int64_t N, double *__restrict__ A, int64_t k0, int w, int nt,
-                                                                     double *__restrict__ Pnext) {
-    extern __shared__ __attribute__((aligned(16))) double tsm[];
-    // tiles before column J: J nt - J (J - 1) / 2; J from the quadratic, corrected for rounding
-    const int64_t idx = blockIdx.x;
+    const int64_t idx = base + blockIdx.x;
     const double bq = 2.0 * nt + 1.0;
-    int64_t J = (int64_t)((bq - sqrt(bq * bq - 8.0 * (double)idx)) * 0.5);
+    int64_t J = (int64_t)((bq - sqrt(bq * bq - 8.0 * (double)idx)) * 0.5); // from the quadratic, then corrected for rounding
     if (J < 0) J = 0;
     if (J > nt - 1) J = nt - 1;
     while (J > 0 && J * nt - J * (J - 1) / 2 > idx) --J;
@@ -246,17 +235,15 @@ __global__ __launch_bounds__(256, 2) void trailing_update_tri_kernel(int64_t N, 
     const int64_t I = J + (idx - (J * nt - J * (J - 1) / 2));
     const int64_t e = k0 + w;
     const double *P = A + k0 * N;
-    // tiles of the next block column (J < w / 128) below the next diagonal block: their new values are the next step's raw panel
-    // P_next[r - (e + w)][c - e] (pointer arithmetic: the tile routine indexes C2 with the absolute column)
-    if (J * kTT < w && (I + 1) * kTT > w) {
-        double *C2 = Pnext - e * N; // (column c of the matrix is column c - e of the buffer; ld = N)
-        if (I == J) gemm_nt_tile<true, false, true>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N, C2, N, e + w, e + w);
-        else gemm_nt_tile<false, false, true>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N, C2, N, e + w, e + w);
+    if (Pnext && J * kTT < w && (I + 1) * kTT > w) {
+        double *C2 = Pnext - e * N; // (the tile routine indexes the second destination with the absolute column)
+        gemm_nt_tile<false, false, true>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim, C2, N, e + w, e + w);
         return;
     }
-    if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N);
-    else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, N, N);
+    if (I == J) gemm_nt_tile<true, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
+    else gemm_nt_tile<false, false>(tsm, P, N, P, N, A, N, w, e + I * kTT, e + J * kTT, lim, lim);
 }
+__host__ __device__ inline int64_t tri_tiles_before(int64_t nt, int64_t J) { return J * nt - J * (J - 1) / 2; }
 
 // ------------------------------------------------------------------------------------------------
 // The diagonal blocks, by our own kernels (round 3).  rocsolver_dpotrf may not run beside another kernel (its results then
@@ -342,7 +329,7 @@ int32_t own_block_potrf(agpl_ctx *ctx, hipStream_t st, int64_t N, double *A, int
         if (rem > 0) {
             const unsigned nt = (unsigned)((rem + kTT - 1) / kTT);
             panel_solve_kernel<<<nt, 256, lds, st>>>(N, A + kj * N, Ubuf, kj + kPB, k + W);
-            trailing_update_kernel<<<dim3(nt, nt), 256, lds, st>>>(N, A, kj, kPB, 0, k + W);
+            trailing_update_kernel<<<(unsigned)tri_tiles_before(nt, nt), 256, lds, st>>>(N, A, kj, kPB, (int)nt, 0, k + W, nullptr);
         }
     }
     AGPL_LAUNCH_CHECK(ctx);
@@ -412,12 +399,13 @@ int32_t blocked_potrf_steps(agpl_ctx *ctx, rocblas_handle h, int64_t N, double *
         // trailing lower triangle: A[e:, e:] -= A21 A21', block column k + 1 first
         const int64_t m = N - e, nt = (m + kTT - 1) / kTT;
         const int64_t ncol1 = nt < nb / kTT ? nt : nb / kTT;
-        trailing_update_kernel<<<dim3((unsigned)nt, (unsigned)ncol1), 256, lds, S>>>(N, A, k, (int)w, 0, N);
+        trailing_update_kernel<<<(unsigned)tri_tiles_before(nt, ncol1), 256, lds, S>>>(N, A, k, (int)w, (int)nt, 0, N, nullptr);
         AGPL_LAUNCH_CHECK(ctx);
         AGPL_HIP(ctx, hipEventRecord(ev_col, S));
         AGPL_HIP(ctx, hipStreamWaitEvent(X, ev_col, 0));
         if (nt > ncol1) {
-            trailing_update_kernel<<<dim3((unsigned)nt, (unsigned)(nt - ncol1)), 256, lds, S>>>(N, A, k, (int)w, (int)ncol1, N);
+            trailing_update_kernel<<<(unsigned)(tri_tiles_before(nt, nt) - tri_tiles_before(nt, ncol1)), 256, lds, S>>>(
+                N, A, k, (int)w, (int)nt, tri_tiles_before(nt, ncol1), N, nullptr);
             AGPL_LAUNCH_CHECK(ctx);
         }
         cur = X;
@@ -562,8 +550,6 @@ int32_t inverse_block_factor(agpl_ctx *ctx, int64_t N, double *A, const InvBlock
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_assign_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    AGPL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trailing_update_tri_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AGPL_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), S));
     AGPL_HIP(ctx, hipMemsetAsync(w.gz, 0, sizeof(double) * kDB, S));
     for (int64_t k = 0; k < N; k += kDB) {
@@ -582,7 +568,7 @@ int32_t inverse_block_factor(agpl_ctx *ctx, int64_t N, double *A, const InvBlock
             if (cb > 256) cb = 256;
             if (k == 0) copy_panel_kernel<<<dim3(cb, kDB), 256, 0, S>>>(N, A, e, k, m, w.P, N); // (later panels: left there by the update)
             gemm_nt_assign_kernel<<<dim3(nt, kDB / kTT), 256, lds, S>>>(w.P, N, Uk, kDB, A + e + k * N, N, m, kDB, kDB, 1);
-            trailing_update_tri_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, lds, S>>>(N, A, k, kDB, (int)nt, w.P);
+            trailing_update_kernel<<<(unsigned)tri_tiles_before(nt, nt), 256, lds, S>>>(N, A, k, kDB, (int)nt, 0, N, w.P);
             AGPL_LAUNCH_CHECK(ctx);
         }
     }
