@@ -517,9 +517,10 @@ def c5_leg(A, args):
     tf = N ** 3 / 3 / dt / 1e12
     out = {"config": {"workload": f"StudentT(3.5, 2.0) full-rank Gibbs step, N={N}, SE kernel lengthscale 2.0, jitter 1e-6"},
            "value": round(1.0 / dt, 4), "unit": "sweeps/s", "ms_per_step": round(dt * 1e3, 1), "steps": steps, "dtype": "f64",
-           "n3_work": "trailing update (the N^3/3): hand-written float64-MFMA lower-triangle kernel (agpl_dense.hip "
-                      "trailing_update_kernel); 2048-wide diagonal blocks: own kernels (potrf64 + panel solve + the same update "
-                      "kernel), overlapped with the update on a side stream; panel solves: rocBLAS dtrsm",
+           "n3_work": "block by block (1024 wide), one stream: U_k = chol(D_k)^-1 by the sparse sweep's one-launch factorisation "
+                      "(factor_pipe_kernel), panel <- panel U_k' and the trailing update (the N^3/3) on the hand-written float64-MFMA "
+                      "tile routine (agpl_dense.hip: gemm_nt_assign_kernel, trailing_update_kernel on a 1-D grid of the lower-triangle "
+                      "tiles); solves with the kept U_k (dtrmv) and one dgemv per panel",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s (N^3/3 per sweep, float64)",
                         "peak": round(peak.value, 1), "peak_source": "agpl_probe_mfma(float64): v_mfma_f64_16x16x4_f64 "
                         "back-to-back on every SIMD, measured on this device in this run",
