@@ -182,15 +182,26 @@ int32_t agpl_factor_fused(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, 
                           double *T_work, double *A_work, double *v_out, float *v32_out, double *logdet_out,
                           int *info_dev, void *coop_work);
 size_t agpl_factor_coop_bytes(int32_t M, int32_t L); // agpl_factor.hip
-// the hand-written factorisation (agpl_factor.hip) takes this shape; everything else -- M > 1024, or a feature count that is not a
+// the hand-written factorisation (agpl_factor.hip) takes this shape; everything else -- M > 2048, or a feature count that is not a
 // multiple of 32 (128 beyond 512) -- goes to rocSOLVER.  A plan pads to a multiple of 256, so its sweeps take the library route only
-// beyond M = 1024.  (Rounds 4-5 had a third route, two block rows of the M <= 512 kernel around four library GEMMs, for
+// beyond M = 2048.  (Rounds 4-5 had a third route, two block rows of the M <= 512 kernel around four library GEMMs, for
 // 512 < M <= 1024 with M % 128 != 0 or L > 8: removed in round 6 -- the pipeline form runs eight latents per launch instead.)
 static inline bool factor_one_launch(int32_t M, int32_t L) {
     if (M % 32 || L > 64) return false;
     if (M <= 512) return true;
-    return M <= 1024 && M % 128 == 0;
+    return M <= 2048 && M % 128 == 0; // (beyond 1024: two block rows around the one-launch kernel, agpl_factor_two_block)
 }
+// agpl_dense.hip: U = chol(I + G)^-1 for 1024 < M <= 2048 as two block rows of the one-launch kernel and four products on the
+// float64 tile routine -- no library call
+size_t agpl_factor_two_block_bytes(int32_t M);
+int32_t agpl_factor_two_block(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, double *T_work, double *A_work, double *logdet_out,
+                              int *info_dev, void *work);
+static inline size_t factor_work_bytes(int32_t M, int32_t L) {
+    return M <= 1024 ? agpl_factor_coop_bytes(M, L) : agpl_factor_two_block_bytes(M);
+}
+// agpl_factor_fused's contract for every M factor_one_launch accepts (defined behind factor_apply_kernel)
+static int32_t factor_any(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0, double *T_work,
+                          double *A_work, double *v_out, float *v32_out, double *logdet_out, int *info_dev, void *work);
 
 namespace {
 // Uz = the factor with its foreign triangle zeroed: Uz[i][j] = A[i][j] for i <= j (row-major; = U[j][i]), else 0
@@ -216,7 +227,7 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
     if (factor_one_launch(M, L)) {
         // hand-written factorisation (agpl_factor.hip): U = chol(I + G)^-1, then S = U'U as one float64 GEMM -- against 3.4 ms for the
         // ~300 launches of potrf + potri
-        const size_t coop_bytes = (agpl_factor_coop_bytes(M, L) + 255) & ~(size_t)255;
+        const size_t coop_bytes = (factor_work_bytes(M, L) + 255) & ~(size_t)255;
         const size_t own = info_off + 1024;
         rc = agpl_ws2_reserve(ctx, own + 3 * mat_bytes + (S_out ? 0 : mat_bytes) + coop_bytes + 1024);
         if (rc) return rc;
@@ -225,7 +236,7 @@ static int32_t gaussian_update_impl(agpl_ctx *ctx, int32_t M, int32_t L, const d
         double *T = (double *)p, *Aw = (double *)(p + mat_bytes), *Uz = (double *)(p + 2 * mat_bytes);
         double *S = S_out ? S_out : (double *)(p + 3 * mat_bytes);
         void *coop = (void *)(p + 3 * mat_bytes + (S_out ? 0 : mat_bytes));
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, coop);
+        rc = factor_any(ctx, M, L, G, g, eta0, T, Aw, nullptr, nullptr, logdet_dev, info, coop);
         if (rc) return rc;
         dim3 grid((unsigned)agpl_cdiv(M, 128), (unsigned)M, (unsigned)L);
         factor_clean_kernel<<<grid, 128, 0, ctx->stream>>>(M, Aw, Uz);
@@ -325,6 +336,18 @@ __global__ __launch_bounds__(256) void factor_apply_kernel(int M, const double *
     }
 }
 } // namespace
+
+static int32_t factor_any(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g, const double *eta0, double *T_work,
+                          double *A_work, double *v_out, float *v32_out, double *logdet_out, int *info_dev, void *work) {
+    if (M <= 1024) return agpl_factor_fused(ctx, M, L, G, g, eta0, T_work, A_work, v_out, v32_out, logdet_out, info_dev, work);
+    const int32_t rc = agpl_factor_two_block(ctx, M, L, G, T_work, A_work, logdet_out, info_dev, work);
+    if (rc) return rc;
+    if (v_out || v32_out) {
+        factor_apply_kernel<<<dim3((unsigned)M, (unsigned)L), 256, 0, ctx->stream>>>(M, A_work, g, eta0, v_out, v32_out);
+        AGPL_LAUNCH_CHECK(ctx);
+    }
+    return AGPL_OK;
+}
 
 // ---- feature counts the hand-written kernels do not take as they are: zero-padded copies (round 6) ------------------------------
 // Zero features change nothing: G, g have zero rows / columns there, I + G is the identity there, U = chol(I + G)^-1 and v are
@@ -472,13 +495,13 @@ static int32_t gaussian_factor_enqueue(agpl_ctx *ctx, int32_t M, int32_t L, cons
     if (factor_one_launch(M, L)) {
         // one launch: blocked Cholesky + inverse factor + v + logdet (agpl_factor.hip)
         const size_t info_off = 16384, mat_bytes = sizeof(double) * (size_t)L * M * M;
-        const size_t coop_bytes = agpl_factor_coop_bytes(M, L);
+        const size_t coop_bytes = factor_work_bytes(M, L);
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + mat_bytes + coop_bytes);
         if (rc) return rc;
         int *info = (int *)((char *)ctx->ws2 + info_off);
         double *T = (double *)((char *)ctx->ws2 + info_off + 1024);
         void *coop = (char *)ctx->ws2 + info_off + 1024 + mat_bytes;
-        rc = agpl_factor_fused(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info, coop);
+        rc = factor_any(ctx, M, L, G, g, eta0, T, A_work, v_out, v32_out, logdet_out, info, coop);
         if (rc) return rc;
         if (U_hi) {
             rc = pending_prepare(ctx);
@@ -671,14 +694,14 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
     if (M <= 0 || L <= 0 || !G || !g || !v_out) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "bad argument");
     if (sweep & 0x80000000u) AGPL_FAIL(ctx, AGPL_ERR_INVALID_ARGUMENT, "sweep must be < 2^31");
     // the feature count the hand-written factorisation runs on: M itself, or (round 6) M zero-padded to the next count it takes --
-    // a multiple of 32 up to 512, of 128 up to 1024.  The draw z ~ N(0, I) stays M-sized (stream index l M + a, whatever the padding)
-    const int32_t Mf = M <= 512 ? (M + 31) / 32 * 32 : (M <= 1024 ? (M + 127) / 128 * 128 : M);
+    // a multiple of 32 up to 512, of 128 up to 2048.  The draw z ~ N(0, I) stays M-sized (stream index l M + a, whatever the padding)
+    const int32_t Mf = M <= 512 ? (M + 31) / 32 * 32 : (M <= 2048 ? (M + 127) / 128 * 128 : M);
     if (factor_one_launch(Mf, L)) {
         // I + G = C C', U = C^-1:  m = U'(U r),  v = m + C^-T z = U'(U r + z)   (one fused factor launch + one matvec)
         const size_t mat_bytes = sizeof(double) * (size_t)L * Mf * Mf;
         const size_t vec_bytes = (sizeof(double) * (size_t)L * Mf + 255) & ~(size_t)255;
         const size_t info_off = 16384;
-        const size_t coop_bytes = (agpl_factor_coop_bytes(Mf, L) + 255) & ~(size_t)255;
+        const size_t coop_bytes = (factor_work_bytes(Mf, L) + 255) & ~(size_t)255;
         const size_t pad_bytes = Mf != M ? mat_bytes + 2 * vec_bytes : 0;
         int32_t rc = agpl_ws2_reserve(ctx, info_off + 1024 + 2 * mat_bytes + 2 * vec_bytes + 512 + coop_bytes + pad_bytes);
         if (rc) return rc;
@@ -694,7 +717,7 @@ extern "C" int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const 
             if (rc) return rc;
             G = Gp, g = gp, eta0 = eta0 ? ep : nullptr;
         }
-        rc = agpl_factor_fused(ctx, Mf, L, G, g, eta0, T, A, vf, nullptr, nullptr, info, coop);
+        rc = factor_any(ctx, Mf, L, G, g, eta0, T, A, vf, nullptr, nullptr, info, coop);
         if (rc) return rc;
         rc = agpl_launch_randn(ctx, (int64_t)L * M, sweep | 0x80000000u, z);
         if (rc) return rc;

@@ -199,7 +199,8 @@ AGPL_API int32_t agpl_accumulate(agpl_ctx *ctx, int64_t N, int32_t M, int32_t L,
 
 /* agpl_gaussian_update: S = (I + G)^-1, m = S (g + eta0)  -- the update of
  *   examples/bernoulli/script.jl:35-36 (CAVI) / :82-83 (Gibbs) in the sparse whitened form of
- *   docs/src/index.md:154-163.  float64 Cholesky (rocSOLVER potrf/potri) on device.
+ *   docs/src/index.md:154-163.  float64, on device: the hand-written inverse-factor kernels up to M = 2048 (S = U'U by
+ *   one GEMM), rocSOLVER potrf/potri beyond and for feature counts they do not take.
  *   G [L,M,M], g [L,M], eta0 [L,M] or NULL.  Outputs (any may be NULL): S_out [L,M,M] f64,
  *   m_out [L,M] f64, Wpack_out [L,M,M] f32 (packed -S, so that var = kdiag + phi' S phi through
  *   agpl_marginals), alpha_out [L,M] f32 (= m).  Returns AGPL_ERR_NOT_POSDEF if I + G is not SPD.
@@ -234,8 +235,9 @@ AGPL_API int32_t agpl_gibbs_pass(agpl_ctx *ctx, const agpl_lik_desc *lik, int64_
                                  double *f_out, double *omega_out, int64_t *n_out, uint32_t *nuni_out);
 
 /* agpl_gibbs_draw_v: v_l ~ N(m_l, S_l), S = (I + G)^-1, m = S (g + eta0): the `rand!(MvNormal(mu, Sigma), f)`
- *   of examples/bernoulli/script.jl:82-84 for the M inducing coordinates.  Cholesky C C' = I + G (rocSOLVER
- *   potrf), m by potrs, v = m + C^-T z with z_a = the normal of Philox stream (seed, l*M + a, sweep | 2^31).
+ *   of examples/bernoulli/script.jl:82-84 for the M inducing coordinates.  I + G = C C', U = C^-1 (the hand-written
+ *   factor kernels up to M = 2048, any M: zero-padded inside; rocSOLVER beyond): m = U'(U r), v = U'(U r + z) with
+ *   z_a = the normal of Philox stream (seed, l*M + a, sweep | 2^31).
  *   v_out [L,M] f64; m_out [L,M] f64 or NULL.  sweep < 2^31.                                            */
 AGPL_API int32_t agpl_gibbs_draw_v(agpl_ctx *ctx, int32_t M, int32_t L, const double *G, const double *g,
                                    const double *eta0, uint32_t sweep, double *v_out, double *m_out);
@@ -261,8 +263,9 @@ AGPL_API int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik, 
  *     var_n = (k_nn - |phi_n|^2) + sum_a T[a,n]^2,   mu_n = mu0_n + sum_a v_a T[a,n],   T = U Phi
  * (the same q(f_n) as agpl_marginals; reference: the marginals of q(u) = N(m, S) pushed through K_XZ K_ZZ^-1).
  * agpl_gaussian_factor : A_work [L,M,M] f64 scratch/out (on return its column-major lower triangle holds U); v_out [L,M] f64 and
- *                        logdet_out [L] f64 (device, log det(I + G)) are optional.  One hand-written launch for M <= 1024
- *                        (rocSOLVER beyond).  ASYNCHRONOUS: a failed factorisation (AGPL_ERR_NOT_POSDEF with the pivot row, ...)
+ *                        logdet_out [L] f64 (device, log det(I + G)) are optional.  One hand-written launch for M <= 1024,
+ *                        two block rows of it with the products on the float64 matrix cores for M <= 2048 (M % 128 == 0;
+ *                        rocSOLVER beyond, and for counts the kernels do not take).  ASYNCHRONOUS: a failed factorisation (AGPL_ERR_NOT_POSDEF with the pivot row, ...)
  *                        is reported by the next agpl_gaussian_factor / agpl_plan_update / agpl_cavi_pass_plan on this context
  *                        -- after that call has enqueued its own kernels, so the host never idles the GPU inside a sweep loop
  *                        (script.jl:34-38) -- or by agpl_ctx_synchronize.  Work enqueued behind a failed factorisation computes

@@ -119,18 +119,19 @@ def ten_sweeps_against_oracle(A, ctx, O, lik, olik, N, M):
 
 
 @pytest.mark.timeout(900)
-def test_m1280_library_factor_route_ten_sweeps_match_oracle(A, ctx, oracle):
-    """M = 1280 (> 1024: the M x M update goes through the rocSOLVER route, the image sweep stays: 5 x 5 panels of 256) -- ten
-    Bernoulli sweeps against the oracle.  Also the route on which the sweep's bad-gamma word is NOT forwarded by the update:
-    it must be dropped at the next sweep, not reported to a later problem on the same context."""
+def test_m1280_two_block_factor_route_ten_sweeps_match_oracle(A, ctx, oracle):
+    """M = 1280 (> 1024: since round 6 the M x M update is two block rows of the one-launch factorisation with four products on the
+    float64 tile routine -- agpl_factor_two_block, no library call; the image sweep stays: 5 x 5 panels of 256) -- ten Bernoulli
+    sweeps against the oracle.  Then M = 2304 (> 2048: the rocSOLVER route), on which the sweep's bad-gamma word is NOT forwarded by
+    the update: it must be dropped at the next sweep, not reported to a later problem on the same context."""
     O = oracle
     lik, olik = A.BernoulliLikelihood(), O.bernoulli()
     cavi, _ = ten_sweeps_against_oracle(A, ctx, O, lik, olik, 6_000, 1280)
     assert cavi.plan is not None and cavi.M == 1280
-    # a problem with a NaN observation-derived gamma on this route ...
+    # a problem with a NaN observation-derived gamma on the library route ...
     bad = A.Context(0, seed=5)
     slik = A.StudentTLikelihood(3.0, 1.0)
-    x, y, Phi, kd = setup_svgp(A, bad, slik, 3_000, 1280)
+    x, y, Phi, kd = setup_svgp(A, bad, slik, 3_000, 2304)
     y[77] = float("nan")
     c1 = shipped(A, slik, Phi, kd, y, bad)
     try:

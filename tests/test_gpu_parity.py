@@ -434,9 +434,10 @@ def test_accumulate_linearity_at_scale(A, ctx):
     assert host(torch.diagonal(Ga[0]).sum()) == pytest.approx(tr, rel=1e-6)
 
 
-@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 768), (1, 1024), (1, 1152)])
+@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 768), (1, 1024), (1, 1152), (2, 1536), (1, 2048), (1, 1100), (1, 2176)])
 def test_gaussian_update_against_lapack(A, ctx, oracle, L, M):
-    """S, m against LAPACK on every route: factor kernel (M <= 512), factor pipeline (M <= 1024, M % 128 == 0), rocSOLVER (1152)."""
+    """S, m against LAPACK on every route: factor kernel (M <= 512), factor pipeline (M <= 1024, M % 128 == 0), two block rows of it
+    (round 6: 1024 < M <= 2048, M % 128 == 0: 1152, 1536, 2048), rocSOLVER (1100: not a multiple of 128; 2176: beyond 2048)."""
     rng = np.random.default_rng(11 + M)
     B = rng.normal(size=(L, M, 3 * M)) / np.sqrt(M / 256.0)
     G = B @ B.transpose(0, 2, 1)
@@ -617,11 +618,13 @@ def test_gibbs_pass_matches_oracle(A, ctx, oracle, name):
     assert relmax(host(g), gr) < 5e-6
 
 
-@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 640), (1, 1024), (1, 1280), (2, 200), (1, 37), (1, 600), (10, 1024)])
+@pytest.mark.parametrize("L,M", [(2, 256), (1, 512), (2, 640), (1, 1024), (1, 1280), (2, 200), (1, 37), (1, 600), (10, 1024), (1, 1300),
+                                 (2, 2048), (1, 2100)])
 def test_gibbs_draw_v_matches_oracle(A, ctx, oracle, L, M):
     """Every route of the conditional draw: the one-launch factor kernel (M <= 512), the factor pipeline (M <= 1024; ten latents in
-    two launches), rocSOLVER (beyond), and -- round 6 -- feature counts the kernels do not take as they are (200, 37, 600), which
-    agpl_gibbs_draw_v zero-pads to the next one they do; the draw z stays M-sized (the oracle's stream indices)."""
+    two launches), two block rows of it (1024 < M <= 2048: 1280, 2048, and 1300 padded to 1408), rocSOLVER (2100), and -- round 6 --
+    feature counts the kernels do not take as they are (200, 37, 600, 1300), which agpl_gibbs_draw_v zero-pads to the next one they do;
+    the draw z stays M-sized (the oracle's stream indices)."""
     import ctypes as C
 
     rng = np.random.default_rng(23 + M)
@@ -822,11 +825,13 @@ def test_cavi_factor_form_matches_oracle(A, ctx, oracle, name, N, M):
 
 
 @pytest.mark.parametrize("M,L", [(32, 1), (64, 2), (96, 1), (128, 1), (256, 1), (352, 1), (384, 3), (512, 2), (544, 1), (640, 3),
-                                 (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 8), (1024, 9), (1536, 1), (256, 30), (512, 9), (256, 20), (512, 40)])
+                                 (768, 1), (896, 2), (1024, 1), (1024, 2), (1024, 8), (1024, 9), (1536, 1), (256, 30), (512, 9), (256, 20), (512, 40),
+                                 (1152, 1), (1280, 3), (1920, 1), (2048, 2), (2176, 1)])
 def test_gaussian_factor_with_prior_term_and_all_routes(A, ctx, M, L):
     """agpl_gaussian_factor with eta0: v = U (g + eta0); the one-launch kernels (M <= 1024: every block count, both
-    latent-per-XCD packings, nine latents at M = 1024 in two launches of the pipeline) and the rocSOLVER route (M = 1536, and 544:
-    not a multiple of 128 beyond 512) satisfy the same identities: U'U = (I+G)^-1,
+    latent-per-XCD packings, nine latents at M = 1024 in two launches of the pipeline), two block rows of them (round 6: 1024 < M <=
+    2048, M % 128 == 0 -- 1152, 1280 with three latents, 1536, 1920, 2048 with two) and the rocSOLVER route (M = 2176, and 544: not a
+    multiple of 128 beyond 512) satisfy the same identities: U'U = (I+G)^-1,
     U'v = (I+G)^-1 (g + eta0), log det."""
     import ctypes as C
 

@@ -305,7 +305,7 @@ def test_plan_path_at_any_feature_count_ten_sweeps(A, oracle, name, N, M):
     docs/src/index.md:154-163) has no shape restriction.  Rounds 3-5 sent M % 256 != 0 to the float32-input kernels (4 x slower) unless
     the caller zero-padded; now agpl_plan_create pads the images itself and G, g, U, v come back at the caller's M: ten CAVI sweeps
     at M = 64 (BASELINE C1's count), 200, 37 (not a multiple of 4: ragged rows), 1280 and 2048 (beyond the one-launch
-    factorisation: the library route for the M x M update) against the oracle's float64 sweep on the same features."""
+    factorisation: two block rows of it) against the oracle's float64 sweep on the same features."""
     O = oracle
     lik, olik = _liks(A, O)[name]
     ctx = A.Context(0, seed=5)
