@@ -765,9 +765,13 @@ extern "C" int32_t agpl_dense_gibbs_step(agpl_ctx *ctx, const agpl_lik_desc *lik
     if (rc) return rc;
     rocblas_handle h = (rocblas_handle)hv;
     // scratch: beta, gamma, z (2N), f0, r; then the kept inverse blocks and the panel buffer of the inverse-block route
-    const bool inv_route = N >= 8192 && N % kDB == 0;
+    bool inv_route = N >= 8192 && N % kDB == 0;
     const size_t vec_bytes = (sizeof(double) * 6 * (size_t)N + 1024 + 255) & ~(size_t)255;
     rc = agpl_ws_reserve(ctx, vec_bytes + (inv_route ? inv_blocks_layout(N, nullptr).bytes : 0));
+    if (rc == AGPL_ERR_OUT_OF_MEMORY && inv_route) { // (8 N^2 / 1024 + 8192 N bytes more than the look-ahead route needs: 1 GB at C5)
+        inv_route = false;
+        rc = agpl_ws_reserve(ctx, vec_bytes);
+    }
     if (rc) return rc;
     double *beta = (double *)ctx->ws, *gamma = beta + N, *z = gamma + N, *f0 = z + 2 * N, *r = f0 + N;
     const InvBlocks ib = inv_route ? inv_blocks_layout(N, (char *)ctx->ws + vec_bytes) : InvBlocks{};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the one-launch factorisation (factor_pipe_kernel's inter-workgroup hand-offs): for every (M, L) a random G, the first result
+"""Soak of the one-launch factorisation (factor_pipe_kernel's inter-workgroup hand-offs; beyond M = 1024 two block rows of it): for every (M, L) a random G, the first result
 checked against its definition (U'U (I + G) = I, v = U (g + eta0), log det), then REPEATS more launches on the same input that must
 reproduce it bit for bit -- a lost or early hand-off shows as different bits long before it shows as a wrong answer.
 python3 tools/soak_factor.py [repeats]  -> one JSON line"""
@@ -18,7 +18,7 @@ ctx = A.Context(0, seed=3)
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 out = {"repeats": REPEATS, "cases": {}}
 gen = torch.Generator(device="cuda").manual_seed(5)
-for M, L in ((128, 1), (256, 1), (256, 9), (384, 2), (512, 1), (512, 3), (512, 12), (640, 1), (768, 2), (896, 1), (1024, 1), (1024, 2), (1024, 5), (640, 9), (1024, 10), (768, 17),
+for M, L in ((128, 1), (256, 1), (256, 9), (384, 2), (512, 1), (512, 3), (512, 12), (640, 1), (768, 2), (896, 1), (1024, 1), (1024, 2), (1024, 5), (640, 9), (1024, 10), (768, 17), (1152, 1), (1536, 2), (2048, 1),
              (1024, 8)):
     B = torch.randn((L, M, 2 * M), dtype=torch.float64, device="cuda", generator=gen) / (2 * M) ** 0.5
     G = (B @ B.transpose(1, 2) * 5.0).contiguous()
